@@ -1,0 +1,89 @@
+/* include/nct.h — C ABI of libnct.so: the MI355X-native hot path of Neural-Color-Transfer.
+ *
+ * The reference (hmmlillian/Neural-Color-Transfer) has no plugin/FFI layer: the path is reached through
+ * ordinary C++ calls and kernel launches inside `transfer_color_single_bds`
+ * (code/windows/neural_color_transfer/source/main.cu:47-454). Each entry point below replaces one seam of
+ * that function; the seam is cited as `main.cu:<line>` (+ the kernel/function it launches).
+ *
+ * Conventions
+ *  - plain C, no C++/torch types. Every function returns 0 on success, <0 on error (nct_status);
+ *    `nct_last_error(ctx)` returns a human-readable message for the last failure on that context.
+ *  - a context is bound to ONE GPU and is NOT thread-safe; use one context per worker thread / process.
+ *    The context owns every device allocation (cached arena, reused across calls and pairs).
+ *  - "host" entry points take host pointers and are synchronous. Feature tensors are CHW fp32 exactly like the
+ *    reference kernels' arguments (`float* a1`, Caffe blob layout). `*_dev` variants (nct_dev.h section below)
+ *    work on device pointers in the library's internal channel-last (HWC) layout.
+ *  - NNF element = uint32 `(y << 12) | x` (GeneralizedPatchMatch.cu:24-34), row-major (ah x aw).
+ *  - there is NO CPU fallback: without a usable HIP device nct_create fails with NCT_ERR_NO_DEVICE.
+ */
+#ifndef NCT_H
+#define NCT_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NCT_VERSION 100
+
+typedef enum {
+    NCT_OK = 0,
+    NCT_ERR_NO_DEVICE = -1,     /* no HIP device / hipInit failed (fail loudly, no fallback) */
+    NCT_ERR_INVALID = -2,       /* bad argument (null pointer, size out of range, unsupported C/patch) */
+    NCT_ERR_HIP = -3,           /* a HIP runtime call or kernel launch failed */
+    NCT_ERR_IO = -4,            /* file not found / unreadable / malformed */
+    NCT_ERR_STATE = -5          /* call order (e.g. features before weights are loaded) */
+} nct_status;
+
+typedef struct nct_ctx nct_ctx;
+
+/* ---- context (replaces cudaSetDevice/cudaDeviceReset + the two Classifier objects, main.cu:562-584) ---- */
+int nct_create(int device, nct_ctx** out);
+void nct_destroy(nct_ctx* ctx);
+const char* nct_last_error(const nct_ctx* ctx);     /* ctx may be NULL: returns the last create() failure */
+int nct_version(void);
+int nct_device_name(nct_ctx* ctx, char* buf, int buflen);
+int nct_synchronize(nct_ctx* ctx);
+
+/* ---- N1: feature L2 normalisation — `norm` (GeneralizedPatchMatch.cu:237-283), called main.cu:265,274,313.
+ * dst = src / sqrt(sum_c src^2) per pixel (no epsilon, like the reference). resp (nullable, H*W) receives the
+ * min-max normalised response map (|x| - min)/(max - min). C must be a multiple of 4. */
+int nct_feat_normalize(nct_ctx* ctx, const float* src_chw, float* dst_chw, float* resp, int C, int H, int W);
+
+/* ---- N2: NNF initialisation / upsampling — init_Ann_kernel (:527-544), upSample_kernel (:546-580);
+ * launched main.cu:232-233 and :240-250. */
+int nct_nnf_init(nct_ctx* ctx, uint32_t* nnf, int ah, int aw, int bh, int bw);
+int nct_nnf_upsample(nct_ctx* ctx, const uint32_t* nnf_half, uint32_t* nnf, int ah, int aw, int bh, int bw, int ah_half, int aw_half);
+
+/* ---- P1: PatchMatch — patchmatch_single (:677-831), launched main.cu:283-284 (S->R) and (R->S).
+ * a/b: L2-normalised CHW features of the query / candidate image. nnf: in/out. dist: out (ah*aw), the
+ * negative mean cosine of the best match. patch must be 3 (Config.h:70), C a multiple of 4.
+ * Deterministic: Jacobi step per (iteration, jump), counter-based RNG keyed by `seed`. */
+int nct_patchmatch(nct_ctx* ctx, const float* a_chw, const float* b_chw, int C, int ah, int aw, int bh, int bw,
+                   int patch, int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist);
+
+/* ---- B2: feature-domain BDS vote + matching error — avg_vote_bds_a/_b/avg_vote_bds (:1074-1202),
+ * feature_distance (:833-855); launched main.cu:303-316.
+ * pin: UN-normalised R features (C,bh,bw). pout: voted features (C,ah,aw). pw (nullable): accumulated weights. */
+int nct_bds_vote_features(nct_ctx* ctx, const uint32_t* ann, const uint32_t* bnn, const float* pin_chw, float* pout_chw, float* pw,
+                          int C, int ah, int aw, int bh, int bw, int patch, float w_coherence, float w_complete);
+int nct_feature_distance(nct_ctx* ctx, const float* a_chw, const float* b_chw, float* err, int C, int H, int W);
+
+/* ---- B1: image-domain BDS vote — reconstruct_bds (GeneralizedPatchMatch.cu:122-235), called main.cu:291.
+ * a, b: u8 BGR HWC level images of S and R; out: guidance image G (ah x aw x 3). */
+int nct_bds_vote_image(nct_ctx* ctx, const uint8_t* a_bgr, int ah, int aw, const uint8_t* b_bgr, int bh, int bw,
+                       const uint32_t* ann, const uint32_t* bnn, int patch, double w_coherence, double w_complete, uint8_t* out_bgr);
+
+/* ---- measurement hooks (bench.py / rocprof): device-resident PatchMatch on synthetic features ----
+ * nct_pm_bench_setup uploads + normalises two CHW feature maps once; nct_pm_bench_run re-initialises the NNF
+ * (scaled identity) and runs one full nct_patchmatch pass (init-dist + iters*4 Jacobi steps) entirely on the
+ * device, returning the kernel time of that pass measured with HIP events on the library's own stream and the
+ * number of distance evaluations actually performed (device counter). */
+int nct_pm_bench_setup(nct_ctx* ctx, const float* a_chw, const float* b_chw, int C, int ah, int aw, int bh, int bw);
+int nct_pm_bench_run(nct_ctx* ctx, int iters, int rs_max, uint32_t seed, float* kernel_ms, uint64_t* evals, uint32_t* nnf_out, float* dist_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NCT_H */

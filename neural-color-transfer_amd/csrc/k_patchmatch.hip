@@ -1,0 +1,212 @@
+// k_patchmatch.hip — P1: dense-correspondence PatchMatch over normalised deep features.
+// Reference: patchmatch_single GeneralizedPatchMatch.cu:677-831 (dist_compute_single :355-405,
+// improve_guess_single :505-515), launched twice per level from main.cu:283-284.
+//
+// MI355X design (not a translation of the 24x24-thread, one-thread-per-query CUDA kernel):
+//  * features are channel-last (HWC): a candidate's 3x3xC tile is three contiguous runs of 3*C floats, so every
+//    load instruction of a query group is a fully coalesced C*4-byte row segment;
+//  * one 16-lane DPP row per query (4 queries per wave64, 16 per 256-thread workgroup, arranged as a 4x4 pixel
+//    tile so that neighbouring queries — whose candidate tiles overlap when the NNF is coherent — share L1/L2);
+//    lane v owns float4 channel chunks v, v+16, …; the 9*C-term dot product is one fmaf chain per lane followed
+//    by a 4-step DPP rotate-add (no LDS traffic, no bpermute);
+//  * for C <= 128 the query's own 3x3xC tile lives in registers for the whole step;
+//  * the racy single launch of the reference becomes 1 + iters*4 Jacobi steps on a double-buffered NNF
+//    (one launch per (iteration, jump)); random search is fused into the jump==1 step; RNG is counter based.
+//    => results are deterministic and bit-identical to oracle/orc_nnf.c.
+// Roofline: memory (gather of candidate tiles): algorithmic bytes = evals*9*C*4 (+ query tile + NNF r/w).
+#include "nct_internal.h"
+#include "nct_device.h"
+#include <cfloat>
+#include <climits>
+
+struct PMGeom { int C, ah, aw, bh, bw, tiles_x, tiles_y; };
+
+// ---- distance of query (ax,ay) to candidate (bx,by): -(sum over valid taps of <a,b>) / n_valid
+template <int NCH, bool AREG>
+__device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const PMGeom& g,
+                                         const float4 (&areg)[9][NCH > 0 ? NCH : 1], int ax, int ay, unsigned amask,
+                                         int bx, int by, int v) {
+    float acc = 0.f;
+    int n = 0;
+    const int nchunk = g.C >> 2;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        const int yy = by + dy, xx = bx + dx;
+        const bool valid = ((amask >> t) & 1u) && yy >= 0 && yy < g.bh && xx >= 0 && xx < g.bw;
+        const int yc = clampi(yy, 0, g.bh - 1), xc = clampi(xx, 0, g.bw - 1);
+        const float4* pb = reinterpret_cast<const float4*>(B + ((size_t)yc * g.bw + xc) * g.C);
+        n += valid ? 1 : 0;
+        if constexpr (AREG) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                float4 b = pb[v + 16 * k];
+                if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);     // adding +0 products == skipping the tap
+                acc = dot4_acc(areg[t][k], b, acc);
+            }
+        } else {
+            const int yac = clampi(ay + dy, 0, g.ah - 1), xac = clampi(ax + dx, 0, g.aw - 1);
+            const float4* pa = reinterpret_cast<const float4*>(A + ((size_t)yac * g.aw + xac) * g.C);
+            if constexpr (NCH > 0) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    float4 a = pa[v + 16 * k];
+                    float4 b = pb[v + 16 * k];
+                    if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc = dot4_acc(a, b, acc);
+                }
+            } else {
+                for (int j = v; j < nchunk; j += 16) {
+                    float4 a = pa[j];
+                    float4 b = pb[j];
+                    if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc = dot4_acc(a, b, acc);
+                }
+            }
+        }
+    }
+    const float sum = row16_sum(acc);
+    return (n == 0) ? 1.0f : (-sum) / (float)n;
+}
+
+// mode 0: init (dist of the current NNF, no cutoff); mode 1: propagation step with `jump`; random search if jump==1
+template <int NCH>
+__global__ __launch_bounds__(256) void k_pm_step(const float* __restrict__ A, const float* __restrict__ B,
+                                                 const uint32_t* __restrict__ nnf_in, const float* __restrict__ d_in,
+                                                 uint32_t* __restrict__ nnf_out, float* __restrict__ d_out,
+                                                 PMGeom g, int mode, int jump, int iter, int rs_max, uint32_t seed,
+                                                 unsigned long long* __restrict__ counter) {
+    constexpr bool AREG = (NCH == 1 || NCH == 2);
+    // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs; give each XCD a contiguous
+    // band of tiles so that overlapping candidate tiles of neighbouring queries meet in the same L2.
+    const int ntiles = g.tiles_x * g.tiles_y;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ty = bid / g.tiles_x, tx = bid - ty * g.tiles_x;
+    const int grp = threadIdx.x >> 4, v = threadIdx.x & 15;
+    const int qx = tx * 4 + (grp & 3), qy = ty * 4 + (grp >> 2);
+    const bool live = qx < g.aw && qy < g.ah;
+    const int ax = live ? qx : g.aw - 1, ay = live ? qy : g.ah - 1;
+    const int qi = ay * g.aw + ax;
+
+    // validity of the query's own taps + (optionally) its tile in registers
+    unsigned amask = 0;
+    float4 areg[9][NCH > 0 ? NCH : 1];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        const int yy = ay + dy, xx = ax + dx;
+        const bool va = yy >= 0 && yy < g.ah && xx >= 0 && xx < g.aw;
+        amask |= (va ? 1u : 0u) << t;
+        if constexpr (AREG) {
+            const int yc = clampi(yy, 0, g.ah - 1), xc = clampi(xx, 0, g.aw - 1);
+            const float4* pa = reinterpret_cast<const float4*>(A + ((size_t)yc * g.aw + xc) * g.C);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) areg[t][k] = pa[v + 16 * k];
+        }
+    }
+
+    uint32_t vbest = nnf_in[qi];
+    int xbest = nnf_x(vbest), ybest = nnf_y(vbest);
+    float dbest;
+    unsigned nevals = 0;
+
+    if (mode == 0) {
+        dbest = pm_dist<NCH, AREG>(A, B, g, areg, ax, ay, amask, xbest, ybest, v);
+        float cut = (float)INT_MAX;                 // dist_single default cutoff
+        if (dbest >= cut) dbest = cut;
+        nevals = 1;
+    } else {
+        dbest = d_in[qi];
+        int rs_start = rs_max;
+        { const int mx = g.bw > g.bh ? g.bw : g.bh; if (rs_start > mx) rs_start = mx; }
+        int nrand = 0;
+        if (jump == 1) for (int mag = rs_start; mag >= 1; mag >>= 1) ++nrand;
+        int mag = rs_start;
+        const int ncand = 4 + nrand;
+        for (int k = 0; k < ncand; ++k) {
+            int xp, yp; bool valid; float rr;
+            if (k < 4) {
+                // 0 left, 1 right, 2 up, 3 down — the neighbour's match shifted back by the jump
+                const int sx = (k == 0) ? -jump : (k == 1 ? jump : 0);
+                const int sy = (k == 2) ? -jump : (k == 3 ? jump : 0);
+                const int nx = ax + sx, ny = ay + sy;
+                valid = nx >= 0 && nx < g.aw && ny >= 0 && ny < g.ah;
+                const uint32_t vp = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
+                xp = nnf_x(vp) - sx; yp = nnf_y(vp) - sy;
+                valid = valid && yp >= 0 && yp < g.bh && xp >= 0 && xp < g.bw;
+                rr = 0.f;
+            } else {
+                const int step = k - 4;
+                const int xmin = max(xbest - mag, 0), xmax = min(xbest + mag + 1, g.bw);
+                const int ymin = max(ybest - mag, 0), ymax = min(ybest + mag + 1, g.bh);
+                xp = xmin + (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)(xmax - xmin)) % (xmax - xmin);
+                yp = ymin + (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)(ymax - ymin)) % (ymax - ymin);
+                mag >>= 1;
+                valid = true; rr = FLT_MIN;
+            }
+            if (valid) {
+                float d = pm_dist<NCH, AREG>(A, B, g, areg, ax, ay, amask, xp, yp, v);
+                if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
+                if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; }
+                ++nevals;
+            }
+        }
+    }
+    if (live && v == 0) { if (mode != 0) nnf_out[qi] = xy_pack(xbest, ybest); d_out[qi] = dbest; }
+    if (counter) {
+        __shared__ unsigned s_cnt;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        if (live && v == 0) atomicAdd(&s_cnt, nevals);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(counter, (unsigned long long)s_cnt);
+    }
+}
+
+template <int NCH>
+static void launch_step(hipStream_t s, int nblocks, const float* A, const float* B, const uint32_t* ni, const float* di, uint32_t* no, float* dout,
+                        const PMGeom& g, int mode, int jump, int iter, int rs_max, uint32_t seed, unsigned long long* counter) {
+    hipLaunchKernelGGL(k_pm_step<NCH>, dim3(nblocks), dim3(256), 0, s, A, B, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, counter);
+}
+
+int nctk_patchmatch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
+                    int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist, unsigned long long* eval_counter) {
+    NCT_REQUIRE(C > 0 && (C & 3) == 0, "patchmatch: C=%d must be a positive multiple of 4", C);
+    NCT_REQUIRE(ah >= 1 && aw >= 1 && bh >= 1 && bw >= 1 && ah < 4096 && aw < 4096 && bh < 4096 && bw < 4096,
+                "patchmatch: dims out of range (%dx%d vs %dx%d); NNF coordinates are 12-bit", ah, aw, bh, bw);
+    NCT_REQUIRE(iters >= 0 && rs_max >= 0, "patchmatch: iters/rs_max must be >= 0");
+    const int n = ah * aw;
+    DevBuf<uint32_t> nnf_tmp(ctx, n);
+    DevBuf<float> d_tmp(ctx, n);
+    if (!nnf_tmp.ok() || !d_tmp.ok()) return NCT_ERR_HIP;
+    PMGeom g{C, ah, aw, bh, bw, cdiv(aw, 4), cdiv(ah, 4)};
+    const int nblocks = g.tiles_x * g.tiles_y;
+    auto step = [&](const uint32_t* ni, const float* di, uint32_t* no, float* dout, int mode, int jump, int iter) {
+        switch (C) {
+            case 64:  launch_step<1>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
+            case 128: launch_step<2>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
+            case 256: launch_step<4>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
+            case 512: launch_step<8>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
+            default:  launch_step<0>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
+        }
+    };
+    // the total number of Jacobi steps is even (iters*4), so ping-ponging (nnf,dist) <-> (tmp) ends in (nnf,dist)
+    uint32_t* nb[2] = {nnf, nnf_tmp};
+    float* db[2] = {dist, d_tmp};
+    step(nnf, nullptr, nullptr, dist, 0, 0, 0);  // init: dist(current NNF), NNF untouched
+    NCT_LAUNCH_CHECK();
+    int cur = 0;
+    for (int iter = 0; iter < iters; ++iter)
+        for (int jump = 8; jump > 0; jump >>= 1) {
+            step(nb[cur], db[cur], nb[cur ^ 1], db[cur ^ 1], 1, jump, iter);
+            NCT_LAUNCH_CHECK();
+            cur ^= 1;
+        }
+    // cur == 0 here. nnf_tmp/d_tmp return to the arena now; that is safe because arena blocks are recycled in
+    // stream order (every user enqueues on the same stream or joins into it before releasing).
+    return 0;
+}

@@ -1,0 +1,217 @@
+// k_vote.hip — bidirectional-similarity votes (B1 image domain, B2 feature domain).
+// Reference: reconstruct_bds GeneralizedPatchMatch.cu:122-235 (serial host loops in the reference);
+//            avg_vote_bds_a :1074-1126, avg_vote_bds_b :1128-1178 (float atomicAdd scatter), avg_vote_bds :1180-1202.
+//
+// MI355X design: the completeness vote is a *gather*, not an atomic scatter. The R->S NNF is inverted once per
+// level (stable radix sort of (matched S pixel, R pixel) pairs + per-S-pixel segment starts), then every S pixel
+// merges the <=9 per-tap source lists in ascending source order. That (a) removes 9*C float atomics per R pixel,
+// (b) makes the fp32 sum order deterministic (ascending source pixel, taps dx-outer/dy-inner) == oracle/orc_vote.c,
+// (c) lets the coherence vote, the completeness vote and the final division fuse into ONE kernel per domain.
+// Roofline: HBM/L2 gather, ~18 feature vectors read + 1 written per S pixel.
+#include "nct_internal.h"
+#include "nct_device.h"
+#include <hipcub/hipcub.hpp>
+
+// ---------------------------------------------------------------- inverse map of the R->S NNF
+__global__ void k_inv_keys(const uint32_t* __restrict__ bnn, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int nb, int aw) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nb) return;
+    uint32_t v = bnn[q];
+    keys[q] = (uint32_t)(nnf_y(v) * aw + nnf_x(v));
+    vals[q] = (uint32_t)q;
+}
+// start[s] = first index i with keys_sorted[i] >= s, s in [0, na]
+__global__ void k_inv_starts(const uint32_t* __restrict__ keys, int nb, int* __restrict__ start, int na) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > na) return;
+    int lo = 0, hi = nb;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (keys[mid] < (uint32_t)s) lo = mid + 1; else hi = mid; }
+    start[s] = lo;
+}
+
+struct InvMap {
+    DevBuf<uint32_t> keys, vals, keys_s, vals_s;
+    DevBuf<int> start;
+    InvMap(nct_ctx* c, int nb, int na) : keys(c, nb), vals(c, nb), keys_s(c, nb), vals_s(c, nb), start(c, na + 1) {}
+    bool ok() const { return keys.ok() && vals.ok() && keys_s.ok() && vals_s.ok() && start.ok(); }
+};
+
+static int build_inverse(nct_ctx* ctx, hipStream_t s, const uint32_t* bnn, int bh, int bw, int ah, int aw, InvMap& inv) {
+    const int nb = bh * bw, na = ah * aw;
+    hipLaunchKernelGGL(k_inv_keys, dim3(cdiv(nb, 256)), dim3(256), 0, s, bnn, (uint32_t*)inv.keys, (uint32_t*)inv.vals, nb, aw);
+    NCT_LAUNCH_CHECK();
+    int end_bit = 1; while ((1u << end_bit) < (unsigned)na && end_bit < 32) ++end_bit;
+    size_t tmp_bytes = 0;
+    NCT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)inv.keys, (uint32_t*)inv.keys_s,
+                                               (const uint32_t*)inv.vals, (uint32_t*)inv.vals_s, nb, 0, end_bit, s));
+    DevBuf<char> tmp(ctx, tmp_bytes ? tmp_bytes : 16);
+    if (!tmp.ok()) return NCT_ERR_HIP;
+    NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const uint32_t*)inv.keys, (uint32_t*)inv.keys_s,
+                                               (const uint32_t*)inv.vals, (uint32_t*)inv.vals_s, nb, 0, end_bit, s));
+    hipLaunchKernelGGL(k_inv_starts, dim3(cdiv(na + 1, 256)), dim3(256), 0, s, (const uint32_t*)inv.keys_s, nb, (int*)inv.start, na);
+    NCT_LAUNCH_CHECK();
+    return 0;                              // tmp returns to the arena (recycled in stream order)
+}
+
+// iterate the sources of target (xa,ya) in canonical order; F(q, dx, dy) is called for every (source, tap) pair
+// whose tapped source pixel (qx+dx, qy+dy) is inside B.
+template <typename F>
+__device__ __forceinline__ void for_each_source(const uint32_t* __restrict__ vals, const int* __restrict__ start,
+                                                int xa, int ya, int ah, int aw, int bh, int bw, F&& f) {
+    int pos[9], end[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dx = t / 3 - 1, dy = t % 3 - 1;        // dx outer, dy inner (the kernels' loop order)
+        const int sx = xa - dx, sy = ya - dy;
+        const bool in = sx >= 0 && sx < aw && sy >= 0 && sy < ah;
+        const int s = in ? sy * aw + sx : 0;
+        pos[t] = in ? start[s] : 0;
+        end[t] = in ? start[s + 1] : 0;
+    }
+    while (true) {
+        uint32_t qbest = 0xFFFFFFFFu; int tsel = -1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (pos[t] < end[t]) { uint32_t q = vals[pos[t]]; if (q < qbest) { qbest = q; tsel = t; } }
+        if (tsel < 0) break;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) if (t == tsel) pos[t]++;
+        const int dx = tsel / 3 - 1, dy = tsel % 3 - 1;
+        const int qy = (int)qbest / bw, qx = (int)qbest - qy * bw;
+        const int xb = qx + dx, yb = qy + dy;
+        if (xb < bw && xb >= 0 && yb < bh && yb >= 0) f(yb * bw + xb);
+    }
+}
+
+// ---------------------------------------------------------------- B2 feature vote (one 16-lane row per S pixel)
+template <int NCH>   // float4 chunks per lane (C = 64*NCH), 0 = generic (loops, re-reads pout from memory)
+__global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restrict__ ann, const uint32_t* __restrict__ inv_vals, const int* __restrict__ inv_start,
+                                                       const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pw_out,
+                                                       int C, int ah, int aw, int bh, int bw, double wa, double wb) {
+    const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int v = threadIdx.x & 15;
+    if (pix >= ah * aw) return;
+    const int ay = pix / aw, ax = pix - ay * aw;
+    constexpr int NR = NCH > 0 ? NCH : 8;                 // generic path supports C <= 512
+    const int nch = NCH > 0 ? NCH : ((C >> 2) + 15 - v) / 16;   // chunks owned by this lane
+    float4 acc[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pw = 0.f;
+    // coherence (avg_vote_bds_a): float += double  ==> evaluate in double, round to float each time
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int nx = ax + dx, ny = ay + dy;
+            if (nx < aw && nx >= 0 && ny < ah && ny >= 0) {
+                const uint32_t vp = ann[ny * aw + nx];
+                const int xp = nnf_x(vp) - dx, yp = nnf_y(vp) - dy;
+                if (xp < bw && xp >= 0 && yp < bh && yp >= 0) {
+                    pw = (float)((double)pw + wa);
+                    const float4* src = reinterpret_cast<const float4*>(pin + ((size_t)yp * bw + xp) * C);
+#pragma unroll
+                    for (int k = 0; k < NR; ++k)
+                        if (k < nch) {
+                            const float4 x = src[v + 16 * k];
+                            acc[k].x = (float)((double)acc[k].x + (double)x.x * wa);
+                            acc[k].y = (float)((double)acc[k].y + (double)x.y * wa);
+                            acc[k].z = (float)((double)acc[k].z + (double)x.z * wa);
+                            acc[k].w = (float)((double)acc[k].w + (double)x.w * wa);
+                        }
+                }
+            }
+        }
+    // completeness (avg_vote_bds_b): atomicAdd(float*, (float)(wb*pin)) in ascending source order
+    const float wbf = (float)wb;
+    for_each_source(inv_vals, inv_start, ax, ay, ah, aw, bh, bw, [&](int bid) {
+        pw = pw + wbf;
+        const float4* src = reinterpret_cast<const float4*>(pin + (size_t)bid * C);
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if (k < nch) {
+                const float4 x = src[v + 16 * k];
+                acc[k].x = acc[k].x + (float)(wb * (double)x.x);
+                acc[k].y = acc[k].y + (float)(wb * (double)x.y);
+                acc[k].z = acc[k].z + (float)(wb * (double)x.z);
+                acc[k].w = acc[k].w + (float)(wb * (double)x.w);
+            }
+    });
+    // avg_vote_bds
+    float4* dst = reinterpret_cast<float4*>(pout + (size_t)pix * C);
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+        if (k < nch) {
+            float4 r = acc[k];
+            if (pw > 0) { r.x /= pw; r.y /= pw; r.z /= pw; r.w /= pw; }
+            dst[v + 16 * k] = r;
+        }
+    if (pw_out && v == 0) pw_out[pix] = pw;
+}
+
+int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, const uint32_t* bnn, const float* pin_hwc, float* pout_hwc, float* pw,
+                           int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp) {
+    NCT_REQUIRE(C > 0 && (C & 3) == 0 && C <= 512, "bds_vote_features: C=%d must be a multiple of 4 and <= 512", C);
+    InvMap inv(ctx, bh * bw, ah * aw);
+    if (!inv.ok()) return NCT_ERR_HIP;
+    int rc = build_inverse(ctx, s, bnn, bh, bw, ah, aw, inv);
+    if (rc) return rc;
+    const double wa = w_coh / (double)(aw * ah);
+    const double wb = w_comp / (double)(bw * bh);
+    dim3 grid(cdiv(ah * aw, 16)), block(256);
+#define NCT_VOTE_LAUNCH(N) hipLaunchKernelGGL(k_vote_features<N>, grid, block, 0, s, ann, (const uint32_t*)inv.vals_s, (const int*)inv.start, \
+                                              pin_hwc, pout_hwc, pw, C, ah, aw, bh, bw, wa, wb)
+    switch (C) {
+        case 64: NCT_VOTE_LAUNCH(1); break;
+        case 128: NCT_VOTE_LAUNCH(2); break;
+        case 256: NCT_VOTE_LAUNCH(4); break;
+        case 512: NCT_VOTE_LAUNCH(8); break;
+        default: NCT_VOTE_LAUNCH(0); break;
+    }
+#undef NCT_VOTE_LAUNCH
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- B1 image vote (one thread per S pixel; integer sums)
+__global__ void k_vote_image(const uint8_t* __restrict__ b, const uint32_t* __restrict__ ann, const uint32_t* __restrict__ inv_vals, const int* __restrict__ inv_start,
+                             int ah, int aw, int bh, int bw, double wa, double wb, uint8_t* __restrict__ out) {
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= ah * aw) return;
+    const int ay = pix / aw, ax = pix - ay * aw;
+    int a0 = 0, a1 = 0, a2 = 0, acnt = 0;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int nx = ax + dx, ny = ay + dy;
+            if (nx < aw && nx >= 0 && ny < ah && ny >= 0) {
+                const uint32_t vp = ann[ny * aw + nx];
+                const int xp = nnf_x(vp) - dx, yp = nnf_y(vp) - dy;
+                if (xp < bw && xp >= 0 && yp < bh && yp >= 0) {
+                    const uint8_t* bv = b + ((size_t)yp * bw + xp) * 3;
+                    a0 += bv[0]; a1 += bv[1]; a2 += bv[2]; ++acnt;
+                }
+            }
+        }
+    int b0 = 0, b1 = 0, b2 = 0, bcnt = 0;
+    for_each_source(inv_vals, inv_start, ax, ay, ah, aw, bh, bw, [&](int bid) {
+        const uint8_t* bv = b + (size_t)bid * 3;
+        b0 += bv[0]; b1 += bv[1]; b2 += bv[2]; ++bcnt;
+    });
+    const double awt = acnt * wa, bwt = bcnt * wb;
+    const double den = awt + bwt;
+    out[(size_t)pix * 3 + 0] = (uint8_t)((a0 * wa + b0 * wb) / den);
+    out[(size_t)pix * 3 + 1] = (uint8_t)((a1 * wa + b1 * wb) / den);
+    out[(size_t)pix * 3 + 2] = (uint8_t)((a2 * wa + b2 * wb) / den);
+}
+
+int nctk_bds_vote_image(nct_ctx* ctx, hipStream_t s, const uint8_t* b_bgr, const uint32_t* ann, const uint32_t* bnn,
+                        int ah, int aw, int bh, int bw, double w_coh, double w_comp, uint8_t* out_bgr) {
+    InvMap inv(ctx, bh * bw, ah * aw);
+    if (!inv.ok()) return NCT_ERR_HIP;
+    int rc = build_inverse(ctx, s, bnn, bh, bw, ah, aw, inv);
+    if (rc) return rc;
+    const double wa = w_coh / (double)(aw * ah);
+    const double wb = w_comp / (double)(bw * bh);
+    hipLaunchKernelGGL(k_vote_image, dim3(cdiv(ah * aw, 256)), dim3(256), 0, s, b_bgr, ann, (const uint32_t*)inv.vals_s, (const int*)inv.start,
+                       ah, aw, bh, bw, wa, wb, out_bgr);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,68 @@
+// nct_internal.h — context, device-memory arena and launch helpers shared by the libnct translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <string>
+#include <vector>
+#include "../../include/nct.h"
+
+struct nct_block { void* p; size_t bytes; bool used; };
+
+struct nct_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;     // main stream (S->R direction, VGG, colour stage)
+    hipStream_t stream2 = nullptr;    // second stream (R->S direction runs concurrently)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    std::string err;
+    std::vector<nct_block> blocks;    // cached device allocations, reused across calls and pairs
+    size_t bytes_allocated = 0;
+    // measurement fixture (nct_pm_bench_*)
+    float *bench_a = nullptr, *bench_b = nullptr; int bench_C = 0, bench_ah = 0, bench_aw = 0, bench_bh = 0, bench_bw = 0;
+    // opaque sub-states owned by other translation units
+    void* vgg = nullptr;              // struct vgg_weights* (nct_vgg.cpp)
+    unsigned long long* d_counter = nullptr;   // device eval counter (profiling builds of pm kernels)
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf; return code;
+    }
+    void* alloc(size_t bytes);        // never returns null on success; sets err and returns null on failure
+    void release(void* p);
+};
+
+// RAII scratch buffer from the context arena
+template <typename T> struct DevBuf {
+    nct_ctx* c; T* p;
+    DevBuf(nct_ctx* ctx, size_t n) : c(ctx), p((T*)ctx->alloc(n * sizeof(T))) {}
+    ~DevBuf() { if (p) c->release(p); }
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    operator T*() const { return p; }
+    bool ok() const { return p != nullptr; }
+};
+
+#define NCT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return ctx->fail(NCT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define NCT_LAUNCH_CHECK() NCT_HIP(hipGetLastError())
+#define NCT_REQUIRE(cond, ...) do { if (!(cond)) return ctx->fail(NCT_ERR_INVALID, __VA_ARGS__); } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device-side launchers (all on device pointers, features channel-last HWC fp32) ----
+// k_feat.hip
+int nctk_chw_to_hwc(nct_ctx* ctx, hipStream_t s, const float* src, float* dst, int C, int HW);
+int nctk_hwc_to_chw(nct_ctx* ctx, hipStream_t s, const float* src, float* dst, int C, int HW);
+int nctk_normalize(nct_ctx* ctx, hipStream_t s, const float* src_hwc, float* dst_hwc, float* resp /*nullable*/, int C, int HW);
+int nctk_feature_distance(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, float* err, int C, int HW);
+// k_nnf.hip
+int nctk_nnf_init(nct_ctx* ctx, hipStream_t s, uint32_t* nnf, int ah, int aw, int bh, int bw);
+int nctk_nnf_upsample(nct_ctx* ctx, hipStream_t s, const uint32_t* nnf_half, uint32_t* nnf, int ah, int aw, int bh, int bw, int ah_half, int aw_half);
+// k_patchmatch.hip — nnf in/out, dist out; tmp buffers come from the arena
+int nctk_patchmatch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
+                    int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist, unsigned long long* eval_counter /*nullable*/);
+// k_vote.hip
+int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, const uint32_t* bnn, const float* pin_hwc, float* pout_hwc, float* pw /*nullable*/,
+                           int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp);
+int nctk_bds_vote_image(nct_ctx* ctx, hipStream_t s, const uint8_t* b_bgr, const uint32_t* ann, const uint32_t* bnn,
+                        int ah, int aw, int bh, int bw, double w_coh, double w_comp, uint8_t* out_bgr);

@@ -1,0 +1,195 @@
+"""nct — thin ctypes binding over libnct.so (the C ABI declared in include/nct.h).
+
+This is plumbing for tests / bench.py only; the product is the shared library + the C++ CLI. There is no CPU
+fallback anywhere in this package: if the library is missing or no HIP device is usable, calls raise NctError.
+Function names and argument meaning mirror include/nct.h, which cites the reference seam each one replaces
+(code/windows/neural_color_transfer/source/main.cu).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))
+REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libnct.so")
+
+
+class NctError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nct error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libnct.so (in-tree build only — never a site-packages copy)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NctError(-4, f"{LIB_PATH} not found — run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+# name -> (restype, argtypes); the single source of truth for the symbol-export test
+SIGNATURES = {
+    "nct_version": (C.c_int, []),
+    "nct_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "nct_destroy": (None, [C.c_void_p]),
+    "nct_last_error": (C.c_char_p, [C.c_void_p]),
+    "nct_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "nct_synchronize": (C.c_int, [C.c_void_p]),
+    "nct_feat_normalize": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "nct_nnf_init": (C.c_int, [C.c_void_p, _u32p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nct_nnf_upsample": (C.c_int, [C.c_void_p, _u32p, _u32p] + [C.c_int] * 6),
+    "nct_patchmatch": (C.c_int, [C.c_void_p, _f32p, _f32p] + [C.c_int] * 8 + [C.c_uint32, _u32p, _f32p]),
+    "nct_bds_vote_features": (C.c_int, [C.c_void_p, _u32p, _u32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_float]),
+    "nct_feature_distance": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),
+    "nct_bds_vote_image": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, _u32p, _u32p, C.c_int, C.c_double, C.c_double, _u8p]),
+    "nct_pm_bench_setup": (C.c_int, [C.c_void_p, _f32p, _f32p] + [C.c_int] * 5),
+    "nct_pm_bench_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
+}
+
+
+def _declare(l):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One context per GPU / process (include/nct.h: not thread-safe)."""
+
+    def __init__(self, device=0):
+        self._l = lib()
+        h = C.c_void_p()
+        rc = self._l.nct_create(device, C.byref(h))
+        if rc != 0:
+            raise NctError(rc, self._l.nct_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.nct_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NctError(rc, self._l.nct_last_error(self._h).decode())
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._chk(self._l.nct_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def synchronize(self):
+        self._chk(self._l.nct_synchronize(self._h))
+
+    # ---- N1
+    def feat_normalize(self, src_chw, want_resp=False):
+        src = np.ascontiguousarray(src_chw, np.float32)
+        Cc, H, W = src.shape
+        dst = np.empty_like(src)
+        resp = np.empty((H, W), np.float32) if want_resp else None
+        self._chk(self._l.nct_feat_normalize(self._h, src, dst, _ptr(resp), Cc, H, W))
+        return (dst, resp) if want_resp else dst
+
+    # ---- N2
+    def nnf_init(self, ah, aw, bh, bw):
+        nnf = np.empty((ah, aw), np.uint32)
+        self._chk(self._l.nct_nnf_init(self._h, nnf, ah, aw, bh, bw))
+        return nnf
+
+    def nnf_upsample(self, nnf_half, ah, aw, bh, bw):
+        half = np.ascontiguousarray(nnf_half, np.uint32)
+        nnf = np.empty((ah, aw), np.uint32)
+        self._chk(self._l.nct_nnf_upsample(self._h, half, nnf, ah, aw, bh, bw, half.shape[0], half.shape[1]))
+        return nnf
+
+    # ---- P1
+    def patchmatch(self, a_chw, b_chw, nnf, iters=10, rs_max=32, seed=0, patch=3):
+        a = np.ascontiguousarray(a_chw, np.float32)
+        b = np.ascontiguousarray(b_chw, np.float32)
+        Cc, ah, aw = a.shape
+        _, bh, bw = b.shape
+        nnf = np.array(nnf, np.uint32, order="C", copy=True).reshape(ah, aw)
+        dist = np.empty((ah, aw), np.float32)
+        self._chk(self._l.nct_patchmatch(self._h, a, b, Cc, ah, aw, bh, bw, patch, iters, rs_max, seed, nnf, dist))
+        return nnf, dist
+
+    # ---- B2
+    def bds_vote_features(self, ann, bnn, pin_chw, w_coh=1.0, w_comp=2.0, patch=3, want_pw=False):
+        pin = np.ascontiguousarray(pin_chw, np.float32)
+        Cc, bh, bw = pin.shape
+        ann = np.ascontiguousarray(ann, np.uint32)
+        bnn = np.ascontiguousarray(bnn, np.uint32)
+        ah, aw = ann.shape
+        pout = np.empty((Cc, ah, aw), np.float32)
+        pw = np.empty((ah, aw), np.float32) if want_pw else None
+        self._chk(self._l.nct_bds_vote_features(self._h, ann, bnn, pin, pout, _ptr(pw), Cc, ah, aw, bh, bw, patch, w_coh, w_comp))
+        return (pout, pw) if want_pw else pout
+
+    def feature_distance(self, a_chw, b_chw):
+        a = np.ascontiguousarray(a_chw, np.float32)
+        b = np.ascontiguousarray(b_chw, np.float32)
+        Cc, H, W = a.shape
+        err = np.empty((H, W), np.float32)
+        self._chk(self._l.nct_feature_distance(self._h, a, b, err, Cc, H, W))
+        return err
+
+    # ---- B1
+    def bds_vote_image(self, a_bgr, b_bgr, ann, bnn, w_coh=1.0, w_comp=2.0, patch=3):
+        a = np.ascontiguousarray(a_bgr, np.uint8)
+        b = np.ascontiguousarray(b_bgr, np.uint8)
+        ah, aw = a.shape[:2]
+        bh, bw = b.shape[:2]
+        out = np.empty((ah, aw, 3), np.uint8)
+        self._chk(self._l.nct_bds_vote_image(self._h, a, ah, aw, b, bh, bw, np.ascontiguousarray(ann, np.uint32),
+                                             np.ascontiguousarray(bnn, np.uint32), patch, w_coh, w_comp, out))
+        return out
+
+    # ---- measurement hooks
+    def pm_bench_setup(self, a_chw, b_chw):
+        a = np.ascontiguousarray(a_chw, np.float32)
+        b = np.ascontiguousarray(b_chw, np.float32)
+        Cc, ah, aw = a.shape
+        _, bh, bw = b.shape
+        self._pm_shape = (ah, aw)
+        self._chk(self._l.nct_pm_bench_setup(self._h, a, b, Cc, ah, aw, bh, bw))
+
+    def pm_bench_run(self, iters=10, rs_max=32, seed=0, count_evals=False, fetch=False):
+        ms = C.c_float()
+        ev = C.c_uint64()
+        ah, aw = self._pm_shape
+        nnf = np.empty((ah, aw), np.uint32) if fetch else None
+        dist = np.empty((ah, aw), np.float32) if fetch else None
+        self._chk(self._l.nct_pm_bench_run(self._h, iters, rs_max, seed, C.byref(ms), C.byref(ev) if count_evals else None,
+                                           _ptr(nnf), _ptr(dist)))
+        return ms.value, (ev.value if count_evals else None), nnf, dist

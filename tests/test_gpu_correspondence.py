@@ -1,0 +1,143 @@
+"""GPU parity for the correspondence sub-path (N1, N2, P1, B1, B2): libnct (HIP, through the C ABI) vs the CPU oracle
+on identical seeded inputs. Bars: BIT-EXACT for NNFs, u8 images and — because the fp32 summation order is part of
+the specification (oracle/orc_nnf.c header) — also for every fp32 output of these functions."""
+import numpy as np
+import pytest
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("dims", [(44, 44, 44, 44), (29, 43, 38, 60), (16, 16, 63, 63), (2, 2, 5, 3), (175, 175, 175, 175)])
+def test_nnf_init_bit_exact(ctx, oracle, dims):
+    assert np.array_equal(ctx.nnf_init(*dims), oracle.nnf_init(*dims))
+
+
+@pytest.mark.parametrize("dims", [(44, 44, 88, 88, 88, 88), (88, 88, 175, 175, 175, 175), (29, 43, 57, 85, 75, 120), (57, 85, 113, 170, 150, 240), (16, 16, 32, 32, 32, 32)])
+def test_nnf_upsample_bit_exact(ctx, oracle, dims):
+    ahh, awh, ah, aw, bh, bw = dims
+    half = synth.random_nnf(5, ahh, awh, (bh + 1) // 2, (bw + 1) // 2)
+    assert np.array_equal(ctx.nnf_upsample(half, ah, aw, bh, bw), oracle.nnf_upsample(half, ah, aw, bh, bw))
+
+
+@pytest.mark.parametrize("shape", [(64, 33, 47), (512, 16, 16), (128, 40, 40), (256, 21, 19), (8, 9, 7), (20, 5, 5)])
+def test_normalize_bit_exact(ctx, oracle, shape):
+    f = synth.features(1, *shape)
+    g, gr = ctx.feat_normalize(f, want_resp=True)
+    o, orr = oracle.feat_normalize(f, want_resp=True)
+    assert np.array_equal(bits(g), bits(o))
+    assert np.array_equal(bits(gr), bits(orr))
+
+
+def test_normalize_zero_pixel_is_nan_like_reference(ctx):
+    f = synth.features(2, 64, 6, 6)
+    f[:, 2, 3] = 0
+    g = ctx.feat_normalize(f)
+    assert np.isnan(g[:, 2, 3]).all() and np.isfinite(g[:, 0, 0]).all()
+
+
+PM_CASES = [
+    # C, ah, aw, bh, bw, iters, rs_max
+    (64, 40, 44, 36, 48, 10, 32),     # ragged A/B sizes, conv1_1-like
+    (512, 16, 16, 16, 16, 10, 16),    # config 1, level 5 (256x256 image)
+    (512, 29, 43, 38, 60, 3, 43),     # demo pair geometry (in0/tar0), level 5
+    (128, 33, 35, 31, 37, 4, 32),
+    (256, 25, 27, 30, 22, 4, 10),
+    (8, 19, 23, 17, 29, 5, 4),        # generic-C path
+    (64, 6, 5, 3, 4, 2, 32),          # tiny: rs_max > max(bw,bh) clamp, every query on a border
+    (64, 70, 70, 70, 70, 2, 0),       # rs_max = 0 -> no random search
+]
+
+
+@pytest.mark.parametrize("case", PM_CASES)
+def test_patchmatch_bit_exact(ctx, oracle, case):
+    C, ah, aw, bh, bw, iters, rs = case
+    a = oracle.feat_normalize(synth.features(10 + C, C, ah, aw))
+    b = oracle.feat_normalize(synth.features(20 + C, C, bh, bw))
+    nnf0 = oracle.nnf_init(ah, aw, bh, bw)
+    gn, gd = ctx.patchmatch(a, b, nnf0, iters=iters, rs_max=rs, seed=1234)
+    on, od = oracle.patchmatch(a, b, nnf0, iters=iters, rs_max=rs, seed=1234)
+    assert np.array_equal(gn, on), f"NNF mismatch at {np.argwhere(gn != on)[:5]}"
+    assert np.array_equal(bits(gd), bits(od))
+
+
+def test_patchmatch_from_random_nnf_and_other_seed(ctx, oracle):
+    a = oracle.feat_normalize(synth.features(31, 64, 30, 30))
+    b = oracle.feat_normalize(synth.features(32, 64, 28, 34))
+    nnf0 = synth.random_nnf(9, 30, 30, 28, 34)
+    for seed in (0, 0xDEADBEEF):
+        gn, gd = ctx.patchmatch(a, b, nnf0, iters=3, rs_max=8, seed=seed)
+        on, od = oracle.patchmatch(a, b, nnf0, iters=3, rs_max=8, seed=seed)
+        assert np.array_equal(gn, on) and np.array_equal(bits(gd), bits(od))
+
+
+def test_patchmatch_rejects_bad_arguments(ctx):
+    import nct
+    a = synth.features(1, 64, 8, 8)
+    with pytest.raises(nct.NctError):
+        ctx.patchmatch(a, a, np.zeros((8, 8), np.uint32), patch=5)
+    with pytest.raises(nct.NctError):
+        ctx.patchmatch(a[:6], a[:6], np.zeros((8, 8), np.uint32))      # C=6 not a multiple of 4
+
+
+def test_patchmatch_full_size_properties(ctx):
+    """BASELINE config-2 finest level (700x700x64): size-independent properties instead of an oracle run:
+    determinism, valid coordinates, per-pixel energy monotone in iterations, planted-shift recovery."""
+    f = synth.features(77, 64, 720, 720, smooth=False)
+    a = f[:, 0:700, 0:700]
+    b = f[:, 7:707, 11:711]
+    an, bn = ctx.feat_normalize(a), ctx.feat_normalize(b)
+    nnf0 = ctx.nnf_init(700, 700, 700, 700)
+    n1, d1 = ctx.patchmatch(an, bn, nnf0, iters=2, rs_max=32, seed=5)
+    n2, d2 = ctx.patchmatch(an, bn, nnf0, iters=2, rs_max=32, seed=5)
+    assert np.array_equal(n1, n2) and np.array_equal(bits(d1), bits(d2))
+    n0, d0 = ctx.patchmatch(an, bn, nnf0, iters=0, rs_max=32, seed=5)
+    assert np.array_equal(n0, nnf0)
+    assert (d1 <= d0).all()
+    n10, d10 = ctx.patchmatch(an, bn, nnf0, iters=10, rs_max=32, seed=5)
+    assert (d10 <= d1).all()
+    assert (n10 & 0xFFF).max() < 700 and ((n10 >> 12) & 0xFFF).max() < 700
+    yy, xx = np.mgrid[20:680, 20:680]
+    ok = ((n10[20:680, 20:680] & 0xFFF) == xx - 11) & (((n10[20:680, 20:680] >> 12) & 0xFFF) == yy - 7)
+    assert ok.mean() > 0.9
+    assert np.allclose(d10[20:680, 20:680][ok], -1.0, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(64, 23, 31), (512, 9, 8), (12, 7, 7)])
+def test_feature_distance_bit_exact(ctx, oracle, shape):
+    a = oracle.feat_normalize(synth.features(40, *shape))
+    b = oracle.feat_normalize(synth.features(41, *shape))
+    assert np.array_equal(bits(ctx.feature_distance(a, b)), bits(oracle.feature_distance(a, b)))
+
+
+VOTE_CASES = [(64, 20, 24, 18, 27), (512, 9, 10, 11, 8), (128, 15, 15, 15, 15), (256, 8, 9, 10, 7), (24, 12, 13, 9, 14)]
+
+
+@pytest.mark.parametrize("case", VOTE_CASES)
+@pytest.mark.parametrize("kind", ["random", "collapsed"])
+def test_bds_vote_features_bit_exact(ctx, oracle, case, kind):
+    C, ah, aw, bh, bw = case
+    pin = synth.features(50 + C, C, bh, bw) * np.float32(37.0)       # un-normalised activations
+    ann = synth.random_nnf(1, ah, aw, bh, bw)
+    bnn = synth.random_nnf(2, bh, bw, ah, aw)
+    if kind == "collapsed":        # many R pixels matched to the same S pixel: long source lists
+        bnn[:, : bw // 2] = (np.uint32(ah // 2) << 12) | np.uint32(aw // 2)
+    for wc in (2.0, 0.0, 8.0):
+        g, gw = ctx.bds_vote_features(ann, bnn, pin, 1.0, wc, want_pw=True)
+        o, ow = oracle.bds_vote_features(ann, bnn, pin, 1.0, wc, want_pw=True)
+        assert np.array_equal(bits(gw), bits(ow))
+        assert np.array_equal(bits(g), bits(o))
+
+
+@pytest.mark.parametrize("dims", [(20, 24, 18, 27), (44, 44, 44, 44), (7, 5, 9, 11)])
+def test_bds_vote_image_bit_exact(ctx, oracle, dims):
+    ah, aw, bh, bw = dims
+    a, b = synth.image(1, ah, aw), synth.image(2, bh, bw)
+    ann = synth.random_nnf(3, ah, aw, bh, bw)
+    bnn = synth.random_nnf(4, bh, bw, ah, aw)
+    for wc in (2.0, 0.0, 1.0, 4.0, 8.0):       # the demo's BDS sweep (demo/example/pairs.txt:5-9)
+        assert np.array_equal(ctx.bds_vote_image(a, b, ann, bnn, 1.0, wc), oracle.bds_vote_image(a, b, ann, bnn, 1.0, wc))
