@@ -75,6 +75,25 @@ int nct_feature_distance(nct_ctx* ctx, const float* a_chw, const float* b_chw, f
 int nct_bds_vote_image(nct_ctx* ctx, const uint8_t* a_bgr, int ah, int aw, const uint8_t* b_bgr, int bh, int bw,
                        const uint32_t* ann, const uint32_t* bnn, int patch, double w_coherence, double w_complete, uint8_t* out_bgr);
 
+/* ---- V1: VGG19 weights — Classifier::Classifier (Classifier.cpp:5-42) -> Net::CopyTrainedLayersFrom
+ * (code/src/caffe/net.cpp:760-813). Reads a .caffemodel (protobuf wire format, V1 `layers`=2 as in the Oxford file, or
+ * V2 `layer`=100), matches conv layers BY NAME, ignores unknown layers, fails on a shape mismatch. Only conv1_1..conv5_1
+ * (13 layers) are required/uploaded. _load_raw takes Caffe-layout arrays [Cout][Cin][3][3] + [Cout] in net order. */
+int nct_vgg19_load_caffemodel(nct_ctx* ctx, const char* path);
+int nct_vgg19_load_raw(nct_ctx* ctx, const float* const* weights, const float* const* biases, int nlayers);
+
+/* ---- V2/R1: VGG19 features — Classifier::Predict (Classifier.cpp:59-143), called main.cu:94,102,426.
+ * bgr: u8 BGR HWC image (row stride in bytes). Runs preprocess (mean subtraction, Classifier.cpp:211-275) and the net
+ * up to tap `deepest_tap` (1 = conv1_1 … 5 = conv5_1; the reference always runs to pool5, SURVEY quirk 9 — the
+ * result is identical). taps_chw[t] (nullable entries) receives the post-ReLU blob of tap t+1 in Caffe's CHW layout;
+ * dims (nullable, int[15]) receives {C,H,W} per tap. */
+int nct_vgg19_features(nct_ctx* ctx, const uint8_t* bgr, int h, int w, int stride, int deepest_tap, float* const* taps_chw, int* dims);
+
+/* single layers (unit parity against Caffe's known-answer tests): 3x3 pad-1 stride-1 conv + bias (+ ReLU) on f32 MFMA
+ * (conv_layer.cpp:8-40; Cout % 64 == 0), 2x2/2 MAX pool with ceil-mode size (pooling_layer.cpp:90-93,147-165). */
+int nct_conv3x3_relu(nct_ctx* ctx, const float* in_chw, int Cin, int H, int W, const float* weights, const float* bias, int Cout, float* out_chw, int relu);
+int nct_maxpool2x2(nct_ctx* ctx, const float* in_chw, int C, int H, int W, float* out_chw);
+
 /* ---- measurement hooks (bench.py / rocprof): device-resident PatchMatch on synthetic features ----
  * nct_pm_bench_setup uploads + normalises two CHW feature maps once; nct_pm_bench_run re-initialises the NNF
  * (scaled identity) and runs one full nct_patchmatch pass (init-dist + iters*4 Jacobi steps) entirely on the

@@ -1,0 +1,177 @@
+// k_vgg.hip — VGG19 feature extractor kernels (V2/R1): preprocess, 3x3 conv + bias + ReLU on f32 MFMA, 2x2 max-pool.
+// Reference semantics: Caffe conv (im2col GEMM, K index = ci*9 + ky*3 + kx: code/src/caffe/util/im2col.cpp:19-56,
+// layers/base_conv_layer.cpp:257-283), in-place ReLU (layers/relu_layer.cpp:14-17), MAX pooling with ceil-mode
+// output size and clipped windows (layers/pooling_layer.cpp:90-93,147-165); preprocessing Classifier.cpp:211-275.
+//
+// MI355X design — im2col-free implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32, = a k-ordered fmaf chain, so the
+// result is bit-identical to oracle/orc_vgg.c):
+//   D[cout][pixel] += W[cout][k] * In[k][pixel],  k = ci*9 + tap ascending, two k per MFMA.
+//   * A operand = weights pre-packed K-major ([k][cout]): lane (i = l&31, half = l>>5) reads Wp[k0+half][m0+i] — a
+//     coalesced 128-B row segment per half-wave;
+//   * B operand = activations in planar CHW: lane (j = l&31, half) reads In[ci][y+dy][x0+j+dx] — 32 consecutive
+//     pixels of one plane, again a coalesced 128-B segment. No im2col buffer, no LDS round trip: an f32 MFMA needs only
+//     512 B of operands per 4096 FLOP, each wave register-tiles 2x2 MFMA tiles (64 cout x 64 pixels, 64 accumulators)
+//     and the 9 taps of a channel re-hit the same L1 lines, so the L1/L2 path feeds the matrix pipe without barriers;
+//   * the D fragment has pixels on lanes and couts on registers, so every store instruction writes 32 consecutive
+//     pixels of one output plane (coalesced), with bias + ReLU fused.
+// Roofline: MFMA (f32 peak 157.3 TF). FLOPs = 2*9*Cin*Cout*H*W per layer.
+#include "nct_internal.h"
+#include "nct_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- preprocess: u8 BGR HWC -> float planar [4][H][W] (plane 3 = 0)
+__global__ void k_vgg_preprocess(const uint8_t* __restrict__ bgr, int stride, float* __restrict__ out, int H, int W) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    int y = i / W, x = i - y * W;
+    const uint8_t* p = bgr + (size_t)y * stride + x * 3;
+    out[i] = (float)p[0] - 103.939f;
+    out[(size_t)H * W + i] = (float)p[1] - 116.779f;
+    out[(size_t)2 * H * W + i] = (float)p[2] - 123.68f;
+    out[(size_t)3 * H * W + i] = 0.f;
+}
+
+// ---------------------------------------------------------------- conv3x3 pad1 stride1 + bias + ReLU
+// TW: pixel-tile width (32 or 16). A 32-pixel MFMA column tile is TW x (32/TW) pixels; a wave owns two of them
+// stacked vertically plus two 32-cout row tiles. Workgroup = 4 waves = WN pixel-tile pairs x (4/WN) cout-tile pairs.
+struct ConvGeom { int Cin, Cout, H, W, tiles_x, tiles_y, nblk_n; };
+
+template <int TW, int WCO>   // WCO = waves along cout (1 => block covers 64 cout x 256 px; 2 => 128 cout x 128 px)
+__global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ in, const float* __restrict__ wp /*[Cin*9][Cout]*/,
+                                                      const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int relu) {
+    constexpr int TH = 32 / TW;              // rows per MFMA pixel tile
+    constexpr int WPX = 4 / WCO;             // waves along pixels
+    constexpr int BLK_ROWS = WPX * 2 * TH;   // pixel rows covered by a workgroup
+    const int HW = g.H * g.W;
+    // block -> (pixel tile, cout block); blocks of one pixel tile differ by multiples of 8 => same XCD/L2
+    int bid = blockIdx.x;
+    const int np = g.tiles_x * g.tiles_y;
+    int pt, nb;
+    {
+        const int grp = bid / (8 * g.nblk_n), rem = bid - grp * 8 * g.nblk_n;
+        nb = rem >> 3; pt = grp * 8 + (rem & 7);
+    }
+    if (pt >= np) return;
+    const int ty = pt / g.tiles_x, tx = pt - ty * g.tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wco = wave % WCO, wpx = wave / WCO;
+    const int m0 = nb * (64 * WCO) + wco * 64;                 // first cout of this wave
+    const int x = tx * TW + (l31 % TW);
+    const int yb = ty * BLK_ROWS + wpx * 2 * TH + (l31 / TW);  // row of pixel tile 0; tile 1 is TH rows below
+
+    // per-lane tap tables for the 9 k-steps of a channel pair (k = 2s + half within 18)
+    int boff[9]; unsigned vm0 = 0, vm1 = 0;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int k = 2 * s + half;
+        const int ci = k / 9, tap = k - 9 * ci, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        boff[s] = ci * HW + dy * g.W + dx;
+        const bool xo = (x + dx) >= 0 && (x + dx) < g.W;
+        const int y0 = yb + dy, y1 = yb + TH + dy;
+        vm0 |= (unsigned)(xo && y0 >= 0 && y0 < g.H) << s;
+        vm1 |= (unsigned)(xo && y1 >= 0 && y1 < g.H) << s;
+    }
+    const int xc = min(x, g.W - 1);
+    const float* b0p = in + (size_t)min(yb, g.H - 1) * g.W + xc;
+    const float* b1p = in + (size_t)min(yb + TH, g.H - 1) * g.W + xc;
+    const float* ap = wp + (size_t)half * g.Cout + m0 + l31;
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};   // [cout tile][pixel tile]
+    for (int c2 = 0; c2 < g.Cin; c2 += 2) {
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const float a0 = ap[(size_t)(2 * s) * g.Cout];
+            const float a1 = ap[(size_t)(2 * s) * g.Cout + 32];
+            float b0 = 0.f, b1 = 0.f;
+            if ((vm0 >> s) & 1u) b0 = b0p[boff[s]];
+            if ((vm1 >> s) & 1u) b1 = b1p[boff[s]];
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
+        ap += (size_t)18 * g.Cout;
+        b0p += (size_t)2 * HW;
+        b1p += (size_t)2 * HW;
+    }
+
+    // epilogue: D row (cout) = (r&3) + 8*(r>>2) + 4*half, D col (pixel) = l31
+    const bool xok = x < g.W;
+    const int y0 = yb, y1 = yb + TH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co0 = m0 + row, co1 = m0 + 32 + row;
+        const float bb0 = bias[co0], bb1 = bias[co1];
+        float v00 = acc00[r] + bb0, v01 = acc01[r] + bb0, v10 = acc10[r] + bb1, v11 = acc11[r] + bb1;
+        if (relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+        if (xok && y0 < g.H) { out[(size_t)co0 * HW + (size_t)y0 * g.W + x] = v00; out[(size_t)co1 * HW + (size_t)y0 * g.W + x] = v10; }
+        if (xok && y1 < g.H) { out[(size_t)co0 * HW + (size_t)y1 * g.W + x] = v01; out[(size_t)co1 * HW + (size_t)y1 * g.W + x] = v11; }
+    }
+}
+
+int nctk_conv3x3(nct_ctx* ctx, hipStream_t s, const float* in, const float* wp, const float* bias, float* out,
+                 int Cin, int Cout, int H, int W, int relu) {
+    NCT_REQUIRE((Cin & 1) == 0 && (Cout & 63) == 0, "conv3x3: Cin=%d must be even (pad) and Cout=%d a multiple of 64", Cin, Cout);
+    const bool wide = W > 176;
+    const int TW = wide ? 32 : 16, TH = 32 / TW;
+    const int WCO = (Cout % 128 == 0) ? 2 : 1;
+    const int blk_rows = (4 / WCO) * 2 * TH;
+    ConvGeom g{Cin, Cout, H, W, cdiv(W, TW), cdiv(H, blk_rows), Cout / (64 * WCO)};
+    const int np = g.tiles_x * g.tiles_y;
+    const int nblocks = cdiv(np, 8) * 8 * g.nblk_n;
+    if (wide) {
+        if (WCO == 2) hipLaunchKernelGGL((k_conv3x3_mfma<32, 2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+        else          hipLaunchKernelGGL((k_conv3x3_mfma<32, 1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+    } else {
+        if (WCO == 2) hipLaunchKernelGGL((k_conv3x3_mfma<16, 2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+        else          hipLaunchKernelGGL((k_conv3x3_mfma<16, 1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+    }
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- 2x2/2 MAX pool, ceil mode, clipped window (CHW)
+__global__ void k_maxpool2x2(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W, int Ho, int Wo) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * Ho * Wo) return;
+    const int px = (int)(i % Wo); const size_t t = i / Wo; const int py = (int)(t % Ho); const int c = (int)(t / Ho);
+    const int hs = py * 2, ws = px * 2, he = min(hs + 2, H), we = min(ws + 2, W);
+    const float* p = in + (size_t)c * H * W;
+    float m = -3.402823466e+38f;
+    for (int y = hs; y < he; ++y)
+        for (int x = ws; x < we; ++x) { const float v = p[(size_t)y * W + x]; m = v > m ? v : m; }
+    out[i] = m;
+}
+
+int nctk_maxpool2x2(nct_ctx* ctx, hipStream_t s, const float* in, float* out, int C, int H, int W) {
+    const int Ho = (H - 2 + 1) / 2 + 1, Wo = (W - 2 + 1) / 2 + 1;      // ceil((n-2)/2)+1
+    const size_t n = (size_t)C * Ho * Wo;
+    hipLaunchKernelGGL(k_maxpool2x2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, C, H, W, Ho, Wo);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+
+int nctk_vgg_preprocess(nct_ctx* ctx, hipStream_t s, const uint8_t* bgr, int stride, float* out, int H, int W) {
+    hipLaunchKernelGGL(k_vgg_preprocess, dim3(cdiv(H * W, 256)), dim3(256), 0, s, bgr, stride, out, H, W);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- weight packing: Caffe [Cout][Cin][3][3] -> [Cin_pad*9][Cout]
+__global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int Cin_pad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Cin_pad * 9 * Cout) return;
+    const int co = (int)(i % Cout); const int k = (int)(i / Cout);
+    const int ci = k / 9, tap = k - ci * 9;
+    wp[i] = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+}
+
+int nctk_pack_weights(nct_ctx* ctx, hipStream_t s, const float* w, float* wp, int Cout, int Cin, int Cin_pad) {
+    const size_t n = (size_t)Cin_pad * 9 * Cout;
+    hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wp, Cout, Cin, Cin_pad);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}

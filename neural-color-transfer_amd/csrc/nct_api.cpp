@@ -5,6 +5,7 @@
 #include <mutex>
 
 static std::string g_create_err;
+void nct_vgg_free(nct_ctx* ctx);   // nct_vgg.cpp
 
 void* nct_ctx::alloc(size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -60,12 +61,11 @@ int nct_create(int device, nct_ctx** out) {
     return NCT_OK;
 }
 
-void nct_vgg_free(nct_ctx* ctx);   // nct_vgg.cpp (weak no-op until that unit is linked)
-
 void nct_destroy(nct_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    nct_vgg_free(ctx);
     for (auto& b : ctx->blocks) if (b.p) (void)hipFree(b.p);
     if (ctx->bench_a) (void)hipFree(ctx->bench_a);
     if (ctx->bench_b) (void)hipFree(ctx->bench_b);

@@ -1,0 +1,279 @@
+// nct_vgg.cpp — VGG19 weights (caffemodel ingest, V1) and the feature forward (V2/R1) on top of k_vgg.hip.
+// Reference: Classifier::Classifier (Classifier.cpp:5-42) -> Net::CopyTrainedLayersFrom (code/src/caffe/net.cpp:760-813):
+// layers are matched BY NAME, unknown source layers (fc6..8, relu, pool, …) are ignored, a shape mismatch is fatal;
+// wire schema code/src/caffe/proto/caffe.proto (NetParameter :64-100, V1LayerParameter :1287-1335, LayerParameter
+// :311-329, BlobProto :6-22). Classifier::Predict (Classifier.cpp:59-143) = preprocess + forward + return named blobs.
+// The 575 MB file is parsed ONCE per context (the reference builds two Nets from it, main.cu:581-582).
+#include "nct_internal.h"
+#include <cstring>
+#include <cstdlib>
+#include <cerrno>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+int nctk_conv3x3(nct_ctx*, hipStream_t, const float* in, const float* wp, const float* bias, float* out, int Cin, int Cout, int H, int W, int relu);
+int nctk_maxpool2x2(nct_ctx*, hipStream_t, const float* in, float* out, int C, int H, int W);
+int nctk_vgg_preprocess(nct_ctx*, hipStream_t, const uint8_t* bgr, int stride, float* out, int H, int W);
+int nctk_pack_weights(nct_ctx*, hipStream_t, const float* w, float* wp, int Cout, int Cin, int Cin_pad);
+
+static const int NCONV = 16;
+static const char* const kConvName[NCONV] = {"conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv3_4",
+                                             "conv4_1", "conv4_2", "conv4_3", "conv4_4", "conv5_1", "conv5_2", "conv5_3", "conv5_4"};
+static const int kCin[NCONV]  = {3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512};
+static const int kCout[NCONV] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512, 512};
+static const bool kPoolAfter[NCONV] = {false, true, false, true, false, false, false, true, false, false, false, true, false, false, false, false};
+static const int kTapConv[5] = {0, 2, 4, 8, 12};     // conv1_1, conv2_1, conv3_1, conv4_1, conv5_1
+static const int kNeeded = 13;                       // conv5_2..conv5_4 are never needed
+
+struct vgg_weights {
+    float* wp[NCONV] = {nullptr};     // packed [Cin_pad*9][Cout]
+    float* bias[NCONV] = {nullptr};
+    bool loaded = false;
+};
+
+static vgg_weights* vgg_of(nct_ctx* ctx) {
+    if (!ctx->vgg) ctx->vgg = new vgg_weights();
+    return (vgg_weights*)ctx->vgg;
+}
+
+static int upload_layer(nct_ctx* ctx, int i, const float* w, const float* b) {
+    vgg_weights* v = vgg_of(ctx);
+    const int cin_pad = (kCin[i] + 1) & ~1;
+    const size_t nw = (size_t)kCout[i] * kCin[i] * 9;
+    if (!v->wp[i]) NCT_HIP(hipMalloc(&v->wp[i], sizeof(float) * (size_t)cin_pad * 9 * kCout[i]));
+    if (!v->bias[i]) NCT_HIP(hipMalloc(&v->bias[i], sizeof(float) * kCout[i]));
+    DevBuf<float> tmp(ctx, nw);
+    if (!tmp.ok()) return NCT_ERR_HIP;
+    NCT_HIP(hipMemcpyAsync(tmp, w, sizeof(float) * nw, hipMemcpyHostToDevice, ctx->stream));
+    int rc = nctk_pack_weights(ctx, ctx->stream, tmp, v->wp[i], kCout[i], kCin[i], cin_pad);
+    if (rc) return rc;
+    NCT_HIP(hipMemcpyAsync(v->bias[i], b, sizeof(float) * kCout[i], hipMemcpyHostToDevice, ctx->stream));
+    NCT_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------- minimal protobuf wire reader
+struct PB { const uint8_t* p; const uint8_t* end; bool ok = true;
+    bool more() const { return ok && p < end; }
+    uint64_t varint() { uint64_t v = 0; int sh = 0; while (p < end && sh < 64) { uint8_t b = *p++; v |= (uint64_t)(b & 0x7F) << sh; if (!(b & 0x80)) return v; sh += 7; } ok = false; return 0; }
+    bool tag(uint32_t& field, uint32_t& wt) { if (!more()) return false; uint64_t t = varint(); field = (uint32_t)(t >> 3); wt = (uint32_t)(t & 7); return ok; }
+    PB sub() { uint64_t n = varint(); if (!ok || n > (uint64_t)(end - p)) { ok = false; return PB{p, p}; } PB s{p, p + n}; p += n; return s; }
+    void skip(uint32_t wt) {
+        switch (wt) { case 0: varint(); break; case 1: if (end - p < 8) ok = false; else p += 8; break;
+                      case 2: sub(); break; case 5: if (end - p < 4) ok = false; else p += 4; break; default: ok = false; }
+    }
+};
+
+struct BlobView { int64_t dims[4] = {0, 0, 0, 0}; int ndim = 0; std::vector<float> data; };
+
+static bool parse_blob(PB b, BlobView& out) {
+    int64_t legacy[4] = {0, 0, 0, 0}; bool has_legacy = false;
+    uint32_t f, wt;
+    while (b.tag(f, wt)) {
+        if (f >= 1 && f <= 4 && wt == 0) { legacy[f - 1] = (int64_t)b.varint(); has_legacy = true; }
+        else if (f == 5 && wt == 2) { PB d = b.sub(); size_t n = (size_t)(d.end - d.p) / 4; size_t o = out.data.size(); out.data.resize(o + n); memcpy(out.data.data() + o, d.p, n * 4); }
+        else if (f == 5 && wt == 5) { if (b.end - b.p < 4) return false; float v; memcpy(&v, b.p, 4); b.p += 4; out.data.push_back(v); }
+        else if (f == 8 && wt == 2) { PB d = b.sub(); size_t n = (size_t)(d.end - d.p) / 8; for (size_t i = 0; i < n; ++i) { double v; memcpy(&v, d.p + 8 * i, 8); out.data.push_back((float)v); } }
+        else if (f == 7 && wt == 2) {   // BlobShape { repeated int64 dim = 1 [packed] }
+            PB s = b.sub(); uint32_t f2, w2; out.ndim = 0;
+            while (s.tag(f2, w2)) {
+                if (f2 == 1 && w2 == 2) { PB d = s.sub(); while (d.more() && out.ndim < 4) out.dims[out.ndim++] = (int64_t)d.varint(); }
+                else if (f2 == 1 && w2 == 0) { if (out.ndim < 4) out.dims[out.ndim++] = (int64_t)s.varint(); else s.varint(); }
+                else s.skip(w2);
+            }
+        } else b.skip(wt);
+    }
+    if (out.ndim == 0 && has_legacy) { out.ndim = 4; for (int i = 0; i < 4; ++i) out.dims[i] = legacy[i]; }
+    return b.ok;
+}
+
+static int64_t blob_count(const BlobView& b) { int64_t n = 1; for (int i = 0; i < b.ndim; ++i) n *= b.dims[i]; return b.ndim ? n : 0; }
+
+extern "C" {
+
+int nct_vgg19_load_raw(nct_ctx* ctx, const float* const* weights, const float* const* biases, int nlayers) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(weights && biases && nlayers >= kNeeded && nlayers <= NCONV, "vgg19_load_raw: need >= %d conv layers (conv1_1..conv5_1)", kNeeded);
+    for (int i = 0; i < kNeeded; ++i) {
+        NCT_REQUIRE(weights[i] && biases[i], "vgg19_load_raw: layer %s missing", kConvName[i]);
+        int rc = upload_layer(ctx, i, weights[i], biases[i]);
+        if (rc) return rc;
+    }
+    vgg_of(ctx)->loaded = true;
+    return NCT_OK;
+}
+
+int nct_vgg19_load_caffemodel(nct_ctx* ctx, const char* path) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(path, "vgg19_load_caffemodel: null path");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return ctx->fail(NCT_ERR_IO, "cannot open caffemodel '%s': %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); return ctx->fail(NCT_ERR_IO, "cannot stat caffemodel '%s'", path); }
+    void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return ctx->fail(NCT_ERR_IO, "mmap of '%s' failed: %s", path, strerror(errno));
+    bool found[NCONV] = {false};
+    int rc = NCT_OK;
+    PB net{(const uint8_t*)map, (const uint8_t*)map + st.st_size};
+    uint32_t f, wt;
+    while (rc == NCT_OK && net.tag(f, wt)) {
+        const bool v1 = (f == 2 && wt == 2), v2 = (f == 100 && wt == 2);   // NetParameter.layers (V1) / .layer (V2)
+        if (!v1 && !v2) { net.skip(wt); continue; }
+        PB layer = net.sub();
+        const uint32_t name_field = v1 ? 4 : 1, blobs_field = v1 ? 6 : 7;
+        std::string name; std::vector<PB> blobs;
+        uint32_t lf, lw;
+        while (layer.tag(lf, lw)) {
+            if (lf == name_field && lw == 2) { PB s = layer.sub(); name.assign((const char*)s.p, (size_t)(s.end - s.p)); }
+            else if (lf == blobs_field && lw == 2) blobs.push_back(layer.sub());
+            else layer.skip(lw);
+        }
+        if (!layer.ok) { rc = ctx->fail(NCT_ERR_IO, "malformed layer message in '%s'", path); break; }
+        int idx = -1;
+        for (int i = 0; i < NCONV; ++i) if (name == kConvName[i]) idx = i;
+        if (idx < 0 || blobs.empty()) continue;          // unknown source layer: ignored (net.cpp:770-773)
+        if (idx >= kNeeded) { found[idx] = true; continue; }
+        if (blobs.size() < 2) { rc = ctx->fail(NCT_ERR_IO, "layer %s has %zu blobs, expected weights + bias", name.c_str(), blobs.size()); break; }
+        BlobView w, b;
+        if (!parse_blob(blobs[0], w) || !parse_blob(blobs[1], b)) { rc = ctx->fail(NCT_ERR_IO, "malformed blob in layer %s", name.c_str()); break; }
+        const int64_t nw = (int64_t)kCout[idx] * kCin[idx] * 9;
+        const bool wshape = w.ndim == 4 && w.dims[0] == kCout[idx] && w.dims[1] == kCin[idx] && w.dims[2] == 3 && w.dims[3] == 3;
+        if (!wshape || (int64_t)w.data.size() != nw)      // shape mismatch is fatal (net.cpp:780-791)
+            { rc = ctx->fail(NCT_ERR_IO, "layer %s: weight shape mismatch (got %lldx%lldx%lldx%lld, %zu values; expected %dx%dx3x3)", name.c_str(),
+                             (long long)w.dims[0], (long long)w.dims[1], (long long)w.dims[2], (long long)w.dims[3], w.data.size(), kCout[idx], kCin[idx]); break; }
+        if (blob_count(b) != kCout[idx] || (int64_t)b.data.size() != kCout[idx])
+            { rc = ctx->fail(NCT_ERR_IO, "layer %s: bias shape mismatch (%zu values, expected %d)", name.c_str(), b.data.size(), kCout[idx]); break; }
+        rc = upload_layer(ctx, idx, w.data.data(), b.data.data());
+        found[idx] = true;
+    }
+    if (rc == NCT_OK && !net.ok) rc = ctx->fail(NCT_ERR_IO, "malformed NetParameter in '%s'", path);
+    munmap(map, (size_t)st.st_size);
+    if (rc != NCT_OK) return rc;
+    for (int i = 0; i < kNeeded; ++i)
+        if (!found[i]) return ctx->fail(NCT_ERR_IO, "caffemodel '%s' has no weights for layer %s", path, kConvName[i]);
+    vgg_of(ctx)->loaded = true;
+    return NCT_OK;
+}
+
+}  // extern "C"
+
+void nct_vgg_free(nct_ctx* ctx) {
+    if (!ctx || !ctx->vgg) return;
+    vgg_weights* v = (vgg_weights*)ctx->vgg;
+    for (int i = 0; i < NCONV; ++i) { if (v->wp[i]) (void)hipFree(v->wp[i]); if (v->bias[i]) (void)hipFree(v->bias[i]); }
+    delete v; ctx->vgg = nullptr;
+}
+
+// ---------------------------------------------------------------- forward (device): taps in CHW
+// d_bgr: device u8 BGR HWC. d_taps[t] (nullable, caller-owned device buffers of C*h*w floats) receive tap t+1.
+// dims[t] = {C,h,w} is filled for every tap <= deepest_tap.
+int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps, int* dims) {
+    vgg_weights* v = (vgg_weights*)ctx->vgg;
+    if (!v || !v->loaded) return ctx->fail(NCT_ERR_STATE, "vgg19: weights not loaded (nct_vgg19_load_caffemodel / _load_raw)");
+    NCT_REQUIRE(deepest_tap >= 1 && deepest_tap <= 5, "vgg19: deepest_tap must be 1..5");
+    NCT_REQUIRE(H >= 2 && W >= 2 && H < 4096 && W < 4096, "vgg19: image size %dx%d out of range", W, H);
+    const size_t big = (size_t)64 * H * W;
+    DevBuf<float> pp0(ctx, big), pp1(ctx, big);
+    if (!pp0.ok() || !pp1.ok()) return NCT_ERR_HIP;
+    float* pp[2] = {pp0, pp1};
+    int h = H, w = W;
+    int rc = nctk_vgg_preprocess(ctx, s, d_bgr, stride, pp[0], H, W);
+    if (rc) return rc;
+    const float* cur = pp[0];
+    const int last = kTapConv[deepest_tap - 1];
+    for (int i = 0; i <= last; ++i) {
+        int tap = -1;
+        for (int t = 0; t < 5; ++t) if (kTapConv[t] == i) tap = t;
+        float* dst;
+        if (tap >= 0 && d_taps && d_taps[tap]) dst = d_taps[tap];
+        else dst = (cur == pp[0]) ? pp[1] : pp[0];
+        rc = nctk_conv3x3(ctx, s, cur, v->wp[i], v->bias[i], dst, (kCin[i] + 1) & ~1, kCout[i], h, w, 1);
+        if (rc) return rc;
+        cur = dst;
+        if (tap >= 0 && dims) { dims[tap * 3 + 0] = kCout[i]; dims[tap * 3 + 1] = h; dims[tap * 3 + 2] = w; }
+        if (kPoolAfter[i] && i < last) {
+            float* pd = (cur == pp[0]) ? pp[1] : pp[0];
+            rc = nctk_maxpool2x2(ctx, s, cur, pd, kCout[i], h, w);
+            if (rc) return rc;
+            cur = pd; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
+        }
+    }
+    return 0;
+}
+
+extern "C" {
+
+int nct_vgg19_features(nct_ctx* ctx, const uint8_t* bgr, int h, int w, int stride, int deepest_tap, float* const* taps_chw, int* dims) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(bgr && h > 0 && w > 0 && stride >= 3 * w, "vgg19_features: bad image arguments");
+    NCT_REQUIRE(deepest_tap >= 1 && deepest_tap <= 5, "vgg19_features: deepest_tap must be 1..5");
+    DevBuf<uint8_t> img(ctx, (size_t)stride * h);
+    if (!img.ok()) return NCT_ERR_HIP;
+    NCT_HIP(hipMemcpyAsync(img, bgr, (size_t)stride * h, hipMemcpyHostToDevice, ctx->stream));
+    // tap buffers
+    int hh = h, ww = w; size_t sizes[5]; int td[5][3];
+    for (int t = 0; t < 5; ++t) { const int C = kCout[kTapConv[t]]; td[t][0] = C; td[t][1] = hh; td[t][2] = ww; sizes[t] = (size_t)C * hh * ww; hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1; }
+    float* d_taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<DevBuf<float>*> bufs;
+    int rc = 0;
+    for (int t = 0; t < deepest_tap && rc == 0; ++t)
+        if (taps_chw && taps_chw[t]) { auto* b = new DevBuf<float>(ctx, sizes[t]); bufs.push_back(b); if (!b->ok()) rc = NCT_ERR_HIP; d_taps[t] = *b; }
+    int ldims[15] = {0};
+    if (rc == 0) rc = nctk_vgg19_forward(ctx, ctx->stream, img, h, w, stride, deepest_tap, d_taps, ldims);
+    if (rc == 0)
+        for (int t = 0; t < deepest_tap; ++t)
+            if (d_taps[t]) { hipError_t e = hipMemcpyAsync(taps_chw[t], d_taps[t], sizeof(float) * sizes[t], hipMemcpyDeviceToHost, ctx->stream);
+                             if (e != hipSuccess) { rc = ctx->fail(NCT_ERR_HIP, "D2H of tap %d failed: %s", t + 1, hipGetErrorString(e)); break; } }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (rc == 0 && e != hipSuccess) rc = ctx->fail(NCT_ERR_HIP, "vgg19_features: %s", hipGetErrorString(e));
+    for (auto* b : bufs) delete b;
+    if (dims) for (int t = 0; t < 5; ++t) for (int k = 0; k < 3; ++k) dims[t * 3 + k] = t < deepest_tap ? td[t][k] : 0;
+    return rc;
+}
+
+// single-layer entry points (unit parity tests against Caffe's known answers / the oracle)
+int nct_conv3x3_relu(nct_ctx* ctx, const float* in_chw, int Cin, int H, int W, const float* weights /*[Cout][Cin][3][3]*/, const float* bias,
+                     int Cout, float* out_chw, int relu) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(in_chw && weights && bias && out_chw, "conv3x3_relu: null pointer");
+    NCT_REQUIRE(Cin >= 1 && (Cout & 63) == 0 && H >= 2 && W >= 2, "conv3x3_relu: need Cout %% 64 == 0, H,W >= 2");
+    const int cin_pad = (Cin + 1) & ~1;
+    const size_t hw = (size_t)H * W;
+    DevBuf<float> din(ctx, cin_pad * hw), dw(ctx, (size_t)Cout * Cin * 9), dwp(ctx, (size_t)cin_pad * 9 * Cout), db(ctx, Cout), dout(ctx, Cout * hw);
+    if (!din.ok() || !dw.ok() || !dwp.ok() || !db.ok() || !dout.ok()) return NCT_ERR_HIP;
+    NCT_HIP(hipMemsetAsync(din, 0, sizeof(float) * cin_pad * hw, ctx->stream));
+    NCT_HIP(hipMemcpyAsync(din, in_chw, sizeof(float) * Cin * hw, hipMemcpyHostToDevice, ctx->stream));
+    NCT_HIP(hipMemcpyAsync(dw, weights, sizeof(float) * (size_t)Cout * Cin * 9, hipMemcpyHostToDevice, ctx->stream));
+    NCT_HIP(hipMemcpyAsync(db, bias, sizeof(float) * Cout, hipMemcpyHostToDevice, ctx->stream));
+    int rc = nctk_pack_weights(ctx, ctx->stream, dw, dwp, Cout, Cin, cin_pad);
+    if (rc) return rc;
+    rc = nctk_conv3x3(ctx, ctx->stream, din, dwp, db, dout, cin_pad, Cout, H, W, relu);
+    if (rc) return rc;
+    NCT_HIP(hipMemcpyAsync(out_chw, dout, sizeof(float) * Cout * hw, hipMemcpyDeviceToHost, ctx->stream));
+    NCT_HIP(hipStreamSynchronize(ctx->stream));
+    return NCT_OK;
+}
+
+int nct_maxpool2x2(nct_ctx* ctx, const float* in_chw, int C, int H, int W, float* out_chw) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(in_chw && out_chw && C >= 1 && H >= 2 && W >= 2, "maxpool2x2: bad arguments");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    DevBuf<float> din(ctx, (size_t)C * H * W), dout(ctx, (size_t)C * Ho * Wo);
+    if (!din.ok() || !dout.ok()) return NCT_ERR_HIP;
+    NCT_HIP(hipMemcpyAsync(din, in_chw, sizeof(float) * C * H * W, hipMemcpyHostToDevice, ctx->stream));
+    int rc = nctk_maxpool2x2(ctx, ctx->stream, din, dout, C, H, W);
+    if (rc) return rc;
+    NCT_HIP(hipMemcpyAsync(out_chw, dout, sizeof(float) * C * Ho * Wo, hipMemcpyDeviceToHost, ctx->stream));
+    NCT_HIP(hipStreamSynchronize(ctx->stream));
+    return NCT_OK;
+}
+
+}  // extern "C"

@@ -56,6 +56,11 @@ SIGNATURES = {
     "nct_bds_vote_features": (C.c_int, [C.c_void_p, _u32p, _u32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_float]),
     "nct_feature_distance": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),
     "nct_bds_vote_image": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, _u32p, _u32p, C.c_int, C.c_double, C.c_double, _u8p]),
+    "nct_vgg19_load_caffemodel": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "nct_vgg19_load_raw": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]),
+    "nct_vgg19_features": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    "nct_conv3x3_relu": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, _f32p, C.c_int]),
+    "nct_maxpool2x2": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "nct_pm_bench_setup": (C.c_int, [C.c_void_p, _f32p, _f32p] + [C.c_int] * 5),
     "nct_pm_bench_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
 }
@@ -173,6 +178,56 @@ class Context:
         out = np.empty((ah, aw, 3), np.uint8)
         self._chk(self._l.nct_bds_vote_image(self._h, a, ah, aw, b, bh, bw, np.ascontiguousarray(ann, np.uint32),
                                              np.ascontiguousarray(bnn, np.uint32), patch, w_coh, w_comp, out))
+        return out
+
+    # ---- V1 / V2
+    VGG_CIN = [3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512]
+    VGG_COUT = [64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512, 512]
+    VGG_NAMES = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv3_4",
+                 "conv4_1", "conv4_2", "conv4_3", "conv4_4", "conv5_1", "conv5_2", "conv5_3", "conv5_4"]
+    TAP_C = [64, 128, 256, 512, 512]
+
+    def vgg19_load_caffemodel(self, path):
+        self._chk(self._l.nct_vgg19_load_caffemodel(self._h, os.fsencode(path)))
+
+    def vgg19_load_raw(self, weights, biases):
+        ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b, np.float32) for b in biases]
+        n = len(ws)
+        wp = (C.c_void_p * n)(*[w.ctypes.data for w in ws])
+        bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+        self._chk(self._l.nct_vgg19_load_raw(self._h, wp, bp, n))
+
+    def vgg19_features(self, bgr, deepest_tap=5):
+        """-> list of `deepest_tap` CHW fp32 arrays (tap 1 = conv1_1 … tap 5 = conv5_1)."""
+        img = np.ascontiguousarray(bgr, np.uint8)
+        h, w = img.shape[:2]
+        outs, hh, ww = [], h, w
+        for t in range(deepest_tap):
+            outs.append(np.empty((self.TAP_C[t], hh, ww), np.float32))
+            hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        ptrs = (C.c_void_p * 5)(*([o.ctypes.data for o in outs] + [None] * (5 - deepest_tap)))
+        dims = np.zeros(15, np.int32)
+        self._chk(self._l.nct_vgg19_features(self._h, img, h, w, w * 3, deepest_tap, ptrs, _ptr(dims)))
+        for t, o in enumerate(outs):
+            assert tuple(dims[3 * t:3 * t + 3]) == o.shape
+        return outs
+
+    def conv3x3_relu(self, x_chw, weights, bias, relu=True):
+        x = np.ascontiguousarray(x_chw, np.float32)
+        w = np.ascontiguousarray(weights, np.float32)
+        b = np.ascontiguousarray(bias, np.float32)
+        cin, H, W = x.shape
+        cout = w.shape[0]
+        out = np.empty((cout, H, W), np.float32)
+        self._chk(self._l.nct_conv3x3_relu(self._h, x, cin, H, W, w, b, cout, out, 1 if relu else 0))
+        return out
+
+    def maxpool2x2(self, x_chw):
+        x = np.ascontiguousarray(x_chw, np.float32)
+        c, H, W = x.shape
+        out = np.empty((c, (H - 1) // 2 + 1, (W - 1) // 2 + 1), np.float32)
+        self._chk(self._l.nct_maxpool2x2(self._h, x, c, H, W, out))
         return out
 
     # ---- measurement hooks

@@ -1,0 +1,88 @@
+"""Test helper: write/read a minimal .caffemodel (protobuf wire format) without libprotobuf.
+Schema restated from code/src/caffe/proto/caffe.proto: NetParameter{name=1, layers=2 (V1), layer=100 (V2)};
+V1LayerParameter{bottom=2, top=3, name=4, type=5 (enum, CONVOLUTION=4), blobs=6}; LayerParameter{name=1, type=2, blobs=7};
+BlobProto{num=1, channels=2, height=3, width=4, data=5 (packed float), shape=7{dim=1 packed int64}}."""
+import struct
+import numpy as np
+
+VGG_NAMES = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv3_4",
+             "conv4_1", "conv4_2", "conv4_3", "conv4_4", "conv5_1", "conv5_2", "conv5_3", "conv5_4"]
+VGG_CIN = [3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512]
+VGG_COUT = [64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512, 512]
+
+
+def varint(v):
+    out = bytearray()
+    v &= (1 << 64) - 1
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def tag(field, wt):
+    return varint((field << 3) | wt)
+
+
+def ld(field, payload):
+    return tag(field, 2) + varint(len(payload)) + payload
+
+
+def blob(arr, legacy_dims=None, shape_dims=None, unpacked=False):
+    a = np.ascontiguousarray(arr, np.float32)
+    out = b""
+    if legacy_dims is not None:
+        for f, d in zip((1, 2, 3, 4), legacy_dims):
+            out += tag(f, 0) + varint(d)
+    if unpacked:
+        out += b"".join(tag(5, 5) + struct.pack("<f", float(x)) for x in a.reshape(-1))
+    else:
+        out += ld(5, a.tobytes())
+    if shape_dims is not None:
+        out += ld(7, ld(1, b"".join(varint(d) for d in shape_dims)))
+    return out
+
+
+def write_caffemodel(path, weights, biases, names=VGG_NAMES, fmt="v1", extra_layers=True, unpacked=False):
+    """weights[i]: (Cout,Cin,3,3); biases[i]: (Cout,). fmt 'v1' = NetParameter.layers (like the Oxford VGG file), 'v2' = .layer."""
+    body = ld(1, b"VGG_ILSVRC_19_layers")
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        co, ci = w.shape[:2]
+        if fmt == "v1":
+            wb = blob(w, legacy_dims=(co, ci, 3, 3), unpacked=unpacked)
+            bb = blob(b, legacy_dims=(1, 1, 1, co), unpacked=unpacked)
+            layer = ld(2, b"x") + ld(3, names[i].encode()) + ld(4, names[i].encode()) + tag(5, 0) + varint(4) + ld(6, wb) + ld(6, bb)
+            body += ld(2, layer)
+            if extra_layers:   # in-place ReLU (type 18) without blobs: must be ignored
+                body += ld(2, ld(4, ("relu" + names[i][4:]).encode()) + tag(5, 0) + varint(18))
+        else:
+            wb = blob(w, shape_dims=(co, ci, 3, 3))
+            bb = blob(b, shape_dims=(co,))
+            layer = ld(1, names[i].encode()) + ld(2, b"Convolution") + ld(7, wb) + ld(7, bb)
+            body += ld(100, layer)
+    if extra_layers:           # an fc layer with blobs under an unknown name: ignored by name matching (net.cpp:770-773)
+        fcw = blob(np.ones((4, 8), np.float32), legacy_dims=(1, 1, 4, 8))
+        if fmt == "v1":
+            body += ld(2, ld(4, b"fc6") + tag(5, 0) + varint(14) + ld(6, fcw))
+        else:
+            body += ld(100, ld(1, b"fc6") + ld(2, b"InnerProduct") + ld(7, fcw))
+    with open(path, "wb") as f:
+        f.write(body)
+
+
+def synthetic_vgg19(seed=19, nlayers=13, bias_scale=0.0):
+    """He-normal N(0, 2/(9*Cin)) weights; conv1_1 additionally scaled for 0-255 inputs so activations stay O(1-10)."""
+    rng = np.random.default_rng(seed)
+    ws, bs = [], []
+    for i in range(nlayers):
+        std = np.sqrt(2.0 / (9 * VGG_CIN[i]))
+        w = rng.standard_normal((VGG_COUT[i], VGG_CIN[i], 3, 3)).astype(np.float32) * np.float32(std)
+        if i == 0:
+            w *= np.float32(1.0 / 64.0)
+        ws.append(np.ascontiguousarray(w))
+        bs.append((rng.standard_normal(VGG_COUT[i]).astype(np.float32) * np.float32(bias_scale)) if bias_scale else np.zeros(VGG_COUT[i], np.float32))
+    return ws, bs

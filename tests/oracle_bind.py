@@ -32,6 +32,68 @@ class Oracle:
         l.orc_bds_vote_features.argtypes = [_u32p, _u32p, _f32p, _f32p, C.c_void_p, I, I, I, I, I, I, C.c_float, C.c_float]
         l.orc_bds_vote_image.argtypes = [_u8p, I, I, _u8p, I, I, _u32p, _u32p, I, C.c_double, C.c_double, _u8p]
 
+    # ---- VGG19 (orc_vgg.c)
+    def _decl_vgg(self):
+        l = self.l
+        if getattr(self, "_vgg_declared", False):
+            return
+        l.orc_vgg_preprocess.argtypes = [_u8p, I, I, _f32p]
+        l.orc_conv3x3.argtypes = [_f32p, I, I, I, _f32p, _f32p, I, _f32p, I]
+        l.orc_maxpool2x2.argtypes = [_f32p, I, I, I, _f32p]
+        l.orc_maxpool_generic.argtypes = [_f32p, I, I, I, I, I, _f32p, C.POINTER(I), C.POINTER(I)]
+        l.orc_vgg19_features.argtypes = [_u8p, I, I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), I, C.POINTER(C.c_void_p), C.c_void_p]
+        self._vgg_declared = True
+
+    def vgg_preprocess(self, bgr):
+        self._decl_vgg()
+        img = np.ascontiguousarray(bgr, np.uint8)
+        out = np.empty((3,) + img.shape[:2], np.float32)
+        self.l.orc_vgg_preprocess(img, img.shape[0], img.shape[1], out)
+        return out
+
+    def conv3x3(self, x, w, b, relu=True):
+        self._decl_vgg()
+        x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32); b = np.ascontiguousarray(b, np.float32)
+        cin, H, W = x.shape
+        out = np.empty((w.shape[0], H, W), np.float32)
+        self.l.orc_conv3x3(x, cin, H, W, w, b, w.shape[0], out, 1 if relu else 0)
+        return out
+
+    def maxpool2x2(self, x):
+        self._decl_vgg()
+        x = np.ascontiguousarray(x, np.float32)
+        c, H, W = x.shape
+        out = np.empty((c, (H - 1) // 2 + 1, (W - 1) // 2 + 1), np.float32)
+        self.l.orc_maxpool2x2(x, c, H, W, out)
+        return out
+
+    def maxpool_generic(self, x, k, s):
+        self._decl_vgg()
+        x = np.ascontiguousarray(x, np.float32)
+        c, H, W = x.shape
+        out = np.empty((c, H, W), np.float32)
+        ho, wo = I(), I()
+        self.l.orc_maxpool_generic(x, c, H, W, k, s, out, C.byref(ho), C.byref(wo))
+        return out.reshape(-1)[: c * ho.value * wo.value].reshape(c, ho.value, wo.value).copy()
+
+    def vgg19_features(self, bgr, weights, biases, deepest_tap=5):
+        self._decl_vgg()
+        img = np.ascontiguousarray(bgr, np.uint8)
+        h, w = img.shape[:2]
+        ws = [np.ascontiguousarray(x, np.float32) for x in weights]
+        bs = [np.ascontiguousarray(x, np.float32) for x in biases]
+        tapc = [64, 128, 256, 512, 512]
+        outs, hh, ww = [], h, w
+        for t in range(deepest_tap):
+            outs.append(np.empty((tapc[t], hh, ww), np.float32))
+            hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        wp = (C.c_void_p * len(ws))(*[x.ctypes.data for x in ws])
+        bp = (C.c_void_p * len(bs))(*[x.ctypes.data for x in bs])
+        tp = (C.c_void_p * 5)(*([o.ctypes.data for o in outs] + [None] * (5 - deepest_tap)))
+        dims = np.zeros(15, np.int32)
+        self.l.orc_vgg19_features(img, h, w, wp, bp, deepest_tap, tp, _ptr(dims))
+        return outs
+
     def feat_normalize(self, src, want_resp=False):
         src = np.ascontiguousarray(src, np.float32)
         Cc, H, W = src.shape
