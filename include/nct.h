@@ -94,6 +94,56 @@ int nct_vgg19_features(nct_ctx* ctx, const uint8_t* bgr, int h, int w, int strid
 int nct_conv3x3_relu(nct_ctx* ctx, const float* in_chw, int Cin, int H, int W, const float* weights, const float* bias, int Cout, float* out_chw, int relu);
 int nct_maxpool2x2(nct_ctx* ctx, const float* in_chw, int C, int H, int W, float* out_chw);
 
+/* ---- parameters: `Config` (ColorTransfer/Config.h:55-98) + the constants hard-coded in transfer_color_single_bds
+ * (main.cu:64-68: iter = 10). nct_params_default fills Config::Config()'s values (bds 2.0, eps 0.60, nl 2.0, l 0.125,
+ * w 0.024, clusters 10, k 8, patch 3, alpha 1.2) — the help strings at main.cu:40-43 quote different numbers; the
+ * constructor is what runs. `seed` keys the counter-based RNG (PatchMatch random search, k-means centres). */
+typedef struct nct_params {
+    double bds_weight, eps, nonlocal_weight, local_weight, wls_lambda_init;
+    int cluster_num, k_num, patch_size;
+    double wls_alpha;
+    int pm_iters;
+    uint32_t seed;
+} nct_params;
+void nct_params_default(nct_params* p);
+
+/* ---- A1 + third-party (OpenCV 2.4.10) arithmetic used on the path: cvtColor(CV_BGR2Lab / CV_Lab2BGR) on 8U
+ * (main.cu:352,371; ColorTransfer.h:58; ColorTransfer.cpp:1469) and cv::resize(INTER_LINEAR) on 8UC3 / 64FC3
+ * (main.cu:106-107; ColorTransfer.cpp:462-463; includes cv::resize's silent INTER_AREA switch for an exact 2x shrink). */
+int nct_bgr2lab_u8(nct_ctx* ctx, const uint8_t* bgr, size_t npix, uint8_t* lab);
+int nct_lab2bgr_u8(nct_ctx* ctx, const uint8_t* lab, size_t npix, uint8_t* bgr);
+int nct_resize_u8c3(nct_ctx* ctx, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
+int nct_resize_f64c3(nct_ctx* ctx, const double* src, int sh, int sw, double* dst, int dh, int dw);
+
+/* ---- C1: k-means labels of the coarsest S features — main.cu:139-168 -> ColorTransfer::clusterFeastures
+ * (ColorTransfer.cpp:355-395; cvflann k-means, branching K, `iters` Lloyd steps). feat_chw: UN-normalised conv5_1 of S;
+ * labels: h*w ints in [0, *nlabels). */
+int nct_cluster_features(nct_ctx* ctx, const float* feat_chw, int C, int h, int w, int K, int iters, uint64_t seed, int* labels, int* nlabels);
+
+/* ---- K1: kNN graph in Lab — ColorTransfer::findKnns (ColorTransfer.cpp:397-423), called main.cu:359.
+ * lab_u8: level image in 8-bit Lab (HWC); labels: coarsest-level cluster labels (lh x lw); samples = 2^level.
+ * knn_id / knn_w: [h*w][k] neighbour ids and weights exp(1 - d/3); k must be 8. */
+int nct_knn_graph(nct_ctx* ctx, const uint8_t* lab_u8, int h, int w, const int* labels, int lh, int lw, int nlabels, int samples, int k,
+                  int* knn_id, double* knn_w);
+
+/* ---- T1,T2,S1,U1,S2,A1: build_accumTable_downsample x2 + transfer_color_downsample + getRes
+ * (ColorTransfer.cpp:425-455,1180-1478), called main.cu:368-380. err: matching-error map of the level (h x w);
+ * s_bgr_level / g_bgr_level: level images of S and the BDS guidance G; s_bgr_full: S at full resolution (H x W);
+ * layer = 0 (coarsest) … 4 (finest). out: recoloured S (H x W x 3, BGR). `stages` (nullable) receives intermediate
+ * coefficient maps for stage-wise validation: arrays are [2][pixels][3] doubles (a-part then b-part). */
+typedef struct nct_color_stages {
+    double* ab_local;      /* [2][h*w][3]  after the local statistics (T1)            */
+    double* ab_nonlocal;   /* [2][h*w][3]  after the truncated CG (S1)                */
+    double* ab_up;         /* [2][H*W][3]  after bilinear upsampling (U1)             */
+    double* roughness;     /* [H*W]                                                   */
+    double* ab_wls;        /* [2][H*W][3]  after WLS smoothing (S2)                   */
+    int* cg_iters;         /* [3]  CG iterations executed per Lab channel             */
+    int* wls_iters;        /* [6]  PCG iterations per right-hand side                 */
+} nct_color_stages;
+int nct_local_color_transfer(nct_ctx* ctx, const float* err, const uint8_t* s_bgr_level, const uint8_t* g_bgr_level, const uint8_t* s_bgr_full,
+                             const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W, const nct_params* prm,
+                             uint8_t* out_bgr_full, nct_color_stages* stages);
+
 /* ---- measurement hooks (bench.py / rocprof): device-resident PatchMatch on synthetic features ----
  * nct_pm_bench_setup uploads + normalises two CHW feature maps once; nct_pm_bench_run re-initialises the NNF
  * (scaled identity) and runs one full nct_patchmatch pass (init-dist + iters*4 Jacobi steps) entirely on the

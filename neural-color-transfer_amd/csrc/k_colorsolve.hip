@@ -1,0 +1,530 @@
+// k_colorsolve.hip — local colour transfer on the GPU: T1 local statistics, T2 confidence weights, S1 nonlocal
+// least squares (truncated CG), U1 upsample + roughness, S2 edge-aware WLS smoothing (PCG), A1 apply.
+// Reference: ColorTransfer::transfer_color_downsample ColorTransfer.cpp:1180-1478 and what it calls:
+//   stats loop :1194-1265 (+ build_accumTable_downsample :425-455), weights :1302-1357,
+//   solve_nonlocal_downsample_gpu_gradient :548-949 -> solve_ls_cg_gpu SparseSolver_GPU.cu:3-198,
+//   upsample_color_coefficients_bilinear :457-490, solve_WLS_roughness_cpu :951-1125 -> PARDISO SparseSolver_CPU.cpp:104-286.
+//
+// MI355X design (the reference assembles CSR on the host, ships it to the GPU three times, forms A^T A with SpGEMM and
+// factorises a 490k x 490k matrix with PARDISO on the CPU at every level):
+//  * nothing leaves the device. All vectors are fp64, interleaved [pixel][3 Lab channels], a-part then b-part;
+//  * S1 is matrix free: A has <= 2 non-zeros per row, so A^T A is (a) a 2x2 data block per pixel and channel,
+//    (b) twice the 5-point graph Laplacian with weights g^2 and (c) the kNN graph Laplacian. The out-edges come from the
+//    [n][8] kNN table, the in-edges from a radix-sorted reverse adjacency. The three Lab channels run in lock step
+//    with their own CG scalars; it is the SAME truncated, un-preconditioned recurrence started from the local-stats
+//    guess and stopped by the 50/100 iteration cap — the iterate count is part of the result;
+//  * S2: the 5-point SPD system is solved for its 6 right-hand sides in lock step by preconditioned CG
+//    (the reference's direct solve is exact, so any converged solver is result-equivalent);
+//  * all reductions are two-stage with fixed-shape trees => run-to-run deterministic.
+// Roofline: HBM streaming of a handful of fp64 vectors per iteration (latency/launch bound at the coarse levels).
+#include "nct_internal.h"
+#include "nct_device.h"
+#include <hipcub/hipcub.hpp>
+
+#define LAB_D(u) ((double)(u) * (1.0 / 255.0))      // Mat::convertTo(CV_64F, 1/255)
+
+// ---------------------------------------------------------------- deterministic block reduction of NQ doubles
+template <int NQ>
+__device__ __forceinline__ void block_reduce_store(double (&v)[NQ], double* __restrict__ partial /*[nblocks][NQ]*/) {
+    __shared__ double s_red[256 * NQ];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s_red[q * 256 + t] = v[q];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) s_red[q * 256 + t] += s_red[q * 256 + t + off];
+        __syncthreads();
+    }
+    if (t < NQ) partial[(size_t)blockIdx.x * NQ + t] = s_red[t * 256];
+}
+// sum partial[nb][NQ] in a fixed order (single block of 256 threads)
+template <int NQ>
+__device__ __forceinline__ void final_reduce(const double* __restrict__ partial, int nb, double (&out)[NQ]) {
+    __shared__ double s_fin[256 * NQ];
+    const int t = threadIdx.x;
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+    for (int b = t; b < nb; b += 256)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] += partial[(size_t)b * NQ + q];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s_fin[q * 256 + t] = acc[q];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) s_fin[q * 256 + t] += s_fin[q * 256 + t + off];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) out[q] = s_fin[q * 256];
+    __syncthreads();
+}
+
+// ================================================================= T1 local statistics
+__global__ void k_local_stats(const uint8_t* __restrict__ cnt, const uint8_t* __restrict__ stl, int h, int w, double eps,
+                              double* __restrict__ a, double* __restrict__ b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, x = i - y * w;
+    const int sx = max(x - 1, 0), sy = max(y - 1, 0), ex = min(x + 2, w), ey = min(y + 2, h);
+    const int cSum = (ex - sx) * (ey - sy);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        long long cs = 0, cs2 = 0, ss = 0, ss2 = 0;
+        for (int yy = sy; yy < ey; ++yy)
+            for (int xx = sx; xx < ex; ++xx) {
+                const int cv = cnt[((size_t)yy * w + xx) * 3 + c], sv = stl[((size_t)yy * w + xx) * 3 + c];
+                cs += cv; cs2 += cv * cv; ss += sv; ss2 += sv * sv;
+            }
+        const double cm = (double)cs / (double)cSum;
+        double cvr = (double)cs2 / (double)cSum - cm * cm; cvr = cvr > 0.0 ? cvr : 0.0;
+        double csd = sqrt(cvr); csd = csd > 0.0 ? csd : 0.0;
+        const double sm = (double)ss / (double)cSum;
+        double svr = (double)ss2 / (double)cSum - sm * sm; svr = svr > 0.0 ? svr : 0.0;
+        double ssd = sqrt(svr); ssd = ssd > 0.0 ? ssd : 0.0;
+        const double av = ssd / (csd + eps);
+        a[(size_t)i * 3 + c] = av;
+        b[(size_t)i * 3 + c] = (sm - cm * av) * (1.0 / 255.0);
+    }
+}
+
+// ================================================================= T2 weights
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+__global__ void k_minmax_f(const float* __restrict__ v, int n, unsigned* __restrict__ mm) {
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const unsigned o = f2ord(v[i]); lo = min(lo, o); hi = max(hi, o); }
+    for (int off = 32; off >= 1; off >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, off)); hi = max(hi, (unsigned)__shfl_xor((int)hi, off)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+}
+__global__ void k_err_weight(const float* __restrict__ err, int n, const unsigned* __restrict__ mm, double* __restrict__ weight) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double mn = (double)ord2f(mm[0]), mx = (double)ord2f(mm[1]);
+    const double e = ((double)err[i] - mn) / (mx - mn);
+    const double wv = 1.0 - e;
+    weight[i] = wv > 1e-6 ? wv : 1e-6;
+}
+
+// gradient weights g = sqrt(lamda / (|dL|^alpha + 1e-4)) of the L channel of an 8-bit Lab image (compute_gradientMat)
+__global__ void k_gradient_weights(const uint8_t* __restrict__ lab, int h, int w, double lamda, double alpha, double* __restrict__ gx, double* __restrict__ gy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, x = i - y * w;
+    const double val = LAB_D(lab[(size_t)i * 3]);
+    double vx = 0.0, vy = 0.0;
+    if (x + 1 < w) { const double g = LAB_D(lab[(size_t)(i + 1) * 3]) - val; vx = sqrt(lamda / (pow(fabs(g), alpha) + 0.0001)); }
+    if (y + 1 < h) { const double g = LAB_D(lab[(size_t)(i + w) * 3]) - val; vy = sqrt(lamda / (pow(fabs(g), alpha) + 0.0001)); }
+    gx[i] = vx; gy[i] = vy;
+}
+
+// ================================================================= S1 nonlocal least squares
+struct S1Sys {
+    int n, h, w;
+    const double *daa, *dab, *dbb;          // [n][3]: (dw s)^2, (dw s) dw, dw^2
+    const double *gx, *gy;                  // [n]
+    const int* knn_id; const double* iw2;   // [n][8]
+    const int* rev_start; const unsigned* rev_edge;   // reverse adjacency: edges e = src*8+ki sorted by target
+};
+struct CGState { double r0[6], r1[6], va[6], vb[6]; int active[6]; int iters[6]; };
+
+__global__ void k_s1_setup(int n, const double* __restrict__ weight, float dWeight, const uint8_t* __restrict__ src, const uint8_t* __restrict__ ref,
+                           const double* __restrict__ knn_w, double nonlocalWeight,
+                           double* __restrict__ daa, double* __restrict__ dab, double* __restrict__ dbb, double* __restrict__ rhs /*[2][n][3]*/,
+                           double* __restrict__ iw2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double dw = sqrt(weight[i]) * (double)sqrtf(dWeight);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double v0 = dw * LAB_D(src[(size_t)i * 3 + c]);
+        const double rb = dw * LAB_D(ref[(size_t)i * 3 + c]);
+        daa[(size_t)i * 3 + c] = v0 * v0; dab[(size_t)i * 3 + c] = v0 * dw; dbb[(size_t)i * 3 + c] = dw * dw;
+        rhs[(size_t)i * 3 + c] = v0 * rb; rhs[(size_t)(n + i) * 3 + c] = dw * rb;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const double iw = sqrt(knn_w[(size_t)i * 8 + k]) * nonlocalWeight; iw2[(size_t)i * 8 + k] = iw * iw; }
+}
+
+__device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__ p, int i, double (&ya)[3], double (&yb)[3]) {
+    const int n = S.n, w = S.w, h = S.h;
+    const int y = i / w, x = i - y * w;
+    const double* pa = p; const double* pb = p + (size_t)n * 3;
+    double a[3], b[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a[c] = pa[(size_t)i * 3 + c]; b[c] = pb[(size_t)i * 3 + c]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ya[c] = S.daa[(size_t)i * 3 + c] * a[c] + S.dab[(size_t)i * 3 + c] * b[c];
+        yb[c] = S.dab[(size_t)i * 3 + c] * a[c] + S.dbb[(size_t)i * 3 + c] * b[c];
+    }
+    auto edge = [&](int j, double wt) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ya[c] += wt * (a[c] - pa[(size_t)j * 3 + c]); yb[c] += wt * (b[c] - pb[(size_t)j * 3 + c]); }
+    };
+    // local smoothness: every edge is entered twice in A (ColorTransfer.cpp:671-843)
+    if (x + 1 < w) { const double g = S.gx[i]; edge(i + 1, 2.0 * (g * g)); }
+    if (x > 0) { const double g = S.gx[i - 1]; edge(i - 1, 2.0 * (g * g)); }
+    if (y + 1 < h) { const double g = S.gy[i]; edge(i + w, 2.0 * (g * g)); }
+    if (y > 0) { const double g = S.gy[i - w]; edge(i - w, 2.0 * (g * g)); }
+    // nonlocal: out-edges, then in-edges
+#pragma unroll
+    for (int k = 0; k < 8; ++k) edge(S.knn_id[(size_t)i * 8 + k], S.iw2[(size_t)i * 8 + k]);
+    for (int e = S.rev_start[i]; e < S.rev_start[i + 1]; ++e) { const unsigned ed = S.rev_edge[e]; edge((int)(ed >> 3), S.iw2[ed]); }
+}
+
+// r = rhs - Op(x0); partial r.r
+__global__ __launch_bounds__(256) void k_s1_residual(S1Sys S, const double* __restrict__ x, const double* __restrict__ rhs, double* __restrict__ r, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[3] = {0, 0, 0};
+    if (i < S.n) {
+        double ya[3], yb[3];
+        s1_op(S, x, i, ya, yb);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double ra = rhs[(size_t)i * 3 + c] - ya[c], rb = rhs[(size_t)(S.n + i) * 3 + c] - yb[c];
+            r[(size_t)i * 3 + c] = ra; r[(size_t)(S.n + i) * 3 + c] = rb;
+            acc[c] = ra * ra + rb * rb;
+        }
+    }
+    block_reduce_store<3>(acc, partial);
+}
+__global__ __launch_bounds__(256) void k_s1_apply(S1Sys S, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[3] = {0, 0, 0};
+    if (i < S.n) {
+        double ya[3], yb[3];
+        s1_op(S, p, i, ya, yb);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            Ap[(size_t)i * 3 + c] = ya[c]; Ap[(size_t)(S.n + i) * 3 + c] = yb[c];
+            acc[c] = p[(size_t)i * 3 + c] * ya[c] + p[(size_t)(S.n + i) * 3 + c] * yb[c];
+        }
+    }
+    block_reduce_store<3>(acc, partial);
+}
+// generic CG pieces over NQ lock-step systems stored as [part][n][3] (S1: NQ=3 channels, both parts share a scalar)
+__global__ void k_cg_init(const double* __restrict__ partial, int nb, CGState* __restrict__ st, double tol2, int nq) {
+    double s[3]; final_reduce<3>(partial, nb, s);
+    if (threadIdx.x < nq) { const int c = threadIdx.x; st->r1[c] = s[c]; st->r0[c] = 0.0; st->va[c] = 0.0; st->vb[c] = 0.0; st->iters[c] = 0; st->active[c] = s[c] > tol2 ? 1 : 0; }
+}
+__global__ void k_cg_alpha(const double* __restrict__ partial, int nb, CGState* __restrict__ st) {
+    double s[3]; final_reduce<3>(partial, nb, s);
+    if (threadIdx.x < 3) { const int c = threadIdx.x; if (st->active[c]) st->va[c] = st->r1[c] / s[c]; }
+}
+__global__ void k_cg_beta(const double* __restrict__ partial, int nb, CGState* __restrict__ st, double tol2) {
+    double s[3]; final_reduce<3>(partial, nb, s);
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        if (st->active[c]) { st->r0[c] = st->r1[c]; st->r1[c] = s[c]; st->vb[c] = s[c] / st->r0[c]; st->iters[c]++; st->active[c] = s[c] > tol2 ? 1 : 0; }
+    }
+}
+__global__ void k_s1_dir(int n, const CGState* __restrict__ st, const double* __restrict__ r, double* __restrict__ p, int first) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over 2*n*3 scalars
+    if (i >= 2 * n * 3) return;
+    const int c = i % 3;
+    if (!st->active[c]) return;
+    p[i] = first ? r[i] : st->vb[c] * p[i] + r[i];
+}
+__global__ __launch_bounds__(256) void k_s1_update(int n, const CGState* __restrict__ st, const double* __restrict__ p, const double* __restrict__ Ap,
+                                                   double* __restrict__ x, double* __restrict__ r, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[3] = {0, 0, 0};
+    if (i < n) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (!st->active[c]) continue;
+            const double va = st->va[c];
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const size_t j = ((size_t)part * n + i) * 3 + c;
+                x[j] += va * p[j];
+                const double rn = r[j] - va * Ap[j];
+                r[j] = rn; acc[c] += rn * rn;
+            }
+        }
+    }
+    block_reduce_store<3>(acc, partial);
+}
+
+__global__ void k_edge_keys(const int* __restrict__ knn_id, int m, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    keys[e] = (unsigned)knn_id[e]; vals[e] = (unsigned)e;
+}
+__global__ void k_seg_starts(const unsigned* __restrict__ keys, int m, int* __restrict__ start, int n) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n) return;
+    int lo = 0, hi = m;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < (unsigned)s) lo = mid + 1; else hi = mid; }
+    start[s] = lo;
+}
+
+// ================================================================= U1 roughness / A1 apply
+__global__ void k_roughness(const double* __restrict__ a, const double* __restrict__ b, const uint8_t* __restrict__ lab, int n, double* __restrict__ rough) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double nc = LAB_D(lab[(size_t)i * 3 + 2]) * a[(size_t)i * 3 + 2] + b[(size_t)i * 3 + 2];     // only channel 2 survives (quirk 5)
+    rough[i] = (nc < 0 || nc > 1) ? 1e-6 : 1.0;
+}
+__global__ void k_apply(const double* __restrict__ a, const double* __restrict__ b, const uint8_t* __restrict__ lab, int n, uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 3) return;
+    double v = LAB_D(lab[i]) * a[i] + b[i];
+    v = v > 0.0 ? v : 0.0; v = v < 1.0 ? v : 1.0;
+    const int q = (int)rint(v * 255.0);
+    out[i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+}
+
+// ================================================================= S2 WLS: (diag(r) + L) x = r x0, 6 right-hand sides
+struct WlsSys { int n, H, W; const double *diag, *wx, *wy; };
+struct PCGState { double rz[6], rr[6], bb[6], al[6], be[6]; int active[6]; int iters[6]; };
+
+__global__ void k_wls_system(const double* __restrict__ gx, const double* __restrict__ gy, const double* __restrict__ rough, int H, int W,
+                             double* __restrict__ diag, double* __restrict__ wx, double* __restrict__ wy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i - y * W;
+    double a00 = 0.0, ex = 0.0, ey = 0.0;
+    a00 += rough[i];
+    if (x + 1 < W) { const double g = gx[i] * gx[i]; a00 += g; ex = g; }
+    if (x > 0) { const double g = gx[i - 1] * gx[i - 1]; a00 += g; }
+    if (y + 1 < H) { const double g = gy[i] * gy[i]; a00 += g; ey = g; }
+    if (y > 0) { const double g = gy[i - W] * gy[i - W]; a00 += g; }
+    diag[i] = a00; wx[i] = ex; wy[i] = ey;
+}
+__device__ __forceinline__ void wls_op(const WlsSys& S, const double* __restrict__ v /*[n][3]*/, int i, double (&y)[3]) {
+    const int W = S.W, H = S.H;
+    const int r = i / W, c0 = i - r * W;
+    const double d = S.diag[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = d * v[(size_t)i * 3 + c];
+    if (c0 + 1 < W) { const double wv = S.wx[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i + 1) * 3 + c]; }
+    if (c0 > 0) { const double wv = S.wx[i - 1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i - 1) * 3 + c]; }
+    if (r + 1 < H) { const double wv = S.wy[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i + W) * 3 + c]; }
+    if (r > 0) { const double wv = S.wy[i - W];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i - W) * 3 + c]; }
+}
+// rhs = rough * x0 (kept in `rhs`), x = x0 (initial guess), r = rhs - M x, z = r/diag, p = z; partial: rz, rr, bb (18 values)
+__global__ __launch_bounds__(256) void k_wls_start(WlsSys S, const double* __restrict__ rough, const double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+                                                   double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[18];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) acc[q] = 0.0;
+    if (i < S.n) {
+        const double rg = rough[i], d = S.diag[i];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const double* xv = x + (size_t)part * S.n * 3;
+            double y[3]; wls_op(S, xv, i, y);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t j = ((size_t)part * S.n + i) * 3 + c;
+                const double bq = rg * xv[(size_t)i * 3 + c];
+                const double rv = bq - y[c], z = rv / d;
+                r[j] = rv; p[j] = z;
+                const int q = part * 3 + c;
+                acc[q] = rv * z; acc[6 + q] = rv * rv; acc[12 + q] = bq * bq;
+            }
+        }
+    }
+    block_reduce_store<18>(acc, partial);
+}
+__global__ void k_pcg_init(const double* __restrict__ partial, int nb, PCGState* __restrict__ st, double rtol2) {
+    double s[18]; final_reduce<18>(partial, nb, s);
+    if (threadIdx.x < 6) { const int q = threadIdx.x; st->rz[q] = s[q]; st->rr[q] = s[6 + q]; st->bb[q] = s[12 + q]; st->iters[q] = 0; st->al[q] = 0; st->be[q] = 0;
+                           st->active[q] = (s[6 + q] > rtol2 * s[12 + q]) ? 1 : 0; }
+}
+__global__ __launch_bounds__(256) void k_wls_apply(WlsSys S, const PCGState* __restrict__ st, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (i < S.n) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const double* pv = p + (size_t)part * S.n * 3;
+            double y[3]; wls_op(S, pv, i, y);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const size_t j = ((size_t)part * S.n + i) * 3 + c; Ap[j] = y[c]; acc[part * 3 + c] = pv[(size_t)i * 3 + c] * y[c]; }
+        }
+    }
+    block_reduce_store<6>(acc, partial);
+}
+__global__ void k_pcg_alpha(const double* __restrict__ partial, int nb, PCGState* __restrict__ st) {
+    double s[6]; final_reduce<6>(partial, nb, s);
+    if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) st->al[q] = st->rz[q] / s[q]; }
+}
+// x += al p; r -= al Ap; z = r/diag; partial rz_new, rr
+__global__ __launch_bounds__(256) void k_wls_update(WlsSys S, const PCGState* __restrict__ st, const double* __restrict__ p, const double* __restrict__ Ap,
+                                                    double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0;
+    if (i < S.n) {
+        const double d = S.diag[i];
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int q = part * 3 + c;
+                if (!st->active[q]) continue;
+                const size_t j = ((size_t)part * S.n + i) * 3 + c;
+                const double al = st->al[q];
+                x[j] += al * p[j];
+                const double rv = r[j] - al * Ap[j];
+                const double zv = rv / d;
+                r[j] = rv; z[j] = zv;
+                acc[q] = rv * zv; acc[6 + q] = rv * rv;
+            }
+    }
+    block_reduce_store<12>(acc, partial);
+}
+__global__ void k_pcg_beta(const double* __restrict__ partial, int nb, PCGState* __restrict__ st, double rtol2) {
+    double s[12]; final_reduce<12>(partial, nb, s);
+    if (threadIdx.x < 6) {
+        const int q = threadIdx.x;
+        if (st->active[q]) { st->be[q] = s[q] / st->rz[q]; st->rz[q] = s[q]; st->rr[q] = s[6 + q]; st->iters[q]++; st->active[q] = (s[6 + q] > rtol2 * st->bb[q]) ? 1 : 0; }
+    }
+}
+__global__ void k_wls_dir(int n, const PCGState* __restrict__ st, const double* __restrict__ z, double* __restrict__ p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n * 3) return;
+    const int q = (i / (n * 3)) * 3 + (i % 3);
+    if (!st->active[q]) return;
+    p[i] = z[i] + st->be[q] * p[i];
+}
+
+// ================================================================= orchestration
+#define LCHK() NCT_LAUNCH_CHECK()
+static int dbg_copy(nct_ctx* ctx, hipStream_t s, double* host, const double* dev, size_t n) {
+    if (!host) return 0;
+    NCT_HIP(hipMemcpyAsync(host, dev, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    NCT_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, const uint8_t* s_lab_level, const uint8_t* g_lab_level,
+                              const uint8_t* s_lab_full, const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W,
+                              const nct_color_params& prm, uint8_t* out_lab_full, const nct_color_debug* dbg) {
+    const int n = h * w, N = H * W;
+    const int nbl = cdiv(n, 256), nbL = cdiv(N, 256);
+    // ---------------- T1 + T2
+    DevBuf<double> x(ctx, (size_t)6 * n), weight(ctx, n);
+    DevBuf<unsigned> mm(ctx, 2);
+    if (!x.ok() || !weight.ok() || !mm.ok()) return NCT_ERR_HIP;
+    double* xa = x; double* xb = (double*)x + (size_t)3 * n;
+    hipLaunchKernelGGL(k_local_stats, dim3(nbl), dim3(256), 0, s, s_lab_level, g_lab_level, h, w, prm.eps, xa, xb); LCHK();
+    if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_local, x, (size_t)6 * n); if (rc) return rc; }
+    NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)(unsigned*)mm, (int)0xFFFFFFFFu, 1, s));
+    NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)((unsigned*)mm + 1), 0, 1, s));
+    hipLaunchKernelGGL(k_minmax_f, dim3(128), dim3(256), 0, s, err, n, (unsigned*)mm); LCHK();
+    hipLaunchKernelGGL(k_err_weight, dim3(nbl), dim3(256), 0, s, err, n, (const unsigned*)mm, (double*)weight); LCHK();
+    // ---------------- S1
+    const double normFactor = (double)(W * H) / (double)(w * h);
+    {
+        DevBuf<double> gx(ctx, n), gy(ctx, n), daa(ctx, (size_t)3 * n), dab(ctx, (size_t)3 * n), dbb(ctx, (size_t)3 * n), rhs(ctx, (size_t)6 * n), iw2(ctx, (size_t)8 * n);
+        DevBuf<double> r(ctx, (size_t)6 * n), p(ctx, (size_t)6 * n), Ap(ctx, (size_t)6 * n), partial(ctx, (size_t)nbl * 3);
+        DevBuf<unsigned> ek(ctx, (size_t)8 * n), ev(ctx, (size_t)8 * n), eks(ctx, (size_t)8 * n), evs(ctx, (size_t)8 * n);
+        DevBuf<int> rstart(ctx, n + 1);
+        DevBuf<CGState> st(ctx, 1);
+        if (!gx.ok() || !gy.ok() || !daa.ok() || !dab.ok() || !dbb.ok() || !rhs.ok() || !iw2.ok() || !r.ok() || !p.ok() || !Ap.ok() || !partial.ok() ||
+            !ek.ok() || !ev.ok() || !eks.ok() || !evs.ok() || !rstart.ok() || !st.ok()) return NCT_ERR_HIP;
+        // lambda / alpha / dWeight arrive as float in the reference signature (ColorTransfer.cpp:548-550)
+        const float lambda_f = (float)prm.local_weight, alpha_f = (float)prm.wls_alpha, dWeight_f = (float)normFactor;
+        hipLaunchKernelGGL(k_gradient_weights, dim3(nbl), dim3(256), 0, s, s_lab_level, h, w, (double)lambda_f, (double)alpha_f, (double*)gx, (double*)gy); LCHK();
+        const double nonlocalWeight = sqrt(prm.nonlocal_weight / prm.k_num);
+        hipLaunchKernelGGL(k_s1_setup, dim3(nbl), dim3(256), 0, s, n, (const double*)weight, dWeight_f, s_lab_level, g_lab_level, knn_w, nonlocalWeight,
+                           (double*)daa, (double*)dab, (double*)dbb, (double*)rhs, (double*)iw2); LCHK();
+        // reverse adjacency of the kNN graph
+        const int m = 8 * n;
+        hipLaunchKernelGGL(k_edge_keys, dim3(cdiv(m, 256)), dim3(256), 0, s, knn_id, m, (unsigned*)ek, (unsigned*)ev); LCHK();
+        int end_bit = 1; while ((1u << end_bit) < (unsigned)n && end_bit < 32) ++end_bit;
+        size_t tmp_bytes = 0;
+        NCT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned*)ek, (unsigned*)eks, (const unsigned*)ev, (unsigned*)evs, m, 0, end_bit, s));
+        DevBuf<char> tmp(ctx, tmp_bytes ? tmp_bytes : 16);
+        if (!tmp.ok()) return NCT_ERR_HIP;
+        NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)ek, (unsigned*)eks, (const unsigned*)ev, (unsigned*)evs, m, 0, end_bit, s));
+        hipLaunchKernelGGL(k_seg_starts, dim3(cdiv(n + 1, 256)), dim3(256), 0, s, (const unsigned*)eks, m, (int*)rstart, n); LCHK();
+        S1Sys S{n, h, w, daa, dab, dbb, gx, gy, knn_id, iw2, rstart, evs};
+        const double tol2 = 1e-6 * 1e-6;
+        const int maxit = layer == 4 ? 50 : 100;                       // ColorTransfer.cpp:916-921
+        hipLaunchKernelGGL(k_s1_residual, dim3(nbl), dim3(256), 0, s, S, (const double*)x, (const double*)rhs, (double*)r, (double*)partial); LCHK();
+        hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2, 3); LCHK();
+        for (int k = 1; k <= maxit; ++k) {
+            hipLaunchKernelGGL(k_s1_dir, dim3(cdiv(6 * n, 256)), dim3(256), 0, s, n, (const CGState*)st, (const double*)r, (double*)p, k == 1 ? 1 : 0); LCHK();
+            hipLaunchKernelGGL(k_s1_apply, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial); LCHK();
+            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st); LCHK();
+            hipLaunchKernelGGL(k_s1_update, dim3(nbl), dim3(256), 0, s, n, (const CGState*)st, (const double*)p, (const double*)Ap, (double*)x, (double*)r, (double*)partial); LCHK();
+            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2); LCHK();
+        }
+        if (dbg && dbg->cg_iters) {
+            CGState hst;
+            NCT_HIP(hipMemcpyAsync(&hst, (CGState*)st, sizeof hst, hipMemcpyDeviceToHost, s));
+            NCT_HIP(hipStreamSynchronize(s));
+            for (int c = 0; c < 3; ++c) dbg->cg_iters[c] = hst.iters[c];
+        }
+    }
+    if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_nonlocal, x, (size_t)6 * n); if (rc) return rc; }
+    // ---------------- U1: bilinear upsample to full resolution + roughness
+    DevBuf<double> X(ctx, (size_t)6 * N), rough(ctx, N);
+    if (!X.ok() || !rough.ok()) return NCT_ERR_HIP;
+    double* Xa = X; double* Xb = (double*)X + (size_t)3 * N;
+    if (W > w || H > h) {
+        int rc = nctk_resize_f64c3(ctx, s, xa, h, w, Xa, H, W); if (rc) return rc;
+        rc = nctk_resize_f64c3(ctx, s, xb, h, w, Xb, H, W); if (rc) return rc;
+    } else {
+        NCT_HIP(hipMemcpyAsync(X, x, sizeof(double) * (size_t)6 * N, hipMemcpyDeviceToDevice, s));
+    }
+    hipLaunchKernelGGL(k_roughness, dim3(nbL), dim3(256), 0, s, (const double*)Xa, (const double*)Xb, s_lab_full, N, (double*)rough); LCHK();
+    if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_up, X, (size_t)6 * N); if (rc) return rc; rc = dbg_copy(ctx, s, dbg->rough, rough, N); if (rc) return rc; }
+    // ---------------- S2: WLS
+    {
+        double lamda = prm.wls_lambda_init * normFactor;
+        if (h == H && w == W) lamda *= 4;                               // ColorTransfer.cpp:1418-1424
+        DevBuf<double> gx(ctx, N), gy(ctx, N), diag(ctx, N), wx(ctx, N), wy(ctx, N);
+        DevBuf<double> r(ctx, (size_t)6 * N), z(ctx, (size_t)6 * N), p(ctx, (size_t)6 * N), Ap(ctx, (size_t)6 * N), partial(ctx, (size_t)nbL * 18);
+        DevBuf<PCGState> st(ctx, 1);
+        if (!gx.ok() || !gy.ok() || !diag.ok() || !wx.ok() || !wy.ok() || !r.ok() || !z.ok() || !p.ok() || !Ap.ok() || !partial.ok() || !st.ok()) return NCT_ERR_HIP;
+        hipLaunchKernelGGL(k_gradient_weights, dim3(nbL), dim3(256), 0, s, s_lab_full, H, W, lamda, prm.wls_alpha, (double*)gx, (double*)gy); LCHK();
+        hipLaunchKernelGGL(k_wls_system, dim3(nbL), dim3(256), 0, s, (const double*)gx, (const double*)gy, (const double*)rough, H, W, (double*)diag, (double*)wx, (double*)wy); LCHK();
+        WlsSys S{N, H, W, diag, wx, wy};
+        const double rtol2 = 1e-10 * 1e-10;
+        hipLaunchKernelGGL(k_wls_start, dim3(nbL), dim3(256), 0, s, S, (const double*)rough, (const double*)X, (double*)r, (double*)p, (double*)partial); LCHK();
+        hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbL, (PCGState*)st, rtol2); LCHK();
+        const int maxit = 100000, check_every = 64;
+        PCGState hst;
+        int it = 0;
+        bool done = false;
+        while (!done && it < maxit) {
+            for (int k = 0; k < check_every; ++k, ++it) {
+                hipLaunchKernelGGL(k_wls_apply, dim3(nbL), dim3(256), 0, s, S, (const PCGState*)st, (const double*)p, (double*)Ap, (double*)partial); LCHK();
+                hipLaunchKernelGGL(k_pcg_alpha, dim3(1), dim3(256), 0, s, (const double*)partial, nbL, (PCGState*)st); LCHK();
+                hipLaunchKernelGGL(k_wls_update, dim3(nbL), dim3(256), 0, s, S, (const PCGState*)st, (const double*)p, (const double*)Ap, (double*)X, (double*)r, (double*)z, (double*)partial); LCHK();
+                hipLaunchKernelGGL(k_pcg_beta, dim3(1), dim3(256), 0, s, (const double*)partial, nbL, (PCGState*)st, rtol2); LCHK();
+                hipLaunchKernelGGL(k_wls_dir, dim3(cdiv(6 * N, 256)), dim3(256), 0, s, N, (const PCGState*)st, (const double*)z, (double*)p); LCHK();
+            }
+            NCT_HIP(hipMemcpyAsync(&hst, (PCGState*)st, sizeof hst, hipMemcpyDeviceToHost, s));
+            NCT_HIP(hipStreamSynchronize(s));
+            done = true;
+            for (int q = 0; q < 6; ++q) if (hst.active[q]) done = false;
+        }
+        if (!done) return ctx->fail(NCT_ERR_HIP, "WLS PCG did not converge in %d iterations", maxit);
+        if (dbg && dbg->wls_iters) for (int q = 0; q < 6; ++q) dbg->wls_iters[q] = hst.iters[q];
+    }
+    if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_wls, X, (size_t)6 * N); if (rc) return rc; }
+    // ---------------- A1
+    hipLaunchKernelGGL(k_apply, dim3(cdiv(3 * N, 256)), dim3(256), 0, s, (const double*)Xa, (const double*)Xb, s_lab_full, N, out_lab_full); LCHK();
+    return 0;
+}

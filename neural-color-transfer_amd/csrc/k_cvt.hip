@@ -1,0 +1,212 @@
+// k_cvt.hip — 8-bit BGR<->Lab conversion and bilinear resizes on the GPU (A1 + the cv::resize / cvtColor call sites).
+// Reference call sites: cvtColor(BGR2Lab) main.cu:352,371, ColorTransfer.h:58; cvtColor(Lab2BGR) ColorTransfer.cpp:1469;
+// resize(INTER_LINEAR) 8UC3 main.cu:106-107, 64FC3 ColorTransfer.cpp:462-463. The arithmetic is OpenCV 2.4.10's
+// (external dependency, not under /root/reference): integer RGB2Lab_b with the sRGB-gamma and cube-root LUTs, float
+// Lab2RGB with the cubic-spline inverse-gamma table, fixed-point (11-bit) bilinear with the >>4,*b,>>16,+2,>>2 chain and
+// the silent INTER_AREA switch for exact 2x shrink.
+// All kernels are trivially bandwidth bound (3-24 B per pixel).
+#include "nct_internal.h"
+#include "nct_device.h"
+#include <cmath>
+#include <mutex>
+
+namespace {
+enum { LAB_SHIFT = 12, LAB_SHIFT2 = 15, GAMMA_SHIFT = 3, CBRT_TAB = 256 * 3 / 2 * (1 << GAMMA_SHIFT), GAMMA_TAB = 1024 };
+
+struct CvtTables { unsigned short gamma[256]; unsigned short cbrt[CBRT_TAB]; float inv_gamma[GAMMA_TAB * 4]; int coeffs[9]; float l2r[9]; };
+
+inline int cv_round_h(double v) { return (int)lrint(v); }
+inline unsigned short sat_u16(float v) { int i = cv_round_h(v); return (unsigned short)(i < 0 ? 0 : (i > 65535 ? 65535 : i)); }
+
+void build_tables(CvtTables& t) {
+    for (int i = 0; i < 256; i++) {
+        float x = i * (1.f / 255.f);
+        t.gamma[i] = sat_u16(255.f * (1 << GAMMA_SHIFT) * (x <= 0.04045f ? x * (1.f / 12.92f) : (float)pow((double)(x + 0.055) * (1. / 1.055), 2.4)));
+    }
+    for (int i = 0; i < CBRT_TAB; i++) {
+        float x = i * (1.f / (255.f * (1 << GAMMA_SHIFT)));
+        t.cbrt[i] = sat_u16((1 << LAB_SHIFT2) * (x < 0.008856f ? x * 7.787f + 0.13793103448275862f : cbrtf(x)));
+    }
+    static float g[GAMMA_TAB + 1];
+    for (int i = 0; i <= GAMMA_TAB; i++) {
+        float x = i * (1.f / GAMMA_TAB);
+        g[i] = x <= 0.0031308 ? x * 12.92f : (float)(1.055 * pow((double)x, 1. / 2.4) - 0.055);
+    }
+    // natural cubic spline through g (OpenCV splineBuild)
+    float* tab = t.inv_gamma; const int n = GAMMA_TAB; float cn = 0;
+    tab[0] = tab[1] = 0.f;
+    for (int i = 1; i < n - 1; i++) {
+        float tt = 3 * (g[i + 1] - 2 * g[i] + g[i - 1]);
+        float l = 1 / (4 - tab[(i - 1) * 4]);
+        tab[i * 4] = l; tab[i * 4 + 1] = (tt - tab[(i - 1) * 4 + 1]) * l;
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        float c = tab[i * 4 + 1] - tab[i * 4] * cn;
+        float b = g[i + 1] - g[i] - (cn + c * 2) * 0.3333333333333333f;
+        float d = (cn - c) * 0.3333333333333333f;
+        tab[i * 4] = g[i]; tab[i * 4 + 1] = b; tab[i * 4 + 2] = c; tab[i * 4 + 3] = d;
+        cn = c;
+    }
+    const float s2x[9] = {0.412453f, 0.357580f, 0.180423f, 0.212671f, 0.715160f, 0.072169f, 0.019334f, 0.119193f, 0.950227f};
+    const float wp[3] = {0.950456f, 1.f, 1.088754f};
+    const float scale[3] = {(1 << LAB_SHIFT) / wp[0], (float)(1 << LAB_SHIFT), (1 << LAB_SHIFT) / wp[2]};
+    for (int i = 0; i < 3; i++) {     // BGR input: the R coefficient sits in column 2, the B coefficient in column 0
+        t.coeffs[i * 3 + 2] = cv_round_h(s2x[i * 3] * scale[i]);
+        t.coeffs[i * 3 + 1] = cv_round_h(s2x[i * 3 + 1] * scale[i]);
+        t.coeffs[i * 3 + 0] = cv_round_h(s2x[i * 3 + 2] * scale[i]);
+    }
+    const float x2s[9] = {3.240479f, -1.53715f, -0.498535f, -0.969256f, 1.875991f, 0.041556f, 0.055648f, -0.204043f, 1.057311f};
+    for (int i = 0; i < 3; i++) { t.l2r[i + 6] = x2s[i] * wp[i]; t.l2r[i + 3] = x2s[i + 3] * wp[i]; t.l2r[i] = x2s[i + 6] * wp[i]; }
+}
+}  // namespace
+
+struct cvt_dev { CvtTables* d = nullptr; };
+
+static int get_tables(nct_ctx* ctx, const CvtTables** out) {
+    if (!ctx->cvt) {
+        CvtTables* h = new CvtTables();
+        build_tables(*h);
+        cvt_dev* cd = new cvt_dev();
+        hipError_t e = hipMalloc(&cd->d, sizeof(CvtTables));
+        if (e == hipSuccess) e = hipMemcpy(cd->d, h, sizeof(CvtTables), hipMemcpyHostToDevice);
+        delete h;
+        if (e != hipSuccess) { delete cd; return ctx->fail(NCT_ERR_HIP, "colour tables: %s", hipGetErrorString(e)); }
+        ctx->cvt = cd;
+    }
+    *out = ((cvt_dev*)ctx->cvt)->d;
+    return 0;
+}
+void nct_cvt_free(nct_ctx* ctx) { if (ctx->cvt) { cvt_dev* cd = (cvt_dev*)ctx->cvt; if (cd->d) (void)hipFree(cd->d); delete cd; ctx->cvt = nullptr; } }
+
+#define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+__device__ __forceinline__ unsigned char sat8(int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ void k_bgr2lab(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n, const CvtTables* __restrict__ t) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int Lscale = (116 * 255 + 50) / 100;
+    const int Lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
+    const int R = t->gamma[src[i * 3]], G = t->gamma[src[i * 3 + 1]], B = t->gamma[src[i * 3 + 2]];
+    const int* C = t->coeffs;
+    const int fX = t->cbrt[DESCALE(R * C[0] + G * C[1] + B * C[2], LAB_SHIFT)];
+    const int fY = t->cbrt[DESCALE(R * C[3] + G * C[4] + B * C[5], LAB_SHIFT)];
+    const int fZ = t->cbrt[DESCALE(R * C[6] + G * C[7] + B * C[8], LAB_SHIFT)];
+    dst[i * 3] = sat8(DESCALE(Lscale * fY + Lshift, LAB_SHIFT2));
+    dst[i * 3 + 1] = sat8(DESCALE(500 * (fX - fY) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
+    dst[i * 3 + 2] = sat8(DESCALE(200 * (fY - fZ) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
+}
+
+__device__ __forceinline__ float spline_eval(float x, const float* __restrict__ tab) {
+    int ix = (int)floorf(x);
+    ix = ix < 0 ? 0 : (ix > GAMMA_TAB - 1 ? GAMMA_TAB - 1 : ix);
+    x -= (float)ix;
+    tab += ix * 4;
+    return ((tab[3] * x + tab[2]) * x + tab[1]) * x + tab[0];
+}
+
+__global__ void k_lab2bgr(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n, const CvtTables* __restrict__ t) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float lThresh = 0.008856f * 903.3f;
+    const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
+    const float li = (float)src[i * 3] * (100.f / 255.f), ai = (float)((int)src[i * 3 + 1] - 128), bi = (float)((int)src[i * 3 + 2] - 128);
+    float y, fy;
+    if (li <= lThresh) { y = li / 903.3f; fy = 7.787f * y + 16.0f / 116.0f; }
+    else { fy = (li + 16.0f) / 116.0f; y = fy * fy * fy; }
+    float fx = ai / 500.0f + fy, fz = fy - bi / 200.0f;
+    fx = fx <= fThresh ? (fx - 16.0f / 116.0f) / 7.787f : fx * fx * fx;
+    fz = fz <= fThresh ? (fz - 16.0f / 116.0f) / 7.787f : fz * fz * fz;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = t->l2r[k * 3] * fx + t->l2r[k * 3 + 1] * y + t->l2r[k * 3 + 2] * fz;
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+        v = spline_eval(v * (float)GAMMA_TAB, t->inv_gamma);
+        dst[i * 3 + k] = sat8((int)rintf(v * 255.f));
+    }
+}
+
+int nctk_bgr2lab(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix) {
+    const CvtTables* t; int rc = get_tables(ctx, &t); if (rc) return rc;
+    hipLaunchKernelGGL(k_bgr2lab, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, src, dst, npix, t);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+int nctk_lab2bgr(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix) {
+    const CvtTables* t; int rc = get_tables(ctx, &t); if (rc) return rc;
+    hipLaunchKernelGGL(k_lab2bgr, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, src, dst, npix, t);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- resize
+struct LinCoef { int s; float a0, a1; bool tail; };     // tail: dx >= xmax => D = S[s] * ONE
+__device__ __forceinline__ LinCoef lin_coef(int d, int ssize, int dsize) {
+    const double scale = (double)ssize / (double)dsize;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    bool tail = false;
+    if (s + 1 >= ssize) { tail = true; if (s >= ssize - 1) { f = 0.f; s = ssize - 1; } }
+    return LinCoef{s, 1.f - f, f, tail};
+}
+
+__global__ void k_resize_u8c3(const uint8_t* __restrict__ src, int sh, int sw, uint8_t* __restrict__ dst, int dh, int dw, int area2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dh * dw) return;
+    const int dy = i / dw, dx = i - dy * dw;
+    if (area2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint8_t* p = src + ((size_t)(2 * dy) * sw + 2 * dx) * 3 + c;
+            dst[(size_t)i * 3 + c] = (uint8_t)((p[0] + p[3] + p[(size_t)sw * 3] + p[(size_t)sw * 3 + 3] + 2) >> 2);
+        }
+        return;
+    }
+    const LinCoef cx = lin_coef(dx, sw, dw), cy = lin_coef(dy, sh, dh);
+    const int a0 = (short)(int)rintf(cx.a0 * 2048.f), a1 = (short)(int)rintf(cx.a1 * 2048.f);
+    const int b0 = (short)(int)rintf(cy.a0 * 2048.f), b1 = (short)(int)rintf(cy.a1 * 2048.f);
+    const int sy0 = cy.s, sy1 = min(cy.s + 1, sh - 1);
+    const int sx1 = min(cx.s + 1, sw - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int p00 = src[((size_t)sy0 * sw + cx.s) * 3 + c], p01 = src[((size_t)sy0 * sw + sx1) * 3 + c];
+        const int p10 = src[((size_t)sy1 * sw + cx.s) * 3 + c], p11 = src[((size_t)sy1 * sw + sx1) * 3 + c];
+        const int r0 = cx.tail ? p00 * 2048 : p00 * a0 + p01 * a1;
+        const int r1 = cx.tail ? p10 * 2048 : p10 * a0 + p11 * a1;
+        dst[(size_t)i * 3 + c] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+int nctk_resize_u8c3(nct_ctx* ctx, hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw) {
+    if (sh == dh && sw == dw) { NCT_HIP(hipMemcpyAsync(dst, src, (size_t)sh * sw * 3, hipMemcpyDeviceToDevice, s)); return 0; }
+    const int area2 = (sw == dw * 2 && sh == dh * 2) ? 1 : 0;
+    hipLaunchKernelGGL(k_resize_u8c3, dim3(cdiv(dh * dw, 256)), dim3(256), 0, s, src, sh, sw, dst, dh, dw, area2);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+
+// 64FC3 bilinear (upsampling of the a,b coefficient maps): float weights, double accumulation, horizontal then vertical
+__global__ void k_resize_f64c3(const double* __restrict__ src, int sh, int sw, double* __restrict__ dst, int dh, int dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dh * dw) return;
+    const int dy = i / dw, dx = i - dy * dw;
+    const LinCoef cx = lin_coef(dx, sw, dw), cy = lin_coef(dy, sh, dh);
+    const int sy0 = cy.s, sy1 = min(cy.s + 1, sh - 1), sx1 = min(cx.s + 1, sw - 1);
+    const double a0 = (double)cx.a0, a1 = (double)cx.a1, b0 = (double)cy.a0, b1 = (double)cy.a1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double p00 = src[((size_t)sy0 * sw + cx.s) * 3 + c], p01 = src[((size_t)sy0 * sw + sx1) * 3 + c];
+        const double p10 = src[((size_t)sy1 * sw + cx.s) * 3 + c], p11 = src[((size_t)sy1 * sw + sx1) * 3 + c];
+        const double r0 = cx.tail ? p00 * 1.0 : p00 * a0 + p01 * a1;
+        const double r1 = cx.tail ? p10 * 1.0 : p10 * a0 + p11 * a1;
+        dst[(size_t)i * 3 + c] = r0 * b0 + r1 * b1;
+    }
+}
+
+int nctk_resize_f64c3(nct_ctx* ctx, hipStream_t s, const double* src, int sh, int sw, double* dst, int dh, int dw) {
+    if (sh == dh && sw == dw) { NCT_HIP(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)sh * sw * 3, hipMemcpyDeviceToDevice, s)); return 0; }
+    hipLaunchKernelGGL(k_resize_f64c3, dim3(cdiv(dh * dw, 256)), dim3(256), 0, s, src, sh, sw, dst, dh, dw);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}

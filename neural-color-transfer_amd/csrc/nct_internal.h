@@ -22,6 +22,7 @@ struct nct_ctx {
     float *bench_a = nullptr, *bench_b = nullptr; int bench_C = 0, bench_ah = 0, bench_aw = 0, bench_bh = 0, bench_bw = 0;
     // opaque sub-states owned by other translation units
     void* vgg = nullptr;              // struct vgg_weights* (nct_vgg.cpp)
+    void* cvt = nullptr;              // struct cvt_dev* (k_cvt.hip): colour-conversion LUTs on the device
     unsigned long long* d_counter = nullptr;   // device eval counter (profiling builds of pm kernels)
 
     int fail(int code, const char* fmt, ...) {
@@ -61,6 +62,25 @@ int nctk_nnf_upsample(nct_ctx* ctx, hipStream_t s, const uint32_t* nnf_half, uin
 // k_patchmatch.hip — nnf in/out, dist out; tmp buffers come from the arena
 int nctk_patchmatch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
                     int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist, unsigned long long* eval_counter /*nullable*/);
+// k_vgg.hip / nct_vgg.cpp
+int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps_chw, int* dims);
+void nct_vgg_free(nct_ctx* ctx);
+// k_cvt.hip
+int nctk_bgr2lab(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix);
+int nctk_lab2bgr(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix);
+int nctk_resize_u8c3(nct_ctx* ctx, hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
+int nctk_resize_f64c3(nct_ctx* ctx, hipStream_t s, const double* src, int sh, int sw, double* dst, int dh, int dw);
+void nct_cvt_free(nct_ctx* ctx);
+// k_cluster.hip
+int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat_hwc_norm, int n, int C, int K, int iters, uint64_t seed, int* labels, int* nlabels_dev);
+int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, int w, const int* labels, int lh, int lw, int nlabels, int samples,
+                   int* knn_id, double* knn_w);
+// k_colorsolve.hip
+struct nct_color_params { double eps, nonlocal_weight, local_weight, wls_lambda_init, wls_alpha, k_num; };
+struct nct_color_debug { double *ab_local, *ab_nonlocal, *ab_up, *rough, *ab_wls; int* cg_iters; int* wls_iters; };   // host pointers, all nullable
+int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, const uint8_t* s_lab_level, const uint8_t* g_lab_level,
+                              const uint8_t* s_lab_full, const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W,
+                              const nct_color_params& prm, uint8_t* out_lab_full, const nct_color_debug* dbg);
 // k_vote.hip
 int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, const uint32_t* bnn, const float* pin_hwc, float* pout_hwc, float* pw /*nullable*/,
                            int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp);

@@ -61,6 +61,14 @@ SIGNATURES = {
     "nct_vgg19_features": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
     "nct_conv3x3_relu": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, _f32p, C.c_int]),
     "nct_maxpool2x2": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
+    "nct_params_default": (None, [C.c_void_p]),
+    "nct_bgr2lab_u8": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p]),
+    "nct_lab2bgr_u8": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p]),
+    "nct_resize_u8c3": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]),
+    "nct_resize_f64c3": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int, _f64p, C.c_int, C.c_int]),
+    "nct_cluster_features": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _i32p, C.POINTER(C.c_int)]),
+    "nct_knn_graph": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _f64p]),
+    "nct_local_color_transfer": (C.c_int, [C.c_void_p, _f32p, _u8p, _u8p, _u8p, _i32p, _f64p] + [C.c_int] * 5 + [C.c_void_p, _u8p, C.c_void_p]),
     "nct_pm_bench_setup": (C.c_int, [C.c_void_p, _f32p, _f32p] + [C.c_int] * 5),
     "nct_pm_bench_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
 }
@@ -75,6 +83,25 @@ def _declare(l):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Params(C.Structure):
+    """struct nct_params (include/nct.h)."""
+    _fields_ = [("bds_weight", C.c_double), ("eps", C.c_double), ("nonlocal_weight", C.c_double), ("local_weight", C.c_double),
+                ("wls_lambda_init", C.c_double), ("cluster_num", C.c_int), ("k_num", C.c_int), ("patch_size", C.c_int),
+                ("wls_alpha", C.c_double), ("pm_iters", C.c_int), ("seed", C.c_uint32)]
+
+    @staticmethod
+    def default():
+        p = Params()
+        lib().nct_params_default(C.byref(p))
+        return p
+
+
+class ColorStages(C.Structure):
+    """struct nct_color_stages (include/nct.h)."""
+    _fields_ = [("ab_local", C.c_void_p), ("ab_nonlocal", C.c_void_p), ("ab_up", C.c_void_p), ("roughness", C.c_void_p),
+                ("ab_wls", C.c_void_p), ("cg_iters", C.c_void_p), ("wls_iters", C.c_void_p)]
 
 
 class Context:
@@ -229,6 +256,66 @@ class Context:
         out = np.empty((c, (H - 1) // 2 + 1, (W - 1) // 2 + 1), np.float32)
         self._chk(self._l.nct_maxpool2x2(self._h, x, c, H, W, out))
         return out
+
+    # ---- colour stage
+    def bgr2lab(self, bgr):
+        a = np.ascontiguousarray(bgr, np.uint8)
+        out = np.empty_like(a)
+        self._chk(self._l.nct_bgr2lab_u8(self._h, a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3)))
+        return out
+
+    def lab2bgr(self, lab):
+        a = np.ascontiguousarray(lab, np.uint8)
+        out = np.empty_like(a)
+        self._chk(self._l.nct_lab2bgr_u8(self._h, a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3)))
+        return out
+
+    def resize_u8c3(self, img, dh, dw):
+        a = np.ascontiguousarray(img, np.uint8)
+        out = np.empty((dh, dw, 3), np.uint8)
+        self._chk(self._l.nct_resize_u8c3(self._h, a, a.shape[0], a.shape[1], out, dh, dw))
+        return out
+
+    def resize_f64c3(self, img, dh, dw):
+        a = np.ascontiguousarray(img, np.float64)
+        out = np.empty((dh, dw, 3), np.float64)
+        self._chk(self._l.nct_resize_f64c3(self._h, a, a.shape[0], a.shape[1], out, dh, dw))
+        return out
+
+    def cluster_features(self, feat_chw, K=10, iters=11, seed=1):
+        f = np.ascontiguousarray(feat_chw, np.float32)
+        Cc, h, w = f.shape
+        labels = np.empty((h, w), np.int32)
+        nl = C.c_int()
+        self._chk(self._l.nct_cluster_features(self._h, f, Cc, h, w, K, iters, seed, labels.reshape(-1), C.byref(nl)))
+        return labels, nl.value
+
+    def knn_graph(self, lab_u8, labels, nlabels, samples, k=8):
+        lab = np.ascontiguousarray(lab_u8, np.uint8)
+        h, w = lab.shape[:2]
+        lb = np.ascontiguousarray(labels, np.int32)
+        ids = np.empty((h * w, k), np.int32)
+        ws = np.empty((h * w, k), np.float64)
+        self._chk(self._l.nct_knn_graph(self._h, lab, h, w, lb.reshape(-1), lb.shape[0], lb.shape[1], nlabels, samples, k, ids.reshape(-1), ws.reshape(-1)))
+        return ids, ws
+
+    def local_color_transfer(self, err, s_level, g_level, s_full, knn_id, knn_w, layer, params=None, want_stages=False):
+        err = np.ascontiguousarray(err, np.float32)
+        h, w = err.shape
+        s_full = np.ascontiguousarray(s_full, np.uint8)
+        H, W = s_full.shape[:2]
+        prm = params or Params.default()
+        out = np.empty((H, W, 3), np.uint8)
+        st, keep = None, {}
+        if want_stages:
+            keep = {"ab_local": np.empty((2, h * w, 3)), "ab_nonlocal": np.empty((2, h * w, 3)), "ab_up": np.empty((2, H * W, 3)),
+                    "roughness": np.empty(H * W), "ab_wls": np.empty((2, H * W, 3)), "cg_iters": np.zeros(3, np.int32), "wls_iters": np.zeros(6, np.int32)}
+            st = ColorStages(*[keep[k].ctypes.data for k in ("ab_local", "ab_nonlocal", "ab_up", "roughness", "ab_wls", "cg_iters", "wls_iters")])
+        self._chk(self._l.nct_local_color_transfer(self._h, err.reshape(-1), np.ascontiguousarray(s_level, np.uint8).reshape(-1, 3),
+                                                   np.ascontiguousarray(g_level, np.uint8).reshape(-1, 3), s_full.reshape(-1, 3),
+                                                   np.ascontiguousarray(knn_id, np.int32).reshape(-1), np.ascontiguousarray(knn_w, np.float64).reshape(-1),
+                                                   layer, h, w, H, W, C.addressof(prm), out.reshape(-1, 3), C.addressof(st) if st else None))
+        return (out, keep) if want_stages else out
 
     # ---- measurement hooks
     def pm_bench_setup(self, a_chw, b_chw):

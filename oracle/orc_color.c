@@ -1,0 +1,546 @@
+/* oracle/orc_color.c — TEST INFRASTRUCTURE ONLY (see oracle/README.md). "parity unpinned" except where noted.
+ *
+ * CPU restatement of the local colour-transfer stage:
+ *   C1  clusterFeastures                 ColorTransfer.cpp:355-395 -> cvflann k-means  Flann/kmeans_index.h:700-880
+ *   K1  findKnns/getClusters/findSubKNNs/sortMergeComputeWeight   ColorTransfer.cpp:397-423, 273-353, 136-195, 60-110
+ *   T1  build_accumTable_downsample + stats loop                  ColorTransfer.cpp:425-455, 1194-1265
+ *   T2  weight map                                                ColorTransfer.cpp:1302-1357
+ *   S1  solve_nonlocal_downsample_gpu_gradient + solve_ls_cg_gpu  ColorTransfer.cpp:548-949, SparseSolver_GPU.cu:3-198
+ *   U1  upsample_color_coefficients_bilinear                      ColorTransfer.cpp:457-490
+ *   S2  solve_WLS_roughness_cpu + solve_direct_cpu (PARDISO)      ColorTransfer.cpp:951-1125, SparseSolver_CPU.cpp:104-286
+ *   A1  apply + Lab->BGR                                          ColorTransfer.cpp:1436-1469
+ *
+ * Documented divergences:
+ *  - k-means initial centres / kNN tie order: std::rand + std::random_shuffle are implementation defined (MSVC vs
+ *    libstdc++); here: SplitMix64 Fisher-Yates for the centres, and "k smallest by (dist, id)" per cluster for kNN
+ *    (consistent with the final cmpDist ordering, ColorTransfer.cpp:44,87). kNN is pinned against the reference's own
+ *    vendored nanoflann (oracle/_ref) up to ties.
+ *  - S1 applies A^T(Ax) with the explicitly assembled A (the reference forms A^T A with cusparseDcsrgemm; same
+ *    operator, different rounding order); same truncated un-preconditioned CG recurrence and iteration caps.
+ *  - S2 is solved exactly (banded Cholesky) for small grids and by Jacobi-PCG to 1e-13 relative residual otherwise;
+ *    the reference's PARDISO solve is exact too. Pinned against MKL PARDISO by tests/golden/gen_wls_pardiso.py.
+ *  - clusters with fewer than k+1 members: the reference asserts (ColorTransfer.cpp:107); here missing neighbours are
+ *    padded with self edges of weight 0.
+ */
+#include "orc_common.h"
+#include <stdio.h>
+
+/* ================================================================= C1: k-means labels */
+static inline uint64_t splitmix64(uint64_t* s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+/* cvflann::L2<float>::operator() with float data and double centres (Flann/dist.h:153-181): float accumulator,
+ * diff = (float)(a - b) evaluated in double, groups of 4. */
+static float l2_fd(const float* a, const double* b, int n) {
+    float result = 0;
+    int i = 0;
+    for (; i + 3 < n; i += 4) {
+        float d0 = (float)(a[i] - b[i]), d1 = (float)(a[i + 1] - b[i + 1]), d2 = (float)(a[i + 2] - b[i + 2]), d3 = (float)(a[i + 3] - b[i + 3]);
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    for (; i < n; ++i) { float d0 = (float)(a[i] - b[i]); result += d0 * d0; }
+    return result;
+}
+static float l2_ff(const float* a, const float* b, int n) {
+    float result = 0;
+    int i = 0;
+    for (; i + 3 < n; i += 4) {
+        float d0 = a[i] - b[i], d1 = a[i + 1] - b[i + 1], d2 = a[i + 2] - b[i + 2], d3 = a[i + 3] - b[i + 3];
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    for (; i < n; ++i) { float d0 = a[i] - b[i]; result += d0 * d0; }
+    return result;
+}
+
+/* features: n points x C (HWC, per-pixel L2-normalised conv5_1 of S, main.cu:139-165). Returns the number of labels
+ * (K, or 1 when the root cannot be split) and writes labels[n] in [0, K). */
+int orc_kmeans_labels(const float* feat, int n, int C, int K, int iters, uint64_t seed, int* labels) {
+    for (int i = 0; i < n; ++i) labels[i] = 0;
+    if (n < K) return 1;
+    /* chooseCentersRandom (kmeans_index.h:108-135) with a SplitMix64 Fisher-Yates permutation */
+    int* perm = (int*)malloc(sizeof(int) * n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    uint64_t st = seed;
+    for (int i = n - 1; i > 0; --i) { int j = (int)(splitmix64(&st) % (uint64_t)(i + 1)); int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
+    int* cidx = (int*)malloc(sizeof(int) * K);
+    int pos = 0, nc = 0;
+    for (int index = 0; index < K; ++index) {
+        int dup = 1;
+        while (dup) {
+            dup = 0;
+            if (pos >= n) goto centres_done;
+            cidx[index] = perm[pos++];
+            for (int j = 0; j < index; ++j)
+                if (l2_ff(feat + (size_t)cidx[index] * C, feat + (size_t)cidx[j] * C, C) < 1e-16) dup = 1;
+        }
+        nc = index + 1;
+    }
+centres_done:
+    free(perm);
+    if (nc < K) { free(cidx); return 1; }
+    double* dc = (double*)malloc(sizeof(double) * K * C);
+    for (int i = 0; i < K; ++i) for (int k = 0; k < C; ++k) dc[(size_t)i * C + k] = (double)feat[(size_t)cidx[i] * C + k];
+    free(cidx);
+    float* radius = (float*)calloc(K, sizeof(float));
+    int* count = (int*)calloc(K, sizeof(int));
+    int* bel = labels;
+    for (int i = 0; i < n; ++i) {
+        float sq = l2_fd(feat + (size_t)i * C, dc, C);
+        bel[i] = 0;
+        for (int j = 1; j < K; ++j) { float nsq = l2_fd(feat + (size_t)i * C, dc + (size_t)j * C, C); if (sq > nsq) { bel[i] = j; sq = nsq; } }
+        if (sq > radius[bel[i]]) radius[bel[i]] = sq;
+        count[bel[i]]++;
+    }
+    int converged = 0, iteration = 0;
+    while (!converged && iteration < iters) {
+        converged = 1; iteration++;
+        for (int i = 0; i < K; ++i) { memset(dc + (size_t)i * C, 0, sizeof(double) * C); radius[i] = 0; }
+        for (int i = 0; i < n; ++i) { const float* v = feat + (size_t)i * C; double* c = dc + (size_t)bel[i] * C; for (int k = 0; k < C; ++k) c[k] += v[k]; }
+        for (int i = 0; i < K; ++i) { int cnt = count[i]; for (int k = 0; k < C; ++k) dc[(size_t)i * C + k] /= cnt; }
+        for (int i = 0; i < n; ++i) {
+            float sq = l2_fd(feat + (size_t)i * C, dc, C);
+            int nc2 = 0;
+            for (int j = 1; j < K; ++j) { float nsq = l2_fd(feat + (size_t)i * C, dc + (size_t)j * C, C); if (sq > nsq) { nc2 = j; sq = nsq; } }
+            if (sq > radius[nc2]) radius[nc2] = sq;
+            if (nc2 != bel[i]) { count[bel[i]]--; count[nc2]++; bel[i] = nc2; converged = 0; }
+        }
+        for (int i = 0; i < K; ++i)
+            if (count[i] == 0) {
+                int j = (i + 1) % K;
+                while (count[j] <= 1) j = (j + 1) % K;
+                for (int k = 0; k < n; ++k)
+                    if (bel[k] == j && l2_fd(feat + (size_t)k * C, dc + (size_t)j * C, C) == radius[j]) { bel[k] = i; count[j]--; count[i]++; break; }
+                converged = 0;
+            }
+    }
+    free(dc); free(radius); free(count);
+    return K;
+}
+
+/* ================================================================= K1: kNN graph in Lab */
+typedef struct { double d; int id; } nn_t;
+static int nn_cmp(const void* a, const void* b) {
+    const nn_t* x = (const nn_t*)a; const nn_t* y = (const nn_t*)b;
+    if (x->d == y->d) return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);     /* cmpDist, ColorTransfer.cpp:44 */
+    return x->d < y->d ? -1 : 1;
+}
+
+/* membership of level pixels in (dilated) clusters — getClusters (ColorTransfer.cpp:273-353): a coarse cell belongs to
+ * its own label's cluster and to the cluster of every 4-neighbour with a different label. member[l*lh*lw + cell]. */
+static void cluster_membership(const int* labels, int lh, int lw, int nlabels, uint8_t* member) {
+    memset(member, 0, (size_t)nlabels * lh * lw);
+    for (int y = 0; y < lh; ++y)
+        for (int x = 0; x < lw; ++x) {
+            int id = y * lw + x, id0 = labels[id];
+            uint8_t* m = member + (size_t)id0 * lh * lw;
+            m[id] = 255;
+            if (x < lw - 1 && id0 != labels[id + 1]) m[id + 1] = 255;
+            if (x > 0 && id0 != labels[id - 1]) m[id - 1] = 255;
+            if (y < lh - 1 && id0 != labels[id + lw]) m[id + lw] = 255;
+            if (y > 0 && id0 != labels[id - lw]) m[id - lw] = 255;
+        }
+}
+
+/* lab: level image, HWC double (Lab8U/255). knn_id/knn_w: [h*w][k]. */
+void orc_knn_graph(const double* lab, int h, int w, const int* labels, int lh, int lw, int nlabels, int samples, int k,
+                   int* knn_id, double* knn_w) {
+    const int n = h * w;
+    uint8_t* member = (uint8_t*)malloc((size_t)nlabels * lh * lw);
+    cluster_membership(labels, lh, lw, nlabels, member);
+    /* per-pixel candidate lists gathered over all clusters the pixel belongs to: k nearest non-self per cluster */
+    nn_t* cand = (nn_t*)malloc(sizeof(nn_t) * (size_t)n * k * 5);      /* a pixel is in at most 5 clusters (own + 4 neighbours) */
+    int* ncand = (int*)calloc(n, sizeof(int));
+    int* ids = (int*)malloc(sizeof(int) * n);
+    for (int l = 0; l < nlabels; ++l) {
+        int m = 0;
+        for (int y = 0; y < lh; ++y)
+            for (int x = 0; x < lw; ++x)
+                if (member[(size_t)l * lh * lw + y * lw + x]) {        /* insertClusterPixel: the samples x samples block */
+                    int sx = x * samples, sy = y * samples, ex = sx + samples < w ? sx + samples : w, ey = sy + samples < h ? sy + samples : h;
+                    for (int yi = sy; yi < ey; ++yi) for (int xi = sx; xi < ex; ++xi) ids[m++] = yi * w + xi;
+                }
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int s = 0; s < m; ++s) {
+            const int id = ids[s];
+            const double* p = lab + (size_t)id * 3;
+            nn_t best[16]; int nb = 0;                                  /* k+1 smallest by (dist, id) over the cluster, self included */
+            for (int t = 0; t < m; ++t) {
+                const int jd = ids[t];
+                const double* q = lab + (size_t)jd * 3;
+                const double d0 = p[0] - q[0], d1 = p[1] - q[1], d2 = p[2] - q[2];
+                double d = sqrt(d0 * d0 + d1 * d1 + d2 * d2);          /* PointColor::kdtree_distance (non-squared) */
+                d = d > 0.0 ? d : 0.0;
+                nn_t e = {d, jd};
+                if (nb < k + 1) { int i = nb++; while (i > 0 && nn_cmp(&e, &best[i - 1]) < 0) { best[i] = best[i - 1]; --i; } best[i] = e; }
+                else if (nn_cmp(&e, &best[k]) < 0) { int i = k; while (i > 0 && nn_cmp(&e, &best[i - 1]) < 0) { best[i] = best[i - 1]; --i; } best[i] = e; }
+            }
+            int ni = 0;                                                 /* findSubKNNs: drop self, keep the first k */
+            for (int t = 0; t < nb; ++t)
+                if (best[t].id != id && ni < k) cand[((size_t)id * 5 + 0) * k + ncand[id] + ni++] = best[t];
+            ncand[id] += ni;
+        }
+    }
+    /* sortMergeComputeWeight: sort by (dist,id), dedupe ids, keep k, w = exp(1 - d/3) */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        nn_t* c = cand + (size_t)i * 5 * k;
+        qsort(c, ncand[i], sizeof(nn_t), nn_cmp);
+        int last_id = -1, lp = 0;
+        for (int t = 0; t < ncand[i] && lp < k; ++t)
+            if (c[t].id != last_id) { last_id = c[t].id; knn_id[(size_t)i * k + lp] = last_id; knn_w[(size_t)i * k + lp] = exp(1.0 - c[t].d / 3.0); lp++; }
+        for (; lp < k; ++lp) { knn_id[(size_t)i * k + lp] = i; knn_w[(size_t)i * k + lp] = 0.0; }      /* quirk 10: pad with zero-weight self edges */
+    }
+    free(member); free(cand); free(ncand); free(ids);
+}
+
+/* ================================================================= T1: local statistics -> initial (a, b) */
+/* cnt/stl: level-size Lab u8 HWC of S_l and G. a,b: [h*w][3] doubles. Window = clipped 3x3; integer sums are exact
+ * (the reference's 1-D prefix tables only ever take differences over <= 3-pixel row spans — SURVEY note on Long3). */
+void orc_local_stats(const uint8_t* cnt, const uint8_t* stl, int h, int w, int patch, double eps, double* a, double* b) {
+    const int left = -patch / 2, right = patch + left;
+    const double scale = 1.0 / 255.0;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int sx = x + left > 0 ? x + left : 0, sy = y + left > 0 ? y + left : 0;
+            int ex = x + right < w ? x + right : w, ey = y + right < h ? y + right : h;
+            int cSum = (ex - sx) * (ey - sy);
+            for (int c = 0; c < 3; ++c) {
+                long long cs = 0, cs2 = 0, ss = 0, ss2 = 0;
+                for (int yy = sy; yy < ey; ++yy)
+                    for (int xx = sx; xx < ex; ++xx) {
+                        int cv = cnt[((size_t)yy * w + xx) * 3 + c], sv = stl[((size_t)yy * w + xx) * 3 + c];
+                        cs += cv; cs2 += cv * cv; ss += sv; ss2 += sv * sv;
+                    }
+                double cm = cs / (double)cSum;
+                double cvr = cs2 / (double)cSum - cm * cm; cvr = cvr > 0.0 ? cvr : 0.0;
+                double csd = sqrt(cvr); csd = csd > 0.0 ? csd : 0.0;
+                double sm = ss / (double)cSum;
+                double svr = ss2 / (double)cSum - sm * sm; svr = svr > 0.0 ? svr : 0.0;
+                double ssd = sqrt(svr); ssd = ssd > 0.0 ? ssd : 0.0;
+                double av = ssd / (csd + eps);
+                a[((size_t)y * w + x) * 3 + c] = av;
+                b[((size_t)y * w + x) * 3 + c] = (sm - cm * av) * scale;
+            }
+        }
+}
+
+/* ================================================================= T2: confidence weights from the matching error */
+void orc_err_weight(const float* err, int n, double* weight) {
+    double mn = 1e8, mx = -(1e8);
+    for (int i = 0; i < n; ++i) { double e = err[i]; if (e < mn) mn = e; if (e > mx) mx = e; }
+    for (int i = 0; i < n; ++i) { double e = (err[i] - mn) / (mx - mn); double w = 1.0 - e; weight[i] = w > 1e-6 ? w : 1e-6; }
+}
+
+/* compute_gradientMat (2-arg form :519-546 and member form :492-517): g = sqrt(lamda / (|dL|^alpha + 1e-4)) */
+void orc_gradient_weights(const double* lab, int h, int w, double lamda, double alpha, double* gx, double* gy) {
+    const double epsilon = 0.0001;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            double val = lab[((size_t)y * w + x) * 3];
+            gx[y * w + x] = 0; gy[y * w + x] = 0;
+            if (x + 1 < w) { double g = lab[((size_t)y * w + x + 1) * 3] - val; gx[y * w + x] = sqrt(lamda / (pow(fabs(g), alpha) + epsilon)); }
+            if (y + 1 < h) { double g = lab[((size_t)(y + 1) * w + x) * 3] - val; gy[y * w + x] = sqrt(lamda / (pow(fabs(g), alpha) + epsilon)); }
+        }
+}
+
+/* ================================================================= S1: nonlocal least squares, truncated CG */
+typedef struct { int rows, nnz; int* rowptr; int* col; double* val[3]; double* rhs[3]; } csr3_t;
+
+static void csr3_matvec(const csr3_t* A, int ch, const double* x, double* y) {
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < A->rows; ++r) {
+        double s = 0;
+        for (int j = A->rowptr[r]; j < A->rowptr[r + 1]; ++j) s += A->val[ch][j] * x[A->col[j]];
+        y[r] = s;
+    }
+}
+static void csr3_matvec_t(const csr3_t* A, int ch, const double* y, double* x, int n) {
+    memset(x, 0, sizeof(double) * n);
+    for (int r = 0; r < A->rows; ++r)
+        for (int j = A->rowptr[r]; j < A->rowptr[r + 1]; ++j) x[A->col[j]] += A->val[ch][j] * y[r];
+}
+static double ddot(const double* a, const double* b, int n) { double s = 0; for (int i = 0; i < n; ++i) s += a[i] * b[i]; return s; }
+
+/* a,b: in (initial guess from T1) / out, [h*w][3]. src/ref: level Lab/255 doubles [h*w][3]. weight: [h*w].
+ * lambda/alpha/dWeight arrive as float in the reference's signature (ColorTransfer.cpp:548-550). iters_out (nullable)
+ * receives the number of CG iterations executed per channel. */
+void orc_nonlocal_solve(double* a, double* b, const double* src, const double* ref, const double* weight,
+                        const int* knn_id, const double* knn_w, int k, int h, int w, int layer,
+                        float lambda, float alpha, float dWeight, double nl_weight_cfg, double k_cfg, int* iters_out) {
+    const int n = h * w, size = 2 * n;
+    double* gx = (double*)malloc(sizeof(double) * n); double* gy = (double*)malloc(sizeof(double) * n);
+    orc_gradient_weights(src, h, w, (double)lambda, (double)alpha, gx, gy);
+    const double nonlocalWeight = sqrt(nl_weight_cfg / k_cfg);
+    const int max_rows = n + size * 4 + n * k * 2;
+    csr3_t A; A.rows = 0; A.nnz = 0;
+    A.rowptr = (int*)malloc(sizeof(int) * (max_rows + 1)); A.col = (int*)malloc(sizeof(int) * 2 * (size_t)max_rows);
+    for (int c = 0; c < 3; ++c) { A.val[c] = (double*)malloc(sizeof(double) * 2 * (size_t)max_rows); A.rhs[c] = (double*)calloc(max_rows, sizeof(double)); }
+    A.rowptr[0] = 0;
+#define PUSH2(c0, v0, c1, v1) do { A.col[A.nnz] = (c0); for (int c_ = 0; c_ < 3; ++c_) A.val[c_][A.nnz] = (v0)[c_]; A.nnz++; \
+                                   A.col[A.nnz] = (c1); for (int c_ = 0; c_ < 3; ++c_) A.val[c_][A.nnz] = (v1)[c_]; A.nnz++; A.rows++; A.rowptr[A.rows] = A.nnz; } while (0)
+    /* data term (:611-658) */
+    for (int i = 0; i < n; ++i) {
+        double dw = sqrt(weight[i]) * (double)sqrtf(dWeight);       /* sqrt(float) resolves to the float overload in C++ */
+        double v0[3], v1[3];
+        for (int c = 0; c < 3; ++c) { v0[c] = dw * src[(size_t)i * 3 + c]; v1[c] = dw; A.rhs[c][A.rows] = dw * ref[(size_t)i * 3 + c]; }
+        PUSH2(i, v0, n + i, v1);
+    }
+    /* local smoothness (:660-847): each neighbour direction present => every edge enters twice */
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int ai = y * w + x, bi = n + ai;
+            double m[3], p[3];
+            if (x + 1 < w) { double g = gx[y * w + x]; for (int c = 0; c < 3; ++c) { m[c] = -g; p[c] = g; } PUSH2(ai, m, ai + 1, p); PUSH2(bi, m, bi + 1, p); }
+            if (x - 1 >= 0) { double g = gx[y * w + x - 1]; for (int c = 0; c < 3; ++c) { m[c] = -g; p[c] = g; } PUSH2(ai - 1, m, ai, p); PUSH2(bi - 1, m, bi, p); }
+            if (y + 1 < h) { double g = gy[y * w + x]; for (int c = 0; c < 3; ++c) { m[c] = -g; p[c] = g; } PUSH2(ai, m, ai + w, p); PUSH2(bi, m, bi + w, p); }
+            if (y - 1 >= 0) { double g = gy[(y - 1) * w + x]; for (int c = 0; c < 3; ++c) { m[c] = -g; p[c] = g; } PUSH2(ai - w, m, ai, p); PUSH2(bi - w, m, bi, p); }
+        }
+    /* nonlocal smoothness (:849-911) */
+    for (int c0 = 0; c0 < n; ++c0)
+        for (int ki = 0; ki < k; ++ki) {
+            const int id1 = knn_id[(size_t)c0 * k + ki];
+            const double iw = sqrt(knn_w[(size_t)c0 * k + ki]) * nonlocalWeight;
+            double p[3] = {iw, iw, iw}, m[3] = {-iw, -iw, -iw};
+            const int lo = c0 < id1 ? c0 : id1, hi = c0 < id1 ? id1 : c0;
+            PUSH2(lo, p, hi, m);
+            PUSH2(n + lo, p, n + hi, m);
+        }
+#undef PUSH2
+    const double tol = 1e-6;
+    const int maxit = layer == 4 ? 50 : 100;
+    double* x = (double*)malloc(sizeof(double) * size); double* r = (double*)malloc(sizeof(double) * size);
+    double* p = (double*)malloc(sizeof(double) * size); double* Ap = (double*)malloc(sizeof(double) * size);
+    double* t = (double*)malloc(sizeof(double) * A.rows);
+    for (int c = 0; c < 3; ++c) {
+        for (int i = 0; i < n; ++i) { x[i] = a[(size_t)i * 3 + c]; x[n + i] = b[(size_t)i * 3 + c]; }
+        csr3_matvec_t(&A, c, A.rhs[c], r, size);                            /* A^T b */
+        csr3_matvec(&A, c, x, t); csr3_matvec_t(&A, c, t, Ap, size);        /* A^T A x0 */
+        for (int i = 0; i < size; ++i) r[i] -= Ap[i];
+        double r1 = ddot(r, r, size), r0 = 0;
+        int kk = 1;
+        while (r1 > tol * tol && kk <= maxit) {                             /* SparseSolver_GPU.cu:132-159 */
+            if (kk > 1) { double vb = r1 / r0; for (int i = 0; i < size; ++i) p[i] = vb * p[i] + r[i]; }
+            else memcpy(p, r, sizeof(double) * size);
+            csr3_matvec(&A, c, p, t); csr3_matvec_t(&A, c, t, Ap, size);
+            double dot = ddot(p, Ap, size);
+            double va = r1 / dot;
+            for (int i = 0; i < size; ++i) x[i] += va * p[i];
+            for (int i = 0; i < size; ++i) r[i] -= va * Ap[i];
+            r0 = r1; r1 = ddot(r, r, size);
+            kk++;
+        }
+        if (iters_out) iters_out[c] = kk - 1;
+        for (int i = 0; i < n; ++i) { a[(size_t)i * 3 + c] = x[i]; b[(size_t)i * 3 + c] = x[n + i]; }
+    }
+    free(x); free(r); free(p); free(Ap); free(t); free(gx); free(gy);
+    free(A.rowptr); free(A.col); for (int c = 0; c < 3; ++c) { free(A.val[c]); free(A.rhs[c]); }
+}
+
+/* ================================================================= U1: roughness mask after upsampling */
+/* a,b: full-res [H*W][3]; lab: m_cntLabD full-res. Only the LAST channel's test survives (:476-486, quirk 5). */
+void orc_roughness(const double* a, const double* b, const double* lab, int n, double* roughness) {
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            double nc = lab[(size_t)i * 3 + c] * a[(size_t)i * 3 + c] + b[(size_t)i * 3 + c];
+            roughness[i] = (nc < 0 || nc > 1) ? 1e-6 : 1.0;
+        }
+}
+
+/* ================================================================= S2: WLS smoothing of a and b at full resolution */
+/* System (ColorTransfer.cpp:996-1070): M = diag(r) + L,  L = 5-point graph Laplacian with edge weights gx^2, gy^2
+ * (pow(grad,2) of orc_gradient_weights on the full-res L channel); 6 right-hand sides r*a_c, r*b_c; a RHS whose
+ * coefficients are all exactly zero is skipped and its solution stays 0 (:1000-1030, SparseSolver_CPU.cpp:205-262). */
+void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha, const double* roughness,
+                    double* diag, double* wx /*edge (x,x+1)*/, double* wy /*edge (y,y+1)*/) {
+    const int n = H * W;
+    double* gx = (double*)malloc(sizeof(double) * n); double* gy = (double*)malloc(sizeof(double) * n);
+    orc_gradient_weights(lab, H, W, lamda, alpha, gx, gy);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int i = y * W + x;
+            double a00 = 0.0;
+            a00 += roughness[i];
+            wx[i] = 0; wy[i] = 0;
+            if (x + 1 < W) { double g = pow(gx[i], 2); a00 += g; wx[i] = g; }
+            if (x - 1 >= 0) { double g = pow(gx[i - 1], 2); a00 += g; }
+            if (y + 1 < H) { double g = pow(gy[i], 2); a00 += g; wy[i] = g; }
+            if (y - 1 >= 0) { double g = pow(gy[i - W], 2); a00 += g; }
+            diag[i] = a00;
+        }
+    free(gx); free(gy);
+}
+
+static void wls_apply(const double* diag, const double* wx, const double* wy, int H, int W, const double* x, double* y) {
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            const int i = r * W + c;
+            double s = diag[i] * x[i];
+            if (c + 1 < W) s -= wx[i] * x[i + 1];
+            if (c > 0) s -= wx[i - 1] * x[i - 1];
+            if (r + 1 < H) s -= wy[i] * x[i + W];
+            if (r > 0) s -= wy[i - W] * x[i - W];
+            y[i] = s;
+        }
+}
+
+/* exact: banded Cholesky (bandwidth W) — used when n*W*W is small enough */
+static int wls_solve_banded(const double* diag, const double* wx, const double* wy, int H, int W, const double* rhs, double* x, int nrhs) {
+    const int n = H * W, bw = W;
+    double* Lb = (double*)calloc((size_t)n * (bw + 1), sizeof(double));     /* Lb[i*(bw+1) + (i-j)] = L(i,j), j in [i-bw, i] */
+    if (!Lb) return -1;
+    for (int i = 0; i < n; ++i) {
+        Lb[(size_t)i * (bw + 1)] = diag[i];
+        if (i % W > 0) Lb[(size_t)i * (bw + 1) + 1] = -wx[i - 1];
+        if (i >= W) Lb[(size_t)i * (bw + 1) + bw] = -wy[i - W];
+    }
+    for (int j = 0; j < n; ++j) {
+        double d = Lb[(size_t)j * (bw + 1)];
+        int k0 = j - bw > 0 ? j - bw : 0;
+        for (int k = k0; k < j; ++k) { double l = Lb[(size_t)j * (bw + 1) + (j - k)]; d -= l * l; }
+        if (d <= 0) { free(Lb); return -2; }
+        d = sqrt(d);
+        Lb[(size_t)j * (bw + 1)] = d;
+        int imax = j + bw < n - 1 ? j + bw : n - 1;
+        for (int i = j + 1; i <= imax; ++i) {
+            double s = Lb[(size_t)i * (bw + 1) + (i - j)];
+            int kk0 = i - bw > k0 ? i - bw : k0;
+            for (int k = kk0; k < j; ++k) s -= Lb[(size_t)i * (bw + 1) + (i - k)] * Lb[(size_t)j * (bw + 1) + (j - k)];
+            Lb[(size_t)i * (bw + 1) + (i - j)] = s / d;
+        }
+    }
+    for (int q = 0; q < nrhs; ++q) {
+        const double* bq = rhs + (size_t)q * n; double* xq = x + (size_t)q * n;
+        for (int i = 0; i < n; ++i) {
+            double s = bq[i];
+            int k0 = i - bw > 0 ? i - bw : 0;
+            for (int k = k0; k < i; ++k) s -= Lb[(size_t)i * (bw + 1) + (i - k)] * xq[k];
+            xq[i] = s / Lb[(size_t)i * (bw + 1)];
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = xq[i];
+            int kmax = i + bw < n - 1 ? i + bw : n - 1;
+            for (int k = i + 1; k <= kmax; ++k) s -= Lb[(size_t)k * (bw + 1) + (k - i)] * xq[k];
+            xq[i] = s / Lb[(size_t)i * (bw + 1)];
+        }
+    }
+    free(Lb);
+    return 0;
+}
+
+static int wls_solve_pcg(const double* diag, const double* wx, const double* wy, int H, int W, const double* rhs, double* x, double rtol, int maxit) {
+    const int n = H * W;
+    double* r = (double*)malloc(sizeof(double) * n); double* z = (double*)malloc(sizeof(double) * n);
+    double* p = (double*)malloc(sizeof(double) * n); double* Ap = (double*)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; ++i) x[i] = rhs[i] / diag[i];
+    wls_apply(diag, wx, wy, H, W, x, Ap);
+    double bn = 0;
+    for (int i = 0; i < n; ++i) { r[i] = rhs[i] - Ap[i]; bn += rhs[i] * rhs[i]; }
+    if (bn == 0) { memset(x, 0, sizeof(double) * n); free(r); free(z); free(p); free(Ap); return 0; }
+    double rz = 0;
+    for (int i = 0; i < n; ++i) { z[i] = r[i] / diag[i]; p[i] = z[i]; rz += r[i] * z[i]; }
+    int it = 0;
+    for (; it < maxit; ++it) {
+        double rn = ddot(r, r, n);
+        if (rn <= rtol * rtol * bn) break;
+        wls_apply(diag, wx, wy, H, W, p, Ap);
+        double al = rz / ddot(p, Ap, n);
+        for (int i = 0; i < n; ++i) { x[i] += al * p[i]; r[i] -= al * Ap[i]; }
+        double rz2 = 0;
+        for (int i = 0; i < n; ++i) { z[i] = r[i] / diag[i]; rz2 += r[i] * z[i]; }
+        double be = rz2 / rz; rz = rz2;
+        for (int i = 0; i < n; ++i) p[i] = z[i] + be * p[i];
+    }
+    free(r); free(z); free(p); free(Ap);
+    return it;
+}
+
+/* a,b: full-res [H*W][3] in (x0) / out. Returns PCG iterations used (0 for the direct path), <0 on failure. */
+int orc_wls_solve(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, int force_pcg) {
+    const int n = H * W;
+    double* diag = (double*)malloc(sizeof(double) * n); double* wx = (double*)malloc(sizeof(double) * n); double* wy = (double*)malloc(sizeof(double) * n);
+    orc_wls_system(lab, H, W, lamda, alpha, roughness, diag, wx, wy);
+    double* rhs = (double*)calloc((size_t)6 * n, sizeof(double)); double* sol = (double*)calloc((size_t)6 * n, sizeof(double));
+    int nonzero[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            double av = a[(size_t)i * 3 + c], bv = b[(size_t)i * 3 + c];
+            if (av) { nonzero[c] = 1; rhs[(size_t)c * n + i] = roughness[i] * av; }
+            if (bv) { nonzero[3 + c] = 1; rhs[(size_t)(3 + c) * n + i] = roughness[i] * bv; }
+        }
+    int rc = 0;
+    const int direct = !force_pcg && ((double)n * W * W < 4e9);
+    if (direct) {
+        rc = wls_solve_banded(diag, wx, wy, H, W, rhs, sol, 6);
+        if (rc) fprintf(stderr, "orc_wls_solve: banded Cholesky failed (%d)\n", rc);
+    } else {
+        for (int q = 0; q < 6; ++q) { int it = nonzero[q] ? wls_solve_pcg(diag, wx, wy, H, W, rhs + (size_t)q * n, sol + (size_t)q * n, 1e-13, 200000) : 0; if (it > rc) rc = it; }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) { a[(size_t)i * 3 + c] = nonzero[c] ? sol[(size_t)c * n + i] : 0.0; b[(size_t)i * 3 + c] = nonzero[3 + c] ? sol[(size_t)(3 + c) * n + i] : 0.0; }
+    free(diag); free(wx); free(wy); free(rhs); free(sol);
+    return rc;
+}
+
+/* ================================================================= A1: apply the affine model, quantise (convertTo CV_8U, 255) */
+void orc_apply_coeffs(const double* a, const double* b, const double* lab, int n, uint8_t* lab_out) {
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            double v = lab[(size_t)i * 3 + c] * a[(size_t)i * 3 + c] + b[(size_t)i * 3 + c];
+            v = v > 0.0 ? v : 0.0; v = v < 1.0 ? v : 1.0;
+            long q = lrint(v * 255.0);                                       /* saturate_cast<uchar>(cvRound(v*255)) */
+            lab_out[(size_t)i * 3 + c] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+        }
+}
+
+/* ================================================================= composed level: transfer_color_downsample + getRes */
+void orc_bgr2lab_u8(const uint8_t* src, size_t npix, uint8_t* dst);
+void orc_lab2bgr_u8(const uint8_t* src, size_t npix, uint8_t* dst);
+void orc_resize_f64c3(const double* src, int sh, int sw, double* dst, int dh, int dw);
+void orc_u8_to_f64_scaled(const uint8_t* src, size_t n, double* dst);
+
+typedef struct { double eps, nonlocal_weight, local_weight, wls_lambda_init, wls_alpha, k_num; } orc_color_params;
+typedef struct { double *ab_local, *ab_nonlocal, *ab_up, *roughness, *ab_wls; int *cg_iters, *wls_iters; } orc_color_stages;
+
+/* Same contract as nct_local_color_transfer (include/nct.h). force_pcg != 0 makes S2 use the iterative path. */
+int orc_local_color_transfer(const float* err, const uint8_t* s_bgr_level, const uint8_t* g_bgr_level, const uint8_t* s_bgr_full,
+                             const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W, const orc_color_params* prm,
+                             uint8_t* out_bgr_full, const orc_color_stages* st, int force_pcg) {
+    const int n = h * w, N = H * W, k = (int)prm->k_num;
+    uint8_t* slab = (uint8_t*)malloc((size_t)n * 3); uint8_t* glab = (uint8_t*)malloc((size_t)n * 3); uint8_t* sflab = (uint8_t*)malloc((size_t)N * 3);
+    orc_bgr2lab_u8(s_bgr_level, n, slab); orc_bgr2lab_u8(g_bgr_level, n, glab); orc_bgr2lab_u8(s_bgr_full, N, sflab);
+    double* src = (double*)malloc(sizeof(double) * 3 * n); double* ref = (double*)malloc(sizeof(double) * 3 * n); double* full = (double*)malloc(sizeof(double) * 3 * N);
+    orc_u8_to_f64_scaled(slab, (size_t)n * 3, src); orc_u8_to_f64_scaled(glab, (size_t)n * 3, ref); orc_u8_to_f64_scaled(sflab, (size_t)N * 3, full);
+    double* a = (double*)malloc(sizeof(double) * 3 * n); double* b = (double*)malloc(sizeof(double) * 3 * n); double* wgt = (double*)malloc(sizeof(double) * n);
+    orc_local_stats(slab, glab, h, w, 3, prm->eps, a, b);
+    if (st && st->ab_local) { memcpy(st->ab_local, a, sizeof(double) * 3 * n); memcpy(st->ab_local + (size_t)3 * n, b, sizeof(double) * 3 * n); }
+    orc_err_weight(err, n, wgt);
+    const double normFactor = (double)(W * H) / (double)(w * h);
+    int cg[3];
+    orc_nonlocal_solve(a, b, src, ref, wgt, knn_id, knn_w, k, h, w, layer, (float)prm->local_weight, (float)prm->wls_alpha, (float)normFactor,
+                       prm->nonlocal_weight, prm->k_num, cg);
+    if (st && st->cg_iters) memcpy(st->cg_iters, cg, sizeof cg);
+    if (st && st->ab_nonlocal) { memcpy(st->ab_nonlocal, a, sizeof(double) * 3 * n); memcpy(st->ab_nonlocal + (size_t)3 * n, b, sizeof(double) * 3 * n); }
+    double* A = (double*)malloc(sizeof(double) * 3 * N); double* B = (double*)malloc(sizeof(double) * 3 * N); double* rough = (double*)malloc(sizeof(double) * N);
+    if (W > w || H > h) { orc_resize_f64c3(a, h, w, A, H, W); orc_resize_f64c3(b, h, w, B, H, W); }
+    else { memcpy(A, a, sizeof(double) * 3 * N); memcpy(B, b, sizeof(double) * 3 * N); }
+    orc_roughness(A, B, full, N, rough);
+    if (st && st->ab_up) { memcpy(st->ab_up, A, sizeof(double) * 3 * N); memcpy(st->ab_up + (size_t)3 * N, B, sizeof(double) * 3 * N); }
+    if (st && st->roughness) memcpy(st->roughness, rough, sizeof(double) * N);
+    double lamda = prm->wls_lambda_init * normFactor;
+    if (h == H && w == W) lamda *= 4;
+    int it = orc_wls_solve(A, B, full, H, W, lamda, prm->wls_alpha, rough, force_pcg);
+    if (st && st->wls_iters) for (int q = 0; q < 6; ++q) st->wls_iters[q] = it;
+    if (st && st->ab_wls) { memcpy(st->ab_wls, A, sizeof(double) * 3 * N); memcpy(st->ab_wls + (size_t)3 * N, B, sizeof(double) * 3 * N); }
+    uint8_t* olab = (uint8_t*)malloc((size_t)N * 3);
+    orc_apply_coeffs(A, B, full, N, olab);
+    orc_lab2bgr_u8(olab, N, out_bgr_full);
+    free(slab); free(glab); free(sflab); free(src); free(ref); free(full); free(a); free(b); free(wgt); free(A); free(B); free(rough); free(olab);
+    return it < 0 ? it : 0;
+}

@@ -94,6 +94,88 @@ class Oracle:
         self.l.orc_vgg19_features(img, h, w, wp, bp, deepest_tap, tp, _ptr(dims))
         return outs
 
+    # ---- colour stage (orc_cvt.c, orc_color.c)
+    def _decl_color(self):
+        l = self.l
+        if getattr(self, "_color_declared", False):
+            return
+        l.orc_bgr2lab_u8.argtypes = [_u8p, C.c_size_t, _u8p]
+        l.orc_lab2bgr_u8.argtypes = [_u8p, C.c_size_t, _u8p]
+        l.orc_resize_u8c3.argtypes = [_u8p, I, I, _u8p, I, I]
+        l.orc_resize_f64c3.argtypes = [_f64p, I, I, _f64p, I, I]
+        l.orc_kmeans_labels.argtypes = [_f32p, I, I, I, I, C.c_uint64, _i32p]
+        l.orc_kmeans_labels.restype = I
+        l.orc_knn_graph.argtypes = [_f64p, I, I, _i32p, I, I, I, I, I, _i32p, _f64p]
+        l.orc_local_color_transfer.argtypes = [_f32p, _u8p, _u8p, _u8p, _i32p, _f64p, I, I, I, I, I, C.c_void_p, _u8p, C.c_void_p, I]
+        l.orc_local_color_transfer.restype = I
+        l.orc_wls_solve.argtypes = [_f64p, _f64p, _f64p, I, I, C.c_double, C.c_double, _f64p, I]
+        l.orc_wls_solve.restype = I
+        l.orc_wls_system.argtypes = [_f64p, I, I, C.c_double, C.c_double, _f64p, _f64p, _f64p, _f64p]
+        self._color_declared = True
+
+    def bgr2lab(self, bgr):
+        self._decl_color()
+        a = np.ascontiguousarray(bgr, np.uint8); out = np.empty_like(a)
+        self.l.orc_bgr2lab_u8(a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3))
+        return out
+
+    def lab2bgr(self, lab):
+        self._decl_color()
+        a = np.ascontiguousarray(lab, np.uint8); out = np.empty_like(a)
+        self.l.orc_lab2bgr_u8(a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3))
+        return out
+
+    def resize_u8c3(self, img, dh, dw):
+        self._decl_color()
+        a = np.ascontiguousarray(img, np.uint8); out = np.empty((dh, dw, 3), np.uint8)
+        self.l.orc_resize_u8c3(a, a.shape[0], a.shape[1], out, dh, dw)
+        return out
+
+    def resize_f64c3(self, img, dh, dw):
+        self._decl_color()
+        a = np.ascontiguousarray(img, np.float64); out = np.empty((dh, dw, 3), np.float64)
+        self.l.orc_resize_f64c3(a, a.shape[0], a.shape[1], out, dh, dw)
+        return out
+
+    def cluster_features(self, feat_chw, K=10, iters=11, seed=1):
+        """Same contract as nct_cluster_features: un-normalised CHW in, labels out (normalisation = orc_feat_normalize)."""
+        self._decl_color()
+        f = self.feat_normalize(feat_chw)
+        Cc, h, w = f.shape
+        hwc = np.ascontiguousarray(f.reshape(Cc, h * w).T)
+        labels = np.empty(h * w, np.int32)
+        nl = self.l.orc_kmeans_labels(hwc, h * w, Cc, K, iters, seed, labels)
+        return labels.reshape(h, w), nl
+
+    def knn_graph(self, lab_u8, labels, nlabels, samples, k=8):
+        self._decl_color()
+        lab = np.ascontiguousarray(lab_u8, np.uint8)
+        h, w = lab.shape[:2]
+        labd = lab.astype(np.float64) * (1.0 / 255.0)
+        lb = np.ascontiguousarray(labels, np.int32)
+        ids = np.empty((h * w, k), np.int32); ws = np.empty((h * w, k), np.float64)
+        self.l.orc_knn_graph(labd.reshape(-1), h, w, lb.reshape(-1), lb.shape[0], lb.shape[1], nlabels, samples, k, ids.reshape(-1), ws.reshape(-1))
+        return ids, ws
+
+    def local_color_transfer(self, err, s_level, g_level, s_full, knn_id, knn_w, layer, params=None, want_stages=False, force_pcg=False):
+        self._decl_color()
+        err = np.ascontiguousarray(err, np.float32)
+        h, w = err.shape
+        s_full = np.ascontiguousarray(s_full, np.uint8)
+        H, W = s_full.shape[:2]
+        p = params or dict(eps=0.60, nonlocal_weight=2.0, local_weight=0.125, wls_lambda_init=0.024, wls_alpha=1.2, k_num=8.0)
+        prm = (C.c_double * 6)(p["eps"], p["nonlocal_weight"], p["local_weight"], p["wls_lambda_init"], p["wls_alpha"], p["k_num"])
+        out = np.empty((H, W, 3), np.uint8)
+        keep = {"ab_local": np.empty((2, h * w, 3)), "ab_nonlocal": np.empty((2, h * w, 3)), "ab_up": np.empty((2, H * W, 3)),
+                "roughness": np.empty(H * W), "ab_wls": np.empty((2, H * W, 3)), "cg_iters": np.zeros(3, np.int32), "wls_iters": np.zeros(6, np.int32)}
+        st = (C.c_void_p * 7)(*[keep[k].ctypes.data for k in ("ab_local", "ab_nonlocal", "ab_up", "roughness", "ab_wls", "cg_iters", "wls_iters")])
+        rc = self.l.orc_local_color_transfer(err.reshape(-1), np.ascontiguousarray(s_level, np.uint8).reshape(-1, 3),
+                                             np.ascontiguousarray(g_level, np.uint8).reshape(-1, 3), s_full.reshape(-1, 3),
+                                             np.ascontiguousarray(knn_id, np.int32).reshape(-1), np.ascontiguousarray(knn_w, np.float64).reshape(-1),
+                                             layer, h, w, H, W, C.addressof(prm), out.reshape(-1, 3), C.addressof(st), 1 if force_pcg else 0)
+        assert rc == 0
+        return (out, keep) if want_stages else out
+
     def feat_normalize(self, src, want_resp=False):
         src = np.ascontiguousarray(src, np.float32)
         Cc, H, W = src.shape

@@ -1,0 +1,105 @@
+"""GPU parity for the colour stage (A1/OpenCV restatements, C1, K1, T1, T2, S1, U1, S2) vs the CPU oracle.
+Bars: bit-exact for u8 images, labels, neighbour ids and the local statistics; fp64 solver outputs within the tolerance
+written at each assert (the reduction order of dot products differs between GPU tree reductions and the oracle's
+sequential sums; the truncated CG amplifies that over its 50/100 iterations)."""
+import numpy as np
+import pytest
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lab_conversions_exact(ctx, oracle):
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (50000, 3)).astype(np.uint8)
+    lab = ctx.bgr2lab(x)
+    assert np.array_equal(lab, oracle.bgr2lab(x))
+    allc = np.stack(np.meshgrid(np.arange(0, 256, 5), np.arange(0, 256, 5), np.arange(0, 256, 5), indexing="ij"), -1).reshape(-1, 3).astype(np.uint8)
+    assert np.array_equal(ctx.bgr2lab(allc), oracle.bgr2lab(allc))
+    back_g, back_o = ctx.lab2bgr(lab), oracle.lab2bgr(lab)
+    # float path (spline inverse gamma): identical formula; allow <=1 LSB on a vanishing fraction from fma/rounding differences
+    d = np.abs(back_g.astype(int) - back_o.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert np.array_equal(ctx.lab2bgr(allc), oracle.lab2bgr(allc)) or np.abs(ctx.lab2bgr(allc).astype(int) - oracle.lab2bgr(allc).astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("dims", [(700, 700, 350, 350), (175, 175, 88, 88), (113, 170, 57, 85), (60, 47, 31, 23), (30, 40, 30, 40), (452, 680, 226, 340)])
+def test_resize_u8_exact(ctx, oracle, dims):
+    sh, sw, dh, dw = dims
+    img = synth.image(5, sh, sw)
+    assert np.array_equal(ctx.resize_u8c3(img, dh, dw), oracle.resize_u8c3(img, dh, dw))
+
+
+@pytest.mark.parametrize("dims", [(44, 44, 700, 700), (88, 88, 175, 175), (12, 17, 100, 90), (29, 43, 452, 680)])
+def test_resize_f64_exact(ctx, oracle, dims):
+    sh, sw, dh, dw = dims
+    src = np.random.default_rng(1).random((sh, sw, 3))
+    g, o = ctx.resize_f64c3(src, dh, dw), oracle.resize_f64c3(src, dh, dw)
+    assert np.array_equal(g.view(np.uint64), o.view(np.uint64))
+
+
+@pytest.mark.parametrize("shape", [(512, 16, 16), (512, 44, 44), (64, 9, 11), (512, 3, 3)])
+def test_kmeans_labels_exact(ctx, oracle, shape):
+    f = synth.features(3, *shape) * np.float32(5.0)
+    for seed in (1, 99):
+        gl, gn = ctx.cluster_features(f, 10, 11, seed)
+        ol, on = oracle.cluster_features(f, 10, 11, seed)
+        assert gn == on and np.array_equal(gl, ol)
+
+
+def test_kmeans_blobs(ctx, oracle):
+    rng = np.random.default_rng(5)
+    blobs = rng.standard_normal((7, 64)).astype(np.float32) * 3
+    pts = np.abs(np.concatenate([blobs[i] + 0.3 * rng.standard_normal((36, 64)).astype(np.float32) for i in range(7)])) + 0.1
+    f = np.ascontiguousarray(pts.T.reshape(64, 12, 21))
+    gl, gn = ctx.cluster_features(f)
+    ol, on = oracle.cluster_features(f)
+    assert gn == on == 10 and np.array_equal(gl, ol)
+
+
+@pytest.mark.parametrize("case", [(12, 14, 6, 7, 2), (32, 32, 16, 16, 2), (64, 60, 16, 15, 4), (40, 40, 5, 5, 8)])
+def test_knn_graph(ctx, oracle, case):
+    h, w, lh, lw, samples = case
+    img = synth.image(9, h, w)
+    img[: h // 3, : w // 3] = (90, 120, 40)              # a flat region: many exact-distance ties
+    lab = oracle.bgr2lab(img)
+    rng = np.random.default_rng(3)
+    labels = rng.integers(0, 4, (lh, lw)).astype(np.int32)
+    labels[lh // 2:, :] = 4
+    gi, gw = ctx.knn_graph(lab, labels, 5, samples)
+    oi, ow = oracle.knn_graph(lab, labels, 5, samples)
+    assert np.array_equal(gi, oi)
+    assert np.allclose(gw, ow, rtol=1e-14, atol=0)
+
+
+def _level_case(seed, H, W, h, w, nlab_grid, samples, oracle):
+    s_full = synth.image(seed, H, W)
+    s_lvl = oracle.resize_u8c3(s_full, h, w) if (h, w) != (H, W) else s_full
+    g_lvl = oracle.resize_u8c3(synth.image(seed + 1, H, W), h, w)
+    lh, lw = nlab_grid
+    labels = (np.arange(lh * lw).reshape(lh, lw) % 3).astype(np.int32)
+    ids, ws = oracle.knn_graph(oracle.bgr2lab(s_lvl), labels, 3, samples)
+    err = -np.random.default_rng(seed).random((h, w)).astype(np.float32)
+    return err, s_lvl, g_lvl, s_full, ids, ws
+
+
+@pytest.mark.parametrize("case", [(48, 48, 12, 12, (3, 3), 4, 2), (40, 56, 20, 28, (5, 7), 4, 3), (32, 32, 32, 32, (2, 2), 16, 4)])
+def test_local_color_transfer_stages(ctx, oracle, case):
+    H, W, h, w, grid, samples, layer = case
+    err, s_lvl, g_lvl, s_full, ids, ws = _level_case(20 + layer, H, W, h, w, grid, samples, oracle)
+    go, gs = ctx.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
+    oo, os_ = oracle.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
+    # T1: closed-form statistics — same fp64 expression order => bit exact
+    assert np.array_equal(gs["ab_local"].view(np.uint64), os_["ab_local"].view(np.uint64))
+    # S1: same truncated CG recurrence, iteration cap reached on both sides
+    assert gs["cg_iters"].tolist() == os_["cg_iters"].tolist() == [50 if layer == 4 else 100] * 3
+    assert np.allclose(gs["ab_nonlocal"], os_["ab_nonlocal"], rtol=1e-7, atol=1e-9)
+    assert np.allclose(gs["ab_up"], os_["ab_up"], rtol=1e-7, atol=1e-9)
+    assert np.array_equal(gs["roughness"], os_["roughness"])
+    # S2: both converged solvers of the same SPD system (oracle: exact banded Cholesky)
+    assert np.allclose(gs["ab_wls"], os_["ab_wls"], rtol=1e-6, atol=1e-8)
+    # A1: 8-bit output — allow isolated 1-LSB flips from the 1e-7 coefficient differences
+    d = np.abs(go.astype(int) - oo.astype(int))
+    assert d.max() <= 2 and (d > 0).mean() < 0.01
+    mse = (d.astype(float) ** 2).mean()
+    assert mse == 0 or 10 * np.log10(255 ** 2 / mse) > 60

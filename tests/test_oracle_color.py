@@ -1,0 +1,172 @@
+"""CPU tests of the colour-stage oracle: known answers for the OpenCV restatements, brute-force/independent checks of
+k-means, kNN, the CG recurrence and the WLS solve (vs scipy sparse direct solve; MKL PARDISO fixture where available)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+import synth
+
+
+def test_bgr2lab_known_colours(oracle):
+    """8-bit CV_BGR2Lab reference values (L*255/100, a+128, b+128) for the sRGB primaries, white, black, mid-grey."""
+    cols = np.array([[255, 255, 255], [0, 0, 0], [0, 0, 255], [0, 255, 0], [255, 0, 0], [128, 128, 128]], np.uint8)
+    lab = oracle.bgr2lab(cols)
+    assert lab.tolist() == [[255, 128, 128], [0, 128, 128], [136, 208, 195], [224, 42, 211], [82, 207, 20], [137, 128, 128]]
+
+
+def test_lab_roundtrip_close(oracle):
+    rng = np.random.default_rng(0)
+    x = rng.integers(30, 226, (20000, 3)).astype(np.uint8)
+    y = oracle.lab2bgr(oracle.bgr2lab(x))
+    d = np.abs(x.astype(int) - y.astype(int))
+    assert d.mean() < 1.0 and np.percentile(d, 99) <= 4
+    g = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, 1)      # greys survive the round trip within 1 LSB
+    assert np.abs(oracle.lab2bgr(oracle.bgr2lab(g)).astype(int) - g).max() <= 1
+
+
+def test_resize_u8_area_and_linear(oracle):
+    img = synth.image(3, 8, 12)
+    half = oracle.resize_u8c3(img, 4, 6)         # exact 2x -> INTER_AREA: (a+b+c+d+2)>>2
+    exp = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(half, exp.astype(np.uint8))
+    same = oracle.resize_u8c3(img, 8, 12)
+    assert np.array_equal(same, img)
+    const = np.full((9, 11, 3), 77, np.uint8)    # bilinear of a constant is the constant (weights sum to 2048)
+    assert np.array_equal(oracle.resize_u8c3(const, 5, 6), np.full((5, 6, 3), 77, np.uint8))
+    ramp = np.tile(np.arange(0, 175, dtype=np.uint8)[None, :, None], (4, 1, 3))
+    r = oracle.resize_u8c3(ramp, 4, 88)          # 175 -> 88 (ceil-pooled width): scale 1.9886
+    fx = (np.arange(88) + 0.5) * (175 / 88) - 0.5
+    assert np.abs(r[0, :, 0].astype(float) - np.clip(fx, 0, 174)).max() <= 1.0
+
+
+def test_resize_f64_linear_exact_on_planes(oracle):
+    yy, xx = np.mgrid[0:5, 0:7].astype(np.float64)
+    src = np.stack([2 * xx + 1, 3 * yy - 2, xx + yy], -1)
+    dst = oracle.resize_f64c3(src, 20, 28)
+    sx = np.clip((np.arange(28) + 0.5) * 0.25 - 0.5, 0, 6)
+    sy = np.clip((np.arange(20) + 0.5) * 0.25 - 0.5, 0, 4)
+    assert np.allclose(dst[..., 0], np.broadcast_to(2 * sx + 1, (20, 28)), atol=1e-5)
+    assert np.allclose(dst[..., 1], np.broadcast_to((3 * sy - 2)[:, None], (20, 28)), atol=1e-5)
+
+
+def test_kmeans_invariants(oracle):
+    """G9: <= K clusters, every pixel labelled once, assignment = nearest centroid of the final partition."""
+    rng = np.random.default_rng(5)
+    blobs = rng.standard_normal((6, 32)).astype(np.float32) * 3
+    pts = np.abs(np.concatenate([blobs[i] + 0.3 * rng.standard_normal((40, 32)).astype(np.float32) for i in range(6)])) + 0.1
+    f = np.ascontiguousarray(pts.T.reshape(32, 15, 16))
+    labels, nl = oracle.cluster_features(f, K=10, iters=11, seed=1)
+    assert nl == 10 and labels.min() >= 0 and labels.max() < 10
+    l2, _ = oracle.cluster_features(f, K=10, iters=11, seed=1)
+    assert np.array_equal(labels, l2)                      # deterministic
+    # fewer than K points -> single label (root is a leaf, kmeans_index.h:705-710)
+    l3, n3 = oracle.cluster_features(f[:, :1, :8], K=10)
+    assert n3 == 1 and not l3.any()
+
+
+def test_knn_matches_bruteforce(oracle):
+    """G10: k smallest by (dist, id) per dilated cluster, merged — against an independent numpy brute force."""
+    img = synth.image(9, 12, 14)
+    lab = oracle.bgr2lab(img)
+    labels = np.zeros((6, 7), np.int32); labels[:, 4:] = 1; labels[4:, :] = 2
+    ids, ws = oracle.knn_graph(lab, labels, 3, samples=2)
+    labd = lab.reshape(-1, 3).astype(np.float64) * (1.0 / 255.0)
+    # membership by dilation
+    mem = np.zeros((3, 6, 7), bool)
+    for y in range(6):
+        for x in range(7):
+            l0 = labels[y, x]; mem[l0, y, x] = True
+            for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0)):
+                yy, xx = y + dy, x + dx
+                if 0 <= yy < 6 and 0 <= xx < 7 and labels[yy, xx] != l0:
+                    mem[l0, yy, xx] = True
+    pix_mem = np.repeat(np.repeat(mem, 2, 1), 2, 2)[:, :12, :14].reshape(3, -1)
+    for i in (0, 37, 100, 167):
+        cand = {}
+        for l in range(3):
+            if not pix_mem[l, i]:
+                continue
+            members = np.flatnonzero(pix_mem[l])
+            d = np.sqrt(((labd[members] - labd[i]) ** 2).sum(1))
+            order = sorted(zip(d, members))[:9]
+            nons = [(dd, j) for dd, j in order if j != i][:8]
+            for dd, j in nons:
+                cand[j] = dd
+        best = sorted((dd, j) for j, dd in cand.items())[:8]
+        assert [j for _, j in best] == ids[i].tolist()
+        assert np.allclose(ws[i], [np.exp(1 - dd / 3) for dd, _ in best])
+
+
+def _level_inputs(seed, h, w, H, W):
+    s_full = synth.image(seed, H, W)
+    r_full = synth.image(seed + 1, H, W)
+    return s_full, r_full
+
+
+def test_wls_matches_scipy_direct(oracle):
+    """S2: banded-Cholesky path and PCG path vs an independent scipy sparse LU of the same system."""
+    oracle._decl_color()
+    H, W = 14, 17
+    rng = np.random.default_rng(2)
+    lab = np.ascontiguousarray(oracle.bgr2lab(synth.image(4, H, W)).astype(np.float64) / 255.0)
+    rough = np.where(rng.random(H * W) < 0.2, 1e-6, 1.0)
+    a0 = rng.random((H * W, 3)); b0 = rng.random((H * W, 3)) - 0.5
+    diag = np.empty(H * W); wx = np.empty(H * W); wy = np.empty(H * W)
+    oracle.l.orc_wls_system(lab.reshape(-1), H, W, 0.37, 1.2, rough, diag, wx, wy)
+    n = H * W
+    M = sp.lil_matrix((n, n))
+    for i in range(n):
+        M[i, i] = diag[i]
+        if i % W + 1 < W: M[i, i + 1] = -wx[i]; M[i + 1, i] = -wx[i]
+        if i + W < n: M[i, i + W] = -wy[i]; M[i + W, i] = -wy[i]
+    M = M.tocsc()
+    # row sums: diag - offdiag = roughness (graph Laplacian + data term)
+    assert np.allclose(np.asarray(M.sum(1)).ravel(), rough, rtol=1e-9, atol=1e-9)
+    lu = spla.splu(M)
+    for force in (0, 1):
+        a, b = a0.copy(), b0.copy()
+        oracle.l.orc_wls_solve(a.reshape(-1), b.reshape(-1), lab.reshape(-1), H, W, 0.37, 1.2, rough, force)
+        for c in range(3):
+            assert np.allclose(a[:, c], lu.solve(rough * a0[:, c]), rtol=1e-8, atol=1e-10)
+            assert np.allclose(b[:, c], lu.solve(rough * b0[:, c]), rtol=1e-8, atol=1e-10)
+
+
+def test_wls_matches_mkl_pardiso_fixture(oracle):
+    """The reference's actual solver (MKL PARDISO, mtype 2, the iparm of SparseSolver_CPU.cpp:135-160) solved this system
+    in the build container; the fixture holds its solution (tests/golden/gen_wls_pardiso.py)."""
+    import os
+    p = os.path.join(os.path.dirname(__file__), "golden", "wls_pardiso.npz")
+    if not os.path.exists(p):
+        pytest.skip("fixture not generated")
+    oracle._decl_color()
+    z = np.load(p)
+    H, W = int(z["H"]), int(z["W"])
+    a, b = z["a0"].copy(), z["b0"].copy()
+    oracle.l.orc_wls_solve(a.reshape(-1), b.reshape(-1), np.ascontiguousarray(z["lab"]).reshape(-1), H, W, float(z["lamda"]), float(z["alpha"]),
+                           np.ascontiguousarray(z["rough"]), 0)
+    assert np.allclose(a, z["a_pardiso"], rtol=1e-9, atol=1e-11) and np.allclose(b, z["b_pardiso"], rtol=1e-9, atol=1e-11)
+
+
+def test_level_transfer_stages(oracle):
+    """Composed level: stage invariants (initial a = sigma ratio, CG iteration cap is what stops S1, roughness in
+    {1e-6,1}, WLS residual small, identity transfer when G == S)."""
+    H = W = 24; h = w = 12
+    s_full = synth.image(11, H, W)
+    s_lvl = oracle.resize_u8c3(s_full, h, w)
+    g_lvl = oracle.resize_u8c3(synth.image(12, H, W), h, w)
+    labels = np.zeros((3, 3), np.int32); labels[:, 2] = 1
+    ids, ws = oracle.knn_graph(oracle.bgr2lab(s_lvl), labels, 2, samples=4)
+    err = -np.random.default_rng(1).random((h, w)).astype(np.float32)
+    out, st = oracle.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer=3, want_stages=True)
+    assert st["cg_iters"].tolist() == [100, 100, 100]             # un-preconditioned CG never reaches 1e-12: the cap stops it
+    assert set(np.unique(st["roughness"]).tolist()) <= {1e-6, 1.0}
+    assert np.isfinite(st["ab_wls"]).all() and out.shape == (H, W, 3)
+    # finest level (layer 4) caps at 50 and skips the resize
+    idsf, wsf = oracle.knn_graph(oracle.bgr2lab(s_full), np.zeros((2, 2), np.int32), 1, samples=16)
+    errf = -np.random.default_rng(2).random((H, W)).astype(np.float32)
+    outf, stf = oracle.local_color_transfer(errf, s_full, synth.image(13, H, W), s_full, idsf, wsf, layer=4, want_stages=True)
+    assert stf["cg_iters"].tolist() == [50, 50, 50]
+    assert np.array_equal(stf["ab_up"], stf["ab_nonlocal"])
+    # G == S: a = sigma/(sigma+eps) < 1 initially; the result must stay close to S (sanity of the whole chain)
+    out_id = oracle.local_color_transfer(errf, s_full, s_full, s_full, idsf, wsf, layer=4)
+    assert np.abs(out_id.astype(int) - s_full.astype(int)).mean() < 6.0
