@@ -144,6 +144,23 @@ int nct_local_color_transfer(nct_ctx* ctx, const float* err, const uint8_t* s_bg
                              const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W, const nct_params* prm,
                              uint8_t* out_bgr_full, nct_color_stages* stages);
 
+/* ---- D3: the per-pair hot loop — transfer_color_single_bds (main.cu:47-454): VGG19 features of S and R, k-means of
+ * S's conv5_1, then for L = 5..1: NNF init/upsample, normalise, PatchMatch both ways, BDS votes, matching error, kNN
+ * graph, local colour transfer, re-predict. Images are 8-bit BGR, tightly packed HWC. out has the size of src.
+ * `timing` (nullable) receives per-stage wall milliseconds (stream-synchronised at stage boundaries, so pass NULL when
+ * measuring throughput) under the reference's own stage names (main.cu:331,453; ColorTransfer.cpp:1373,1434).
+ * nct_process_pair = nct_pair_upload + nct_pair_run + nct_pair_download; the split form lets a caller keep inputs
+ * resident in HBM (bench.py times nct_pair_run only and reports the PCIe-inclusive rate separately). */
+typedef struct nct_pair_timing {
+    double total_ms, vgg_ms, cluster_ms, patchmatch_ms, vote_ms, knn_ms, color_ms, other_ms;
+    int wls_iters[5];     /* PCG iterations of the WLS solve per level */
+} nct_pair_timing;
+int nct_process_pair(nct_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, const uint8_t* ref_bgr, int rh, int rw, const nct_params* prm,
+                     uint8_t* out_bgr, nct_pair_timing* timing);
+int nct_pair_upload(nct_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, const uint8_t* ref_bgr, int rh, int rw);
+int nct_pair_run(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing);
+int nct_pair_download(nct_ctx* ctx, uint8_t* out_bgr);
+
 /* ---- measurement hooks (bench.py / rocprof): device-resident PatchMatch on synthetic features ----
  * nct_pm_bench_setup uploads + normalises two CHW feature maps once; nct_pm_bench_run re-initialises the NNF
  * (scaled identity) and runs one full nct_patchmatch pass (init-dist + iters*4 Jacobi steps) entirely on the

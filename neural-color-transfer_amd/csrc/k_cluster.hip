@@ -14,6 +14,7 @@
 //    (dist, id) order (= the reference's cmpDist order; ties are first-come in the reference's KD-tree).
 #include "nct_internal.h"
 #include "nct_device.h"
+#include "nct_detmath.h"
 
 // ================================================================= C1: k-means
 __device__ __forceinline__ uint64_t sm64(uint64_t& s) {
@@ -253,7 +254,7 @@ __global__ void k_knn_merge(int npix, const int* __restrict__ nslot, const doubl
         if (bid < 0) break;
         // the reference dedupes on consecutive equal ids after sorting by (dist,id): equal ids have equal distances
         knn_id[(size_t)i * KNN_K + lp] = bid;
-        knn_w[(size_t)i * KNN_K + lp] = exp(1.0 - bd / 3.0);
+        knn_w[(size_t)i * KNN_K + lp] = nct_exp(1.0 - bd / 3.0);
         last_d = bd; last_id = bid; ++lp;
     }
     for (; lp < KNN_K; ++lp) { knn_id[(size_t)i * KNN_K + lp] = i; knn_w[(size_t)i * KNN_K + lp] = 0.0; }

@@ -19,6 +19,7 @@
 // Roofline: HBM streaming of a handful of fp64 vectors per iteration (latency/launch bound at the coarse levels).
 #include "nct_internal.h"
 #include "nct_device.h"
+#include "nct_detmath.h"
 #include <hipcub/hipcub.hpp>
 
 #define LAB_D(u) ((double)(u) * (1.0 / 255.0))      // Mat::convertTo(CV_64F, 1/255)
@@ -117,8 +118,8 @@ __global__ void k_gradient_weights(const uint8_t* __restrict__ lab, int h, int w
     const int y = i / w, x = i - y * w;
     const double val = LAB_D(lab[(size_t)i * 3]);
     double vx = 0.0, vy = 0.0;
-    if (x + 1 < w) { const double g = LAB_D(lab[(size_t)(i + 1) * 3]) - val; vx = sqrt(lamda / (pow(fabs(g), alpha) + 0.0001)); }
-    if (y + 1 < h) { const double g = LAB_D(lab[(size_t)(i + w) * 3]) - val; vy = sqrt(lamda / (pow(fabs(g), alpha) + 0.0001)); }
+    if (x + 1 < w) { const double g = LAB_D(lab[(size_t)(i + 1) * 3]) - val; vx = sqrt(lamda / (nct_pow(fabs(g), alpha) + 0.0001)); }
+    if (y + 1 < h) { const double g = LAB_D(lab[(size_t)(i + w) * 3]) - val; vy = sqrt(lamda / (nct_pow(fabs(g), alpha) + 0.0001)); }
     gx[i] = vx; gy[i] = vy;
 }
 

@@ -67,6 +67,7 @@ void nct_destroy(nct_ctx* ctx) {
     (void)hipDeviceSynchronize();
     nct_vgg_free(ctx);
     nct_cvt_free(ctx);
+    nct_pair_free(ctx);
     for (auto& b : ctx->blocks) if (b.p) (void)hipFree(b.p);
     if (ctx->bench_a) (void)hipFree(ctx->bench_a);
     if (ctx->bench_b) (void)hipFree(ctx->bench_b);

@@ -23,6 +23,7 @@ struct nct_ctx {
     // opaque sub-states owned by other translation units
     void* vgg = nullptr;              // struct vgg_weights* (nct_vgg.cpp)
     void* cvt = nullptr;              // struct cvt_dev* (k_cvt.hip): colour-conversion LUTs on the device
+    void* pair = nullptr;             // struct pair_state* (nct_pipeline.cpp): device-resident source/reference/result images
     unsigned long long* d_counter = nullptr;   // device eval counter (profiling builds of pm kernels)
 
     int fail(int code, const char* fmt, ...) {
@@ -71,6 +72,7 @@ int nctk_lab2bgr(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, 
 int nctk_resize_u8c3(nct_ctx* ctx, hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
 int nctk_resize_f64c3(nct_ctx* ctx, hipStream_t s, const double* src, int sh, int sw, double* dst, int dh, int dw);
 void nct_cvt_free(nct_ctx* ctx);
+void nct_pair_free(nct_ctx* ctx);   // nct_pipeline.cpp
 // k_cluster.hip
 int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat_hwc_norm, int n, int C, int K, int iters, uint64_t seed, int* labels, int* nlabels_dev);
 int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, int w, const int* labels, int lh, int lw, int nlabels, int samples,

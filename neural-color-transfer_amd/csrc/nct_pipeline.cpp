@@ -1,0 +1,224 @@
+// nct_pipeline.cpp — the per-pair hot loop: the MI355X counterpart of transfer_color_single_bds (main.cu:47-454).
+// Everything between "two BGR images in" and "one BGR image out" stays on the device: no per-level cudaMalloc/Free churn
+// (main.cu:238-257,297-326), no D2H of NNFs/error maps (main.cu:286-289,318), no host-side BDS vote (main.cu:291),
+// no CSR ping-pong for the solvers. S features are recomputed from the intermediate result only up to the tap the
+// next level needs (1115 instead of 2297 GFLOP per 700x700 pair, identical values).
+#include "nct_internal.h"
+#include <chrono>
+#include <cstring>
+#include <algorithm>
+
+struct pair_state {
+    uint8_t *src = nullptr, *ref = nullptr, *out = nullptr;    // device BGR images
+    int sh = 0, sw = 0, rh = 0, rw = 0;
+};
+static pair_state* pair_of(nct_ctx* ctx) {
+    if (!ctx->pair) ctx->pair = new pair_state();
+    return (pair_state*)ctx->pair;
+}
+void nct_pair_free(nct_ctx* ctx) {
+    if (!ctx->pair) return;
+    pair_state* p = (pair_state*)ctx->pair;
+    if (p->src) (void)hipFree(p->src);
+    if (p->ref) (void)hipFree(p->ref);
+    if (p->out) (void)hipFree(p->out);
+    delete p; ctx->pair = nullptr;
+}
+
+static const int kTapC[5] = {64, 128, 256, 512, 512};       // tap 1 (conv1_1) … tap 5 (conv5_1)
+
+struct StageClock {
+    nct_ctx* ctx; hipStream_t s; nct_pair_timing* t; std::chrono::steady_clock::time_point t0;
+    StageClock(nct_ctx* c, hipStream_t st, nct_pair_timing* tm) : ctx(c), s(st), t(tm) { if (t) { (void)hipStreamSynchronize(s); t0 = std::chrono::steady_clock::now(); } }
+    void lap(double* acc) {
+        if (!t) return;
+        (void)hipStreamSynchronize(s);
+        auto t1 = std::chrono::steady_clock::now();
+        *acc += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t0 = t1;
+    }
+};
+
+// run the whole L=5->1 loop on device-resident images
+static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing) {
+    pair_state* P = (pair_state*)ctx->pair;
+    if (!P || !P->src || !P->ref) return ctx->fail(NCT_ERR_STATE, "process: no pair uploaded");
+    hipStream_t s = ctx->stream;
+    const int H = P->sh, W = P->sw, RH = P->rh, RW = P->rw;
+    NCT_REQUIRE(prm->patch_size == 3 && prm->k_num == 8, "process: patch_size must be 3 and k_num 8 (Config.h:68-70)");
+    NCT_REQUIRE(prm->cluster_num >= 1 && prm->cluster_num <= 16, "process: cluster_num out of range");
+    if (timing) memset(timing, 0, sizeof *timing);
+    auto wall0 = std::chrono::steady_clock::now();
+    StageClock clk(ctx, s, timing);
+
+    // level geometry, coarse -> fine (level 0 = conv5_1)
+    int ah[5], aw[5], bh[5], bw[5];
+    { int h = H, w = W, h2 = RH, w2 = RW;
+      for (int t = 0; t < 5; ++t) { ah[4 - t] = h; aw[4 - t] = w; bh[4 - t] = h2; bw[4 - t] = w2; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; h2 = (h2 - 1) / 2 + 1; w2 = (w2 - 1) / 2 + 1; } }
+    const int maxLen = std::max(std::max(W, H), std::max(RW, RH));
+    const int rs_range[5] = {maxLen / 16, maxLen / 32, maxLen / 64, 32, 32};                   // main.cu:77-83
+    const size_t N = (size_t)H * W;
+
+    // ---- S in Lab (ColorTransfer ctor, ColorTransfer.h:54-75) and image pyramids (main.cu:104-108)
+    DevBuf<uint8_t> s_lab_full(ctx, N * 3);
+    if (!s_lab_full.ok()) return NCT_ERR_HIP;
+    int rc = nctk_bgr2lab(ctx, s, P->src, s_lab_full, N); if (rc) return rc;
+    std::vector<DevBuf<uint8_t>*> spyr(5, nullptr), rpyr(5, nullptr);
+    struct Cleanup { std::vector<DevBuf<uint8_t>*>&a, &b; ~Cleanup() { for (auto* p : a) delete p; for (auto* p : b) delete p; } } cleanup{spyr, rpyr};
+    const uint8_t* simg[5]; const uint8_t* rimg[5];
+    simg[4] = P->src; rimg[4] = P->ref;
+    for (int l = 3; l >= 0; --l) {
+        spyr[l] = new DevBuf<uint8_t>(ctx, (size_t)ah[l] * aw[l] * 3); rpyr[l] = new DevBuf<uint8_t>(ctx, (size_t)bh[l] * bw[l] * 3);
+        if (!spyr[l]->ok() || !rpyr[l]->ok()) return NCT_ERR_HIP;
+        rc = nctk_resize_u8c3(ctx, s, simg[l + 1], ah[l + 1], aw[l + 1], *spyr[l], ah[l], aw[l]); if (rc) return rc;
+        rc = nctk_resize_u8c3(ctx, s, rimg[l + 1], bh[l + 1], bw[l + 1], *rpyr[l], bh[l], bw[l]); if (rc) return rc;
+        simg[l] = *spyr[l]; rimg[l] = *rpyr[l];
+    }
+    clk.lap(timing ? &timing->other_ms : nullptr);
+
+    // ---- VGG19: R once (all five taps kept, HWC), S to conv5_1 (main.cu:94,102)
+    std::vector<DevBuf<float>*> rfeat(5, nullptr);     // R features, un-normalised, HWC, indexed by level
+    struct Cleanup2 { std::vector<DevBuf<float>*>& a; ~Cleanup2() { for (auto* p : a) delete p; } } cleanup2{rfeat};
+    {
+        float* taps[5]; std::vector<DevBuf<float>*> chw(5, nullptr);
+        Cleanup2 c3{chw};
+        for (int t = 0; t < 5; ++t) { const int l = 4 - t; chw[t] = new DevBuf<float>(ctx, (size_t)kTapC[t] * bh[l] * bw[l]); if (!chw[t]->ok()) return NCT_ERR_HIP; taps[t] = *chw[t]; }
+        rc = nctk_vgg19_forward(ctx, s, P->ref, RH, RW, RW * 3, 5, taps, nullptr); if (rc) return rc;
+        for (int t = 0; t < 5; ++t) {
+            const int l = 4 - t;
+            rfeat[l] = new DevBuf<float>(ctx, (size_t)kTapC[t] * bh[l] * bw[l]); if (!rfeat[l]->ok()) return NCT_ERR_HIP;
+            rc = nctk_chw_to_hwc(ctx, s, taps[t], *rfeat[l], kTapC[t], bh[l] * bw[l]); if (rc) return rc;
+        }
+    }
+    DevBuf<float> sfeat_chw(ctx, (size_t)64 * N), sfeat(ctx, (size_t)64 * N);   // S features of the current level (largest: 64 x H x W)
+    if (!sfeat_chw.ok() || !sfeat.ok()) return NCT_ERR_HIP;
+    {
+        float* taps[5] = {nullptr, nullptr, nullptr, nullptr, sfeat_chw};
+        rc = nctk_vgg19_forward(ctx, s, P->src, H, W, W * 3, 5, taps, nullptr); if (rc) return rc;
+        rc = nctk_chw_to_hwc(ctx, s, sfeat_chw, sfeat, 512, ah[0] * aw[0]); if (rc) return rc;
+    }
+    clk.lap(timing ? &timing->vgg_ms : nullptr);
+
+    // ---- C1: cluster the coarsest S features (main.cu:139-168)
+    DevBuf<int> labels(ctx, (size_t)ah[0] * aw[0]), nlab_dev(ctx, 1);
+    DevBuf<float> na(ctx, (size_t)64 * N), nb(ctx, (size_t)64 * (size_t)RH * RW), voted(ctx, (size_t)64 * N), nvoted(ctx, (size_t)64 * N);
+    if (!labels.ok() || !nlab_dev.ok() || !na.ok() || !nb.ok() || !voted.ok() || !nvoted.ok()) return NCT_ERR_HIP;
+    rc = nctk_normalize(ctx, s, sfeat, na, nullptr, 512, ah[0] * aw[0]); if (rc) return rc;
+    rc = nctk_kmeans_labels(ctx, s, na, ah[0] * aw[0], 512, prm->cluster_num, 11, (uint64_t)prm->seed, labels, nlab_dev); if (rc) return rc;
+    int nlabels = 0;
+    NCT_HIP(hipMemcpyAsync(&nlabels, (int*)nlab_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    NCT_HIP(hipStreamSynchronize(s));
+    clk.lap(timing ? &timing->cluster_ms : nullptr);
+
+    // ---- level loop (main.cu:179-428)
+    DevBuf<uint32_t> ann(ctx, N), bnn(ctx, (size_t)RH * RW), ann_prev(ctx, N), bnn_prev(ctx, (size_t)RH * RW);
+    DevBuf<float> annd(ctx, N), bnnd(ctx, (size_t)RH * RW), err(ctx, N);
+    DevBuf<uint8_t> guide(ctx, N * 3), s_lab_l(ctx, N * 3), g_lab_l(ctx, N * 3), out_lab(ctx, N * 3);
+    DevBuf<int> knn_id(ctx, N * 8);
+    DevBuf<double> knn_w(ctx, N * 8);
+    if (!ann.ok() || !bnn.ok() || !ann_prev.ok() || !bnn_prev.ok() || !annd.ok() || !bnnd.ok() || !err.ok() || !guide.ok() || !s_lab_l.ok() ||
+        !g_lab_l.ok() || !out_lab.ok() || !knn_id.ok() || !knn_w.ok()) return NCT_ERR_HIP;
+    if (!P->out) NCT_HIP(hipMalloc(&P->out, N * 3));
+    nct_color_params cp{prm->eps, prm->nonlocal_weight, prm->local_weight, prm->wls_lambda_init, prm->wls_alpha, (double)prm->k_num};
+
+    for (int l = 0; l < 5; ++l) {
+        const int C = kTapC[4 - l];
+        const int na_px = ah[l] * aw[l], nb_px = bh[l] * bw[l];
+        // NNF init / upsample (main.cu:230-251)
+        if (l == 0) {
+            rc = nctk_nnf_init(ctx, s, ann, ah[0], aw[0], bh[0], bw[0]); if (rc) return rc;
+            rc = nctk_nnf_init(ctx, s, bnn, bh[0], bw[0], ah[0], aw[0]); if (rc) return rc;
+        } else {
+            NCT_HIP(hipMemcpyAsync(ann_prev, ann, sizeof(uint32_t) * ah[l - 1] * aw[l - 1], hipMemcpyDeviceToDevice, s));
+            NCT_HIP(hipMemcpyAsync(bnn_prev, bnn, sizeof(uint32_t) * bh[l - 1] * bw[l - 1], hipMemcpyDeviceToDevice, s));
+            rc = nctk_nnf_upsample(ctx, s, ann_prev, ann, ah[l], aw[l], bh[l], bw[l], ah[l - 1], aw[l - 1]); if (rc) return rc;
+            rc = nctk_nnf_upsample(ctx, s, bnn_prev, bnn, bh[l], bw[l], ah[l], aw[l], bh[l - 1], bw[l - 1]); if (rc) return rc;
+        }
+        // normalise (main.cu:259-275), PatchMatch both directions (main.cu:283-284)
+        if (l > 0) { rc = nctk_normalize(ctx, s, sfeat, na, nullptr, C, na_px); if (rc) return rc; }
+        rc = nctk_normalize(ctx, s, *rfeat[l], nb, nullptr, C, nb_px); if (rc) return rc;
+        const uint32_t seed_ab = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 1)), seed_ba = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 2));
+        rc = nctk_patchmatch(ctx, s, na, nb, C, ah[l], aw[l], bh[l], bw[l], prm->pm_iters, rs_range[l], seed_ab, ann, annd, nullptr); if (rc) return rc;
+        rc = nctk_patchmatch(ctx, s, nb, na, C, bh[l], bw[l], ah[l], aw[l], prm->pm_iters, rs_range[l], seed_ba, bnn, bnnd, nullptr); if (rc) return rc;
+        clk.lap(timing ? &timing->patchmatch_ms : nullptr);
+        // BDS votes: guidance image (main.cu:291) and features + matching error (main.cu:303-318)
+        rc = nctk_bds_vote_image(ctx, s, rimg[l], ann, bnn, ah[l], aw[l], bh[l], bw[l], 1.0, prm->bds_weight, guide); if (rc) return rc;
+        rc = nctk_bds_vote_features(ctx, s, ann, bnn, *rfeat[l], voted, nullptr, C, ah[l], aw[l], bh[l], bw[l], 1.f, (float)prm->bds_weight); if (rc) return rc;
+        rc = nctk_normalize(ctx, s, voted, nvoted, nullptr, C, na_px); if (rc) return rc;
+        rc = nctk_feature_distance(ctx, s, na, nvoted, err, C, na_px); if (rc) return rc;
+        clk.lap(timing ? &timing->vote_ms : nullptr);
+        // kNN graph in Lab (main.cu:351-359)
+        rc = nctk_bgr2lab(ctx, s, simg[l], s_lab_l, na_px); if (rc) return rc;
+        rc = nctk_bgr2lab(ctx, s, guide, g_lab_l, na_px); if (rc) return rc;
+        rc = nctk_knn_graph(ctx, s, s_lab_l, ah[l], aw[l], labels, ah[0], aw[0], nlabels, 1 << l, knn_id, knn_w); if (rc) return rc;
+        clk.lap(timing ? &timing->knn_ms : nullptr);
+        // local colour transfer (main.cu:368-380)
+        nct_color_debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        int wls_it[6] = {0, 0, 0, 0, 0, 0};
+        dbg.wls_iters = wls_it;
+        rc = nctk_local_color_transfer(ctx, s, err, s_lab_l, g_lab_l, s_lab_full, knn_id, knn_w, l, ah[l], aw[l], H, W, cp, out_lab, timing ? &dbg : nullptr); if (rc) return rc;
+        rc = nctk_lab2bgr(ctx, s, out_lab, P->out, N); if (rc) return rc;
+        if (timing) { timing->wls_iters[l] = *std::max_element(wls_it, wls_it + 6); }
+        clk.lap(timing ? &timing->color_ms : nullptr);
+        // re-predict: S features of the next level from the intermediate result (main.cu:424-427)
+        if (l < 4) {
+            const int tap = 4 - l;                         // next level uses tap (5 - (l+1))
+            float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+            taps[tap - 1] = sfeat_chw;
+            rc = nctk_vgg19_forward(ctx, s, P->out, H, W, W * 3, tap, taps, nullptr); if (rc) return rc;
+            rc = nctk_chw_to_hwc(ctx, s, sfeat_chw, sfeat, kTapC[tap - 1], ah[l + 1] * aw[l + 1]); if (rc) return rc;
+            clk.lap(timing ? &timing->vgg_ms : nullptr);
+        }
+    }
+    NCT_HIP(hipStreamSynchronize(s));
+    if (timing) timing->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return NCT_OK;
+}
+
+extern "C" {
+
+int nct_pair_upload(nct_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, const uint8_t* ref_bgr, int rh, int rw) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(src_bgr && ref_bgr, "pair_upload: null image");
+    NCT_REQUIRE(sh >= 16 && sw >= 16 && rh >= 16 && rw >= 16 && sh <= 4000 && sw <= 4000 && rh <= 4000 && rw <= 4000,
+                "pair_upload: image sides must be in [16, 4000] (got %dx%d and %dx%d)", sw, sh, rw, rh);
+    pair_state* P = pair_of(ctx);
+    if (P->src) { (void)hipFree(P->src); P->src = nullptr; }
+    if (P->ref) { (void)hipFree(P->ref); P->ref = nullptr; }
+    if (P->out) { (void)hipFree(P->out); P->out = nullptr; }
+    NCT_HIP(hipMalloc(&P->src, (size_t)sh * sw * 3));
+    NCT_HIP(hipMalloc(&P->ref, (size_t)rh * rw * 3));
+    NCT_HIP(hipMemcpyAsync(P->src, src_bgr, (size_t)sh * sw * 3, hipMemcpyHostToDevice, ctx->stream));
+    NCT_HIP(hipMemcpyAsync(P->ref, ref_bgr, (size_t)rh * rw * 3, hipMemcpyHostToDevice, ctx->stream));
+    NCT_HIP(hipStreamSynchronize(ctx->stream));
+    P->sh = sh; P->sw = sw; P->rh = rh; P->rw = rw;
+    return NCT_OK;
+}
+
+int nct_pair_run(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(prm, "pair_run: null params");
+    return process_resident(ctx, prm, timing);
+}
+
+int nct_pair_download(nct_ctx* ctx, uint8_t* out_bgr) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    pair_state* P = (pair_state*)ctx->pair;
+    if (!P || !P->out) return ctx->fail(NCT_ERR_STATE, "pair_download: no result (call nct_pair_run first)");
+    NCT_REQUIRE(out_bgr, "pair_download: null pointer");
+    NCT_HIP(hipMemcpyAsync(out_bgr, P->out, (size_t)P->sh * P->sw * 3, hipMemcpyDeviceToHost, ctx->stream));
+    NCT_HIP(hipStreamSynchronize(ctx->stream));
+    return NCT_OK;
+}
+
+int nct_process_pair(nct_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, const uint8_t* ref_bgr, int rh, int rw, const nct_params* prm,
+                     uint8_t* out_bgr, nct_pair_timing* timing) {
+    int rc = nct_pair_upload(ctx, src_bgr, sh, sw, ref_bgr, rh, rw); if (rc) return rc;
+    rc = nct_pair_run(ctx, prm, timing); if (rc) return rc;
+    return nct_pair_download(ctx, out_bgr);
+}
+
+}  // extern "C"

@@ -69,6 +69,10 @@ SIGNATURES = {
     "nct_cluster_features": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _i32p, C.POINTER(C.c_int)]),
     "nct_knn_graph": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _f64p]),
     "nct_local_color_transfer": (C.c_int, [C.c_void_p, _f32p, _u8p, _u8p, _u8p, _i32p, _f64p] + [C.c_int] * 5 + [C.c_void_p, _u8p, C.c_void_p]),
+    "nct_process_pair": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_void_p, _u8p, C.c_void_p]),
+    "nct_pair_upload": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]),
+    "nct_pair_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nct_pair_download": (C.c_int, [C.c_void_p, _u8p]),
     "nct_pm_bench_setup": (C.c_int, [C.c_void_p, _f32p, _f32p] + [C.c_int] * 5),
     "nct_pm_bench_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
 }
@@ -96,6 +100,17 @@ class Params(C.Structure):
         p = Params()
         lib().nct_params_default(C.byref(p))
         return p
+
+
+class PairTiming(C.Structure):
+    """struct nct_pair_timing (include/nct.h)."""
+    _fields_ = [("total_ms", C.c_double), ("vgg_ms", C.c_double), ("cluster_ms", C.c_double), ("patchmatch_ms", C.c_double),
+                ("vote_ms", C.c_double), ("knn_ms", C.c_double), ("color_ms", C.c_double), ("other_ms", C.c_double), ("wls_iters", C.c_int * 5)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "wls_iters"}
+        d["wls_iters"] = list(self.wls_iters)
+        return d
 
 
 class ColorStages(C.Structure):
@@ -316,6 +331,34 @@ class Context:
                                                    np.ascontiguousarray(knn_id, np.int32).reshape(-1), np.ascontiguousarray(knn_w, np.float64).reshape(-1),
                                                    layer, h, w, H, W, C.addressof(prm), out.reshape(-1, 3), C.addressof(st) if st else None))
         return (out, keep) if want_stages else out
+
+    # ---- per-pair hot loop
+    def process_pair(self, src_bgr, ref_bgr, params=None, want_timing=False):
+        s = np.ascontiguousarray(src_bgr, np.uint8)
+        r = np.ascontiguousarray(ref_bgr, np.uint8)
+        prm = params or Params.default()
+        out = np.empty_like(s)
+        tm = PairTiming() if want_timing else None
+        self._chk(self._l.nct_process_pair(self._h, s.reshape(-1, 3), s.shape[0], s.shape[1], r.reshape(-1, 3), r.shape[0], r.shape[1],
+                                           C.addressof(prm), out.reshape(-1, 3), C.addressof(tm) if tm is not None else None))
+        return (out, tm.as_dict()) if want_timing else out
+
+    def pair_upload(self, src_bgr, ref_bgr):
+        s = np.ascontiguousarray(src_bgr, np.uint8)
+        r = np.ascontiguousarray(ref_bgr, np.uint8)
+        self._pair_shape = s.shape
+        self._chk(self._l.nct_pair_upload(self._h, s.reshape(-1, 3), s.shape[0], s.shape[1], r.reshape(-1, 3), r.shape[0], r.shape[1]))
+
+    def pair_run(self, params=None, want_timing=False):
+        prm = params or Params.default()
+        tm = PairTiming() if want_timing else None
+        self._chk(self._l.nct_pair_run(self._h, C.addressof(prm), C.addressof(tm) if tm is not None else None))
+        return tm.as_dict() if want_timing else None
+
+    def pair_download(self):
+        out = np.empty(self._pair_shape, np.uint8)
+        self._chk(self._l.nct_pair_download(self._h, out.reshape(-1, 3)))
+        return out
 
     # ---- measurement hooks
     def pm_bench_setup(self, a_chw, b_chw):

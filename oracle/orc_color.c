@@ -23,6 +23,7 @@
  *    padded with self edges of weight 0.
  */
 #include "orc_common.h"
+#include "orc_detmath.h"
 #include <stdio.h>
 
 /* ================================================================= C1: k-means labels */
@@ -191,7 +192,7 @@ void orc_knn_graph(const double* lab, int h, int w, const int* labels, int lh, i
         qsort(c, ncand[i], sizeof(nn_t), nn_cmp);
         int last_id = -1, lp = 0;
         for (int t = 0; t < ncand[i] && lp < k; ++t)
-            if (c[t].id != last_id) { last_id = c[t].id; knn_id[(size_t)i * k + lp] = last_id; knn_w[(size_t)i * k + lp] = exp(1.0 - c[t].d / 3.0); lp++; }
+            if (c[t].id != last_id) { last_id = c[t].id; knn_id[(size_t)i * k + lp] = last_id; knn_w[(size_t)i * k + lp] = orc_exp(1.0 - c[t].d / 3.0);   /* exp() via orc_detmath.h: see that header */ lp++; }
         for (; lp < k; ++lp) { knn_id[(size_t)i * k + lp] = i; knn_w[(size_t)i * k + lp] = 0.0; }      /* quirk 10: pad with zero-weight self edges */
     }
     free(member); free(cand); free(ncand); free(ids);
@@ -244,8 +245,8 @@ void orc_gradient_weights(const double* lab, int h, int w, double lamda, double 
         for (int x = 0; x < w; ++x) {
             double val = lab[((size_t)y * w + x) * 3];
             gx[y * w + x] = 0; gy[y * w + x] = 0;
-            if (x + 1 < w) { double g = lab[((size_t)y * w + x + 1) * 3] - val; gx[y * w + x] = sqrt(lamda / (pow(fabs(g), alpha) + epsilon)); }
-            if (y + 1 < h) { double g = lab[((size_t)(y + 1) * w + x) * 3] - val; gy[y * w + x] = sqrt(lamda / (pow(fabs(g), alpha) + epsilon)); }
+            if (x + 1 < w) { double g = lab[((size_t)y * w + x + 1) * 3] - val; gx[y * w + x] = sqrt(lamda / (orc_pow(fabs(g), alpha) + epsilon)); }
+            if (y + 1 < h) { double g = lab[((size_t)(y + 1) * w + x) * 3] - val; gy[y * w + x] = sqrt(lamda / (orc_pow(fabs(g), alpha) + epsilon)); }
         }
 }
 
@@ -270,9 +271,9 @@ static double ddot(const double* a, const double* b, int n) { double s = 0; for 
 /* a,b: in (initial guess from T1) / out, [h*w][3]. src/ref: level Lab/255 doubles [h*w][3]. weight: [h*w].
  * lambda/alpha/dWeight arrive as float in the reference's signature (ColorTransfer.cpp:548-550). iters_out (nullable)
  * receives the number of CG iterations executed per channel. */
-void orc_nonlocal_solve(double* a, double* b, const double* src, const double* ref, const double* weight,
+void orc_nonlocal_solve_explicit(double* a, double* b, const double* src, const double* ref, const double* weight,
                         const int* knn_id, const double* knn_w, int k, int h, int w, int layer,
-                        float lambda, float alpha, float dWeight, double nl_weight_cfg, double k_cfg, int* iters_out) {
+                        float lambda, float alpha, float dWeight, double nl_weight_cfg, double k_cfg, int* iters_out, int maxit_override) {
     const int n = h * w, size = 2 * n;
     double* gx = (double*)malloc(sizeof(double) * n); double* gy = (double*)malloc(sizeof(double) * n);
     orc_gradient_weights(src, h, w, (double)lambda, (double)alpha, gx, gy);
@@ -313,7 +314,7 @@ void orc_nonlocal_solve(double* a, double* b, const double* src, const double* r
         }
 #undef PUSH2
     const double tol = 1e-6;
-    const int maxit = layer == 4 ? 50 : 100;
+    const int maxit = maxit_override > 0 ? maxit_override : (layer == 4 ? 50 : 100);
     double* x = (double*)malloc(sizeof(double) * size); double* r = (double*)malloc(sizeof(double) * size);
     double* p = (double*)malloc(sizeof(double) * size); double* Ap = (double*)malloc(sizeof(double) * size);
     double* t = (double*)malloc(sizeof(double) * A.rows);
@@ -508,10 +509,15 @@ void orc_u8_to_f64_scaled(const uint8_t* src, size_t n, double* dst);
 typedef struct { double eps, nonlocal_weight, local_weight, wls_lambda_init, wls_alpha, k_num; } orc_color_params;
 typedef struct { double *ab_local, *ab_nonlocal, *ab_up, *roughness, *ab_wls; int *cg_iters, *wls_iters; } orc_color_stages;
 
-/* Same contract as nct_local_color_transfer (include/nct.h). force_pcg != 0 makes S2 use the iterative path. */
+void orc_nonlocal_solve(double* a, double* b, const double* src, const double* ref, const double* weight, const int* knn_id, const double* knn_w,
+                        int k, int h, int w, int layer, float lambda, float alpha, float dWeight, double nl_weight_cfg, double k_cfg, int* iters_out, int maxit_override);
+int orc_wls_solve_canon(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, int* iters_out);
+
+/* Same contract as nct_local_color_transfer (include/nct.h). S1 = canonical-order truncated CG (orc_color_canon.c).
+ * s2_exact == 0: S2 by the canonical-order PCG; != 0: S2 by the exact solve (banded Cholesky / converged PCG). */
 int orc_local_color_transfer(const float* err, const uint8_t* s_bgr_level, const uint8_t* g_bgr_level, const uint8_t* s_bgr_full,
                              const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W, const orc_color_params* prm,
-                             uint8_t* out_bgr_full, const orc_color_stages* st, int force_pcg) {
+                             uint8_t* out_bgr_full, const orc_color_stages* st, int s2_exact) {
     const int n = h * w, N = H * W, k = (int)prm->k_num;
     uint8_t* slab = (uint8_t*)malloc((size_t)n * 3); uint8_t* glab = (uint8_t*)malloc((size_t)n * 3); uint8_t* sflab = (uint8_t*)malloc((size_t)N * 3);
     orc_bgr2lab_u8(s_bgr_level, n, slab); orc_bgr2lab_u8(g_bgr_level, n, glab); orc_bgr2lab_u8(s_bgr_full, N, sflab);
@@ -524,7 +530,7 @@ int orc_local_color_transfer(const float* err, const uint8_t* s_bgr_level, const
     const double normFactor = (double)(W * H) / (double)(w * h);
     int cg[3];
     orc_nonlocal_solve(a, b, src, ref, wgt, knn_id, knn_w, k, h, w, layer, (float)prm->local_weight, (float)prm->wls_alpha, (float)normFactor,
-                       prm->nonlocal_weight, prm->k_num, cg);
+                       prm->nonlocal_weight, prm->k_num, cg, 0);
     if (st && st->cg_iters) memcpy(st->cg_iters, cg, sizeof cg);
     if (st && st->ab_nonlocal) { memcpy(st->ab_nonlocal, a, sizeof(double) * 3 * n); memcpy(st->ab_nonlocal + (size_t)3 * n, b, sizeof(double) * 3 * n); }
     double* A = (double*)malloc(sizeof(double) * 3 * N); double* B = (double*)malloc(sizeof(double) * 3 * N); double* rough = (double*)malloc(sizeof(double) * N);
@@ -535,8 +541,10 @@ int orc_local_color_transfer(const float* err, const uint8_t* s_bgr_level, const
     if (st && st->roughness) memcpy(st->roughness, rough, sizeof(double) * N);
     double lamda = prm->wls_lambda_init * normFactor;
     if (h == H && w == W) lamda *= 4;
-    int it = orc_wls_solve(A, B, full, H, W, lamda, prm->wls_alpha, rough, force_pcg);
-    if (st && st->wls_iters) for (int q = 0; q < 6; ++q) st->wls_iters[q] = it;
+    int wit[6] = {0, 0, 0, 0, 0, 0};
+    int it = s2_exact ? orc_wls_solve(A, B, full, H, W, lamda, prm->wls_alpha, rough, 0)
+                      : orc_wls_solve_canon(A, B, full, H, W, lamda, prm->wls_alpha, rough, wit);
+    if (st && st->wls_iters) memcpy(st->wls_iters, wit, sizeof wit);
     if (st && st->ab_wls) { memcpy(st->ab_wls, A, sizeof(double) * 3 * N); memcpy(st->ab_wls + (size_t)3 * N, B, sizeof(double) * 3 * N); }
     uint8_t* olab = (uint8_t*)malloc((size_t)N * 3);
     orc_apply_coeffs(A, B, full, N, olab);

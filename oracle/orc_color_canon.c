@@ -1,0 +1,240 @@
+/* oracle/orc_color_canon.c — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+ *
+ * "Canonical-order" restatements of the two iterative solvers of the colour stage:
+ *   S1  truncated un-preconditioned CG on A^T A x = A^T b   (ColorTransfer.cpp:548-949, SparseSolver_GPU.cu:119-159)
+ *   S2  WLS system (diag(r) + L) x = r x0, 6 RHS            (ColorTransfer.cpp:951-1125)
+ *
+ * Why a second restatement next to orc_color.c's literal one (orc_nonlocal_solve_explicit / banded Cholesky):
+ * S1 is stopped by its iteration cap long before convergence, and the iterate at the cap is CHAOTIC in the rounding order
+ * (tests/test_oracle_color.py::test_truncated_cg_is_chaotic: a 1e-15 relative perturbation of one weight moves the
+ * coefficients by 1e-2 and the 8-bit output by several levels). Two implementations agree only if they perform the
+ * same IEEE operations in the same order. This file fixes that order so that it is natural for a GPU:
+ *   - the normal-equations operator is applied matrix-free per pixel: 2x2 data block, then the four grid neighbours in
+ *     the order +x, -x, +y, -y with weight 2 g^2 (every edge is entered twice in A), then the 8 kNN out-edges, then the
+ *     in-edges in ascending edge id — mathematically identical to A^T A of the assembled A;
+ *   - every dot product is a two-stage sum: 256-element blocks reduced by a halving tree, block partials accumulated by
+ *     256 strided accumulators and reduced by the same tree.
+ * The literal versions stay as cross-checks: the operators agree to rounding for few iterations
+ * (test_canonical_cg_matches_explicit_for_few_iterations) and the S2 solutions agree with the exact solve to 1e-8.
+ */
+#include "orc_common.h"
+#include "orc_detmath.h"
+#include <stdio.h>
+
+void orc_gradient_weights(const double* lab, int h, int w, double lamda, double alpha, double* gx, double* gy);
+void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double* diag, double* wx, double* wy);
+
+/* ---- canonical two-stage reduction of per-pixel values v[i*nq + q], i < n */
+static void tree256(double* s) { for (int off = 128; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) s[t] += s[t + off]; }
+static void canon_sum(const double* v, int n, int nq, double* out) {
+    const int nb = (n + 255) / 256;
+    double* partial = (double*)malloc(sizeof(double) * (size_t)nb * nq);
+    double s[256];
+    for (int b = 0; b < nb; ++b)
+        for (int q = 0; q < nq; ++q) {
+            for (int t = 0; t < 256; ++t) { int i = b * 256 + t; s[t] = i < n ? v[(size_t)i * nq + q] : 0.0; }
+            tree256(s);
+            partial[(size_t)b * nq + q] = s[0];
+        }
+    for (int q = 0; q < nq; ++q) {
+        for (int t = 0; t < 256; ++t) { double acc = 0.0; for (int b = t; b < nb; b += 256) acc += partial[(size_t)b * nq + q]; s[t] = acc; }
+        tree256(s);
+        out[q] = s[0];
+    }
+    free(partial);
+}
+
+/* ================================================================= S1 */
+typedef struct {
+    int n, h, w;
+    double *daa, *dab, *dbb, *gx, *gy, *iw2;
+    const int* knn_id;
+    int* rev_start; unsigned* rev_edge;
+} s1sys_t;
+
+static void s1_op(const s1sys_t* S, const double* p, int i, double* ya, double* yb) {
+    const int n = S->n, w = S->w, h = S->h;
+    const int y = i / w, x = i - y * w;
+    const double* pa = p; const double* pb = p + (size_t)n * 3;
+    double a[3], b[3];
+    for (int c = 0; c < 3; ++c) { a[c] = pa[(size_t)i * 3 + c]; b[c] = pb[(size_t)i * 3 + c]; }
+    for (int c = 0; c < 3; ++c) {
+        ya[c] = S->daa[(size_t)i * 3 + c] * a[c] + S->dab[(size_t)i * 3 + c] * b[c];
+        yb[c] = S->dab[(size_t)i * 3 + c] * a[c] + S->dbb[(size_t)i * 3 + c] * b[c];
+    }
+#define EDGE(j, wt) do { const int j_ = (j); const double w_ = (wt); \
+        for (int c = 0; c < 3; ++c) { ya[c] += w_ * (a[c] - pa[(size_t)j_ * 3 + c]); yb[c] += w_ * (b[c] - pb[(size_t)j_ * 3 + c]); } } while (0)
+    if (x + 1 < w) { const double g = S->gx[i]; EDGE(i + 1, 2.0 * (g * g)); }
+    if (x > 0) { const double g = S->gx[i - 1]; EDGE(i - 1, 2.0 * (g * g)); }
+    if (y + 1 < h) { const double g = S->gy[i]; EDGE(i + w, 2.0 * (g * g)); }
+    if (y > 0) { const double g = S->gy[i - w]; EDGE(i - w, 2.0 * (g * g)); }
+    for (int k = 0; k < 8; ++k) EDGE(S->knn_id[(size_t)i * 8 + k], S->iw2[(size_t)i * 8 + k]);
+    for (int e = S->rev_start[i]; e < S->rev_start[i + 1]; ++e) { const unsigned ed = S->rev_edge[e]; EDGE((int)(ed >> 3), S->iw2[ed]); }
+#undef EDGE
+}
+
+/* a,b: [n][3] in/out; src/ref: level Lab/255 [n][3]; k must be 8. */
+void orc_nonlocal_solve(double* a, double* b, const double* src, const double* ref, const double* weight,
+                        const int* knn_id, const double* knn_w, int k, int h, int w, int layer,
+                        float lambda, float alpha, float dWeight, double nl_weight_cfg, double k_cfg, int* iters_out, int maxit_override) {
+    const int n = h * w;
+    if (k != 8) { fprintf(stderr, "orc_nonlocal_solve: k must be 8\n"); return; }
+    s1sys_t S; S.n = n; S.h = h; S.w = w; S.knn_id = knn_id;
+    S.gx = (double*)malloc(sizeof(double) * n); S.gy = (double*)malloc(sizeof(double) * n);
+    orc_gradient_weights(src, h, w, (double)lambda, (double)alpha, S.gx, S.gy);
+    S.daa = (double*)malloc(sizeof(double) * 3 * n); S.dab = (double*)malloc(sizeof(double) * 3 * n); S.dbb = (double*)malloc(sizeof(double) * 3 * n);
+    S.iw2 = (double*)malloc(sizeof(double) * 8 * n);
+    double* rhs = (double*)malloc(sizeof(double) * 6 * n);
+    const double nonlocalWeight = sqrt(nl_weight_cfg / k_cfg);
+    for (int i = 0; i < n; ++i) {
+        const double dw = sqrt(weight[i]) * (double)sqrtf(dWeight);
+        for (int c = 0; c < 3; ++c) {
+            const double v0 = dw * src[(size_t)i * 3 + c], rb = dw * ref[(size_t)i * 3 + c];
+            S.daa[(size_t)i * 3 + c] = v0 * v0; S.dab[(size_t)i * 3 + c] = v0 * dw; S.dbb[(size_t)i * 3 + c] = dw * dw;
+            rhs[(size_t)i * 3 + c] = v0 * rb; rhs[(size_t)(n + i) * 3 + c] = dw * rb;
+        }
+        for (int kk = 0; kk < 8; ++kk) { const double iw = sqrt(knn_w[(size_t)i * 8 + kk]) * nonlocalWeight; S.iw2[(size_t)i * 8 + kk] = iw * iw; }
+    }
+    /* reverse adjacency: edges e = src*8 + ki, stably sorted by target (counting sort keeps ascending e per target) */
+    S.rev_start = (int*)calloc(n + 1, sizeof(int)); S.rev_edge = (unsigned*)malloc(sizeof(unsigned) * 8 * (size_t)n);
+    for (int e = 0; e < 8 * n; ++e) S.rev_start[knn_id[e] + 1]++;
+    for (int i = 0; i < n; ++i) S.rev_start[i + 1] += S.rev_start[i];
+    { int* cur = (int*)malloc(sizeof(int) * n); memcpy(cur, S.rev_start, sizeof(int) * n);
+      for (int e = 0; e < 8 * n; ++e) S.rev_edge[cur[knn_id[e]]++] = (unsigned)e;
+      free(cur); }
+
+    double* x = (double*)malloc(sizeof(double) * 6 * n); double* r = (double*)malloc(sizeof(double) * 6 * n);
+    double* p = (double*)calloc(6 * (size_t)n, sizeof(double)); double* Ap = (double*)malloc(sizeof(double) * 6 * n);
+    double* acc = (double*)malloc(sizeof(double) * 3 * n);
+    memcpy(x, a, sizeof(double) * 3 * n); memcpy(x + (size_t)3 * n, b, sizeof(double) * 3 * n);
+    const double tol2 = 1e-6 * 1e-6;
+    const int maxit = maxit_override > 0 ? maxit_override : (layer == 4 ? 50 : 100);
+    double r0[3] = {0, 0, 0}, r1[3], va[3] = {0, 0, 0}, vb[3] = {0, 0, 0}, s[3];
+    int active[3], iters[3] = {0, 0, 0};
+    /* r = rhs - Op(x0) */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        double ya[3], yb[3]; s1_op(&S, x, i, ya, yb);
+        for (int c = 0; c < 3; ++c) {
+            const double ra = rhs[(size_t)i * 3 + c] - ya[c], rb = rhs[(size_t)(n + i) * 3 + c] - yb[c];
+            r[(size_t)i * 3 + c] = ra; r[(size_t)(n + i) * 3 + c] = rb; acc[(size_t)i * 3 + c] = ra * ra + rb * rb;
+        }
+    }
+    canon_sum(acc, n, 3, s);
+    for (int c = 0; c < 3; ++c) { r1[c] = s[c]; active[c] = s[c] > tol2; }
+    for (int kk = 1; kk <= maxit; ++kk) {
+        for (size_t j = 0; j < (size_t)6 * n; ++j) { const int c = (int)(j % 3); if (active[c]) p[j] = (kk == 1) ? r[j] : vb[c] * p[j] + r[j]; }
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            double ya[3], yb[3]; s1_op(&S, p, i, ya, yb);
+            for (int c = 0; c < 3; ++c) {
+                Ap[(size_t)i * 3 + c] = ya[c]; Ap[(size_t)(n + i) * 3 + c] = yb[c];
+                acc[(size_t)i * 3 + c] = p[(size_t)i * 3 + c] * ya[c] + p[(size_t)(n + i) * 3 + c] * yb[c];
+            }
+        }
+        canon_sum(acc, n, 3, s);
+        for (int c = 0; c < 3; ++c) if (active[c]) va[c] = r1[c] / s[c];
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < 3; ++c) {
+                double t = 0.0;
+                if (active[c])
+                    for (int part = 0; part < 2; ++part) {
+                        const size_t j = ((size_t)part * n + i) * 3 + c;
+                        x[j] += va[c] * p[j];
+                        const double rn = r[j] - va[c] * Ap[j];
+                        r[j] = rn; t += rn * rn;
+                    }
+                acc[(size_t)i * 3 + c] = t;
+            }
+        canon_sum(acc, n, 3, s);
+        for (int c = 0; c < 3; ++c)
+            if (active[c]) { r0[c] = r1[c]; r1[c] = s[c]; vb[c] = s[c] / r0[c]; iters[c]++; active[c] = s[c] > tol2; }
+    }
+    if (iters_out) memcpy(iters_out, iters, sizeof iters);
+    memcpy(a, x, sizeof(double) * 3 * n); memcpy(b, x + (size_t)3 * n, sizeof(double) * 3 * n);
+    free(x); free(r); free(p); free(Ap); free(acc); free(rhs);
+    free(S.gx); free(S.gy); free(S.daa); free(S.dab); free(S.dbb); free(S.iw2); free(S.rev_start); free(S.rev_edge);
+}
+
+/* ================================================================= S2: Jacobi-PCG in canonical order (mirrors k_colorsolve.hip) */
+static void wls_op3(const double* diag, const double* wx, const double* wy, int H, int W, const double* v, int i, double* y) {
+    const int r = i / W, c0 = i - r * W;
+    const double d = diag[i];
+    for (int c = 0; c < 3; ++c) y[c] = d * v[(size_t)i * 3 + c];
+    if (c0 + 1 < W) { const double wv = wx[i]; for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i + 1) * 3 + c]; }
+    if (c0 > 0) { const double wv = wx[i - 1]; for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i - 1) * 3 + c]; }
+    if (r + 1 < H) { const double wv = wy[i]; for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i + W) * 3 + c]; }
+    if (r > 0) { const double wv = wy[i - W]; for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i - W) * 3 + c]; }
+}
+
+/* a,b: full-res [N][3] in (x0) / out. iters_out[6] (nullable). Returns max iterations, <0 if maxit hit. */
+int orc_wls_solve_canon(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, int* iters_out) {
+    const int n = H * W;
+    double* diag = (double*)malloc(sizeof(double) * n); double* wx = (double*)malloc(sizeof(double) * n); double* wy = (double*)malloc(sizeof(double) * n);
+    orc_wls_system(lab, H, W, lamda, alpha, roughness, diag, wx, wy);
+    double* x = (double*)malloc(sizeof(double) * 6 * n); double* r = (double*)malloc(sizeof(double) * 6 * n); double* z = (double*)calloc(6 * (size_t)n, sizeof(double));
+    double* p = (double*)malloc(sizeof(double) * 6 * n); double* Ap = (double*)malloc(sizeof(double) * 6 * n); double* acc = (double*)malloc(sizeof(double) * 18 * (size_t)n);
+    memcpy(x, a, sizeof(double) * 3 * n); memcpy(x + (size_t)3 * n, b, sizeof(double) * 3 * n);
+    const double rtol2 = 1e-10 * 1e-10;
+    double rz[6], rr[6], bb[6], al[6] = {0}, be[6] = {0}, s[18];
+    int active[6], iters[6] = {0, 0, 0, 0, 0, 0};
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        const double rg = roughness[i], d = diag[i];
+        for (int part = 0; part < 2; ++part) {
+            const double* xv = x + (size_t)part * n * 3;
+            double y[3]; wls_op3(diag, wx, wy, H, W, xv, i, y);
+            for (int c = 0; c < 3; ++c) {
+                const size_t j = ((size_t)part * n + i) * 3 + c;
+                const double bq = rg * xv[(size_t)i * 3 + c];
+                const double rv = bq - y[c], zv = rv / d;
+                r[j] = rv; p[j] = zv;
+                const int q = part * 3 + c;
+                acc[(size_t)i * 18 + q] = rv * zv; acc[(size_t)i * 18 + 6 + q] = rv * rv; acc[(size_t)i * 18 + 12 + q] = bq * bq;
+            }
+        }
+    }
+    canon_sum(acc, n, 18, s);
+    for (int q = 0; q < 6; ++q) { rz[q] = s[q]; rr[q] = s[6 + q]; bb[q] = s[12 + q]; active[q] = s[6 + q] > rtol2 * s[12 + q]; }
+    int it = 0, any = 0;
+    for (int q = 0; q < 6; ++q) any |= active[q];
+    const int maxit = 100000;
+    while (any && it < maxit) {
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; ++i)
+            for (int part = 0; part < 2; ++part) {
+                const double* pv = p + (size_t)part * n * 3;
+                double y[3]; wls_op3(diag, wx, wy, H, W, pv, i, y);
+                for (int c = 0; c < 3; ++c) { const size_t j = ((size_t)part * n + i) * 3 + c; Ap[j] = y[c]; acc[(size_t)i * 6 + part * 3 + c] = pv[(size_t)i * 3 + c] * y[c]; }
+            }
+        canon_sum(acc, n, 6, s);
+        for (int q = 0; q < 6; ++q) if (active[q]) al[q] = rz[q] / s[q];
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            const double d = diag[i];
+            for (int q = 0; q < 12; ++q) acc[(size_t)i * 12 + q] = 0.0;
+            for (int part = 0; part < 2; ++part)
+                for (int c = 0; c < 3; ++c) {
+                    const int q = part * 3 + c;
+                    if (!active[q]) continue;
+                    const size_t j = ((size_t)part * n + i) * 3 + c;
+                    x[j] += al[q] * p[j];
+                    const double rv = r[j] - al[q] * Ap[j];
+                    const double zv = rv / d;
+                    r[j] = rv; z[j] = zv;
+                    acc[(size_t)i * 12 + q] = rv * zv; acc[(size_t)i * 12 + 6 + q] = rv * rv;
+                }
+        }
+        canon_sum(acc, n, 12, s);
+        for (int q = 0; q < 6; ++q)
+            if (active[q]) { be[q] = s[q] / rz[q]; rz[q] = s[q]; rr[q] = s[6 + q]; iters[q]++; active[q] = s[6 + q] > rtol2 * bb[q]; }
+        for (size_t j = 0; j < (size_t)6 * n; ++j) { const int q = (int)(j / ((size_t)n * 3)) * 3 + (int)(j % 3); if (active[q]) p[j] = z[j] + be[q] * p[j]; }
+        ++it; any = 0;
+        for (int q = 0; q < 6; ++q) any |= active[q];
+    }
+    if (iters_out) memcpy(iters_out, iters, sizeof iters);
+    memcpy(a, x, sizeof(double) * 3 * n); memcpy(b, x + (size_t)3 * n, sizeof(double) * 3 * n);
+    int mx = 0; for (int q = 0; q < 6; ++q) if (iters[q] > mx) mx = iters[q];
+    free(diag); free(wx); free(wy); free(x); free(r); free(z); free(p); free(Ap); free(acc);
+    return any ? -1 : mx;
+}

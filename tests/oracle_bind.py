@@ -157,7 +157,7 @@ class Oracle:
         self.l.orc_knn_graph(labd.reshape(-1), h, w, lb.reshape(-1), lb.shape[0], lb.shape[1], nlabels, samples, k, ids.reshape(-1), ws.reshape(-1))
         return ids, ws
 
-    def local_color_transfer(self, err, s_level, g_level, s_full, knn_id, knn_w, layer, params=None, want_stages=False, force_pcg=False):
+    def local_color_transfer(self, err, s_level, g_level, s_full, knn_id, knn_w, layer, params=None, want_stages=False, s2_exact=False):
         self._decl_color()
         err = np.ascontiguousarray(err, np.float32)
         h, w = err.shape
@@ -172,9 +172,34 @@ class Oracle:
         rc = self.l.orc_local_color_transfer(err.reshape(-1), np.ascontiguousarray(s_level, np.uint8).reshape(-1, 3),
                                              np.ascontiguousarray(g_level, np.uint8).reshape(-1, 3), s_full.reshape(-1, 3),
                                              np.ascontiguousarray(knn_id, np.int32).reshape(-1), np.ascontiguousarray(knn_w, np.float64).reshape(-1),
-                                             layer, h, w, H, W, C.addressof(prm), out.reshape(-1, 3), C.addressof(st), 1 if force_pcg else 0)
+                                             layer, h, w, H, W, C.addressof(prm), out.reshape(-1, 3), C.addressof(st), 1 if s2_exact else 0)
         assert rc == 0
         return (out, keep) if want_stages else out
+
+    # ---- whole pair (orc_pipeline.c)
+    def process_pair(self, src, ref, weights, biases, params=None, want_levels=False, s2_exact=False):
+        import ctypes as Cc
+
+        class P(Cc.Structure):
+            _fields_ = [("bds_weight", Cc.c_double), ("eps", Cc.c_double), ("nonlocal_weight", Cc.c_double), ("local_weight", Cc.c_double),
+                        ("wls_lambda_init", Cc.c_double), ("cluster_num", Cc.c_int), ("k_num", Cc.c_int), ("patch_size", Cc.c_int),
+                        ("wls_alpha", Cc.c_double), ("pm_iters", Cc.c_int), ("seed", Cc.c_uint32)]
+        d = dict(bds_weight=2.0, eps=0.60, nonlocal_weight=2.0, local_weight=0.125, wls_lambda_init=0.024, cluster_num=10, k_num=8,
+                 patch_size=3, wls_alpha=1.2, pm_iters=10, seed=1)
+        if params:
+            d.update(params)
+        prm = P(**d)
+        s = np.ascontiguousarray(src, np.uint8); r = np.ascontiguousarray(ref, np.uint8)
+        H, W = s.shape[:2]; RH, RW = r.shape[:2]
+        ws = [np.ascontiguousarray(x, np.float32) for x in weights]; bs = [np.ascontiguousarray(x, np.float32) for x in biases]
+        wp = (C.c_void_p * len(ws))(*[x.ctypes.data for x in ws]); bp = (C.c_void_p * len(bs))(*[x.ctypes.data for x in bs])
+        out = np.empty_like(s)
+        lv = np.empty((5, H, W, 3), np.uint8) if want_levels else None
+        self.l.orc_process_pair.argtypes = [_u8p, I, I, _u8p, I, I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, _u8p, C.c_void_p, I]
+        self.l.orc_process_pair.restype = I
+        rc = self.l.orc_process_pair(s.reshape(-1, 3), H, W, r.reshape(-1, 3), RH, RW, wp, bp, C.addressof(prm), out.reshape(-1, 3), _ptr(lv), 1 if s2_exact else 0)
+        assert rc == 0
+        return (out, lv) if want_levels else out
 
     def feat_normalize(self, src, want_resp=False):
         src = np.ascontiguousarray(src, np.float32)
