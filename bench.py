@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the hot path on N MI355X GPUs (one process per GPU, pairs sharded, no data collective).
+"""bench.py — end-to-end throughput of the hot path on N MI355X GPUs (one process per GPU, pairs sharded, no data collective).
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-A "step" = one pass of the hot path over one synthetic 700x700 source/reference pair per GPU (BASELINE config 2).
-`value` = pairs/s summed over all ranks, inputs resident in HBM when the timed region starts.
+A "step" = one full pass of the hot path (VGG19 features, k-means, L=5->1 PatchMatch both ways, BDS votes, kNN graph,
+nonlocal + WLS colour solves, re-predicts) over one synthetic 700x700 source/reference pair per GPU — BASELINE config 2.
+`value` = pairs/s summed over ranks, inputs resident in HBM when the timed region starts (nct_pair_run only).
 
-Extra objects on the JSON line:
-  roofline     — dominant kernel (PatchMatch Jacobi step at the finest level, k_pm_step<1>): algorithmic GB/s from the
-                 device eval counter x SURVEY §8d bytes-per-eval, over the kernel time measured with HIP events on the
-                 library's own stream (nct_pm_bench_run), vs the 8 TB/s HBM peak.
-  cpu_baseline — the CPU oracle (oracle/liboracle.so, "port") timed on this box's host cores on a bounded sample.
+Extra objects:
+  roofline     — dominant PatchMatch kernel (Jacobi step at the finest level, k_pm_step<1>): algorithmic GB/s from the device
+                 eval counter x SURVEY §8d bytes-per-eval over the kernel time measured with HIP events on the library's
+                 own stream, vs the 8 TB/s HBM peak. `traffic` stays null until the PMC pass is recorded in profiles/.
+  cpu_baseline — the CPU oracle ("port") end-to-end on a bounded sample, on this box's host cores.
+  stages_ms    — per-stage wall time of one extra, instrumented pair (not part of the timed region).
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -24,18 +27,6 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
-
-
-def level_geometry(h, w):
-    """Feature pyramid of a HxW image, coarse -> fine (Caffe ceil-mode pooling) + rs_max (main.cu:77-83)."""
-    dims, hh, ww = [], h, w
-    for c in (64, 128, 256, 512, 512):
-        dims.append((c, hh, ww))
-        hh, ww = (hh + 1) // 2, (ww + 1) // 2
-    dims = dims[::-1]
-    max_len = max(h, w)
-    rs = [max_len // 16, max_len // 32, max_len // 64, 32, 32]
-    return [(c, hh, ww, r) for (c, hh, ww), r in zip(dims, rs)]
 
 
 def pm_bytes(evals, n_queries, n_launches, C):
@@ -50,6 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=700, help="image side (BASELINE config 2 = 700)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -64,46 +56,37 @@ def main():
 
     import nct
     import synth
+    from caffemodel_io import synthetic_vgg19, write_caffemodel
+
     ctx = nct.Context(local_rank)
-    levels = level_geometry(args.size, args.size)
+    # synthetic VGG19 (He-normal, seed 19) serialised as a V1-format caffemodel and loaded through the ingest path
+    ws, bs = synthetic_vgg19(19)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "VGG_ILSVRC_19_layers.caffemodel")
+        write_caffemodel(path, ws, bs, fmt="v1")
+        ctx.vgg19_load_caffemodel(path)
 
-    # ---- synthetic, device-resident inputs (one pair per rank; seeds follow SURVEY §8d: 1000+2i / 1001+2i)
-    ctxs = []
-    for li, (C, h, w, rs) in enumerate(levels):
-        c = ctx if li == 0 else nct.Context(local_rank)
-        fa = synth.features(1000 + 2 * rank + 10 * li, C, h, w)
-        fb = synth.features(1001 + 2 * rank + 10 * li, C, h, w)
-        c.pm_bench_setup(fa, fb)
-        ctxs.append(c)
+    S = args.size
+    # pair i of this rank: seeds 1000+2i / 1001+2i; every step processes a fresh pair index
+    def pair(i):
+        return synth.image(1000 + 2 * i, S, S), synth.image(1001 + 2 * i, S, S)
 
-    def one_pair(count=False):
-        """PatchMatch L=5->1, both directions (the second direction reuses the same feature pair, roles swapped in
-        cost terms only: same geometry => same work)."""
-        tot_ms, per_level = 0.0, []
-        for (C, h, w, rs), c in zip(levels, ctxs):
-            ms_l, ev_l = 0.0, 0
-            for d in range(2):
-                ms, ev, _, _ = c.pm_bench_run(iters=10, rs_max=rs, seed=17 + d, count_evals=count)
-                ms_l += ms
-                ev_l += ev or 0
-            per_level.append((ms_l, ev_l))
-            tot_ms += ms_l
-        return tot_ms, per_level
+    prm = nct.Params.default()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    src, ref = pair(rank)
+    ctx.pair_upload(src, ref)
     for _ in range(args.warmup):
-        one_pair()
+        ctx.pair_run(prm)
     barrier()
     t0 = time.perf_counter()
-    kern_levels = None
     for _ in range(args.steps):
-        _, kern_levels = one_pair()
-    for c in ctxs:
-        c.synchronize()
+        ctx.pair_run(prm)
+    ctx.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -111,19 +94,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (finest level, C=64): un-timed counting pass + the timed pass' event time
-    _, counted = one_pair(count=True)
-    C, h, w, rs = levels[-1]
-    n_launch = 2 * 41
-    evals = counted[-1][1]
-    fin_ms = kern_levels[-1][0]
-    alg_bytes = pm_bytes(evals, h * w, n_launch, C)
-    achieved = alg_bytes / (fin_ms * 1e-3) / 1e9
-    tot_evals = sum(e for _, e in counted)
-    tot_bytes = sum(pm_bytes(e, hh * ww, n_launch, cc) for (_, e), (cc, hh, ww, _) in zip(counted, levels))
-    tot_ms = sum(m for m, _ in kern_levels)
+    # host-in -> host-out rate for DESIGN.md (never `value`)
+    t1 = time.perf_counter()
+    out = ctx.process_pair(src, ref, prm)
+    pcie_inclusive_s = time.perf_counter() - t1
+    stages = ctx.pair_run(prm, want_timing=True)
 
-    out = {
+    res = {
         "metric": "700x700 pairs/sec end-to-end L=5->1; PatchMatch HBM GB/s vs peak",
         "value": world * args.steps / elapsed,
         "unit": "pairs/s",
@@ -131,55 +108,67 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"PARTIAL: PatchMatch stage only (L=5->1, both directions, iters=10) of one {args.size}x{args.size} pair; "
-                               "VGG19 + colour stage not yet in the timed region",
+        "config": {"workload": f"one {S}x{S} source/reference pair per GPU per step, full L=5->1 pyramid, bds=2.0, Config.h defaults "
+                               "(BASELINE config 2); synthetic He-init VGG19 loaded from a V1 caffemodel",
                    "pairs_per_gpu_per_step": 1, "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
-        "roofline": {"bound": "hbm", "kernel": "k_pm_step<1> (C=64, %dx%d)" % (h, w), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "launches": n_launch, "avg_launch_ms": fin_ms / n_launch, "algorithmic_bytes_per_launch": alg_bytes / n_launch,
-                     "evals": evals},
-        "patchmatch_all_levels": {"evals": tot_evals, "algorithmic_GB": tot_bytes / 1e9, "kernel_ms": tot_ms,
-                                  "algorithmic_GBps": tot_bytes / (tot_ms * 1e-3) / 1e9,
-                                  "per_level_ms": [m for m, _ in kern_levels]},
+        "stages_ms": stages,
+        "pcie_inclusive_pairs_per_s": 1.0 / pcie_inclusive_s,
+        "output_checksum": int(out.astype(np.uint64).sum()),
     }
 
+    if rank == 0 and not args.no_roofline:
+        res["roofline"] = patchmatch_roofline(nct, synth, local_rank, S)
     if rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(levels, tot_evals)
+        res["cpu_baseline"] = cpu_baseline(synth, ws, bs, S)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(levels, evals_per_pair):
-    """Oracle ('port') PatchMatch on a bounded sample: one direction of level 4 (88x88x512) with few iterations,
-    all host cores (OpenMP). Reported as pairs/s by scaling with distance evaluations weighted by 9*C MACs."""
+def patchmatch_roofline(nct, synth, device, S):
+    """Finest-level PatchMatch (S x S x 64, both directions, 10 iterations = 82 launches of k_pm_step<1>) on device-resident
+    synthetic features: kernel time from HIP events inside the library, evals from the device counter (separate pass)."""
+    c = nct.Context(device)
+    C = 64
+    c.pm_bench_setup(synth.features(11, C, S, S), synth.features(12, C, S, S))
+    c.pm_bench_run(iters=10, rs_max=32, seed=1)                      # warm-up
+    ms = 0.0
+    reps = 3
+    for r in range(reps):
+        for d in range(2):
+            m, _, _, _ = c.pm_bench_run(iters=10, rs_max=32, seed=17 + d)
+            ms += m
+    ms /= reps
+    evals = 0
+    for d in range(2):
+        _, ev, _, _ = c.pm_bench_run(iters=10, rs_max=32, seed=17 + d, count_evals=True)
+        evals += ev
+    n_launch = 82
+    alg = pm_bytes(evals, S * S, n_launch, C)
+    achieved = alg / (ms * 1e-3) / 1e9
+    c.close()
+    return {"bound": "hbm", "kernel": f"k_pm_step<1> (C=64, {S}x{S}, both directions, 10 iters)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": n_launch, "avg_launch_ms": ms / n_launch,
+            "algorithmic_bytes_per_launch": alg / n_launch, "evals": evals,
+            "note": "algorithmic bytes (SURVEY 8d) exceed HBM traffic: overlapping candidate tiles are served by L2/Infinity Cache"}
+
+
+def cpu_baseline(synth, ws, bs, S):
+    """Oracle ('port') end-to-end on a bounded sample: one 112x112 pair, scaled to the SxS pair by pixel count."""
     import oracle_bind
-    import synth
     orc = oracle_bind.load()
-    C, h, w, rs = levels[1]
-    a = orc.feat_normalize(synth.features(1, C, h, w))
-    b = orc.feat_normalize(synth.features(2, C, h, w))
-    nnf0 = orc.nnf_init(h, w, h, w)
-    iters = 2
+    threads = min(32, os.cpu_count() or 1)
+    orc.l.orc_set_threads(threads)
+    n = 112
+    src, ref = synth.image(1000, n, n), synth.image(1001, n, n)
     t0 = time.perf_counter()
-    orc.patchmatch(a, b, nnf0, iters=iters, rs_max=rs, seed=1)
+    orc.process_pair(src, ref, ws, bs)
     dt = time.perf_counter() - t0
-    ev = orc.last_evals()
-    mac_rate = ev * 9 * C / dt                      # MAC/s of the oracle on this host
-    # MACs per pair: evals per level * 9*C (both directions) — use the model E*n per level
-    macs_pair = 0
-    for (c, hh, ww, r) in levels:
-        R = 0
-        m = min(r, max(hh, ww))
-        while m >= 1:
-            R += 1
-            m //= 2
-        macs_pair += 2 * hh * ww * (1 + 10 * (16 + R)) * 9 * c
-    cores = os.cpu_count() or 1
-    return {"value": mac_rate / macs_pair, "unit": "pairs/s (PatchMatch stage only)", "cores": cores, "kind": "port",
-            "sample": f"oracle orc_patchmatch, one direction, level 4 ({h}x{w}x{C}), {iters} iters, {ev} evals in {dt:.2f} s, "
-                      f"OpenMP on {cores} threads; scaled to a pair by 9*C MACs per eval over both directions of 5 levels"}
+    scale = (n * n) / float(S * S)
+    return {"value": scale / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"oracle orc_process_pair on one {n}x{n} pair (full L=5->1 loop, same synthetic VGG19) took {dt:.2f} s on {threads} OpenMP threads; "
+                      f"scaled to a {S}x{S} pair by pixel count ({1 / scale:.1f}x)"}
 
 
 if __name__ == "__main__":

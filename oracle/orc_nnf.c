@@ -27,6 +27,23 @@
 #include <omp.h>
 #endif
 
+/* thread control for the test harness: the GPU boxes expose 256 host cores and libgomp's default team (one thread
+ * per core, spinning) turns the thousands of tiny parallel regions of the solvers into a 600x slowdown. */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int orc_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* ---- layout helper: CHW -> HWC with channel padding to a multiple of 4 (zeros) ---- */
 static float* chw_to_hwc(const float* src, int C, int H, int W, int* Cpad_out) {
     int Cp = (C + 3) & ~3;

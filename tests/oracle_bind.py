@@ -271,5 +271,8 @@ def load(build=True):
     if _cached is None:
         if build:
             subprocess.run(["make", "-C", ORC_DIR, "-s"], check=True)
-        _cached = Oracle(C.CDLL(ORC_LIB))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        l = C.CDLL(ORC_LIB)
+        l.orc_set_threads(int(os.environ.get("ORC_THREADS", min(16, os.cpu_count() or 1))))
+        _cached = Oracle(l)
     return _cached
