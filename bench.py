@@ -73,26 +73,19 @@ def main():
 
     prm = nct.Params.default()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    from nct.shard import shard_pairs, timed_region
+
+    # global pair list of this job: one pair per GPU per step, pair i -> rank i mod N (weak scaling)
+    my_pairs = shard_pairs(world, rank, world)
+    src, ref = pair(my_pairs[0])
+    ctx.pair_upload(src, ref)
+
+    def sync():
+        ctx.synchronize()
         torch.cuda.synchronize()
 
-    src, ref = pair(rank)
-    ctx.pair_upload(src, ref)
-    for _ in range(args.warmup):
-        ctx.pair_run(prm)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.pair_run(prm)
-    ctx.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_region(lambda i: ctx.pair_run(prm), args.steps, args.warmup, dist=dist, sync=sync,
+                           device=torch.device("cuda", local_rank) if dist is not None else None)
 
     # host-in -> host-out rate for DESIGN.md (never `value`)
     t1 = time.perf_counter()

@@ -1,0 +1,166 @@
+// neural_color_transfer — the reference's console driver re-created on top of libnct (C ABI, include/nct.h).
+// Mirrors: get_input / main (main.cu:29-44, 546-590), transfer_single (main.cu:456-543), Utility::CmdLine
+// (CmdLine.h:58-69,132-147; CmdLine.cpp:21-56,93-109). Same flags, same pairs.txt, same output names, same log lines.
+// Differences: portable path handling ('/' and '\\'), PNG-only I/O (in-repo codec), a missing pairs.txt
+// is an error instead of a NULL dereference (main.cu:463-471), real defaults in the help text (Config.h:58-72 — the strings at
+// main.cu:40-43 quote other numbers), plus `-gpus N` (pairs sharded over N GPUs, one context per worker thread) and `-seed`.
+#include <sys/stat.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "nct.h"
+#include "png_io.h"
+
+namespace {
+constexpr int MAX_SIZE = 1000;                 // Config.h:5
+
+struct Param { std::string flag, comment; enum { STR, INT, DBL } kind; void* dst; };
+struct CmdLine {
+    std::vector<Param> params;
+    void add(const char* flag, std::string& v, const char* c) { params.push_back({flag, c, Param::STR, &v}); }
+    void add(const char* flag, int& v, const char* c) { params.push_back({flag, c, Param::INT, &v}); }
+    void add(const char* flag, double& v, const char* c) { params.push_back({flag, c, Param::DBL, &v}); }
+    static bool is_arg(const char* a) { return a && (a[0] == '-' || a[0] == '/') && a[1] != 0 && !(a[1] >= '0' && a[1] <= '9') && a[1] != '.'; }
+    void help(const char* prog) const {
+        std::cout << "Running: " << prog << std::endl;
+        for (const auto& p : params) std::cout << "-" << p.flag << ": " << p.comment << std::endl;
+    }
+    bool parse(int argc, char** argv) const {
+        int i = 1;
+        while (i < argc) {
+            if (!is_arg(argv[i])) { ++i; continue; }                       // positional "files" are collected and ignored (CmdLine.cpp:26-29)
+            const std::string a(argv[i] + 1);
+            if (a == "h" || a == "?" || a == "help") { help(argv[0]); return false; }
+            bool done = false;
+            for (const auto& p : params)
+                if (a == p.flag) {
+                    if (i + 1 < argc) {
+                        if (p.kind == Param::STR) *(std::string*)p.dst = argv[i + 1];
+                        else if (p.kind == Param::INT) *(int*)p.dst = atoi(argv[i + 1]);
+                        else *(double*)p.dst = atof(argv[i + 1]);
+                        ++i;
+                    }
+                    ++i; done = true; break;
+                }
+            if (!done) { std::cout << "Unrecognized parameter: " << argv[i] << std::endl << std::endl; help(argv[0]); return false; }
+        }
+        return true;
+    }
+};
+
+std::string stem(const std::string& path) {          // main.cu:524-531 (find_last_of on both separators, strip the extension)
+    const size_t pos = path.find_last_of("\\/") + 1;
+    const size_t dot = path.find_last_of('.');
+    return path.substr(pos, dot == std::string::npos || dot < pos ? std::string::npos : dot - pos);
+}
+
+struct Pair { std::string cnt, stl; float bds; };
+std::mutex g_print;
+
+struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; };
+
+// shrink so that the longer side is <= MAX_SIZE, int truncation as in main.cu:500-522
+bool shrink(nct_ctx* ctx, ImageBGR& img) {
+    if (img.w <= MAX_SIZE && img.h <= MAX_SIZE) return true;
+    int cw = MAX_SIZE, ch = (int)(cw / (float)img.w * img.h);
+    if (img.w < img.h) { ch = MAX_SIZE; cw = (int)(ch / (float)img.h * img.w); }
+    ImageBGR out; out.h = ch; out.w = cw; out.px.resize((size_t)ch * cw * 3);
+    if (nct_resize_u8c3(ctx, img.px.data(), img.h, img.w, out.px.data(), ch, cw) != NCT_OK) return false;
+    img = std::move(out);
+    return true;
+}
+
+void process(nct_ctx* ctx, const Config& cfg, const Pair& p) {
+    char line[1024];
+    std::string log;
+    auto say = [&](const char* fmt, auto... a) { snprintf(line, sizeof line, fmt, a...); log += line; };
+    log += "-----------------***********************----------------------\n";
+    say("Content: %s, style: %s, BDS weight: %f.\n", p.cnt.c_str(), p.stl.c_str(), (double)p.bds);
+    const std::string cntStr = cfg.input_dir + "/" + p.cnt, stlStr = cfg.input_dir + "/" + p.stl;
+    ImageBGR cnt, stl; std::string err;
+    auto flush = [&] { std::lock_guard<std::mutex> g(g_print); fputs(log.c_str(), stdout); fflush(stdout); };
+    if (!pngio::read(cntStr, cnt, err)) { say("Error: Fail reading content image: %s\n", cntStr.c_str()); flush(); return; }
+    say("\n**Read content file: %s, w = %d, h = %d\n", cntStr.c_str(), cnt.w, cnt.h);
+    if (!pngio::read(stlStr, stl, err)) { say("Error: Fail reading style image: %s\n", stlStr.c_str()); flush(); return; }
+    say("Read style file: %s, w = %d, h = %d\n", stlStr.c_str(), stl.w, stl.h);
+    if (!shrink(ctx, cnt) || !shrink(ctx, stl)) { say("Error: resize failed: %s\n", nct_last_error(ctx)); flush(); return; }
+    nct_params prm = cfg.prm;
+    prm.bds_weight = p.bds;                                     // the per-line weight overrides -bds (main.cu:475)
+    std::vector<uint8_t> out((size_t)cnt.h * cnt.w * 3);
+    nct_pair_timing tm;
+    const int rc = nct_process_pair(ctx, cnt.px.data(), cnt.h, cnt.w, stl.px.data(), stl.h, stl.w, &prm, out.data(), &tm);
+    if (rc != NCT_OK) { say("Error: %s\n", nct_last_error(ctx)); flush(); return; }
+    say("VGG19 Time: %lf sec.\n", tm.vgg_ms * 1e-3);
+    say("Patch Match Time: %lf sec.\n", (tm.patchmatch_ms + tm.vote_ms) * 1e-3);
+    say("Color Time (kNN + Nonlocal Solve + WLS Solve): %lf sec.\n", (tm.knn_ms + tm.color_ms + tm.cluster_ms) * 1e-3);
+    say("**Finished Time: %lf sec.\n", tm.total_ms * 1e-3);
+    char name[1024];
+    snprintf(name, sizeof name, "%s/%s_%s_%2.2f.png", cfg.output_dir.c_str(), stem(cntStr).c_str(), stem(stlStr).c_str(), (double)p.bds);
+    if (!pngio::write(name, out.data(), cnt.h, cnt.w, err)) { say("Error: cannot write %s: %s\n", name, err.c_str()); flush(); return; }
+    say("Final output file: %s.\n\n", name);
+    flush();
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc == 4 && !strcmp(argv[1], "--png-roundtrip")) {       // codec self-test hook (no GPU): decode argv[2], re-encode to argv[3]
+        ImageBGR im; std::string err;
+        if (!pngio::read(argv[2], im, err)) { printf("Error: %s: %s\n", argv[2], err.c_str()); return 1; }
+        if (!pngio::write(argv[3], im.px.data(), im.h, im.w, err)) { printf("Error: %s: %s\n", argv[3], err.c_str()); return 1; }
+        printf("%d %d\n", im.w, im.h);
+        return 0;
+    }
+    CmdLine cl;
+    Config cfg;
+    nct_params_default(&cfg.prm);
+    int gpu = 0, ngpus = 1, seed = 1;
+    cl.add("m", cfg.model_dir, "Directory of network models.");
+    cl.add("i", cfg.input_dir, "Input directory of content and style images and pairs.txt.");
+    cl.add("o", cfg.output_dir, "Output directory of result images.");
+    cl.add("g", gpu, "GPU ID (default: 0).");
+    cl.add("bds", cfg.prm.bds_weight, "Weight of reverse color in BDS voting (default: 2.0).");
+    cl.add("eps", cfg.prm.eps, "Eps is used to avoid dividing zero (default: 0.6 with range in [0-255]).");
+    cl.add("nl", cfg.prm.nonlocal_weight, "Weight of nonlocal constraint (default: 2.0).");
+    cl.add("l", cfg.prm.local_weight, "Weight of local constraint (default: 0.125).");
+    cl.add("w", cfg.prm.wls_lambda_init, "Initial value of WLS weight (default: 0.024).");
+    cl.add("gpus", ngpus, "[extension] number of GPUs to shard pairs.txt over, starting at -g (default: 1).");
+    cl.add("seed", seed, "[extension] seed of the counter-based RNG (default: 1).");
+    if (!cl.parse(argc, argv)) return -1;
+    cfg.prm.seed = (uint32_t)seed;
+    if (ngpus < 1) ngpus = 1;
+
+    mkdir(cfg.output_dir.c_str(), 0777);                                    // main.cu:458
+    const std::string pairsFile = cfg.input_dir + "/pairs.txt";
+    FILE* fp = fopen(pairsFile.c_str(), "r");
+    if (!fp) { printf("Error: File %s does not exist in the input directory.\n", pairsFile.c_str()); return -1; }
+    std::vector<Pair> pairs;
+    char a[260], b[260]; float w = 0.f;
+    while (fscanf(fp, "%259s %259s %f\n", a, b, &w) == 3) pairs.push_back({a, b, w});
+    fclose(fp);
+
+    // model path: <model_dir>/vgg19/VGG_ILSVRC_19_layers.caffemodel (main.cu:575-580; '\\' or '/' accepted in model_dir)
+    const std::string model = cfg.model_dir + "/vgg19/VGG_ILSVRC_19_layers.caffemodel";
+    std::vector<nct_ctx*> ctxs(ngpus, nullptr);
+    for (int g = 0; g < ngpus; ++g) {
+        if (nct_create(gpu + g, &ctxs[g]) != NCT_OK) { printf("Error: %s\n", nct_last_error(nullptr)); return -1; }
+        char name[256]; nct_device_name(ctxs[g], name, sizeof name);
+        printf("Set device %d: %s.\n", gpu + g, name);
+        if (nct_vgg19_load_caffemodel(ctxs[g], model.c_str()) != NCT_OK) { printf("Error: %s\n", nct_last_error(ctxs[g])); return -1; }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> workers;
+    for (int g = 0; g < ngpus; ++g)
+        workers.emplace_back([&, g] { for (size_t i = g; i < pairs.size(); i += ngpus) process(ctxs[g], cfg, pairs[i]); });   // static i mod G
+    for (auto& t : workers) t.join();
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("Processed %zu pair(s) on %d GPU(s) in %.3f sec (%.3f pairs/sec).\n", pairs.size(), ngpus, sec, pairs.empty() ? 0.0 : pairs.size() / sec);
+    for (auto* c : ctxs) nct_destroy(c);
+    return 0;
+}

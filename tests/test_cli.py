@@ -1,0 +1,98 @@
+"""D1/D2: the console driver (flags, help, pairs.txt handling, PNG codec). CPU tests cover the parts that need no GPU;
+the GPU test runs a real pairs.txt batch and compares the written PNGs with nct_process_pair's result."""
+import os
+import subprocess
+import numpy as np
+import pytest
+from PIL import Image
+
+import nct
+import synth
+
+BIN = os.path.join(nct.PKG_ROOT, "bin", "neural_color_transfer")
+REF_DEMO = "/root/reference/demo/example/in"
+
+
+def run(*args):
+    return subprocess.run([BIN, *args], capture_output=True, text=True)
+
+
+def test_help_prints_flags_and_returns_minus_one():
+    for h in ("-h", "-?", "-help", "/h"):
+        r = run(h)
+        assert r.returncode == 255                               # main.cu:557-560: `return -1`
+        for flag in ("-m:", "-i:", "-o:", "-g:", "-bds:", "-eps:", "-nl:", "-l:", "-w:"):
+            assert flag in r.stdout
+    assert "default: 0.125" in r.stdout and "default: 0.024" in r.stdout      # real Config.h defaults
+
+
+def test_unknown_flag():
+    r = run("-zzz", "1")
+    assert r.returncode == 255 and "Unrecognized parameter: -zzz" in r.stdout and "-bds:" in r.stdout
+
+
+def test_missing_pairs_txt_is_an_error_not_a_crash(tmp_path):
+    r = run("-i", str(tmp_path), "-o", str(tmp_path / "out"), "-m", str(tmp_path))
+    assert r.returncode == 255 and "pairs.txt does not exist" in r.stdout
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "P", "LA", "I;16"])
+def test_png_codec_roundtrip_matches_pillow(tmp_path, mode):
+    """imread semantics: 8-bit 3-channel BGR, alpha dropped (not blended), gray replicated, palette expanded, 16->8 bit."""
+    rgb = synth.image(3, 37, 53)[..., ::-1].copy()
+    if mode == "RGB":
+        im = Image.fromarray(rgb, "RGB"); exp = rgb
+    elif mode == "RGBA":
+        a = np.full(rgb.shape[:2] + (1,), 77, np.uint8); im = Image.fromarray(np.concatenate([rgb, a], -1), "RGBA"); exp = rgb
+    elif mode == "L":
+        g = rgb[..., 0]; im = Image.fromarray(g, "L"); exp = np.stack([g] * 3, -1)
+    elif mode == "LA":
+        g = rgb[..., 1]; im = Image.fromarray(np.stack([g, 255 - g], -1), "LA"); exp = np.stack([g] * 3, -1)
+    elif mode == "P":
+        im = Image.fromarray(rgb, "RGB").quantize(64); exp = np.asarray(im.convert("RGB"))
+    else:
+        g16 = (rgb[..., 0].astype(np.uint16) << 8) | rgb[..., 1]; im = Image.fromarray(g16, "I;16"); exp = np.stack([rgb[..., 0]] * 3, -1)
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    im.save(src)
+    r = run("--png-roundtrip", src, dst)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.split() == ["53", "37"]
+    got = np.asarray(Image.open(dst).convert("RGB"))
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DEMO), reason="reference demo images not mounted")
+def test_png_codec_reads_the_reference_demo_inputs(tmp_path):
+    """demo/example/in/*.png (5 of 10 are RGBA) decode to the same pixels Pillow sees."""
+    for name in sorted(os.listdir(REF_DEMO))[:10]:
+        if not name.endswith(".png"):
+            continue
+        dst = str(tmp_path / name)
+        r = run("--png-roundtrip", os.path.join(REF_DEMO, name), dst)
+        assert r.returncode == 0, (name, r.stdout)
+        assert np.array_equal(np.asarray(Image.open(dst).convert("RGB")), np.asarray(Image.open(os.path.join(REF_DEMO, name)).convert("RGB")))
+
+
+@pytest.mark.gpu
+def test_cli_batch_matches_library(tmp_path, ctx):
+    from caffemodel_io import synthetic_vgg19, write_caffemodel
+    ws, bs = synthetic_vgg19(19)
+    (tmp_path / "model" / "vgg19").mkdir(parents=True)
+    write_caffemodel(str(tmp_path / "model" / "vgg19" / "VGG_ILSVRC_19_layers.caffemodel"), ws, bs)
+    inp = tmp_path / "in"; (inp / "sub").mkdir(parents=True)
+    a, b, c = synth.image(1, 72, 64), synth.image(2, 60, 80), synth.image(3, 64, 64)
+    Image.fromarray(a[..., ::-1].copy()).save(inp / "a.png"); Image.fromarray(b[..., ::-1].copy()).save(inp / "sub" / "b.png")
+    Image.fromarray(c[..., ::-1].copy()).save(inp / "c.png")
+    (inp / "pairs.txt").write_text("a.png sub/b.png 2.0\nmissing.png c.png 1.0\nc.png a.png 0.5\n")
+    out = tmp_path / "out"
+    r = run("-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(out), "-g", "0")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Fail reading content image" in r.stdout                       # unreadable image: message, skip, continue (main.cu:484-496)
+    assert "Patch Match Time:" in r.stdout and "**Finished Time:" in r.stdout and "Final output file:" in r.stdout
+    assert sorted(os.listdir(out)) == ["a_b_2.00.png", "c_a_0.50.png"]     # <srcbase>_<refbase>_<%2.2f bds>.png (main.cu:537)
+    ctx.vgg19_load_raw(ws, bs)
+    for name, (s, rf, w) in {"a_b_2.00.png": (a, b, 2.0), "c_a_0.50.png": (c, a, 0.5)}.items():
+        prm = nct.Params.default(); prm.bds_weight = w
+        exp = ctx.process_pair(s, rf, prm)
+        got = np.asarray(Image.open(out / name).convert("RGB"))[..., ::-1]
+        assert np.array_equal(got, exp)

@@ -170,3 +170,65 @@ def test_level_transfer_stages(oracle):
     # G == S: a = sigma/(sigma+eps) < 1 initially; the result must stay close to S (sanity of the whole chain)
     out_id = oracle.local_color_transfer(errf, s_full, s_full, s_full, idsf, wsf, layer=4)
     assert np.abs(out_id.astype(int) - s_full.astype(int)).mean() < 6.0
+
+
+def _s1_inputs(oracle, seed=3, h=12, w=12):
+    s = oracle.resize_u8c3(synth.image(seed, 48, 48), h, w)
+    g = oracle.resize_u8c3(synth.image(seed + 1, 48, 48), h, w)
+    labels = (np.arange(9).reshape(3, 3) % 3).astype(np.int32)
+    ids, ws = oracle.knn_graph(oracle.bgr2lab(s), labels, 3, samples=4)
+    err = -np.random.default_rng(seed).random((h, w)).astype(np.float32)
+    return err, s, g, ids, ws
+
+
+def test_truncated_cg_is_chaotic(oracle):
+    """the reference's S1 (un-preconditioned CG stopped at its iteration cap) amplifies a 1e-15 relative
+    perturbation of ONE kNN weight into O(1e-3..1e-2) coefficient changes — bit-level agreement needs identical arithmetic."""
+    err, s, g, ids, ws = _s1_inputs(oracle)
+    full = synth.image(3, 48, 48)
+    _, st1 = oracle.local_color_transfer(err, s, g, full, ids, ws, layer=2, want_stages=True)
+    ws2 = ws.copy(); ws2[5, 3] *= (1 + 1e-15)
+    _, st2 = oracle.local_color_transfer(err, s, g, full, ids, ws2, layer=2, want_stages=True)
+    d = np.abs(st1["ab_nonlocal"] - st2["ab_nonlocal"]).max()
+    assert d > 1e-6, f"expected chaotic amplification, got {d}"
+    assert np.array_equal(st1["ab_local"], st2["ab_local"])
+
+
+def test_canonical_cg_matches_explicit_for_few_iterations(oracle):
+    """The canonical-order matrix-free operator (orc_color_canon.c) and the literally assembled A^T(Ax) (orc_color.c) are the same
+    linear operator: before the chaos sets in (few iterations) both CG variants agree to rounding."""
+    import ctypes as C
+    oracle._decl_color()
+    err, s, g, ids, ws = _s1_inputs(oracle)
+    h = w = 12; n = h * w
+    lab_s = oracle.bgr2lab(s).reshape(-1, 3).astype(np.float64) * (1.0 / 255.0)
+    lab_g = oracle.bgr2lab(g).reshape(-1, 3).astype(np.float64) * (1.0 / 255.0)
+    _, st = oracle.local_color_transfer(err, s, g, synth.image(3, 48, 48), ids, ws, layer=2, want_stages=True)
+    a0, b0 = st["ab_local"][0].copy(), st["ab_local"][1].copy()
+    e = err.reshape(-1).astype(np.float64)
+    wgt = np.maximum(1.0 - (e - e.min()) / (e.max() - e.min()), 1e-6)
+    f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"); i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    sig = [f64, f64, f64, f64, f64, i32, f64] + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_double, C.c_double, i32, C.c_int]
+    oracle.l.orc_nonlocal_solve.argtypes = sig
+    oracle.l.orc_nonlocal_solve_explicit.argtypes = sig
+    for maxit, tol in ((1, 1e-12), (3, 1e-10), (8, 1e-7)):
+        res = []
+        for fn in (oracle.l.orc_nonlocal_solve, oracle.l.orc_nonlocal_solve_explicit):
+            a, b = a0.copy(), b0.copy(); it = np.zeros(3, np.int32)
+            fn(a.reshape(-1), b.reshape(-1), lab_s.reshape(-1), lab_g.reshape(-1), wgt, ids.reshape(-1), ws.reshape(-1), 8, h, w, 2,
+               0.125, 1.2, 16.0, 2.0, 8.0, it, maxit)
+            assert it.tolist() == [maxit] * 3
+            res.append((a, b))
+        assert np.allclose(res[0][0], res[1][0], rtol=tol, atol=tol) and np.allclose(res[0][1], res[1][1], rtol=tol, atol=tol)
+        assert not np.array_equal(res[0][0], a0)       # the solve moved the coefficients
+
+
+def test_canonical_wls_matches_exact_solve(oracle):
+    """S2: the canonical-order PCG (mirror of the product) agrees with the exact banded-Cholesky solve to 1e-8."""
+    err, s, g, ids, ws = _s1_inputs(oracle)
+    full = synth.image(3, 48, 48)
+    o1, s1 = oracle.local_color_transfer(err, s, g, full, ids, ws, layer=2, want_stages=True, s2_exact=False)
+    o2, s2 = oracle.local_color_transfer(err, s, g, full, ids, ws, layer=2, want_stages=True, s2_exact=True)
+    assert np.array_equal(s1["ab_up"], s2["ab_up"])
+    assert np.allclose(s1["ab_wls"], s2["ab_wls"], rtol=1e-7, atol=1e-9)
+    assert np.abs(o1.astype(int) - o2.astype(int)).max() <= 1
