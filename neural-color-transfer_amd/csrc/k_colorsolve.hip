@@ -282,8 +282,6 @@ __global__ void k_apply(const double* __restrict__ a, const double* __restrict__
 }
 
 // ================================================================= S2 WLS: (diag(r) + L) x = r x0, 6 right-hand sides
-struct WlsSys { int n, H, W; const double *diag, *wx, *wy; };
-struct PCGState { double rz[6], rr[6], bb[6], al[6], be[6]; int active[6]; int iters[6]; };
 
 __global__ void k_wls_system(const double* __restrict__ gx, const double* __restrict__ gy, const double* __restrict__ rough, int H, int W,
                              double* __restrict__ diag, double* __restrict__ wx, double* __restrict__ wy) {
@@ -298,115 +296,6 @@ __global__ void k_wls_system(const double* __restrict__ gx, const double* __rest
     if (y > 0) { const double g = gy[i - W] * gy[i - W]; a00 += g; }
     diag[i] = a00; wx[i] = ex; wy[i] = ey;
 }
-__device__ __forceinline__ void wls_op(const WlsSys& S, const double* __restrict__ v /*[n][3]*/, int i, double (&y)[3]) {
-    const int W = S.W, H = S.H;
-    const int r = i / W, c0 = i - r * W;
-    const double d = S.diag[i];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) y[c] = d * v[(size_t)i * 3 + c];
-    if (c0 + 1 < W) { const double wv = S.wx[i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i + 1) * 3 + c]; }
-    if (c0 > 0) { const double wv = S.wx[i - 1];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i - 1) * 3 + c]; }
-    if (r + 1 < H) { const double wv = S.wy[i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i + W) * 3 + c]; }
-    if (r > 0) { const double wv = S.wy[i - W];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) y[c] -= wv * v[(size_t)(i - W) * 3 + c]; }
-}
-// rhs = rough * x0 (kept in `rhs`), x = x0 (initial guess), r = rhs - M x, z = r/diag, p = z; partial: rz, rr, bb (18 values)
-__global__ __launch_bounds__(256) void k_wls_start(WlsSys S, const double* __restrict__ rough, const double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
-                                                   double* __restrict__ partial) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double acc[18];
-#pragma unroll
-    for (int q = 0; q < 18; ++q) acc[q] = 0.0;
-    if (i < S.n) {
-        const double rg = rough[i], d = S.diag[i];
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const double* xv = x + (size_t)part * S.n * 3;
-            double y[3]; wls_op(S, xv, i, y);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const size_t j = ((size_t)part * S.n + i) * 3 + c;
-                const double bq = rg * xv[(size_t)i * 3 + c];
-                const double rv = bq - y[c], z = rv / d;
-                r[j] = rv; p[j] = z;
-                const int q = part * 3 + c;
-                acc[q] = rv * z; acc[6 + q] = rv * rv; acc[12 + q] = bq * bq;
-            }
-        }
-    }
-    block_reduce_store<18>(acc, partial);
-}
-__global__ void k_pcg_init(const double* __restrict__ partial, int nb, PCGState* __restrict__ st, double rtol2) {
-    double s[18]; final_reduce<18>(partial, nb, s);
-    if (threadIdx.x < 6) { const int q = threadIdx.x; st->rz[q] = s[q]; st->rr[q] = s[6 + q]; st->bb[q] = s[12 + q]; st->iters[q] = 0; st->al[q] = 0; st->be[q] = 0;
-                           st->active[q] = (s[6 + q] > rtol2 * s[12 + q]) ? 1 : 0; }
-}
-__global__ __launch_bounds__(256) void k_wls_apply(WlsSys S, const PCGState* __restrict__ st, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (i < S.n) {
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const double* pv = p + (size_t)part * S.n * 3;
-            double y[3]; wls_op(S, pv, i, y);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const size_t j = ((size_t)part * S.n + i) * 3 + c; Ap[j] = y[c]; acc[part * 3 + c] = pv[(size_t)i * 3 + c] * y[c]; }
-        }
-    }
-    block_reduce_store<6>(acc, partial);
-}
-__global__ void k_pcg_alpha(const double* __restrict__ partial, int nb, PCGState* __restrict__ st) {
-    double s[6]; final_reduce<6>(partial, nb, s);
-    if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) st->al[q] = st->rz[q] / s[q]; }
-}
-// x += al p; r -= al Ap; z = r/diag; partial rz_new, rr
-__global__ __launch_bounds__(256) void k_wls_update(WlsSys S, const PCGState* __restrict__ st, const double* __restrict__ p, const double* __restrict__ Ap,
-                                                    double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double acc[12];
-#pragma unroll
-    for (int q = 0; q < 12; ++q) acc[q] = 0.0;
-    if (i < S.n) {
-        const double d = S.diag[i];
-#pragma unroll
-        for (int part = 0; part < 2; ++part)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int q = part * 3 + c;
-                if (!st->active[q]) continue;
-                const size_t j = ((size_t)part * S.n + i) * 3 + c;
-                const double al = st->al[q];
-                x[j] += al * p[j];
-                const double rv = r[j] - al * Ap[j];
-                const double zv = rv / d;
-                r[j] = rv; z[j] = zv;
-                acc[q] = rv * zv; acc[6 + q] = rv * rv;
-            }
-    }
-    block_reduce_store<12>(acc, partial);
-}
-__global__ void k_pcg_beta(const double* __restrict__ partial, int nb, PCGState* __restrict__ st, double rtol2) {
-    double s[12]; final_reduce<12>(partial, nb, s);
-    if (threadIdx.x < 6) {
-        const int q = threadIdx.x;
-        if (st->active[q]) { st->be[q] = s[q] / st->rz[q]; st->rz[q] = s[q]; st->rr[q] = s[6 + q]; st->iters[q]++; st->active[q] = (s[6 + q] > rtol2 * st->bb[q]) ? 1 : 0; }
-    }
-}
-__global__ void k_wls_dir(int n, const PCGState* __restrict__ st, const double* __restrict__ z, double* __restrict__ p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * n * 3) return;
-    const int q = (i / (n * 3)) * 3 + (i % 3);
-    if (!st->active[q]) return;
-    p[i] = z[i] + st->be[q] * p[i];
-}
-
 // ================================================================= orchestration
 #define LCHK() NCT_LAUNCH_CHECK()
 static int dbg_copy(nct_ctx* ctx, hipStream_t s, double* host, const double* dev, size_t n) {
@@ -490,39 +379,17 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
     }
     hipLaunchKernelGGL(k_roughness, dim3(nbL), dim3(256), 0, s, (const double*)Xa, (const double*)Xb, s_lab_full, N, (double*)rough); LCHK();
     if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_up, X, (size_t)6 * N); if (rc) return rc; rc = dbg_copy(ctx, s, dbg->rough, rough, N); if (rc) return rc; }
-    // ---------------- S2: WLS
+    // ---------------- S2: WLS (k_wls_mg.hip)
     {
         double lamda = prm.wls_lambda_init * normFactor;
         if (h == H && w == W) lamda *= 4;                               // ColorTransfer.cpp:1418-1424
         DevBuf<double> gx(ctx, N), gy(ctx, N), diag(ctx, N), wx(ctx, N), wy(ctx, N);
-        DevBuf<double> r(ctx, (size_t)6 * N), z(ctx, (size_t)6 * N), p(ctx, (size_t)6 * N), Ap(ctx, (size_t)6 * N), partial(ctx, (size_t)nbL * 18);
-        DevBuf<PCGState> st(ctx, 1);
-        if (!gx.ok() || !gy.ok() || !diag.ok() || !wx.ok() || !wy.ok() || !r.ok() || !z.ok() || !p.ok() || !Ap.ok() || !partial.ok() || !st.ok()) return NCT_ERR_HIP;
+        if (!gx.ok() || !gy.ok() || !diag.ok() || !wx.ok() || !wy.ok()) return NCT_ERR_HIP;
         hipLaunchKernelGGL(k_gradient_weights, dim3(nbL), dim3(256), 0, s, s_lab_full, H, W, lamda, prm.wls_alpha, (double*)gx, (double*)gy); LCHK();
         hipLaunchKernelGGL(k_wls_system, dim3(nbL), dim3(256), 0, s, (const double*)gx, (const double*)gy, (const double*)rough, H, W, (double*)diag, (double*)wx, (double*)wy); LCHK();
-        WlsSys S{N, H, W, diag, wx, wy};
-        const double rtol2 = 1e-10 * 1e-10;
-        hipLaunchKernelGGL(k_wls_start, dim3(nbL), dim3(256), 0, s, S, (const double*)rough, (const double*)X, (double*)r, (double*)p, (double*)partial); LCHK();
-        hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbL, (PCGState*)st, rtol2); LCHK();
-        const int maxit = 100000, check_every = 64;
-        PCGState hst;
-        int it = 0;
-        bool done = false;
-        while (!done && it < maxit) {
-            for (int k = 0; k < check_every; ++k, ++it) {
-                hipLaunchKernelGGL(k_wls_apply, dim3(nbL), dim3(256), 0, s, S, (const PCGState*)st, (const double*)p, (double*)Ap, (double*)partial); LCHK();
-                hipLaunchKernelGGL(k_pcg_alpha, dim3(1), dim3(256), 0, s, (const double*)partial, nbL, (PCGState*)st); LCHK();
-                hipLaunchKernelGGL(k_wls_update, dim3(nbL), dim3(256), 0, s, S, (const PCGState*)st, (const double*)p, (const double*)Ap, (double*)X, (double*)r, (double*)z, (double*)partial); LCHK();
-                hipLaunchKernelGGL(k_pcg_beta, dim3(1), dim3(256), 0, s, (const double*)partial, nbL, (PCGState*)st, rtol2); LCHK();
-                hipLaunchKernelGGL(k_wls_dir, dim3(cdiv(6 * N, 256)), dim3(256), 0, s, N, (const PCGState*)st, (const double*)z, (double*)p); LCHK();
-            }
-            NCT_HIP(hipMemcpyAsync(&hst, (PCGState*)st, sizeof hst, hipMemcpyDeviceToHost, s));
-            NCT_HIP(hipStreamSynchronize(s));
-            done = true;
-            for (int q = 0; q < 6; ++q) if (hst.active[q]) done = false;
-        }
-        if (!done) return ctx->fail(NCT_ERR_HIP, "WLS PCG did not converge in %d iterations", maxit);
-        if (dbg && dbg->wls_iters) for (int q = 0; q < 6; ++q) dbg->wls_iters[q] = hst.iters[q];
+        int wit[6] = {0, 0, 0, 0, 0, 0};
+        int rc = nctk_wls_solve_mg(ctx, s, X, rough, wx, wy, H, W, 1e-8, wit); if (rc) return rc;
+        if (dbg && dbg->wls_iters) for (int q = 0; q < 6; ++q) dbg->wls_iters[q] = wit[q];
     }
     if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_wls, X, (size_t)6 * N); if (rc) return rc; }
     // ---------------- A1

@@ -1,0 +1,379 @@
+// k_wls_mg.hip — S2: edge-aware WLS smoothing of the (a, b) coefficient maps at full resolution.
+// Reference: ColorTransfer::solve_WLS_roughness_cpu (ColorTransfer.cpp:951-1125) assembles the 5-point SPD system
+//   (diag(r) + L_g) x = r * x0,   g^2 = lamda / (|dL|^alpha + 1e-4),   6 right-hand sides (a,b x 3 Lab channels)
+// and factorises it on the CPU with MKL PARDISO (SparseSolver_CPU.cpp:104-286), five times per pair (n = W*H = 490k @700^2).
+//
+// MI355X design: conjugate gradients preconditioned by one aggregation-multigrid V(2,2) cycle, all 6 right-hand sides in
+// lock step, everything in fp64 on the device.
+//  * the hierarchy needs no Galerkin triple products: with 2x2 aggregates and piecewise-constant interpolation, P^T A P of a
+//    weighted 5-point graph Laplacian + diagonal is again one (coarse data term = sum of the 4 fine ones, coarse edge = sum of
+//    the fine edges crossing between the two aggregates);
+//  * smoother = damped Jacobi (omega 0.8) — order independent, so the result is reproducible; the first two pre-smoothing
+//    sweeps (zero initial guess) and "prolong + first post-smoothing sweep" are each fused into one kernel;
+//  * vectors are interleaved [pixel][6] (48 B per pixel: one cache-line-friendly gather per neighbour);
+//  * every dot product is the same two-stage fixed-tree reduction as in k_colorsolve.hip (mirrored by the oracle).
+// Jacobi-PCG needed 2633/1391/701/359/357 iterations on the five levels of a 700x700 pair (profiles/r1b); this needs ~100/80/65/60/60.
+// Roofline: HBM streaming at the fine level (~60 B/pixel/sweep), launch-latency bound below 175x175.
+#include "nct_internal.h"
+#include "nct_device.h"
+#include <vector>
+#include <cstring>
+
+namespace {
+constexpr double OMEGA = 0.8;
+constexpr int NQ = 6;
+
+struct Lvl { int H, W, n; double *r, *wx, *wy, *diag, *b, *x, *x2; };
+
+template <int NV>
+__device__ __forceinline__ void mg_block_reduce(double (&v)[NV], double* __restrict__ partial) {
+    __shared__ double s_red[256 * NV];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) s_red[q * 256 + t] = v[q];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) s_red[q * 256 + t] += s_red[q * 256 + t + off];
+        __syncthreads();
+    }
+    if (t < NV) partial[(size_t)blockIdx.x * NV + t] = s_red[t * 256];
+}
+template <int NV>
+__device__ __forceinline__ void mg_final_reduce(const double* __restrict__ partial, int nb, double (&out)[NV]) {
+    __shared__ double s_fin[256 * NV];
+    const int t = threadIdx.x;
+    double acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = 0.0;
+    for (int b = t; b < nb; b += 256)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) acc[q] += partial[(size_t)b * NV + q];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) s_fin[q * 256 + t] = acc[q];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) s_fin[q * 256 + t] += s_fin[q * 256 + t + off];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) out[q] = s_fin[q * 256];
+    __syncthreads();
+}
+
+// y = M v at pixel i of a level (diag*v - sum_w w*v_nbr, neighbour order +x, -x, +y, -y)
+template <typename F>
+__device__ __forceinline__ void lvl_op(const Lvl& L, int i, F&& val /* val(j, q) */, double (&y)[NQ]) {
+    const int W = L.W, H = L.H;
+    const int r = i / W, c = i - r * W;
+    const double d = L.diag[i];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) y[q] = d * val(i, q);
+    if (c + 1 < W) { const double w = L.wx[i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= w * val(i + 1, q); }
+    if (c > 0) { const double w = L.wx[i - 1];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= w * val(i - 1, q); }
+    if (r + 1 < H) { const double w = L.wy[i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= w * val(i + W, q); }
+    if (r > 0) { const double w = L.wy[i - W];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= w * val(i - W, q); }
+}
+
+// ---- hierarchy construction
+__global__ void k_mg_coarsen(Lvl F, Lvl C) {
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= C.n) return;
+    const int Y = I / C.W, X = I - Y * C.W;
+    const int y0 = 2 * Y, x0 = 2 * X;
+    const bool x1ok = x0 + 1 < F.W, y1ok = y0 + 1 < F.H;
+    double rs = F.r[y0 * F.W + x0];
+    if (x1ok) rs += F.r[y0 * F.W + x0 + 1];
+    if (y1ok) rs += F.r[(y0 + 1) * F.W + x0];
+    if (x1ok && y1ok) rs += F.r[(y0 + 1) * F.W + x0 + 1];
+    double ex = 0.0, ey = 0.0;
+    if (x0 + 2 < F.W) {                       // fine edges (x0+1 -> x0+2) of both rows
+        ex = F.wx[y0 * F.W + x0 + 1];
+        if (y1ok) ex += F.wx[(y0 + 1) * F.W + x0 + 1];
+    }
+    if (y0 + 2 < F.H) {
+        ey = F.wy[(y0 + 1) * F.W + x0];
+        if (x1ok) ey += F.wy[(y0 + 1) * F.W + x0 + 1];
+    }
+    C.r[I] = rs; C.wx[I] = ex; C.wy[I] = ey;
+}
+__global__ void k_mg_diag(Lvl L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    const int y = i / L.W, x = i - y * L.W;
+    double a00 = 0.0;
+    a00 += L.r[i];
+    if (x + 1 < L.W) a00 += L.wx[i];
+    if (x > 0) a00 += L.wx[i - 1];
+    if (y + 1 < L.H) a00 += L.wy[i];
+    if (y > 0) a00 += L.wy[i - L.W];
+    L.diag[i] = a00;
+}
+
+// ---- V-cycle pieces (vectors [n][6])
+// two damped-Jacobi sweeps from a zero initial guess: x1 = om*b/d ; x = x1 + om*(b - M x1)/d
+__global__ void k_mg_pre2(Lvl L, const double* __restrict__ b, double* __restrict__ x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    auto x1 = [&](int j, int q) { return (OMEGA * b[(size_t)j * NQ + q]) / L.diag[j]; };
+    double y[NQ]; lvl_op(L, i, x1, y);
+    const double d = L.diag[i];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) x[(size_t)i * NQ + q] = x1(i, q) + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+}
+// coarse rhs = sum over the aggregate of (b - M x)
+__global__ void k_mg_restrict(Lvl F, const double* __restrict__ b, const double* __restrict__ x, Lvl C, double* __restrict__ bc) {
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= C.n) return;
+    const int Y = I / C.W, X = I - Y * C.W;
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+    auto xv = [&](int j, int q) { return x[(size_t)j * NQ + q]; };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int y = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
+        if (y < F.H && xx < F.W) {
+            const int i = y * F.W + xx;
+            double yv[NQ]; lvl_op(F, i, xv, yv);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] += b[(size_t)i * NQ + q] - yv[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bc[(size_t)I * NQ + q] = acc[q];
+}
+// xo = xe + om*(b - M xe)/d with xe = x + e_coarse(parent)   (prolongation fused with the first post-smoothing sweep)
+__global__ void k_mg_prolong_smooth(Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, const double* __restrict__ ec, double* __restrict__ xo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    auto xe = [&](int j, int q) { const int y = j / L.W, xx = j - y * L.W; return x[(size_t)j * NQ + q] + ec[(size_t)((y >> 1) * Wc + (xx >> 1)) * NQ + q]; };
+    double y[NQ]; lvl_op(L, i, xe, y);
+    const double d = L.diag[i];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) xo[(size_t)i * NQ + q] = xe(i, q) + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+}
+// plain sweep xo = x + om*(b - M x)/d ; optionally accumulates the partial sums of r.z (r = b at level 0, z = xo)
+template <bool DOT>
+__global__ __launch_bounds__(256) void k_mg_smooth(Lvl L, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xo, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+    if (i < L.n) {
+        auto xv = [&](int j, int q) { return x[(size_t)j * NQ + q]; };
+        double y[NQ]; lvl_op(L, i, xv, y);
+        const double d = L.diag[i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double bq = b[(size_t)i * NQ + q];
+            const double v = x[(size_t)i * NQ + q] + (OMEGA * (bq - y[q])) / d;
+            xo[(size_t)i * NQ + q] = v;
+            if (DOT) acc[q] = bq * v;
+        }
+    }
+    if (DOT) mg_block_reduce<NQ>(acc, partial);
+}
+// coarsest level: `sweeps` Jacobi sweeps from zero inside one workgroup (n <= 1024)
+__global__ __launch_bounds__(1024) void k_mg_coarsest(Lvl L, const double* __restrict__ b, double* __restrict__ xa, double* __restrict__ xb, int sweeps) {
+    const int i = threadIdx.x;
+    double* cur = xa; double* nxt = xb;
+    if (i < L.n)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) cur[(size_t)i * NQ + q] = 0.0;
+    __syncthreads();
+    for (int s = 0; s < sweeps; ++s) {
+        if (i < L.n) {
+            auto xv = [&](int j, int q) { return cur[(size_t)j * NQ + q]; };
+            double y[NQ]; lvl_op(L, i, xv, y);
+            const double d = L.diag[i];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+        }
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    // result is in `cur`; sweeps is even => cur == xa
+}
+
+// ---- PCG pieces at the fine level
+struct PState { double rz[6], rr[6], bb[6], al[6], be[6]; int active[6]; int iters[6]; };
+
+// x6 = interleave(X); r = rough*x0 - M x0 ; partial: rr, bb (12)
+__global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restrict__ X /*[2][n][3]*/, double* __restrict__ x6, double* __restrict__ r, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0;
+    if (i < L.n) {
+        auto xv = [&](int j, int q) { return X[((size_t)(q / 3) * L.n + j) * 3 + (q % 3)]; };
+        double y[NQ]; lvl_op(L, i, xv, y);
+        const double rg = L.r[i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double x0 = xv(i, q);
+            const double bq = rg * x0;
+            const double rv = bq - y[q];
+            x6[(size_t)i * NQ + q] = x0; r[(size_t)i * NQ + q] = rv;
+            acc[q] = rv * rv; acc[6 + q] = bq * bq;
+        }
+    }
+    mg_block_reduce<12>(acc, partial);
+}
+__global__ void k_pcg_start_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, double rtol2) {
+    double s[12]; mg_final_reduce<12>(partial, nb, s);
+    if (threadIdx.x < 6) { const int q = threadIdx.x; st->rr[q] = s[q]; st->bb[q] = s[6 + q]; st->rz[q] = 0; st->al[q] = 0; st->be[q] = 0; st->iters[q] = 0;
+                           st->active[q] = (s[q] > rtol2 * s[6 + q]) ? 1 : 0; }
+}
+// after the V-cycle: rz = r.z ; first iteration: p = z, else be = rz/rz_old, p = z + be p
+__global__ void k_pcg_rz_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, int first) {
+    double s[6]; mg_final_reduce<6>(partial, nb, s);
+    if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) { st->be[q] = first ? 0.0 : s[q] / st->rz[q]; st->rz[q] = s[q]; } }
+}
+__global__ void k_pcg_dir(int n, const PState* __restrict__ st, const double* __restrict__ z, double* __restrict__ p, int first) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * NQ) return;
+    const int q = i % NQ;
+    if (!st->active[q]) return;
+    p[i] = first ? z[i] : z[i] + st->be[q] * p[i];
+}
+__global__ __launch_bounds__(256) void k_pcg_apply(Lvl L, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+    if (i < L.n) {
+        auto pv = [&](int j, int q) { return p[(size_t)j * NQ + q]; };
+        double y[NQ]; lvl_op(L, i, pv, y);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { Ap[(size_t)i * NQ + q] = y[q]; acc[q] = p[(size_t)i * NQ + q] * y[q]; }
+    }
+    mg_block_reduce<NQ>(acc, partial);
+}
+__global__ void k_pcg_alpha_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st) {
+    double s[6]; mg_final_reduce<6>(partial, nb, s);
+    if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) st->al[q] = st->rz[q] / s[q]; }
+}
+__global__ __launch_bounds__(256) void k_pcg_update(int n, const PState* __restrict__ st, const double* __restrict__ p, const double* __restrict__ Ap,
+                                                    double* __restrict__ x, double* __restrict__ r, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+    if (i < n) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (!st->active[q]) continue;
+            const size_t j = (size_t)i * NQ + q;
+            const double al = st->al[q];
+            x[j] += al * p[j];
+            const double rv = r[j] - al * Ap[j];
+            r[j] = rv; acc[q] = rv * rv;
+        }
+    }
+    mg_block_reduce<NQ>(acc, partial);
+}
+__global__ void k_pcg_rr_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, double rtol2) {
+    double s[6]; mg_final_reduce<6>(partial, nb, s);
+    if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) { st->rr[q] = s[q]; st->iters[q]++; st->active[q] = (s[q] > rtol2 * st->bb[q]) ? 1 : 0; } }
+}
+__global__ void k_pcg_finish(int n, const double* __restrict__ x6, double* __restrict__ X) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * NQ) return;
+    const int px = i / NQ, q = i - px * NQ;
+    X[((size_t)(q / 3) * n + px) * 3 + (q % 3)] = x6[i];
+}
+}  // namespace
+
+#define LCHK() NCT_LAUNCH_CHECK()
+
+// X: [2][N][3] in (x0) / out. rough, wx, wy: fine-level data term and edge weights (wx[i] = edge (i,i+1), wy[i] = edge (i,i+W)).
+int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* rough, const double* wx, const double* wy, int H, int W,
+                      double rtol, int* iters_out /*host[6], nullable*/) {
+    // ---- hierarchy
+    std::vector<Lvl> lv;
+    std::vector<DevBuf<double>*> bufs;
+    struct Cleanup { std::vector<DevBuf<double>*>& b; ~Cleanup() { for (auto* p : b) delete p; } } cleanup{bufs};
+    auto newbuf = [&](size_t n) -> double* { auto* b = new DevBuf<double>(ctx, n); bufs.push_back(b); return b->ok() ? (double*)*b : nullptr; };
+    {
+        int h = H, w = W;
+        for (int l = 0;; ++l) {
+            Lvl L{h, w, h * w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            if (l == 0) { L.r = (double*)rough; L.wx = (double*)wx; L.wy = (double*)wy; }
+            else { L.r = newbuf(L.n); L.wx = newbuf(L.n); L.wy = newbuf(L.n); }
+            L.diag = newbuf(L.n); L.b = newbuf((size_t)L.n * NQ); L.x = newbuf((size_t)L.n * NQ); L.x2 = newbuf((size_t)L.n * NQ);
+            if (!L.r || !L.wx || !L.wy || !L.diag || !L.b || !L.x || !L.x2) return NCT_ERR_HIP;
+            lv.push_back(L);
+            if (L.n <= 64 || (h <= 8 && w <= 8) || lv.size() >= 16) break;
+            h = (h + 1) / 2; w = (w + 1) / 2;
+        }
+        if (lv.back().n > 1024) return ctx->fail(NCT_ERR_INVALID, "wls: coarsest level too large (%d)", lv.back().n);
+    }
+    const int nl = (int)lv.size();
+    for (int l = 0; l < nl; ++l) {
+        if (l > 0) { hipLaunchKernelGGL(k_mg_coarsen, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l - 1], lv[l]); LCHK(); }
+        hipLaunchKernelGGL(k_mg_diag, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l]); LCHK();
+    }
+    const Lvl& F = lv[0];
+    const int N = F.n, nb = cdiv(N, 256);
+    DevBuf<double> x6(ctx, (size_t)N * NQ), r(ctx, (size_t)N * NQ), p(ctx, (size_t)N * NQ), Ap(ctx, (size_t)N * NQ), partial(ctx, (size_t)nb * 12);
+    DevBuf<PState> st(ctx, 1);
+    if (!x6.ok() || !r.ok() || !p.ok() || !Ap.ok() || !partial.ok() || !st.ok()) return NCT_ERR_HIP;
+    const double rtol2 = rtol * rtol;
+    hipLaunchKernelGGL(k_pcg_start, dim3(nb), dim3(256), 0, s, F, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
+    hipLaunchKernelGGL(k_pcg_start_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
+
+    // z = Vcycle(r): result in lv[0].x (even number of buffer swaps per level)
+    auto vcycle = [&]() -> int {
+        for (int l = 0; l < nl - 1; ++l) {
+            const double* b = l == 0 ? (const double*)r : lv[l].b;
+            hipLaunchKernelGGL(k_mg_pre2, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, lv[l].x); LCHK();
+            hipLaunchKernelGGL(k_mg_restrict, dim3(cdiv(lv[l + 1].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1], lv[l + 1].b); LCHK();
+        }
+        hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(1024), 0, s, lv[nl - 1], (const double*)lv[nl - 1].b, lv[nl - 1].x, lv[nl - 1].x2, 60); LCHK();
+        for (int l = nl - 2; l >= 0; --l) {
+            const double* b = l == 0 ? (const double*)r : lv[l].b;
+            hipLaunchKernelGGL(k_mg_prolong_smooth, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, (const double*)lv[l + 1].x, lv[l].x2); LCHK();
+            if (l == 0) hipLaunchKernelGGL(k_mg_smooth<true>, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x2, lv[l].x, (double*)partial);
+            else        hipLaunchKernelGGL(k_mg_smooth<false>, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x2, lv[l].x, (double*)nullptr);
+            LCHK();
+        }
+        return 0;
+    };
+    const int maxit = 5000, check_every = 8;
+    PState hst; memset(&hst, 0, sizeof hst);
+    int it = 0; bool done = false;
+    // state may already be converged (x0 solves the system): check once
+    NCT_HIP(hipMemcpyAsync(&hst, (PState*)st, sizeof hst, hipMemcpyDeviceToHost, s));
+    NCT_HIP(hipStreamSynchronize(s));
+    done = true; for (int q = 0; q < 6; ++q) if (hst.active[q]) done = false;
+    while (!done && it < maxit) {
+        for (int k = 0; k < check_every; ++k, ++it) {
+            int rc = vcycle(); if (rc) return rc;
+            hipLaunchKernelGGL(k_pcg_rz_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, it == 0 ? 1 : 0); LCHK();
+            hipLaunchKernelGGL(k_pcg_dir, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const PState*)st, (const double*)F.x, (double*)p, it == 0 ? 1 : 0); LCHK();
+            hipLaunchKernelGGL(k_pcg_apply, dim3(nb), dim3(256), 0, s, F, (const double*)p, (double*)Ap, (double*)partial); LCHK();
+            hipLaunchKernelGGL(k_pcg_alpha_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st); LCHK();
+            hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(256), 0, s, N, (const PState*)st, (const double*)p, (const double*)Ap, (double*)x6, (double*)r, (double*)partial); LCHK();
+            hipLaunchKernelGGL(k_pcg_rr_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
+        }
+        NCT_HIP(hipMemcpyAsync(&hst, (PState*)st, sizeof hst, hipMemcpyDeviceToHost, s));
+        NCT_HIP(hipStreamSynchronize(s));
+        done = true; for (int q = 0; q < 6; ++q) if (hst.active[q]) done = false;
+    }
+    if (!done) return ctx->fail(NCT_ERR_HIP, "WLS MG-PCG did not converge in %d iterations", maxit);
+    hipLaunchKernelGGL(k_pcg_finish, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const double*)x6, X); LCHK();
+    if (iters_out) for (int q = 0; q < 6; ++q) iters_out[q] = hst.iters[q];
+    return 0;
+}

@@ -83,6 +83,9 @@ struct nct_color_debug { double *ab_local, *ab_nonlocal, *ab_up, *rough, *ab_wls
 int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, const uint8_t* s_lab_level, const uint8_t* g_lab_level,
                               const uint8_t* s_lab_full, const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W,
                               const nct_color_params& prm, uint8_t* out_lab_full, const nct_color_debug* dbg);
+// k_wls_mg.hip
+int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* rough, const double* wx, const double* wy, int H, int W,
+                      double rtol, int* iters_out);
 // k_vote.hip
 int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, const uint32_t* bnn, const float* pin_hwc, float* pout_hwc, float* pw /*nullable*/,
                            int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp);

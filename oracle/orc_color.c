@@ -368,10 +368,10 @@ void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha,
             double a00 = 0.0;
             a00 += roughness[i];
             wx[i] = 0; wy[i] = 0;
-            if (x + 1 < W) { double g = pow(gx[i], 2); a00 += g; wx[i] = g; }
-            if (x - 1 >= 0) { double g = pow(gx[i - 1], 2); a00 += g; }
-            if (y + 1 < H) { double g = pow(gy[i], 2); a00 += g; wy[i] = g; }
-            if (y - 1 >= 0) { double g = pow(gy[i - W], 2); a00 += g; }
+            if (x + 1 < W) { double g = gx[i] * gx[i]; a00 += g; wx[i] = g;        /* pow(g, 2) */ }
+            if (x - 1 >= 0) { double g = gx[i - 1] * gx[i - 1]; a00 += g; }
+            if (y + 1 < H) { double g = gy[i] * gy[i]; a00 += g; wy[i] = g; }
+            if (y - 1 >= 0) { double g = gy[i - W] * gy[i - W]; a00 += g; }
             diag[i] = a00;
         }
     free(gx); free(gy);
@@ -512,6 +512,7 @@ typedef struct { double *ab_local, *ab_nonlocal, *ab_up, *roughness, *ab_wls; in
 void orc_nonlocal_solve(double* a, double* b, const double* src, const double* ref, const double* weight, const int* knn_id, const double* knn_w,
                         int k, int h, int w, int layer, float lambda, float alpha, float dWeight, double nl_weight_cfg, double k_cfg, int* iters_out, int maxit_override);
 int orc_wls_solve_canon(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, int* iters_out);
+int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double rtol, int* iters_out);
 
 /* Same contract as nct_local_color_transfer (include/nct.h). S1 = canonical-order truncated CG (orc_color_canon.c).
  * s2_exact == 0: S2 by the canonical-order PCG; != 0: S2 by the exact solve (banded Cholesky / converged PCG). */
@@ -543,7 +544,7 @@ int orc_local_color_transfer(const float* err, const uint8_t* s_bgr_level, const
     if (h == H && w == W) lamda *= 4;
     int wit[6] = {0, 0, 0, 0, 0, 0};
     int it = s2_exact ? orc_wls_solve(A, B, full, H, W, lamda, prm->wls_alpha, rough, 0)
-                      : orc_wls_solve_canon(A, B, full, H, W, lamda, prm->wls_alpha, rough, wit);
+                      : orc_wls_solve_mg(A, B, full, H, W, lamda, prm->wls_alpha, rough, 1e-8, wit);
     if (st && st->wls_iters) memcpy(st->wls_iters, wit, sizeof wit);
     if (st && st->ab_wls) { memcpy(st->ab_wls, A, sizeof(double) * 3 * N); memcpy(st->ab_wls + (size_t)3 * N, B, sizeof(double) * 3 * N); }
     uint8_t* olab = (uint8_t*)malloc((size_t)N * 3);

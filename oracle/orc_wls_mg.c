@@ -1,0 +1,218 @@
+/* oracle/orc_wls_mg.c — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+ *
+ * S2 (ColorTransfer.cpp:951-1125): canonical-order restatement of the product's multigrid-preconditioned CG for the WLS
+ * system (diag(r) + L_g) x = r x0 with 6 right-hand sides. The reference solves this system exactly (MKL PARDISO);
+ * this solver converges to 1e-8 relative residual and is cross-checked against the exact solve (banded Cholesky / PARDISO
+ * fixture) in tests/test_oracle_color.py. It exists in this exact arithmetic order so that the 8-bit result of the GPU
+ * path can be compared bit-for-bit (see orc_color_canon.c for why that matters: S1 downstream is chaotic).
+ * Hierarchy: 2x2 aggregation (coarse data term = sum of the 4 fine ones, coarse edge = sum of the crossing fine edges);
+ * V(2,2) cycle, damped Jacobi (omega 0.8), 60 Jacobi sweeps on the coarsest grid; two-stage 256-wide tree reductions. */
+#include "orc_common.h"
+#include <stdio.h>
+
+void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double* diag, double* wx, double* wy);
+
+#define NQ 6
+static const double OMEGA = 0.8;
+typedef struct { int H, W, n; double *r, *wx, *wy, *diag, *b, *x, *x2; } lvl_t;
+
+static void tree256(double* s) { for (int off = 128; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) s[t] += s[t + off]; }
+static void canon_sum(const double* v, int n, int nq, double* out) {
+    const int nb = (n + 255) / 256;
+    double* partial = (double*)malloc(sizeof(double) * (size_t)nb * nq);
+    double s[256];
+    for (int b = 0; b < nb; ++b)
+        for (int q = 0; q < nq; ++q) {
+            for (int t = 0; t < 256; ++t) { int i = b * 256 + t; s[t] = i < n ? v[(size_t)i * nq + q] : 0.0; }
+            tree256(s);
+            partial[(size_t)b * nq + q] = s[0];
+        }
+    for (int q = 0; q < nq; ++q) {
+        for (int t = 0; t < 256; ++t) { double acc = 0.0; for (int b = t; b < nb; b += 256) acc += partial[(size_t)b * nq + q]; s[t] = acc; }
+        tree256(s);
+        out[q] = s[0];
+    }
+    free(partial);
+}
+
+/* y = M v at pixel i; VAL(j,q) is an expression giving v_j[q] */
+#define LVL_OP(L, i, VAL, y) do { \
+    const int W_ = (L)->W, H_ = (L)->H; const int r_ = (i) / W_, c_ = (i) - r_ * W_; const double d_ = (L)->diag[i]; \
+    for (int q = 0; q < NQ; ++q) (y)[q] = d_ * VAL((i), q); \
+    if (c_ + 1 < W_) { const double w_ = (L)->wx[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + 1, q); } \
+    if (c_ > 0) { const double w_ = (L)->wx[(i) - 1]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - 1, q); } \
+    if (r_ + 1 < H_) { const double w_ = (L)->wy[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + W_, q); } \
+    if (r_ > 0) { const double w_ = (L)->wy[(i) - W_]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - W_, q); } } while (0)
+
+static void vcycle(lvl_t* lv, int nl, const double* r0) {
+    for (int l = 0; l < nl - 1; ++l) {
+        lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
+        const double* b = l == 0 ? r0 : L->b;
+#define X1(j, q) ((OMEGA * b[(size_t)(j) * NQ + (q)]) / L->diag[j])
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < L->n; ++i) {
+            double y[NQ]; LVL_OP(L, i, X1, y);
+            const double d = L->diag[i];
+            for (int q = 0; q < NQ; ++q) L->x[(size_t)i * NQ + q] = X1(i, q) + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+        }
+#undef X1
+#define XV(j, q) (L->x[(size_t)(j) * NQ + (q)])
+#pragma omp parallel for schedule(static)
+        for (int I = 0; I < C->n; ++I) {
+            const int Y = I / C->W, X = I - Y * C->W;
+            double acc[NQ] = {0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < 4; ++t) {
+                const int y = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
+                if (y < L->H && xx < L->W) {
+                    const int i = y * L->W + xx;
+                    double yv[NQ]; LVL_OP(L, i, XV, yv);
+                    for (int q = 0; q < NQ; ++q) acc[q] += b[(size_t)i * NQ + q] - yv[q];
+                }
+            }
+            for (int q = 0; q < NQ; ++q) C->b[(size_t)I * NQ + q] = acc[q];
+        }
+#undef XV
+    }
+    {   /* coarsest: 60 Jacobi sweeps from zero */
+        lvl_t* L = &lv[nl - 1];
+        double* cur = L->x; double* nxt = L->x2;
+        memset(cur, 0, sizeof(double) * (size_t)L->n * NQ);
+        for (int s = 0; s < 60; ++s) {
+#define CV(j, q) (cur[(size_t)(j) * NQ + (q)])
+            for (int i = 0; i < L->n; ++i) {
+                double y[NQ]; LVL_OP(L, i, CV, y);
+                const double d = L->diag[i];
+                for (int q = 0; q < NQ; ++q) nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + (OMEGA * (L->b[(size_t)i * NQ + q] - y[q])) / d;
+            }
+#undef CV
+            double* t = cur; cur = nxt; nxt = t;
+        }
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
+        const double* b = l == 0 ? r0 : L->b;
+        const int Wc = C->W;
+#define XE(j, q) (L->x[(size_t)(j) * NQ + (q)] + C->x[(size_t)((((j) / L->W) >> 1) * Wc + ((((j) % L->W)) >> 1)) * NQ + (q)])
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < L->n; ++i) {
+            double y[NQ]; LVL_OP(L, i, XE, y);
+            const double d = L->diag[i];
+            for (int q = 0; q < NQ; ++q) L->x2[(size_t)i * NQ + q] = XE(i, q) + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+        }
+#undef XE
+#define X2(j, q) (L->x2[(size_t)(j) * NQ + (q)])
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < L->n; ++i) {
+            double y[NQ]; LVL_OP(L, i, X2, y);
+            const double d = L->diag[i];
+            for (int q = 0; q < NQ; ++q) L->x[(size_t)i * NQ + q] = L->x2[(size_t)i * NQ + q] + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+        }
+#undef X2
+    }
+}
+
+/* a,b: full-res [N][3] in (x0) / out. iters_out[6] nullable. Returns max iterations, or -1 if not converged. */
+int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double rtol, int* iters_out) {
+    lvl_t lv[16]; int nl = 0;
+    { int h = H, w = W;
+      for (;;) {
+          lvl_t* L = &lv[nl]; L->H = h; L->W = w; L->n = h * w;
+          L->r = (double*)malloc(sizeof(double) * L->n); L->wx = (double*)malloc(sizeof(double) * L->n); L->wy = (double*)malloc(sizeof(double) * L->n);
+          L->diag = (double*)malloc(sizeof(double) * L->n);
+          L->b = (double*)malloc(sizeof(double) * (size_t)L->n * NQ); L->x = (double*)malloc(sizeof(double) * (size_t)L->n * NQ); L->x2 = (double*)malloc(sizeof(double) * (size_t)L->n * NQ);
+          ++nl;
+          if (L->n <= 64 || (h <= 8 && w <= 8) || nl >= 16) break;
+          h = (h + 1) / 2; w = (w + 1) / 2;
+      } }
+    { double* dtmp = (double*)malloc(sizeof(double) * lv[0].n);
+      orc_wls_system(lab, H, W, lamda, alpha, roughness, dtmp, lv[0].wx, lv[0].wy);
+      memcpy(lv[0].r, roughness, sizeof(double) * lv[0].n); free(dtmp); }
+    for (int l = 0; l < nl; ++l) {
+        lvl_t* L = &lv[l];
+        if (l > 0) {
+            lvl_t* F = &lv[l - 1];
+            for (int I = 0; I < L->n; ++I) {
+                const int Y = I / L->W, X = I - Y * L->W, y0 = 2 * Y, x0 = 2 * X;
+                const int x1ok = x0 + 1 < F->W, y1ok = y0 + 1 < F->H;
+                double rs = F->r[y0 * F->W + x0];
+                if (x1ok) rs += F->r[y0 * F->W + x0 + 1];
+                if (y1ok) rs += F->r[(y0 + 1) * F->W + x0];
+                if (x1ok && y1ok) rs += F->r[(y0 + 1) * F->W + x0 + 1];
+                double ex = 0.0, ey = 0.0;
+                if (x0 + 2 < F->W) { ex = F->wx[y0 * F->W + x0 + 1]; if (y1ok) ex += F->wx[(y0 + 1) * F->W + x0 + 1]; }
+                if (y0 + 2 < F->H) { ey = F->wy[(y0 + 1) * F->W + x0]; if (x1ok) ey += F->wy[(y0 + 1) * F->W + x0 + 1]; }
+                L->r[I] = rs; L->wx[I] = ex; L->wy[I] = ey;
+            }
+        }
+        for (int i = 0; i < L->n; ++i) {
+            const int y = i / L->W, x = i - y * L->W;
+            double a00 = 0.0;
+            a00 += L->r[i];
+            if (x + 1 < L->W) a00 += L->wx[i];
+            if (x > 0) a00 += L->wx[i - 1];
+            if (y + 1 < L->H) a00 += L->wy[i];
+            if (y > 0) a00 += L->wy[i - L->W];
+            L->diag[i] = a00;
+        }
+    }
+    lvl_t* F = &lv[0];
+    const int n = F->n;
+    double* x6 = (double*)malloc(sizeof(double) * (size_t)n * NQ); double* r = (double*)malloc(sizeof(double) * (size_t)n * NQ);
+    double* p = (double*)calloc((size_t)n * NQ, sizeof(double)); double* Ap = (double*)malloc(sizeof(double) * (size_t)n * NQ);
+    double* acc = (double*)malloc(sizeof(double) * (size_t)n * 12);
+    const double rtol2 = rtol * rtol;
+    double rz[6] = {0}, rr[6], bb[6], al[6] = {0}, be[6] = {0}, s[12];
+    int active[6], iters[6] = {0, 0, 0, 0, 0, 0};
+#define X0(j, q) ((q) < 3 ? a[(size_t)(j) * 3 + (q)] : b[(size_t)(j) * 3 + (q) - 3])
+    for (int i = 0; i < n; ++i) {
+        double y[NQ]; LVL_OP(F, i, X0, y);
+        const double rg = F->r[i];
+        for (int q = 0; q < NQ; ++q) {
+            const double x0 = X0(i, q), bq = rg * x0, rv = bq - y[q];
+            x6[(size_t)i * NQ + q] = x0; r[(size_t)i * NQ + q] = rv;
+            acc[(size_t)i * 12 + q] = rv * rv; acc[(size_t)i * 12 + 6 + q] = bq * bq;
+        }
+    }
+#undef X0
+    canon_sum(acc, n, 12, s);
+    int any = 0;
+    for (int q = 0; q < 6; ++q) { rr[q] = s[q]; bb[q] = s[6 + q]; active[q] = s[q] > rtol2 * s[6 + q]; any |= active[q]; }
+    int it = 0;
+    const int maxit = 5000;
+    while (any && it < maxit) {
+        vcycle(lv, nl, r);                                             /* z = F->x */
+        for (int i = 0; i < n; ++i) for (int q = 0; q < NQ; ++q) acc[(size_t)i * NQ + q] = r[(size_t)i * NQ + q] * F->x[(size_t)i * NQ + q];
+        canon_sum(acc, n, NQ, s);
+        for (int q = 0; q < 6; ++q) if (active[q]) { be[q] = it == 0 ? 0.0 : s[q] / rz[q]; rz[q] = s[q]; }
+        for (size_t j = 0; j < (size_t)n * NQ; ++j) { const int q = (int)(j % NQ); if (active[q]) p[j] = it == 0 ? F->x[j] : F->x[j] + be[q] * p[j]; }
+#define PV(j, q) (p[(size_t)(j) * NQ + (q)])
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            double y[NQ]; LVL_OP(F, i, PV, y);
+            for (int q = 0; q < NQ; ++q) { Ap[(size_t)i * NQ + q] = y[q]; acc[(size_t)i * NQ + q] = p[(size_t)i * NQ + q] * y[q]; }
+        }
+#undef PV
+        canon_sum(acc, n, NQ, s);
+        for (int q = 0; q < 6; ++q) if (active[q]) al[q] = rz[q] / s[q];
+        for (int i = 0; i < n; ++i)
+            for (int q = 0; q < NQ; ++q) {
+                const size_t j = (size_t)i * NQ + q;
+                acc[j] = 0.0;
+                if (!active[q]) continue;
+                x6[j] += al[q] * p[j];
+                const double rv = r[j] - al[q] * Ap[j];
+                r[j] = rv; acc[j] = rv * rv;
+            }
+        canon_sum(acc, n, NQ, s);
+        any = 0;
+        for (int q = 0; q < 6; ++q) { if (active[q]) { rr[q] = s[q]; iters[q]++; active[q] = s[q] > rtol2 * bb[q]; } any |= active[q]; }
+        ++it;
+    }
+    (void)rr;
+    for (int i = 0; i < n; ++i) for (int q = 0; q < NQ; ++q) { if (q < 3) a[(size_t)i * 3 + q] = x6[(size_t)i * NQ + q]; else b[(size_t)i * 3 + q - 3] = x6[(size_t)i * NQ + q]; }
+    if (iters_out) memcpy(iters_out, iters, sizeof iters);
+    int mx = 0; for (int q = 0; q < 6; ++q) if (iters[q] > mx) mx = iters[q];
+    for (int l = 0; l < nl; ++l) { free(lv[l].r); free(lv[l].wx); free(lv[l].wy); free(lv[l].diag); free(lv[l].b); free(lv[l].x); free(lv[l].x2); }
+    free(x6); free(r); free(p); free(Ap); free(acc);
+    return any ? -1 : mx;
+}
