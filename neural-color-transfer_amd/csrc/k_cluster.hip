@@ -5,16 +5,19 @@
 // (nanoflann KD-trees, one per cluster, built and queried on the host under OpenMP in the reference).
 //
 // MI355X design:
-//  * k-means: the problem is tiny (<= 63x63 points x 512-d, k=10, <= 11 Lloyd steps) and strictly sequential between
-//    steps, so it runs as ONE persistent 1024-thread workgroup: no host round trips, fp64 centre sums accumulated in
-//    point order exactly like the reference loop (bit-identical labels to the oracle).
-//  * kNN: exact brute force per cluster instead of KD-trees. Lab comes from 8-bit images, so the squared distance is an
-//    exact small integer: candidates are streamed through LDS as packed u32 (L,a,b), pre-filtered with integer
-//    arithmetic against the current 9th-best, and only survivors pay for the fp64 sqrt that defines the final
+//  * k-means: tiny (<= 63x63 points x 512-d, k=10, <= 11 Lloyd steps) and sequential between steps: four small kernels per
+//    step (centres: one thread per (cluster, dim) summing members in point order in fp64 exactly like the reference loop;
+//    distances: one thread per (point, centre) in the reference's float accumulation order; relabel; step end), all
+//    gated by a device-side `done` flag so the host never synchronises (bit-identical labels to the oracle).
+//  * kNN: exact search on a colour grid instead of KD-trees. Lab comes from 8-bit images, so the squared distance is an
+//    exact small integer: all (cluster, pixel) memberships are radix-sorted by (cluster, 8-unit colour cell), a query visits
+//    cells in Chebyshev rings around its own cell with an integer pre-filter against the current 9th-best and stops when no
+//    unvisited cell can hold a closer or tying point; only survivors pay for the fp64 sqrt that defines the final
 //    (dist, id) order (= the reference's cmpDist order; ties are first-come in the reference's KD-tree).
 #include "nct_internal.h"
 #include "nct_device.h"
 #include "nct_detmath.h"
+#include <hipcub/hipcub.hpp>
 
 // ================================================================= C1: k-means
 __device__ __forceinline__ uint64_t sm64(uint64_t& s) {
@@ -46,93 +49,100 @@ __device__ float l2_ff(const float* __restrict__ a, const float* __restrict__ b,
 }
 
 constexpr int KM_MAXK = 16;
-__global__ __launch_bounds__(1024) void k_kmeans(const float* __restrict__ feat, int n, int C, int K, int iters, uint64_t seed,
-                                                 int* __restrict__ labels, int* __restrict__ nlabels, int* __restrict__ perm, double* __restrict__ dc) {
-    __shared__ int s_cidx[KM_MAXK], s_count[KM_MAXK], s_flag, s_nc;
-    __shared__ unsigned s_radius[KM_MAXK];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < n; i += nt) labels[i] = 0;
-    if (tid == 0) {
-        s_nc = 0;
-        if (n >= K) {
-            for (int i = 0; i < n; ++i) perm[i] = i;
-            uint64_t st = seed;
-            for (int i = n - 1; i > 0; --i) { const int j = (int)(sm64(st) % (uint64_t)(i + 1)); const int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
-            int pos = 0, nc = 0; bool out = false;
-            for (int index = 0; index < K && !out; ++index) {
-                bool dup = true;
-                while (dup) {
-                    dup = false;
-                    if (pos >= n) { out = true; break; }
-                    s_cidx[index] = perm[pos++];
-                    for (int j = 0; j < index; ++j)
-                        if (l2_ff(feat + (size_t)s_cidx[index] * C, feat + (size_t)s_cidx[j] * C, C) < 1e-16) dup = true;
-                }
-                if (!out) nc = index + 1;
-            }
-            s_nc = nc;
+struct KMState { int cidx[KM_MAXK]; int count[KM_MAXK]; unsigned radius[KM_MAXK]; int nc, changed, done; };
+
+// centre selection (chooseCentersRandom with a SplitMix64 Fisher-Yates permutation) — one thread, ~n steps
+__global__ void k_km_init(const float* __restrict__ feat, int n, int C, int K, uint64_t seed, int* __restrict__ perm, KMState* __restrict__ st, int* __restrict__ labels) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) labels[i] = 0;
+    if (threadIdx.x != 0) return;
+    st->nc = 0; st->changed = 0; st->done = 0;
+    for (int i = 0; i < KM_MAXK; ++i) { st->count[i] = 0; st->radius[i] = 0u; }
+    if (n < K) { st->done = 1; return; }
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    uint64_t sd = seed;
+    for (int i = n - 1; i > 0; --i) { const int j = (int)(sm64(sd) % (uint64_t)(i + 1)); const int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
+    int pos = 0, nc = 0; bool out = false;
+    for (int index = 0; index < K && !out; ++index) {
+        bool dup = true;
+        while (dup) {
+            dup = false;
+            if (pos >= n) { out = true; break; }
+            st->cidx[index] = perm[pos++];
+            for (int j = 0; j < index; ++j)
+                if (l2_ff(feat + (size_t)st->cidx[index] * C, feat + (size_t)st->cidx[j] * C, C) < 1e-16) dup = true;
         }
+        if (!out) nc = index + 1;
     }
-    __syncthreads();
-    if (s_nc < K) { if (tid == 0) *nlabels = 1; return; }
-    for (int i = tid; i < K * C; i += nt) { const int c = i / C, k = i - c * C; dc[i] = (double)feat[(size_t)s_cidx[c] * C + k]; }
-    if (tid < K) { s_count[tid] = 0; s_radius[tid] = 0u; }
-    __syncthreads();
-    for (int i = tid; i < n; i += nt) {
-        const float* v = feat + (size_t)i * C;
-        float sq = l2_fd(v, dc, C); int b = 0;
-        for (int j = 1; j < K; ++j) { const float nsq = l2_fd(v, dc + (size_t)j * C, C); if (sq > nsq) { b = j; sq = nsq; } }
-        labels[i] = b;
-        atomicMax(&s_radius[b], __float_as_uint(sq));
-        atomicAdd(&s_count[b], 1);
-    }
-    __syncthreads();
-    for (int iteration = 0; iteration < iters; ++iteration) {
-        if (tid == 0) s_flag = 1;               // converged
-        // new centres: fp64 sums in point order, one (cluster, dim) pair per thread slice
-        for (int i = tid; i < K * C; i += nt) {
-            const int c = i / C, k = i - c * C;
-            double s = 0.0;
-            for (int p = 0; p < n; ++p) if (labels[p] == c) s += (double)feat[(size_t)p * C + k];
-            dc[i] = s / (double)s_count[c];
-        }
-        if (tid < K) s_radius[tid] = 0u;
-        __syncthreads();
-        for (int i = tid; i < n; i += nt) {
-            const float* v = feat + (size_t)i * C;
-            float sq = l2_fd(v, dc, C); int b = 0;
-            for (int j = 1; j < K; ++j) { const float nsq = l2_fd(v, dc + (size_t)j * C, C); if (sq > nsq) { b = j; sq = nsq; } }
-            atomicMax(&s_radius[b], __float_as_uint(sq));
-            const int old = labels[i];
-            if (b != old) { atomicSub(&s_count[old], 1); atomicAdd(&s_count[b], 1); labels[i] = b; s_flag = 0; }
-        }
-        __syncthreads();
-        if (tid == 0) {      // an emptied cluster takes the farthest point of the next cluster with > 1 members
-            for (int i = 0; i < K; ++i)
-                if (s_count[i] == 0) {
-                    int j = (i + 1) % K;
-                    while (s_count[j] <= 1) j = (j + 1) % K;
-                    const float rj = __uint_as_float(s_radius[j]);
-                    for (int k = 0; k < n; ++k)
-                        if (labels[k] == j && l2_fd(feat + (size_t)k * C, dc + (size_t)j * C, C) == rj) { labels[k] = i; s_count[j]--; s_count[i]++; break; }
-                    s_flag = 0;
-                }
-        }
-        __syncthreads();
-        const int conv = s_flag;
-        __syncthreads();
-        if (conv) break;
-    }
-    if (tid == 0) *nlabels = K;
+    st->nc = nc;
+    if (nc < K) st->done = 1;           // root cannot be split: one label
 }
+// first = 1: centres = the chosen points; else: fp64 mean of the members, accumulated in point order (kmeans_index.h:771-785)
+__global__ void k_km_centres(const float* __restrict__ feat, int n, int C, int K, const int* __restrict__ labels, KMState* __restrict__ st, double* __restrict__ dc, int first) {
+    if (st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * C) return;
+    const int c = i / C, k = i - c * C;
+    if (first) { dc[i] = (double)feat[(size_t)st->cidx[c] * C + k]; return; }
+    double s = 0.0;
+    for (int p = 0; p < n; ++p) if (labels[p] == c) s += (double)feat[(size_t)p * C + k];
+    dc[i] = s / (double)st->count[c];
+}
+__global__ void k_km_dist(const float* __restrict__ feat, int n, int C, int K, const double* __restrict__ dc, const KMState* __restrict__ st, float* __restrict__ dist) {
+    if (st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * K) return;
+    const int p = i / K, c = i - p * K;
+    dist[i] = l2_fd(feat + (size_t)p * C, dc + (size_t)c * C, C);
+}
+// first-minimum assignment (`if (sq_dist > new_sq_dist)`), radius = max, counts, change flag
+__global__ void k_km_relabel(int n, int K, const float* __restrict__ dist, int* __restrict__ labels, KMState* __restrict__ st, int first) {
+    if (st->done) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float sq = dist[(size_t)p * K]; int b = 0;
+    for (int j = 1; j < K; ++j) { const float nsq = dist[(size_t)p * K + j]; if (sq > nsq) { b = j; sq = nsq; } }
+    atomicMax(&st->radius[b], __float_as_uint(sq));
+    if (first) { labels[p] = b; atomicAdd(&st->count[b], 1); return; }
+    const int old = labels[p];
+    if (b != old) { atomicSub(&st->count[old], 1); atomicAdd(&st->count[b], 1); labels[p] = b; st->changed = 1; }
+}
+// end of a Lloyd step: empty-cluster repair (kmeans_index.h:808-829), convergence, reset for the next step
+__global__ void k_km_step_end(const float* __restrict__ feat, int n, int C, int K, const double* __restrict__ dc, int* __restrict__ labels, KMState* __restrict__ st, int first, int last) {
+    if (st->done) return;
+    if (!first) {
+        for (int i = 0; i < K; ++i)
+            if (st->count[i] == 0) {
+                int j = (i + 1) % K, tries = 0;
+                while (st->count[j] <= 1 && tries < K) { j = (j + 1) % K; ++tries; }    // bounded: the reference spins forever if no donor exists
+                if (st->count[j] <= 1) continue;
+                const float rj = __uint_as_float(st->radius[j]);
+                for (int k = 0; k < n; ++k)
+                    if (labels[k] == j && l2_fd(feat + (size_t)k * C, dc + (size_t)j * C, C) == rj) { labels[k] = i; st->count[j]--; st->count[i]++; break; }
+                st->changed = 1;
+            }
+        if (!st->changed || last) { st->done = 2; return; }
+    }
+    st->changed = 0;
+    for (int i = 0; i < K; ++i) st->radius[i] = 0u;
+}
+__global__ void k_km_finish(const KMState* __restrict__ st, int K, int* __restrict__ nlabels) { *nlabels = (st->done == 1) ? 1 : K; }
 
 int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat, int n, int C, int K, int iters, uint64_t seed, int* labels, int* nlabels_dev) {
     NCT_REQUIRE(K >= 1 && K <= KM_MAXK, "kmeans: K=%d out of range", K);
     DevBuf<int> perm(ctx, n);
     DevBuf<double> dc(ctx, (size_t)K * C);
-    if (!perm.ok() || !dc.ok()) return NCT_ERR_HIP;
-    hipLaunchKernelGGL(k_kmeans, dim3(1), dim3(1024), 0, s, feat, n, C, K, iters, seed, labels, nlabels_dev, (int*)perm, (double*)dc);
-    NCT_LAUNCH_CHECK();
+    DevBuf<float> dist(ctx, (size_t)n * K);
+    DevBuf<KMState> st(ctx, 1);
+    if (!perm.ok() || !dc.ok() || !dist.ok() || !st.ok()) return NCT_ERR_HIP;
+    hipLaunchKernelGGL(k_km_init, dim3(1), dim3(256), 0, s, feat, n, C, K, seed, (int*)perm, (KMState*)st, labels); NCT_LAUNCH_CHECK();
+    for (int it = 0; it <= iters; ++it) {          // it == 0: initial assignment to the chosen centres; 1..iters: Lloyd steps
+        const int first = it == 0 ? 1 : 0, last = it == iters ? 1 : 0;
+        hipLaunchKernelGGL(k_km_centres, dim3(cdiv(K * C, 256)), dim3(256), 0, s, feat, n, C, K, (const int*)labels, (KMState*)st, (double*)dc, first); NCT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_km_dist, dim3(cdiv(n * K, 256)), dim3(256), 0, s, feat, n, C, K, (const double*)dc, (const KMState*)st, (float*)dist); NCT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_km_relabel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, K, (const float*)dist, labels, (KMState*)st, first); NCT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_km_step_end, dim3(1), dim3(1), 0, s, feat, n, C, K, (const double*)dc, labels, (KMState*)st, first, last); NCT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_km_finish, dim3(1), dim3(1), 0, s, (const KMState*)st, K, nlabels_dev); NCT_LAUNCH_CHECK();
     return 0;
 }
 
@@ -152,18 +162,33 @@ __global__ void k_cell_masks(const int* __restrict__ labels, int lh, int lw, uns
     mask[i] = m;
 }
 
-__global__ void k_cluster_members(const unsigned* __restrict__ mask, int lw, int lh, int h, int w, int samples, int nlabels,
-                                  int* __restrict__ cnt, int* __restrict__ mem) {
+// ---- (cluster, colour-cell) membership entries: key = cluster << 15 | cell(L,a,b) with 8-unit cells (32^3), value = pixel id
+constexpr int CELL_SHIFT = 3;                 // 8 Lab units per cell
+constexpr int CELLS = 32;                     // per axis
+constexpr unsigned KEY_SENTINEL = 1u << 19;   // sorts after every real key (16 clusters x 32768 cells)
+__device__ __forceinline__ unsigned cell_key(int l, unsigned col) {
+    return ((unsigned)l << 15) | (((col >> 16) & 255u) >> CELL_SHIFT) << 10 | (((col >> 8) & 255u) >> CELL_SHIFT) << 5 | ((col & 255u) >> CELL_SHIFT);
+}
+__global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* __restrict__ lab, int lw, int lh, int h, int w, int samples, int nlabels,
+                              int* __restrict__ count, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= h * w) return;
     const int y = i / w, x = i - y * w;
     const int cx = min(x / samples, lw - 1), cy = min(y / samples, lh - 1);
-    unsigned m = mask[cy * lw + cx];
+    const unsigned m = mask[cy * lw + cx];
+    const unsigned col = (unsigned)lab[(size_t)i * 3] | ((unsigned)lab[(size_t)i * 3 + 1] << 8) | ((unsigned)lab[(size_t)i * 3 + 2] << 16);
     for (int l = 0; l < nlabels; ++l)
-        if ((m >> l) & 1u) { const int pos = atomicAdd(&cnt[l], 1); mem[(size_t)l * h * w + pos] = i; }
+        if ((m >> l) & 1u) { const int pos = atomicAdd(count, 1); keys[pos] = cell_key(l, col); vals[pos] = (unsigned)i; }
+}
+// start[k] = first sorted entry with key >= k, k in [0, nkeys]
+__global__ void k_knn_cell_starts(const unsigned* __restrict__ keys, int m, int* __restrict__ start, int nkeys) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nkeys) return;
+    int lo = 0, hi = m;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < (unsigned)k) lo = mid + 1; else hi = mid; }
+    start[k] = lo;
 }
 
-struct KnnEnt { double d; int id; };
 __device__ __forceinline__ bool ent_less(double d1, int i1, double d2, int i2) { return d1 == d2 ? i1 < i2 : d1 < d2; }
 __device__ __forceinline__ double lab_dist(unsigned p, unsigned q) {
     const double s = 1.0 / 255.0;
@@ -174,41 +199,29 @@ __device__ __forceinline__ double lab_dist(unsigned p, unsigned q) {
     return d > 0.0 ? d : 0.0;
 }
 
-// one thread per member query; the cluster's members stream through LDS in tiles of 256
-__global__ __launch_bounds__(256) void k_knn_cluster(const uint8_t* __restrict__ lab, int npix, const int* __restrict__ cnt, const int* __restrict__ mem,
-                                                     int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
-    const int l = blockIdx.y;
-    const int m = cnt[l];
-    const int q0 = blockIdx.x * 256;
-    if (q0 >= m) return;
-    const int* members = mem + (size_t)l * npix;
-    __shared__ unsigned s_col[256];
-    __shared__ int s_id[256];
-    const int qi = q0 + threadIdx.x;
-    const bool live = qi < m;
-    const int id = live ? members[qi] : -1;
-    unsigned pc = 0;
-    if (live) pc = (unsigned)lab[(size_t)id * 3] | ((unsigned)lab[(size_t)id * 3 + 1] << 8) | ((unsigned)lab[(size_t)id * 3 + 2] << 16);
-    double bd[KNN_K + 1]; int bi[KNN_K + 1]; int bq[KNN_K + 1];      // distance, id, integer squared distance
+// One thread per (cluster, member) entry. Exact k+1 nearest by (dist, id) inside the cluster: colour cells are visited in
+// Chebyshev rings around the query's cell; every point outside ring r differs by at least r*8+1 Lab units in some channel,
+// so the search stops as soon as the current (k+1)-th best squared distance is < (r*8+1)^2 (strict: ties cannot hide outside).
+__global__ __launch_bounds__(256) void k_knn_grid(const uint8_t* __restrict__ lab, const int* __restrict__ count, const unsigned* __restrict__ keys,
+                                                  const unsigned* __restrict__ vals, const int* __restrict__ start,
+                                                  int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= *count) return;
+    const unsigned key = keys[e];
+    const int id = (int)vals[e];
+    const int l = (int)(key >> 15);
+    const int cz = (int)((key >> 10) & 31u), cy = (int)((key >> 5) & 31u), cx = (int)(key & 31u);
+    const unsigned pc = (unsigned)lab[(size_t)id * 3] | ((unsigned)lab[(size_t)id * 3 + 1] << 8) | ((unsigned)lab[(size_t)id * 3 + 2] << 16);
+    double bd[KNN_K + 1]; int bi[KNN_K + 1]; int bq[KNN_K + 1];
 #pragma unroll
     for (int t = 0; t <= KNN_K; ++t) { bd[t] = 1e300; bi[t] = 0x7fffffff; bq[t] = 0x7fffffff; }
-    for (int t0 = 0; t0 < m; t0 += 256) {
-        __syncthreads();
-        const int j = t0 + threadIdx.x;
-        if (j < m) {
-            const int jd = members[j];
-            s_id[threadIdx.x] = jd;
-            s_col[threadIdx.x] = (unsigned)lab[(size_t)jd * 3] | ((unsigned)lab[(size_t)jd * 3 + 1] << 8) | ((unsigned)lab[(size_t)jd * 3 + 2] << 16);
-        }
-        __syncthreads();
-        if (!live) continue;
-        const int tn = min(256, m - t0);
-        for (int t = 0; t < tn; ++t) {
-            const unsigned qc = s_col[t];
+    auto scan = [&](int b0, int b1) {
+        for (int t = b0; t < b1; ++t) {
+            const int jd = (int)vals[t];
+            const unsigned qc = (unsigned)lab[(size_t)jd * 3] | ((unsigned)lab[(size_t)jd * 3 + 1] << 8) | ((unsigned)lab[(size_t)jd * 3 + 2] << 16);
             const int e0 = (int)(pc & 255u) - (int)(qc & 255u), e1 = (int)((pc >> 8) & 255u) - (int)((qc >> 8) & 255u), e2 = (int)((pc >> 16) & 255u) - (int)((qc >> 16) & 255u);
             const int q2 = e0 * e0 + e1 * e1 + e2 * e2;
-            if (q2 > bq[KNN_K]) continue;                       // exact integer pre-filter
-            const int jd = s_id[t];
+            if (q2 > bq[KNN_K]) continue;
             const double d = lab_dist(pc, qc);
             if (!ent_less(d, jd, bd[KNN_K], bi[KNN_K])) continue;
             bd[KNN_K] = d; bi[KNN_K] = jd; bq[KNN_K] = q2;
@@ -220,8 +233,25 @@ __global__ __launch_bounds__(256) void k_knn_cluster(const uint8_t* __restrict__
                     const int tq = bq[u]; bq[u] = bq[u - 1]; bq[u - 1] = tq;
                 }
         }
+    };
+    const int base = l << 15;
+    for (int r = 0; r < CELLS; ++r) {
+        if (r > 0) { const int bound = (r - 1) * (1 << CELL_SHIFT) + 1; if (bq[KNN_K] < bound * bound) break; }
+        for (int dz = -r; dz <= r; ++dz) {
+            const int z = cz + dz; if (z < 0 || z >= CELLS) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int yy = cy + dy; if (yy < 0 || yy >= CELLS) continue;
+                const int row = base | (z << 10) | (yy << 5);
+                if (max(abs(dz), abs(dy)) == r) {                       // full x range of the shell face
+                    const int x0 = max(cx - r, 0), x1 = min(cx + r, CELLS - 1);
+                    scan(start[row | x0], start[(row | x1) + 1]);
+                } else {                                                 // only the two end cells
+                    if (cx - r >= 0) scan(start[row | (cx - r)], start[(row | (cx - r)) + 1]);
+                    if (cx + r < CELLS) scan(start[row | (cx + r)], start[(row | (cx + r)) + 1]);
+                }
+            }
+        }
     }
-    if (!live) return;
     const int slot = atomicAdd(&nslot[id], 1);
     double* od = cand_d + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
     int* oi = cand_id + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
@@ -264,18 +294,28 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
                    int* knn_id, double* knn_w) {
     NCT_REQUIRE(nlabels >= 1 && nlabels <= 16, "knn_graph: nlabels=%d out of range", nlabels);
     const int n = h * w;
-    DevBuf<unsigned> mask(ctx, (size_t)lh * lw);
-    DevBuf<int> cnt(ctx, 16), mem(ctx, (size_t)nlabels * n), nslot(ctx, n), cand_id(ctx, (size_t)n * KNN_SLOTS * KNN_K);
+    const int cap = n * KNN_SLOTS, nkeys = 16 << 15;
+    DevBuf<unsigned> mask(ctx, (size_t)lh * lw), keys(ctx, cap), vals(ctx, cap), keys_s(ctx, cap), vals_s(ctx, cap);
+    DevBuf<int> count(ctx, 1), start(ctx, nkeys + 2), nslot(ctx, n), cand_id(ctx, (size_t)n * KNN_SLOTS * KNN_K);
     DevBuf<double> cand_d(ctx, (size_t)n * KNN_SLOTS * KNN_K);
-    if (!mask.ok() || !cnt.ok() || !mem.ok() || !nslot.ok() || !cand_id.ok() || !cand_d.ok()) return NCT_ERR_HIP;
-    NCT_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * 16, s));
+    if (!mask.ok() || !keys.ok() || !vals.ok() || !keys_s.ok() || !vals_s.ok() || !count.ok() || !start.ok() || !nslot.ok() || !cand_id.ok() || !cand_d.ok()) return NCT_ERR_HIP;
+    NCT_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
     NCT_HIP(hipMemsetAsync(nslot, 0, sizeof(int) * n, s));
+    NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)(unsigned*)keys, (int)KEY_SENTINEL, cap, s));       // unused slots sort to the end
     hipLaunchKernelGGL(k_cell_masks, dim3(cdiv(lh * lw, 256)), dim3(256), 0, s, labels, lh, lw, (unsigned*)mask);
     NCT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cluster_members, dim3(cdiv(n, 256)), dim3(256), 0, s, (const unsigned*)mask, lw, lh, h, w, samples, nlabels, (int*)cnt, (int*)mem);
+    hipLaunchKernelGGL(k_knn_entries, dim3(cdiv(n, 256)), dim3(256), 0, s, (const unsigned*)mask, lab_u8, lw, lh, h, w, samples, nlabels,
+                       (int*)count, (unsigned*)keys, (unsigned*)vals);
     NCT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_knn_cluster, dim3(cdiv(n, 256), nlabels), dim3(256), 0, s, lab_u8, n, (const int*)cnt, (const int*)mem, (int*)nslot,
-                       (double*)cand_d, (int*)cand_id);
+    size_t tmp_bytes = 0;
+    NCT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 20, s));
+    DevBuf<char> tmp(ctx, tmp_bytes ? tmp_bytes : 16);
+    if (!tmp.ok()) return NCT_ERR_HIP;
+    NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 20, s));
+    hipLaunchKernelGGL(k_knn_cell_starts, dim3(cdiv(nkeys + 1, 256)), dim3(256), 0, s, (const unsigned*)keys_s, cap, (int*)start, nkeys);
+    NCT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_knn_grid, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
+                       (const int*)start, (int*)nslot, (double*)cand_d, (int*)cand_id);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_merge, dim3(cdiv(n, 256)), dim3(256), 0, s, n, (const int*)nslot, (const double*)cand_d, (const int*)cand_id, knn_id, knn_w);
     NCT_LAUNCH_CHECK();

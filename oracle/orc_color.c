@@ -111,8 +111,9 @@ centres_done:
         }
         for (int i = 0; i < K; ++i)
             if (count[i] == 0) {
-                int j = (i + 1) % K;
-                while (count[j] <= 1) j = (j + 1) % K;
+                int j = (i + 1) % K, tries = 0;
+                while (count[j] <= 1 && tries < K) { j = (j + 1) % K; ++tries; }      /* bounded: the reference spins forever if no donor exists */
+                if (count[j] <= 1) continue;
                 for (int k = 0; k < n; ++k)
                     if (bel[k] == j && l2_fd(feat + (size_t)k * C, dc + (size_t)j * C, C) == radius[j]) { bel[k] = i; count[j]--; count[i]++; break; }
                 converged = 0;
