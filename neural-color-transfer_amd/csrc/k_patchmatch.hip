@@ -70,17 +70,25 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 }
 
 // mode 0: init (dist of the current NNF, no cutoff); mode 1: propagation step with `jump`; random search if jump==1
+// A launch carries up to two independent jobs (the S->R and the R->S field of one level): workgroups [0, nblk0) belong to
+// job 0, the rest to job 1. Fusing the two directions doubles the number of resident workgroups at the coarse levels
+// (44x44 queries are only 121 workgroups for 256 CUs) and halves the launch count; each job's result is unaffected.
+struct PMJob { const float* A; const float* B; const uint32_t* nnf_in; const float* d_in; uint32_t* nnf_out; float* d_out; PMGeom g; int rs_max; uint32_t seed; };
+
 template <int NCH>
-__global__ __launch_bounds__(256) void k_pm_step(const float* __restrict__ A, const float* __restrict__ B,
-                                                 const uint32_t* __restrict__ nnf_in, const float* __restrict__ d_in,
-                                                 uint32_t* __restrict__ nnf_out, float* __restrict__ d_out,
-                                                 PMGeom g, int mode, int jump, int iter, int rs_max, uint32_t seed,
+__global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
                                                  unsigned long long* __restrict__ counter) {
     constexpr bool AREG = (NCH == 1 || NCH == 2);
+    const bool second = (int)blockIdx.x >= nblk0;
+    const PMJob& J = second ? j1 : j0;
+    const float* __restrict__ A = J.A; const float* __restrict__ B = J.B;
+    const uint32_t* __restrict__ nnf_in = J.nnf_in; const float* __restrict__ d_in = J.d_in;
+    uint32_t* __restrict__ nnf_out = J.nnf_out; float* __restrict__ d_out = J.d_out;
+    const PMGeom g = J.g; const int rs_max = J.rs_max; const uint32_t seed = J.seed;
     // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs; give each XCD a contiguous
     // band of tiles so that overlapping candidate tiles of neighbouring queries meet in the same L2.
     const int ntiles = g.tiles_x * g.tiles_y;
-    int bid = blockIdx.x;
+    int bid = (int)blockIdx.x - (second ? nblk0 : 0);
     {
         const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -168,45 +176,58 @@ __global__ __launch_bounds__(256) void k_pm_step(const float* __restrict__ A, co
 }
 
 template <int NCH>
-static void launch_step(hipStream_t s, int nblocks, const float* A, const float* B, const uint32_t* ni, const float* di, uint32_t* no, float* dout,
-                        const PMGeom& g, int mode, int jump, int iter, int rs_max, uint32_t seed, unsigned long long* counter) {
-    hipLaunchKernelGGL(k_pm_step<NCH>, dim3(nblocks), dim3(256), 0, s, A, B, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, counter);
+static void launch_step(hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
+    hipLaunchKernelGGL(k_pm_step<NCH>, dim3(nblk0 + nblk1), dim3(256), 0, s, j0, j1, nblk0, mode, jump, iter, counter);
 }
 
-int nctk_patchmatch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
-                    int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist, unsigned long long* eval_counter) {
+// Runs one PatchMatch (bnn == nullptr) or both directions of a level fused in the same launches (A->B in ann, B->A in bnn).
+static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw, int iters, int rs_max,
+                  uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, unsigned long long* eval_counter) {
     NCT_REQUIRE(C > 0 && (C & 3) == 0, "patchmatch: C=%d must be a positive multiple of 4", C);
     NCT_REQUIRE(ah >= 1 && aw >= 1 && bh >= 1 && bw >= 1 && ah < 4096 && aw < 4096 && bh < 4096 && bw < 4096,
                 "patchmatch: dims out of range (%dx%d vs %dx%d); NNF coordinates are 12-bit", ah, aw, bh, bw);
     NCT_REQUIRE(iters >= 0 && rs_max >= 0, "patchmatch: iters/rs_max must be >= 0");
-    const int n = ah * aw;
-    DevBuf<uint32_t> nnf_tmp(ctx, n);
-    DevBuf<float> d_tmp(ctx, n);
-    if (!nnf_tmp.ok() || !d_tmp.ok()) return NCT_ERR_HIP;
-    PMGeom g{C, ah, aw, bh, bw, cdiv(aw, 4), cdiv(ah, 4)};
-    const int nblocks = g.tiles_x * g.tiles_y;
-    auto step = [&](const uint32_t* ni, const float* di, uint32_t* no, float* dout, int mode, int jump, int iter) {
+    const bool two = bnn != nullptr;
+    const int na = ah * aw, nb = bh * bw;
+    DevBuf<uint32_t> a_tmp(ctx, na), b_tmp(ctx, two ? nb : 1);
+    DevBuf<float> ad_tmp(ctx, na), bd_tmp(ctx, two ? nb : 1);
+    if (!a_tmp.ok() || !b_tmp.ok() || !ad_tmp.ok() || !bd_tmp.ok()) return NCT_ERR_HIP;
+    const PMGeom ga{C, ah, aw, bh, bw, cdiv(aw, 4), cdiv(ah, 4)}, gb{C, bh, bw, ah, aw, cdiv(bw, 4), cdiv(bh, 4)};
+    const int nblk0 = ga.tiles_x * ga.tiles_y, nblk1 = two ? gb.tiles_x * gb.tiles_y : 0;
+    uint32_t* na_buf[2] = {ann, a_tmp}; float* da_buf[2] = {annd, ad_tmp};
+    uint32_t* nb_buf[2] = {bnn, b_tmp}; float* db_buf[2] = {bnnd, bd_tmp};
+    auto step = [&](int in, int out, int mode, int jump, int iter) {
+        PMJob j0{a_hwc, b_hwc, na_buf[in], da_buf[in], mode ? na_buf[out] : nullptr, da_buf[out], ga, rs_max, seed_ab};
+        PMJob j1{b_hwc, a_hwc, nb_buf[in], db_buf[in], mode ? nb_buf[out] : nullptr, db_buf[out], gb, rs_max, seed_ba};
         switch (C) {
-            case 64:  launch_step<1>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
-            case 128: launch_step<2>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
-            case 256: launch_step<4>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
-            case 512: launch_step<8>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
-            default:  launch_step<0>(s, nblocks, a_hwc, b_hwc, ni, di, no, dout, g, mode, jump, iter, rs_max, seed, eval_counter); break;
+            case 64:  launch_step<1>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
+            case 128: launch_step<2>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
+            case 256: launch_step<4>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
+            case 512: launch_step<8>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
+            default:  launch_step<0>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
         }
     };
     // the total number of Jacobi steps is even (iters*4), so ping-ponging (nnf,dist) <-> (tmp) ends in (nnf,dist)
-    uint32_t* nb[2] = {nnf, nnf_tmp};
-    float* db[2] = {dist, d_tmp};
-    step(nnf, nullptr, nullptr, dist, 0, 0, 0);  // init: dist(current NNF), NNF untouched
+    step(0, 0, 0, 0, 0);                           // init: dist(current NNF), NNF untouched
     NCT_LAUNCH_CHECK();
     int cur = 0;
     for (int iter = 0; iter < iters; ++iter)
         for (int jump = 8; jump > 0; jump >>= 1) {
-            step(nb[cur], db[cur], nb[cur ^ 1], db[cur ^ 1], 1, jump, iter);
+            step(cur, cur ^ 1, 1, jump, iter);
             NCT_LAUNCH_CHECK();
             cur ^= 1;
         }
-    // cur == 0 here. nnf_tmp/d_tmp return to the arena now; that is safe because arena blocks are recycled in
+    // cur == 0 here. The tmp buffers return to the arena now; that is safe because arena blocks are recycled in
     // stream order (every user enqueues on the same stream or joins into it before releasing).
     return 0;
+}
+
+int nctk_patchmatch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
+                    int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist, unsigned long long* eval_counter) {
+    return pm_run(ctx, s, a_hwc, b_hwc, C, ah, aw, bh, bw, iters, rs_max, seed, 0u, nnf, dist, nullptr, nullptr, eval_counter);
+}
+
+int nctk_patchmatch_bidir(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
+                          int iters, int rs_max, uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd) {
+    return pm_run(ctx, s, a_hwc, b_hwc, C, ah, aw, bh, bw, iters, rs_max, seed_ab, seed_ba, ann, annd, bnn, bnnd, nullptr);
 }

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256) void k_mg_smooth(Lvl L, const double* __restri
 // coarsest level: `sweeps` Jacobi sweeps from zero inside one workgroup (n <= 1024)
 __global__ __launch_bounds__(1024) void k_mg_coarsest(Lvl L, const double* __restrict__ b, double* __restrict__ xa, double* __restrict__ xb, int sweeps) {
     const int i = threadIdx.x;
-    double* cur = xa; double* nxt = xb;
+    __shared__ double s_x[2][256 * NQ];
+    const bool in_lds = L.n <= 256;                 // the usual case (coarsest grid <= 8x8): keep both Jacobi buffers in LDS
+    double* cur = in_lds ? s_x[0] : xa; double* nxt = in_lds ? s_x[1] : xb;
     if (i < L.n)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) cur[(size_t)i * NQ + q] = 0.0;
@@ -204,7 +206,10 @@ __global__ __launch_bounds__(1024) void k_mg_coarsest(Lvl L, const double* __res
         __syncthreads();
         double* t = cur; cur = nxt; nxt = t;
     }
-    // result is in `cur`; sweeps is even => cur == xa
+    // result is in `cur`; sweeps is even => cur is the first buffer
+    if (in_lds && i < L.n)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xa[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q];
 }
 
 // ---- PCG pieces at the fine level
