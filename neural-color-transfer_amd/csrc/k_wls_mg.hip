@@ -10,7 +10,8 @@
 //    the fine edges crossing between the two aggregates);
 //  * smoother = damped Jacobi (omega 0.8) — order independent, so the result is reproducible; the first two pre-smoothing
 //    sweeps (zero initial guess) and "prolong + first post-smoothing sweep" are each fused into one kernel;
-//  * vectors are interleaved [pixel][6] (48 B per pixel: one cache-line-friendly gather per neighbour);
+//  * vectors are planar [6][pixels]: on a regular 5-point stencil the neighbours of consecutive pixels are consecutive, so
+//    every load/store of a wave is one fully coalesced 512-B segment per right-hand side;
 //  * every dot product is the same two-stage fixed-tree reduction as in k_colorsolve.hip (mirrored by the oracle).
 // Jacobi-PCG needed 2633/1391/701/359/357 iterations on the five levels of a 700x700 pair (profiles/r1b); this needs ~100/80/65/60/60.
 // Roofline: HBM streaming at the fine level (~60 B/pixel/sweep), launch-latency bound below 175x175.
@@ -126,11 +127,11 @@ __global__ void k_mg_diag(Lvl L) {
 __global__ void k_mg_pre2(Lvl L, const double* __restrict__ b, double* __restrict__ x) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.n) return;
-    auto x1 = [&](int j, int q) { return (OMEGA * b[(size_t)j * NQ + q]) / L.diag[j]; };
+    auto x1 = [&](int j, int q) { return (OMEGA * b[(size_t)q * L.n + j]) / L.diag[j]; };
     double y[NQ]; lvl_op(L, i, x1, y);
     const double d = L.diag[i];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) x[(size_t)i * NQ + q] = x1(i, q) + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+    for (int q = 0; q < NQ; ++q) x[(size_t)q * L.n + i] = x1(i, q) + (OMEGA * (b[(size_t)q * L.n + i] - y[q])) / d;
 }
 // coarse rhs = sum over the aggregate of (b - M x)
 __global__ void k_mg_restrict(Lvl F, const double* __restrict__ b, const double* __restrict__ x, Lvl C, double* __restrict__ bc) {
@@ -140,7 +141,7 @@ __global__ void k_mg_restrict(Lvl F, const double* __restrict__ b, const double*
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-    auto xv = [&](int j, int q) { return x[(size_t)j * NQ + q]; };
+    auto xv = [&](int j, int q) { return x[(size_t)q * F.n + j]; };
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int y = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
@@ -148,21 +149,21 @@ __global__ void k_mg_restrict(Lvl F, const double* __restrict__ b, const double*
             const int i = y * F.W + xx;
             double yv[NQ]; lvl_op(F, i, xv, yv);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] += b[(size_t)i * NQ + q] - yv[q];
+            for (int q = 0; q < NQ; ++q) acc[q] += b[(size_t)q * F.n + i] - yv[q];
         }
     }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) bc[(size_t)I * NQ + q] = acc[q];
+    for (int q = 0; q < NQ; ++q) bc[(size_t)q * C.n + I] = acc[q];
 }
 // xo = xe + om*(b - M xe)/d with xe = x + e_coarse(parent)   (prolongation fused with the first post-smoothing sweep)
-__global__ void k_mg_prolong_smooth(Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, const double* __restrict__ ec, double* __restrict__ xo) {
+__global__ void k_mg_prolong_smooth(Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc, const double* __restrict__ ec, double* __restrict__ xo) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.n) return;
-    auto xe = [&](int j, int q) { const int y = j / L.W, xx = j - y * L.W; return x[(size_t)j * NQ + q] + ec[(size_t)((y >> 1) * Wc + (xx >> 1)) * NQ + q]; };
+    auto xe = [&](int j, int q) { const int y = j / L.W, xx = j - y * L.W; return x[(size_t)q * L.n + j] + ec[(size_t)q * nc + ((y >> 1) * Wc + (xx >> 1))]; };
     double y[NQ]; lvl_op(L, i, xe, y);
     const double d = L.diag[i];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) xo[(size_t)i * NQ + q] = xe(i, q) + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+    for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xe(i, q) + (OMEGA * (b[(size_t)q * L.n + i] - y[q])) / d;
 }
 // plain sweep xo = x + om*(b - M x)/d ; optionally accumulates the partial sums of r.z (r = b at level 0, z = xo)
 template <bool DOT>
@@ -172,14 +173,14 @@ __global__ __launch_bounds__(256) void k_mg_smooth(Lvl L, const double* __restri
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
     if (i < L.n) {
-        auto xv = [&](int j, int q) { return x[(size_t)j * NQ + q]; };
+        auto xv = [&](int j, int q) { return x[(size_t)q * L.n + j]; };
         double y[NQ]; lvl_op(L, i, xv, y);
         const double d = L.diag[i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const double bq = b[(size_t)i * NQ + q];
-            const double v = x[(size_t)i * NQ + q] + (OMEGA * (bq - y[q])) / d;
-            xo[(size_t)i * NQ + q] = v;
+            const double bq = b[(size_t)q * L.n + i];
+            const double v = x[(size_t)q * L.n + i] + (OMEGA * (bq - y[q])) / d;
+            xo[(size_t)q * L.n + i] = v;
             if (DOT) acc[q] = bq * v;
         }
     }
@@ -193,15 +194,15 @@ __global__ __launch_bounds__(1024) void k_mg_coarsest(Lvl L, const double* __res
     double* cur = in_lds ? s_x[0] : xa; double* nxt = in_lds ? s_x[1] : xb;
     if (i < L.n)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) cur[(size_t)i * NQ + q] = 0.0;
+        for (int q = 0; q < NQ; ++q) cur[(size_t)q * L.n + i] = 0.0;
     __syncthreads();
     for (int s = 0; s < sweeps; ++s) {
         if (i < L.n) {
-            auto xv = [&](int j, int q) { return cur[(size_t)j * NQ + q]; };
+            auto xv = [&](int j, int q) { return cur[(size_t)q * L.n + j]; };
             double y[NQ]; lvl_op(L, i, xv, y);
             const double d = L.diag[i];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+            for (int q = 0; q < NQ; ++q) nxt[(size_t)q * L.n + i] = cur[(size_t)q * L.n + i] + (OMEGA * (b[(size_t)q * L.n + i] - y[q])) / d;
         }
         __syncthreads();
         double* t = cur; cur = nxt; nxt = t;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_mg_coarsest(Lvl L, const double* __res
     // result is in `cur`; sweeps is even => cur is the first buffer
     if (in_lds && i < L.n)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) xa[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q];
+        for (int q = 0; q < NQ; ++q) xa[(size_t)q * L.n + i] = cur[(size_t)q * L.n + i];
 }
 
 // ---- PCG pieces at the fine level
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restri
             const double x0 = xv(i, q);
             const double bq = rg * x0;
             const double rv = bq - y[q];
-            x6[(size_t)i * NQ + q] = x0; r[(size_t)i * NQ + q] = rv;
+            x6[(size_t)q * L.n + i] = x0; r[(size_t)q * L.n + i] = rv;
             acc[q] = rv * rv; acc[6 + q] = bq * bq;
         }
     }
@@ -249,7 +250,7 @@ __global__ void k_pcg_rz_fin(const double* __restrict__ partial, int nb, PState*
 __global__ void k_pcg_dir(int n, const PState* __restrict__ st, const double* __restrict__ z, double* __restrict__ p, int first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * NQ) return;
-    const int q = i % NQ;
+    const int q = i / n;                      // planar [6][n]
     if (!st->active[q]) return;
     p[i] = first ? z[i] : z[i] + st->be[q] * p[i];
 }
@@ -259,10 +260,10 @@ __global__ __launch_bounds__(256) void k_pcg_apply(Lvl L, const double* __restri
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
     if (i < L.n) {
-        auto pv = [&](int j, int q) { return p[(size_t)j * NQ + q]; };
+        auto pv = [&](int j, int q) { return p[(size_t)q * L.n + j]; };
         double y[NQ]; lvl_op(L, i, pv, y);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { Ap[(size_t)i * NQ + q] = y[q]; acc[q] = p[(size_t)i * NQ + q] * y[q]; }
+        for (int q = 0; q < NQ; ++q) { Ap[(size_t)q * L.n + i] = y[q]; acc[q] = p[(size_t)q * L.n + i] * y[q]; }
     }
     mg_block_reduce<NQ>(acc, partial);
 }
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void k_pcg_update(int n, const PState* __restr
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (!st->active[q]) continue;
-            const size_t j = (size_t)i * NQ + q;
+            const size_t j = (size_t)q * n + i;
             const double al = st->al[q];
             x[j] += al * p[j];
             const double rv = r[j] - al * Ap[j];
@@ -296,7 +297,7 @@ __global__ void k_pcg_rr_fin(const double* __restrict__ partial, int nb, PState*
 __global__ void k_pcg_finish(int n, const double* __restrict__ x6, double* __restrict__ X) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * NQ) return;
-    const int px = i / NQ, q = i - px * NQ;
+    const int q = i / n, px = i - q * n;
     X[((size_t)(q / 3) * n + px) * 3 + (q % 3)] = x6[i];
 }
 }  // namespace
@@ -349,7 +350,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
         hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(1024), 0, s, lv[nl - 1], (const double*)lv[nl - 1].b, lv[nl - 1].x, lv[nl - 1].x2, 60); LCHK();
         for (int l = nl - 2; l >= 0; --l) {
             const double* b = l == 0 ? (const double*)r : lv[l].b;
-            hipLaunchKernelGGL(k_mg_prolong_smooth, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, (const double*)lv[l + 1].x, lv[l].x2); LCHK();
+            hipLaunchKernelGGL(k_mg_prolong_smooth, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, (const double*)lv[l + 1].x, lv[l].x2); LCHK();
             if (l == 0) hipLaunchKernelGGL(k_mg_smooth<true>, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x2, lv[l].x, (double*)partial);
             else        hipLaunchKernelGGL(k_mg_smooth<false>, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x2, lv[l].x, (double*)nullptr);
             LCHK();
