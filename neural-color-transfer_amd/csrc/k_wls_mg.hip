@@ -24,7 +24,7 @@ namespace {
 constexpr double OMEGA = 0.8;
 constexpr int NQ = 6;
 
-struct Lvl { int H, W, n; double *r, *wx, *wy, *diag, *b, *x, *x2; };
+struct Lvl { int H, W, n; double *r, *wx, *wy, *diag, *dinv, *b, *x, *x2; };   // dinv = omega / diag (one division per pixel per solve)
 
 template <int NV>
 __device__ __forceinline__ void mg_block_reduce(double (&v)[NV], double* __restrict__ partial) {
@@ -120,18 +120,19 @@ __global__ void k_mg_diag(Lvl L) {
     if (y + 1 < L.H) a00 += L.wy[i];
     if (y > 0) a00 += L.wy[i - L.W];
     L.diag[i] = a00;
+    L.dinv[i] = OMEGA / a00;
 }
 
 // ---- V-cycle pieces (vectors [n][6])
-// two damped-Jacobi sweeps from a zero initial guess: x1 = om*b/d ; x = x1 + om*(b - M x1)/d
+// two damped-Jacobi sweeps from a zero initial guess: x1 = b*dinv ; x = x1 + (b - M x1)*dinv   (dinv = omega/diag)
 __global__ void k_mg_pre2(Lvl L, const double* __restrict__ b, double* __restrict__ x) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.n) return;
-    auto x1 = [&](int j, int q) { return (OMEGA * b[(size_t)q * L.n + j]) / L.diag[j]; };
+    auto x1 = [&](int j, int q) { return b[(size_t)q * L.n + j] * L.dinv[j]; };
     double y[NQ]; lvl_op(L, i, x1, y);
-    const double d = L.diag[i];
+    const double d = L.dinv[i];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) x[(size_t)q * L.n + i] = x1(i, q) + (OMEGA * (b[(size_t)q * L.n + i] - y[q])) / d;
+    for (int q = 0; q < NQ; ++q) x[(size_t)q * L.n + i] = x1(i, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
 }
 // coarse rhs = sum over the aggregate of (b - M x)
 __global__ void k_mg_restrict(Lvl F, const double* __restrict__ b, const double* __restrict__ x, Lvl C, double* __restrict__ bc) {
@@ -161,9 +162,9 @@ __global__ void k_mg_prolong_smooth(Lvl L, const double* __restrict__ b, const d
     if (i >= L.n) return;
     auto xe = [&](int j, int q) { const int y = j / L.W, xx = j - y * L.W; return x[(size_t)q * L.n + j] + ec[(size_t)q * nc + ((y >> 1) * Wc + (xx >> 1))]; };
     double y[NQ]; lvl_op(L, i, xe, y);
-    const double d = L.diag[i];
+    const double d = L.dinv[i];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xe(i, q) + (OMEGA * (b[(size_t)q * L.n + i] - y[q])) / d;
+    for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xe(i, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
 }
 // plain sweep xo = x + om*(b - M x)/d ; optionally accumulates the partial sums of r.z (r = b at level 0, z = xo)
 template <bool DOT>
@@ -175,11 +176,11 @@ __global__ __launch_bounds__(256) void k_mg_smooth(Lvl L, const double* __restri
     if (i < L.n) {
         auto xv = [&](int j, int q) { return x[(size_t)q * L.n + j]; };
         double y[NQ]; lvl_op(L, i, xv, y);
-        const double d = L.diag[i];
+        const double d = L.dinv[i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const double bq = b[(size_t)q * L.n + i];
-            const double v = x[(size_t)q * L.n + i] + (OMEGA * (bq - y[q])) / d;
+            const double v = x[(size_t)q * L.n + i] + (bq - y[q]) * d;
             xo[(size_t)q * L.n + i] = v;
             if (DOT) acc[q] = bq * v;
         }
@@ -200,9 +201,9 @@ __global__ __launch_bounds__(1024) void k_mg_coarsest(Lvl L, const double* __res
         if (i < L.n) {
             auto xv = [&](int j, int q) { return cur[(size_t)q * L.n + j]; };
             double y[NQ]; lvl_op(L, i, xv, y);
-            const double d = L.diag[i];
+            const double d = L.dinv[i];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) nxt[(size_t)q * L.n + i] = cur[(size_t)q * L.n + i] + (OMEGA * (b[(size_t)q * L.n + i] - y[q])) / d;
+            for (int q = 0; q < NQ; ++q) nxt[(size_t)q * L.n + i] = cur[(size_t)q * L.n + i] + (b[(size_t)q * L.n + i] - y[q]) * d;
         }
         __syncthreads();
         double* t = cur; cur = nxt; nxt = t;
@@ -315,11 +316,11 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     {
         int h = H, w = W;
         for (int l = 0;; ++l) {
-            Lvl L{h, w, h * w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            Lvl L{h, w, h * w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (l == 0) { L.r = (double*)rough; L.wx = (double*)wx; L.wy = (double*)wy; }
             else { L.r = newbuf(L.n); L.wx = newbuf(L.n); L.wy = newbuf(L.n); }
-            L.diag = newbuf(L.n); L.b = newbuf((size_t)L.n * NQ); L.x = newbuf((size_t)L.n * NQ); L.x2 = newbuf((size_t)L.n * NQ);
-            if (!L.r || !L.wx || !L.wy || !L.diag || !L.b || !L.x || !L.x2) return NCT_ERR_HIP;
+            L.diag = newbuf(L.n); L.dinv = newbuf(L.n); L.b = newbuf((size_t)L.n * NQ); L.x = newbuf((size_t)L.n * NQ); L.x2 = newbuf((size_t)L.n * NQ);
+            if (!L.r || !L.wx || !L.wy || !L.diag || !L.dinv || !L.b || !L.x || !L.x2) return NCT_ERR_HIP;
             lv.push_back(L);
             if (L.n <= 64 || (h <= 8 && w <= 8) || lv.size() >= 16) break;
             h = (h + 1) / 2; w = (w + 1) / 2;

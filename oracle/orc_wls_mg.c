@@ -14,7 +14,7 @@ void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha,
 
 #define NQ 6
 static const double OMEGA = 0.8;
-typedef struct { int H, W, n; double *r, *wx, *wy, *diag, *b, *x, *x2; } lvl_t;
+typedef struct { int H, W, n; double *r, *wx, *wy, *diag, *dinv, *b, *x, *x2; } lvl_t;   /* dinv = omega / diag */
 
 static void tree256(double* s) { for (int off = 128; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) s[t] += s[t + off]; }
 static void canon_sum(const double* v, int n, int nq, double* out) {
@@ -48,12 +48,12 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
     for (int l = 0; l < nl - 1; ++l) {
         lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
         const double* b = l == 0 ? r0 : L->b;
-#define X1(j, q) ((OMEGA * b[(size_t)(j) * NQ + (q)]) / L->diag[j])
+#define X1(j, q) (b[(size_t)(j) * NQ + (q)] * L->dinv[j])
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < L->n; ++i) {
             double y[NQ]; LVL_OP(L, i, X1, y);
-            const double d = L->diag[i];
-            for (int q = 0; q < NQ; ++q) L->x[(size_t)i * NQ + q] = X1(i, q) + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+            const double d = L->dinv[i];
+            for (int q = 0; q < NQ; ++q) L->x[(size_t)i * NQ + q] = X1(i, q) + (b[(size_t)i * NQ + q] - y[q]) * d;
         }
 #undef X1
 #define XV(j, q) (L->x[(size_t)(j) * NQ + (q)])
@@ -81,8 +81,8 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
 #define CV(j, q) (cur[(size_t)(j) * NQ + (q)])
             for (int i = 0; i < L->n; ++i) {
                 double y[NQ]; LVL_OP(L, i, CV, y);
-                const double d = L->diag[i];
-                for (int q = 0; q < NQ; ++q) nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + (OMEGA * (L->b[(size_t)i * NQ + q] - y[q])) / d;
+                const double d = L->dinv[i];
+                for (int q = 0; q < NQ; ++q) nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + (L->b[(size_t)i * NQ + q] - y[q]) * d;
             }
 #undef CV
             double* t = cur; cur = nxt; nxt = t;
@@ -96,16 +96,16 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < L->n; ++i) {
             double y[NQ]; LVL_OP(L, i, XE, y);
-            const double d = L->diag[i];
-            for (int q = 0; q < NQ; ++q) L->x2[(size_t)i * NQ + q] = XE(i, q) + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+            const double d = L->dinv[i];
+            for (int q = 0; q < NQ; ++q) L->x2[(size_t)i * NQ + q] = XE(i, q) + (b[(size_t)i * NQ + q] - y[q]) * d;
         }
 #undef XE
 #define X2(j, q) (L->x2[(size_t)(j) * NQ + (q)])
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < L->n; ++i) {
             double y[NQ]; LVL_OP(L, i, X2, y);
-            const double d = L->diag[i];
-            for (int q = 0; q < NQ; ++q) L->x[(size_t)i * NQ + q] = L->x2[(size_t)i * NQ + q] + (OMEGA * (b[(size_t)i * NQ + q] - y[q])) / d;
+            const double d = L->dinv[i];
+            for (int q = 0; q < NQ; ++q) L->x[(size_t)i * NQ + q] = L->x2[(size_t)i * NQ + q] + (b[(size_t)i * NQ + q] - y[q]) * d;
         }
 #undef X2
     }
@@ -118,7 +118,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
       for (;;) {
           lvl_t* L = &lv[nl]; L->H = h; L->W = w; L->n = h * w;
           L->r = (double*)malloc(sizeof(double) * L->n); L->wx = (double*)malloc(sizeof(double) * L->n); L->wy = (double*)malloc(sizeof(double) * L->n);
-          L->diag = (double*)malloc(sizeof(double) * L->n);
+          L->diag = (double*)malloc(sizeof(double) * L->n); L->dinv = (double*)malloc(sizeof(double) * L->n);
           L->b = (double*)malloc(sizeof(double) * (size_t)L->n * NQ); L->x = (double*)malloc(sizeof(double) * (size_t)L->n * NQ); L->x2 = (double*)malloc(sizeof(double) * (size_t)L->n * NQ);
           ++nl;
           if (L->n <= 64 || (h <= 8 && w <= 8) || nl >= 16) break;
@@ -152,7 +152,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
             if (x > 0) a00 += L->wx[i - 1];
             if (y + 1 < L->H) a00 += L->wy[i];
             if (y > 0) a00 += L->wy[i - L->W];
-            L->diag[i] = a00;
+            L->diag[i] = a00; L->dinv[i] = OMEGA / a00;
         }
     }
     lvl_t* F = &lv[0];
@@ -212,7 +212,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     for (int i = 0; i < n; ++i) for (int q = 0; q < NQ; ++q) { if (q < 3) a[(size_t)i * 3 + q] = x6[(size_t)i * NQ + q]; else b[(size_t)i * 3 + q - 3] = x6[(size_t)i * NQ + q]; }
     if (iters_out) memcpy(iters_out, iters, sizeof iters);
     int mx = 0; for (int q = 0; q < 6; ++q) if (iters[q] > mx) mx = iters[q];
-    for (int l = 0; l < nl; ++l) { free(lv[l].r); free(lv[l].wx); free(lv[l].wy); free(lv[l].diag); free(lv[l].b); free(lv[l].x); free(lv[l].x2); }
+    for (int l = 0; l < nl; ++l) { free(lv[l].r); free(lv[l].wx); free(lv[l].wy); free(lv[l].diag); free(lv[l].dinv); free(lv[l].b); free(lv[l].x); free(lv[l].x2); }
     free(x6); free(r); free(p); free(Ap); free(acc);
     return any ? -1 : mx;
 }
