@@ -399,7 +399,7 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         hipLaunchKernelGGL(k_gradient_weights, dim3(nbL), dim3(256), 0, s, s_lab_full, H, W, lamda, prm.wls_alpha, (double*)gx, (double*)gy); LCHK();
         hipLaunchKernelGGL(k_wls_system, dim3(nbL), dim3(256), 0, s, (const double*)gx, (const double*)gy, (const double*)rough, H, W, (double*)diag, (double*)wx, (double*)wy); LCHK();
         int wit[6] = {0, 0, 0, 0, 0, 0};
-        int rc = nctk_wls_solve_mg(ctx, s, X, rough, wx, wy, H, W, 1e-8, wit); if (rc) return rc;
+        int rc = nctk_wls_solve_mg(ctx, s, X, rough, wx, wy, H, W, 1e-6, wit); if (rc) return rc;
         if (dbg && dbg->wls_iters) for (int q = 0; q < 6; ++q) dbg->wls_iters[q] = wit[q];
     }
     if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_wls, X, (size_t)6 * N); if (rc) return rc; }

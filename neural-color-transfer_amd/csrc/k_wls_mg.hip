@@ -123,21 +123,17 @@ __global__ void k_mg_diag(Lvl L) {
     L.dinv[i] = OMEGA / a00;
 }
 
-// ---- V-cycle pieces (vectors [n][6])
+// ---- V-cycle pieces (vectors planar [6][n]); per-pixel bodies shared by the per-level kernels and the fused tail kernel
 // two damped-Jacobi sweeps from a zero initial guess: x1 = b*dinv ; x = x1 + (b - M x1)*dinv   (dinv = omega/diag)
-__global__ void k_mg_pre2(Lvl L, const double* __restrict__ b, double* __restrict__ x) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.n) return;
+__device__ __forceinline__ void pre2_px(const Lvl& L, const double* __restrict__ b, double* __restrict__ x, int i) {
     auto x1 = [&](int j, int q) { return b[(size_t)q * L.n + j] * L.dinv[j]; };
     double y[NQ]; lvl_op(L, i, x1, y);
     const double d = L.dinv[i];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) x[(size_t)q * L.n + i] = x1(i, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
 }
-// coarse rhs = sum over the aggregate of (b - M x)
-__global__ void k_mg_restrict(Lvl F, const double* __restrict__ b, const double* __restrict__ x, Lvl C, double* __restrict__ bc) {
-    const int I = blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= C.n) return;
+// coarse rhs = sum over the aggregate of (b - M x), fine pixels in the order (0,0),(0,1),(1,0),(1,1)
+__device__ __forceinline__ void restrict_px(const Lvl& F, const double* __restrict__ b, const double* __restrict__ x, const Lvl& C, double* __restrict__ bc, int I) {
     const int Y = I / C.W, X = I - Y * C.W;
     double acc[NQ];
 #pragma unroll
@@ -156,62 +152,114 @@ __global__ void k_mg_restrict(Lvl F, const double* __restrict__ b, const double*
 #pragma unroll
     for (int q = 0; q < NQ; ++q) bc[(size_t)q * C.n + I] = acc[q];
 }
-// xo = xe + om*(b - M xe)/d with xe = x + e_coarse(parent)   (prolongation fused with the first post-smoothing sweep)
-__global__ void k_mg_prolong_smooth(Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc, const double* __restrict__ ec, double* __restrict__ xo) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.n) return;
+// xo = xe + (b - M xe)*dinv with xe = x + e_coarse(parent)   (prolongation fused with the first post-smoothing sweep)
+__device__ __forceinline__ void prolong_px(const Lvl& L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc, const double* __restrict__ ec,
+                                           double* __restrict__ xo, int i) {
     auto xe = [&](int j, int q) { const int y = j / L.W, xx = j - y * L.W; return x[(size_t)q * L.n + j] + ec[(size_t)q * nc + ((y >> 1) * Wc + (xx >> 1))]; };
     double y[NQ]; lvl_op(L, i, xe, y);
     const double d = L.dinv[i];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xe(i, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
 }
-// plain sweep xo = x + om*(b - M x)/d ; optionally accumulates the partial sums of r.z (r = b at level 0, z = xo)
+// plain sweep xo = x + (b - M x)*dinv ; returns b.xo per q in acc (for r.z at level 0)
+__device__ __forceinline__ void smooth_px(const Lvl& L, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xo, int i, double (&acc)[NQ]) {
+    auto xv = [&](int j, int q) { return x[(size_t)q * L.n + j]; };
+    double y[NQ]; lvl_op(L, i, xv, y);
+    const double d = L.dinv[i];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double bq = b[(size_t)q * L.n + i];
+        const double v = x[(size_t)q * L.n + i] + (bq - y[q]) * d;
+        xo[(size_t)q * L.n + i] = v;
+        acc[q] = bq * v;
+    }
+}
+
+__global__ void k_mg_pre2(Lvl L, const double* __restrict__ b, double* __restrict__ x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L.n) pre2_px(L, b, x, i);
+}
+__global__ void k_mg_restrict(Lvl F, const double* __restrict__ b, const double* __restrict__ x, Lvl C, double* __restrict__ bc) {
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I < C.n) restrict_px(F, b, x, C, bc, I);
+}
+__global__ void k_mg_prolong_smooth(Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc, const double* __restrict__ ec, double* __restrict__ xo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L.n) prolong_px(L, b, x, Wc, nc, ec, xo, i);
+}
 template <bool DOT>
 __global__ __launch_bounds__(256) void k_mg_smooth(Lvl L, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xo, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-    if (i < L.n) {
-        auto xv = [&](int j, int q) { return x[(size_t)q * L.n + j]; };
-        double y[NQ]; lvl_op(L, i, xv, y);
-        const double d = L.dinv[i];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const double bq = b[(size_t)q * L.n + i];
-            const double v = x[(size_t)q * L.n + i] + (bq - y[q]) * d;
-            xo[(size_t)q * L.n + i] = v;
-            if (DOT) acc[q] = bq * v;
-        }
-    }
+    if (i < L.n) smooth_px(L, b, x, xo, i, acc);
     if (DOT) mg_block_reduce<NQ>(acc, partial);
 }
-// coarsest level: `sweeps` Jacobi sweeps from zero inside one workgroup (n <= 1024)
-__global__ __launch_bounds__(1024) void k_mg_coarsest(Lvl L, const double* __restrict__ b, double* __restrict__ xa, double* __restrict__ xb, int sweeps) {
-    const int i = threadIdx.x;
+
+// Fused tail of the V-cycle: every level with <= 2048 pixels (44x44 and below at 700x700) plus the coarsest-grid solve run in ONE
+// 1024-thread workgroup — these grids cannot fill more than a few CUs anyway and each separate launch costs ~5 us of latency.
+// lv[0] is the first tail level (its rhs lv[0].b was written by the restriction of the level above; the result goes to lv[0].x).
+constexpr int MG_TAIL_MAX = 8;
+struct LvlPack { Lvl lv[MG_TAIL_MAX]; int nl; };
+__global__ __launch_bounds__(1024) void k_mg_tail(LvlPack P, int sweeps) {
+    const int tid = threadIdx.x;
     __shared__ double s_x[2][256 * NQ];
-    const bool in_lds = L.n <= 256;                 // the usual case (coarsest grid <= 8x8): keep both Jacobi buffers in LDS
-    double* cur = in_lds ? s_x[0] : xa; double* nxt = in_lds ? s_x[1] : xb;
-    if (i < L.n)
+    for (int l = 0; l < P.nl - 1; ++l) {
+        const Lvl& L = P.lv[l]; const Lvl& C = P.lv[l + 1];
+        for (int i = tid; i < L.n; i += 1024) pre2_px(L, L.b, L.x, i);
+        __syncthreads();
+        for (int I = tid; I < C.n; I += 1024) restrict_px(L, L.b, L.x, C, C.b, I);
+        __syncthreads();
+    }
+    {   // coarsest grid: `sweeps` damped-Jacobi sweeps from zero; coefficients and rhs in registers, iterates in LDS (n <= 256)
+        const Lvl& L = P.lv[P.nl - 1];
+        const int n = L.n, i = tid;
+        const bool live = i < n;
+        double bq[NQ], d = 0, dv = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        int r = 0, c = 0;
+        if (live) {
+            r = i / L.W; c = i - r * L.W;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) cur[(size_t)q * L.n + i] = 0.0;
-    __syncthreads();
-    for (int s = 0; s < sweeps; ++s) {
-        if (i < L.n) {
-            auto xv = [&](int j, int q) { return cur[(size_t)q * L.n + j]; };
-            double y[NQ]; lvl_op(L, i, xv, y);
-            const double d = L.dinv[i];
+            for (int q = 0; q < NQ; ++q) bq[q] = L.b[(size_t)q * n + i];
+            d = L.diag[i]; dv = L.dinv[i];
+            if (c + 1 < L.W) w0 = L.wx[i];
+            if (c > 0) w1 = L.wx[i - 1];
+            if (r + 1 < L.H) w2 = L.wy[i];
+            if (r > 0) w3 = L.wy[i - L.W];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) nxt[(size_t)q * L.n + i] = cur[(size_t)q * L.n + i] + (b[(size_t)q * L.n + i] - y[q]) * d;
+            for (int q = 0; q < NQ; ++q) s_x[0][q * n + i] = 0.0;
         }
         __syncthreads();
-        double* t = cur; cur = nxt; nxt = t;
-    }
-    // result is in `cur`; sweeps is even => cur is the first buffer
-    if (in_lds && i < L.n)
+        int cur = 0;
+        for (int s = 0; s < sweeps; ++s) {
+            if (live) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) xa[(size_t)q * L.n + i] = cur[(size_t)q * L.n + i];
+                for (int q = 0; q < NQ; ++q) {
+                    const double* xc = &s_x[cur][q * n];
+                    double y = d * xc[i];                                   // same operation order as lvl_op: +x, -x, +y, -y
+                    if (c + 1 < L.W) y -= w0 * xc[i + 1];
+                    if (c > 0) y -= w1 * xc[i - 1];
+                    if (r + 1 < L.H) y -= w2 * xc[i + L.W];
+                    if (r > 0) y -= w3 * xc[i - L.W];
+                    s_x[cur ^ 1][q * n + i] = xc[i] + (bq[q] - y) * dv;
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        if (live)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) L.x[(size_t)q * n + i] = s_x[cur][q * n + i];
+        __syncthreads();
+    }
+    for (int l = P.nl - 2; l >= 0; --l) {
+        const Lvl& L = P.lv[l]; const Lvl& C = P.lv[l + 1];
+        for (int i = tid; i < L.n; i += 1024) prolong_px(L, L.b, L.x, C.W, C.n, C.x, L.x2, i);
+        __syncthreads();
+        for (int i = tid; i < L.n; i += 1024) { double acc[NQ]; smooth_px(L, L.b, L.x2, L.x, i, acc); }
+        __syncthreads();
+    }
 }
 
 // ---- PCG pieces at the fine level
@@ -325,7 +373,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             if (L.n <= 64 || (h <= 8 && w <= 8) || lv.size() >= 16) break;
             h = (h + 1) / 2; w = (w + 1) / 2;
         }
-        if (lv.back().n > 1024) return ctx->fail(NCT_ERR_INVALID, "wls: coarsest level too large (%d)", lv.back().n);
+        if (lv.back().n > 256 || lv.size() < 2) return ctx->fail(NCT_ERR_INVALID, "wls: unsupported grid %dx%d (coarsest level %d)", W, H, lv.back().n);
     }
     const int nl = (int)lv.size();
     for (int l = 0; l < nl; ++l) {
@@ -341,15 +389,19 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     hipLaunchKernelGGL(k_pcg_start, dim3(nb), dim3(256), 0, s, F, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
     hipLaunchKernelGGL(k_pcg_start_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
 
-    // z = Vcycle(r): result in lv[0].x (even number of buffer swaps per level)
+    // z = Vcycle(r): result in lv[0].x. Levels [0, tail0) run as grid-wide kernels, levels [tail0, nl) in the fused tail kernel.
+    int tail0 = nl - 1;
+    while (tail0 > 1 && lv[tail0 - 1].n <= 2048 && nl - (tail0 - 1) <= MG_TAIL_MAX) --tail0;
+    LvlPack pack; pack.nl = nl - tail0;
+    for (int l = tail0; l < nl; ++l) pack.lv[l - tail0] = lv[l];
     auto vcycle = [&]() -> int {
-        for (int l = 0; l < nl - 1; ++l) {
+        for (int l = 0; l < tail0; ++l) {
             const double* b = l == 0 ? (const double*)r : lv[l].b;
             hipLaunchKernelGGL(k_mg_pre2, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, lv[l].x); LCHK();
             hipLaunchKernelGGL(k_mg_restrict, dim3(cdiv(lv[l + 1].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1], lv[l + 1].b); LCHK();
         }
-        hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(1024), 0, s, lv[nl - 1], (const double*)lv[nl - 1].b, lv[nl - 1].x, lv[nl - 1].x2, 60); LCHK();
-        for (int l = nl - 2; l >= 0; --l) {
+        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, s, pack, 60); LCHK();
+        for (int l = tail0 - 1; l >= 0; --l) {
             const double* b = l == 0 ? (const double*)r : lv[l].b;
             hipLaunchKernelGGL(k_mg_prolong_smooth, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, (const double*)lv[l + 1].x, lv[l].x2); LCHK();
             if (l == 0) hipLaunchKernelGGL(k_mg_smooth<true>, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x2, lv[l].x, (double*)partial);

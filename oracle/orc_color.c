@@ -545,7 +545,7 @@ int orc_local_color_transfer(const float* err, const uint8_t* s_bgr_level, const
     if (h == H && w == W) lamda *= 4;
     int wit[6] = {0, 0, 0, 0, 0, 0};
     int it = s2_exact ? orc_wls_solve(A, B, full, H, W, lamda, prm->wls_alpha, rough, 0)
-                      : orc_wls_solve_mg(A, B, full, H, W, lamda, prm->wls_alpha, rough, 1e-8, wit);
+                      : orc_wls_solve_mg(A, B, full, H, W, lamda, prm->wls_alpha, rough, 1e-6, wit);
     if (st && st->wls_iters) memcpy(st->wls_iters, wit, sizeof wit);
     if (st && st->ab_wls) { memcpy(st->ab_wls, A, sizeof(double) * 3 * N); memcpy(st->ab_wls + (size_t)3 * N, B, sizeof(double) * 3 * N); }
     uint8_t* olab = (uint8_t*)malloc((size_t)N * 3);

@@ -224,11 +224,13 @@ def test_canonical_cg_matches_explicit_for_few_iterations(oracle):
 
 
 def test_canonical_wls_matches_exact_solve(oracle):
-    """S2: the canonical-order PCG (mirror of the product) agrees with the exact banded-Cholesky solve to 1e-8."""
+    """S2: the canonical-order MG-PCG (mirror of the product, stopped at 1e-6 relative residual) agrees with the exact
+    banded-Cholesky solve to ~1e-5 in the coefficients, i.e. far below one 8-bit quantisation step of the output."""
     err, s, g, ids, ws = _s1_inputs(oracle)
     full = synth.image(3, 48, 48)
     o1, s1 = oracle.local_color_transfer(err, s, g, full, ids, ws, layer=2, want_stages=True, s2_exact=False)
     o2, s2 = oracle.local_color_transfer(err, s, g, full, ids, ws, layer=2, want_stages=True, s2_exact=True)
     assert np.array_equal(s1["ab_up"], s2["ab_up"])
-    assert np.allclose(s1["ab_wls"], s2["ab_wls"], rtol=1e-7, atol=1e-9)
-    assert np.abs(o1.astype(int) - o2.astype(int)).max() <= 1
+    assert np.allclose(s1["ab_wls"], s2["ab_wls"], rtol=2e-5, atol=2e-6)
+    d = np.abs(o1.astype(int) - o2.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
