@@ -62,16 +62,18 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
     const int yb = ty * BLK_ROWS + wpx * 2 * TH + (l31 / TW);  // row of pixel tile 0; tile 1 is TH rows below
 
     // per-lane tap tables for the 9 k-steps of a channel pair (k = 2s + half within 18)
-    int boff[9]; unsigned vm0 = 0, vm1 = 0;
+    // out-of-image taps read the (in-bounds) tile origin instead and are zeroed by a select: no divergent branches in the K loop
+    int off0[9], off1[9]; unsigned vm0 = 0, vm1 = 0;
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         const int k = 2 * s + half;
         const int ci = k / 9, tap = k - 9 * ci, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        boff[s] = ci * HW + dy * g.W + dx;
+        const int boff = ci * HW + dy * g.W + dx;
         const bool xo = (x + dx) >= 0 && (x + dx) < g.W;
         const int y0 = yb + dy, y1 = yb + TH + dy;
-        vm0 |= (unsigned)(xo && y0 >= 0 && y0 < g.H) << s;
-        vm1 |= (unsigned)(xo && y1 >= 0 && y1 < g.H) << s;
+        const bool v0 = xo && y0 >= 0 && y0 < g.H, v1 = xo && y1 >= 0 && y1 < g.H;
+        vm0 |= (unsigned)v0 << s; vm1 |= (unsigned)v1 << s;
+        off0[s] = v0 ? boff : ci * HW; off1[s] = v1 ? boff : ci * HW;
     }
     const int xc = min(x, g.W - 1);
     const float* b0p = in + (size_t)min(yb, g.H - 1) * g.W + xc;
@@ -79,22 +81,37 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
     const float* ap = wp + (size_t)half * g.Cout + m0 + l31;
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};   // [cout tile][pixel tile]
-    for (int c2 = 0; c2 < g.Cin; c2 += 2) {
+    // Software pipeline in registers: the 36 operands of channel pair c2+2 are requested before the 36 MFMAs of pair c2 issue
+    // (36 x 64 = 2304 cycles of matrix work cover the L1/L2 latency of the next pair even at one wave per SIMD).
+    float a0c[9], a1c[9], b0c[9], b1c[9], a0n[9], a1n[9], b0n[9], b1n[9];
+    auto load_pair = [&](float (&a0)[9], float (&a1)[9], float (&b0)[9], float (&b1)[9]) {
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            const float a0 = ap[(size_t)(2 * s) * g.Cout];
-            const float a1 = ap[(size_t)(2 * s) * g.Cout + 32];
-            float b0 = 0.f, b1 = 0.f;
-            if ((vm0 >> s) & 1u) b0 = b0p[boff[s]];
-            if ((vm1 >> s) & 1u) b1 = b1p[boff[s]];
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+            a0[s] = ap[(size_t)(2 * s) * g.Cout];
+            a1[s] = ap[(size_t)(2 * s) * g.Cout + 32];
+            const float t0 = b0p[off0[s]], t1 = b1p[off1[s]];
+            b0[s] = ((vm0 >> s) & 1u) ? t0 : 0.f;
+            b1[s] = ((vm1 >> s) & 1u) ? t1 : 0.f;
         }
         ap += (size_t)18 * g.Cout;
         b0p += (size_t)2 * HW;
         b1p += (size_t)2 * HW;
+    };
+    load_pair(a0c, a1c, b0c, b1c);
+    for (int c2 = 0; c2 < g.Cin; c2 += 2) {
+        const bool more = c2 + 2 < g.Cin;
+        if (more) load_pair(a0n, a1n, b0n, b1n);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c[s], b0c[s], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c[s], b1c[s], acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c[s], b0c[s], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c[s], b1c[s], acc11, 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < 9; ++s) { a0c[s] = a0n[s]; a1c[s] = a1n[s]; b0c[s] = b0n[s]; b1c[s] = b1n[s]; }
+        }
     }
 
     // epilogue: D row (cout) = (r&3) + 8*(r>>2) + 4*half, D col (pixel) = l31
