@@ -109,6 +109,7 @@ def main():
         "output_checksum": int(out.astype(np.uint64).sum()),
     }
 
+    res["vgg_mfma"] = vgg_mfma(S, stages["vgg_ms"])
     if rank == 0 and not args.no_roofline:
         res["roofline"] = patchmatch_roofline(nct, synth, local_rank, S)
     if rank == 0 and not args.no_cpu_baseline:
@@ -141,10 +142,36 @@ def patchmatch_roofline(nct, synth, device, S):
     alg = pm_bytes(evals, S * S, n_launch, C)
     achieved = alg / (ms * 1e-3) / 1e9
     c.close()
-    return {"bound": "hbm", "kernel": f"k_pm_step<1> (C=64, {S}x{S}, both directions, 10 iters)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": n_launch, "avg_launch_ms": ms / n_launch,
-            "algorithmic_bytes_per_launch": alg / n_launch, "evals": evals,
-            "note": "algorithmic bytes (SURVEY 8d) exceed HBM traffic: overlapping candidate tiles are served by L2/Infinity Cache"}
+    # HBM/fabric-side bytes per launch come from the recorded, calibrated PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # cannot run inside this process); they apply to the 700x700 workload only.
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "r1_pmc_patchmatch.json")
+    if S == 700 and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["corrected_bytes_per_launch"]["total"]
+    return {"bound": "hbm", "kernel": f"k_pm_step<1> (C=64, {S}x{S}, one direction per launch, 10 iters x 2 directions)", "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launch,
+            "avg_launch_ms": ms / n_launch, "algorithmic_bytes_per_launch": alg / n_launch, "evals": evals,
+            "note": "algorithmic bytes (SURVEY 8d) exceed the memory-side traffic: overlapping candidate tiles are served by L1/L2 "
+                    "(traffic = FETCH_SIZE x2 (gfx950 correction, calibrated) + WRITE_SIZE per launch, profiles/r1_pmc_patchmatch.json)"}
+
+
+def vgg_mfma(S, vgg_ms):
+    """VGG19 conv work of one pair (S and R forwards to conv5_1 + re-predicts to conv4_1, 3_1, 2_1, 1_1: SURVEY 8a V2) over the
+    instrumented pair's VGG stage time (which also contains preprocess, pools and layout transposes) vs the f32-MFMA peak."""
+    cin = [3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512]
+    cout = [64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512]
+    pool_after = {1, 3, 7, 11}
+    tap_conv = [0, 2, 4, 8, 12]
+    cum, flops, h, w = [], 0, S, S
+    for i in range(13):
+        flops += 2 * 9 * cin[i] * cout[i] * h * w
+        cum.append(flops)
+        if i in pool_after:
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    per_pair = 2 * cum[tap_conv[4]] + sum(cum[tap_conv[t]] for t in range(4))
+    tf = per_pair / (vgg_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_conv3x3_mfma (v_mfma_f32_32x32x2_f32), all 6 forwards of a pair", "flops_per_pair": per_pair,
+            "stage_ms": vgg_ms, "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
 
 
 def cpu_baseline(synth, ws, bs, S):
