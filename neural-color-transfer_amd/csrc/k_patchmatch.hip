@@ -75,14 +75,10 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 // (44x44 queries are only 121 workgroups for 256 CUs) and halves the launch count; each job's result is unaffected.
 struct PMJob { const float* A; const float* B; const uint32_t* nnf_in; const float* d_in; uint32_t* nnf_out; float* d_out; PMGeom g; int rs_max; uint32_t seed; };
 
-// WPQ ("wave per query", used for C >= 256 where the grids are small and the step is latency bound): the four 16-lane rows of
-// a wave evaluate the four propagation candidates of ONE query concurrently and the usual left/right/up/down acceptance
-// order is then applied to the four distances; random-search candidates (sequentially dependent) are evaluated by all four
-// rows redundantly. Same evaluations, same acceptance order => bit-identical NNF, 2.2x shorter dependent chain per step.
-template <int NCH, bool WPQ>
+template <int NCH>
 __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
                                                  unsigned long long* __restrict__ counter) {
-    constexpr bool AREG = (NCH == 1 || NCH == 2) && !WPQ;
+    constexpr bool AREG = (NCH == 1 || NCH == 2);
     const bool second = (int)blockIdx.x >= nblk0;
     const PMJob& J = second ? j1 : j0;
     const float* __restrict__ A = J.A; const float* __restrict__ B = J.B;
@@ -99,8 +95,7 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
     }
     const int ty = bid / g.tiles_x, tx = bid - ty * g.tiles_x;
     const int grp = threadIdx.x >> 4, v = threadIdx.x & 15;
-    const int wv = threadIdx.x >> 6, row = grp & 3;                       // WPQ: wave -> query of a 2x2 tile, row -> candidate slot
-    const int qx = WPQ ? tx * 2 + (wv & 1) : tx * 4 + (grp & 3), qy = WPQ ? ty * 2 + (wv >> 1) : ty * 4 + (grp >> 2);
+    const int qx = tx * 4 + (grp & 3), qy = ty * 4 + (grp >> 2);
     const bool live = qx < g.aw && qy < g.ah;
     const int ax = live ? qx : g.aw - 1, ay = live ? qy : g.ah - 1;
     const int qi = ay * g.aw + ax;
@@ -140,35 +135,7 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
         if (jump == 1) for (int mag = rs_start; mag >= 1; mag >>= 1) ++nrand;
         int mag = rs_start;
         const int ncand = 4 + nrand;
-        int k0 = 0;
-        if constexpr (WPQ) {
-            // this row's propagation candidate
-            const int k = row;
-            const int sx = (k == 0) ? -jump : (k == 1 ? jump : 0);
-            const int sy = (k == 2) ? -jump : (k == 3 ? jump : 0);
-            const int nx = ax + sx, ny = ay + sy;
-            bool valid = nx >= 0 && nx < g.aw && ny >= 0 && ny < g.ah;
-            const uint32_t vp = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
-            const int xp = nnf_x(vp) - sx, yp = nnf_y(vp) - sy;
-            valid = valid && yp >= 0 && yp < g.bh && xp >= 0 && xp < g.bw;
-            float d = 0.f;
-            if (valid) d = pm_dist<NCH, AREG>(A, B, g, areg, ax, ay, amask, xp, yp, v);
-            const int lane0 = (threadIdx.x & 63) & ~63;        // 0: lanes are wave-relative for __shfl
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {                  // left, right, up, down — sequential acceptance on the broadcast results
-                const int src = lane0 + kk * 16;
-                const int vk = __shfl((int)valid, src);
-                float dk = __shfl(d, src);
-                const int xk = __shfl(xp, src), yk = __shfl(yp, src);
-                if (vk) {
-                    if (dk >= dbest) dk = dbest;
-                    if (dk + 0.f < dbest) { xbest = xk; ybest = yk; dbest = dk; }
-                    ++nevals;
-                }
-            }
-            k0 = 4;
-        }
-        for (int k = k0; k < ncand; ++k) {
+        for (int k = 0; k < ncand; ++k) {
             int xp, yp; bool valid; float rr;
             if (k < 4) {
                 // 0 left, 1 right, 2 up, 3 down — the neighbour's match shifted back by the jump
@@ -197,20 +164,20 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
             }
         }
     }
-    if (live && v == 0 && (!WPQ || row == 0)) { if (mode != 0) nnf_out[qi] = xy_pack(xbest, ybest); d_out[qi] = dbest; }
+    if (live && v == 0) { if (mode != 0) nnf_out[qi] = xy_pack(xbest, ybest); d_out[qi] = dbest; }
     if (counter) {
         __shared__ unsigned s_cnt;
         if (threadIdx.x == 0) s_cnt = 0;
         __syncthreads();
-        if (live && v == 0 && (!WPQ || row == 0)) atomicAdd(&s_cnt, nevals);
+        if (live && v == 0) atomicAdd(&s_cnt, nevals);
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(counter, (unsigned long long)s_cnt);
     }
 }
 
-template <int NCH, bool WPQ>
+template <int NCH>
 static void launch_step(hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
-    hipLaunchKernelGGL((k_pm_step<NCH, WPQ>), dim3(nblk0 + nblk1), dim3(256), 0, s, j0, j1, nblk0, mode, jump, iter, counter);
+    hipLaunchKernelGGL(k_pm_step<NCH>, dim3(nblk0 + nblk1), dim3(256), 0, s, j0, j1, nblk0, mode, jump, iter, counter);
 }
 
 // Runs one PatchMatch (bnn == nullptr) or both directions of a level fused in the same launches (A->B in ann, B->A in bnn).
@@ -225,9 +192,7 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
     DevBuf<uint32_t> a_tmp(ctx, na), b_tmp(ctx, two ? nb : 1);
     DevBuf<float> ad_tmp(ctx, na), bd_tmp(ctx, two ? nb : 1);
     if (!a_tmp.ok() || !b_tmp.ok() || !ad_tmp.ok() || !bd_tmp.ok()) return NCT_ERR_HIP;
-    const bool wpq = C >= 256;                       // small, latency-bound levels: one wave per query
-    const int tq = wpq ? 2 : 4;                      // query tile side per workgroup
-    const PMGeom ga{C, ah, aw, bh, bw, cdiv(aw, tq), cdiv(ah, tq)}, gb{C, bh, bw, ah, aw, cdiv(bw, tq), cdiv(bh, tq)};
+    const PMGeom ga{C, ah, aw, bh, bw, cdiv(aw, 4), cdiv(ah, 4)}, gb{C, bh, bw, ah, aw, cdiv(bw, 4), cdiv(bh, 4)};
     const int nblk0 = ga.tiles_x * ga.tiles_y, nblk1 = two ? gb.tiles_x * gb.tiles_y : 0;
     uint32_t* na_buf[2] = {ann, a_tmp}; float* da_buf[2] = {annd, ad_tmp};
     uint32_t* nb_buf[2] = {bnn, b_tmp}; float* db_buf[2] = {bnnd, bd_tmp};
@@ -235,13 +200,11 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
         PMJob j0{a_hwc, b_hwc, na_buf[in], da_buf[in], mode ? na_buf[out] : nullptr, da_buf[out], ga, rs_max, seed_ab};
         PMJob j1{b_hwc, a_hwc, nb_buf[in], db_buf[in], mode ? nb_buf[out] : nullptr, db_buf[out], gb, rs_max, seed_ba};
         switch (C) {
-            case 64:  launch_step<1, false>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
-            case 128: launch_step<2, false>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
-            case 256: launch_step<4, true>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
-            case 512: launch_step<8, true>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
-            default:  if (wpq) launch_step<0, true>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter);
-                      else     launch_step<0, false>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter);
-                      break;
+            case 64:  launch_step<1>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
+            case 128: launch_step<2>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
+            case 256: launch_step<4>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
+            case 512: launch_step<8>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
+            default:  launch_step<0>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
         }
     };
     // the total number of Jacobi steps is even (iters*4), so ping-ponging (nnf,dist) <-> (tmp) ends in (nnf,dist)
