@@ -25,7 +25,7 @@ struct PMGeom { int C, ah, aw, bh, bw, tiles_x, tiles_y; };
 template <int NCH, bool AREG>
 __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const PMGeom& g,
                                          const float4 (&areg)[9][NCH > 0 ? NCH : 1], int ax, int ay, unsigned amask,
-                                         int bx, int by, int v) {
+                                         int bx, int by, int v, const float4* __restrict__ a_lds = nullptr, int lx = 0, int ly = 0) {
     float acc = 0.f;
     int n = 0;
     const int nchunk = g.C >> 2;
@@ -46,7 +46,9 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
             }
         } else {
             const int yac = clampi(ay + dy, 0, g.ah - 1), xac = clampi(ax + dx, 0, g.aw - 1);
-            const float4* pa = reinterpret_cast<const float4*>(A + ((size_t)yac * g.aw + xac) * g.C);
+            // C >= 256: the workgroup's 6x6xC query region sits in LDS (a_lds); otherwise read the query tile through L1
+            const float4* pa = (NCH >= 4) ? a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * (g.C >> 2)
+                                          : reinterpret_cast<const float4*>(A + ((size_t)yac * g.aw + xac) * g.C);
             if constexpr (NCH > 0) {
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
@@ -99,6 +101,21 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
     const bool live = qx < g.aw && qy < g.ah;
     const int ax = live ? qx : g.aw - 1, ay = live ? qy : g.ah - 1;
     const int qi = ay * g.aw + ax;
+    const int lx = ax - tx * 4, ly = ay - ty * 4;       // position inside the 4x4 query tile (clamped queries stay inside the region)
+
+    // C >= 256: stage the 6x6xC region of A that the 16 queries of this workgroup read (their 3x3 tiles overlap) into LDS once
+    // per launch: 36 KB (C=256) / 72 KB (C=512). Without it every evaluation re-reads its 9*C*4-byte query tile and four such
+    // tiles per wave overflow the 32 KB L1.
+    extern __shared__ float4 s_a[];
+    if constexpr (NCH >= 4) {
+        const int c4 = g.C >> 2;
+        for (int e = threadIdx.x; e < 36 * c4; e += 256) {
+            const int r = e / c4, j = e - r * c4;
+            const int ry = clampi(ty * 4 - 1 + r / 6, 0, g.ah - 1), rx = clampi(tx * 4 - 1 + r % 6, 0, g.aw - 1);
+            s_a[e] = reinterpret_cast<const float4*>(A + ((size_t)ry * g.aw + rx) * g.C)[j];
+        }
+        __syncthreads();
+    }
 
     // validity of the query's own taps + (optionally) its tile in registers
     unsigned amask = 0;
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
     unsigned nevals = 0;
 
     if (mode == 0) {
-        dbest = pm_dist<NCH, AREG>(A, B, g, areg, ax, ay, amask, xbest, ybest, v);
+        dbest = pm_dist<NCH, AREG>(A, B, g, areg, ax, ay, amask, xbest, ybest, v, s_a, lx, ly);
         float cut = (float)INT_MAX;                 // dist_single default cutoff
         if (dbest >= cut) dbest = cut;
         nevals = 1;
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
                 valid = true; rr = FLT_MIN;
             }
             if (valid) {
-                float d = pm_dist<NCH, AREG>(A, B, g, areg, ax, ay, amask, xp, yp, v);
+                float d = pm_dist<NCH, AREG>(A, B, g, areg, ax, ay, amask, xp, yp, v, s_a, lx, ly);
                 if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
                 if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; }
                 ++nevals;
@@ -177,7 +194,8 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
 
 template <int NCH>
 static void launch_step(hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
-    hipLaunchKernelGGL(k_pm_step<NCH>, dim3(nblk0 + nblk1), dim3(256), 0, s, j0, j1, nblk0, mode, jump, iter, counter);
+    const size_t lds = NCH >= 4 ? (size_t)36 * NCH * 16 * sizeof(float4) : 0;      // 6x6 pixels x C/4 float4
+    hipLaunchKernelGGL(k_pm_step<NCH>, dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
 }
 
 // Runs one PatchMatch (bnn == nullptr) or both directions of a level fused in the same launches (A->B in ann, B->A in bnn).
@@ -207,6 +225,9 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
             default:  launch_step<0>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
         }
     };
+    // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device
+    if (C == 512) NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 8 * 16 * (int)sizeof(float4)));
+    if (C == 256) NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 4 * 16 * (int)sizeof(float4)));
     // the total number of Jacobi steps is even (iters*4), so ping-ponging (nnf,dist) <-> (tmp) ends in (nnf,dist)
     step(0, 0, 0, 0, 0);                           // init: dist(current NNF), NNF untouched
     NCT_LAUNCH_CHECK();
