@@ -47,7 +47,7 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
         } else {
             const int yac = clampi(ay + dy, 0, g.ah - 1), xac = clampi(ax + dx, 0, g.aw - 1);
             // C >= 256: the workgroup's 6x6xC query region sits in LDS (a_lds); otherwise read the query tile through L1
-            const float4* pa = (NCH >= 4) ? a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * (g.C >> 2)
+            const float4* pa = (NCH >= 1) ? a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * (g.C >> 2)
                                           : reinterpret_cast<const float4*>(A + ((size_t)yac * g.aw + xac) * g.C);
             if constexpr (NCH > 0) {
 #pragma unroll
@@ -80,7 +80,7 @@ struct PMJob { const float* A; const float* B; const uint32_t* nnf_in; const flo
 template <int NCH>
 __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
                                                  unsigned long long* __restrict__ counter) {
-    constexpr bool AREG = (NCH == 1 || NCH == 2);
+    constexpr bool AREG = false;   // experiment: query region always in LDS
     const bool second = (int)blockIdx.x >= nblk0;
     const PMJob& J = second ? j1 : j0;
     const float* __restrict__ A = J.A; const float* __restrict__ B = J.B;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
     // per launch: 36 KB (C=256) / 72 KB (C=512). Without it every evaluation re-reads its 9*C*4-byte query tile and four such
     // tiles per wave overflow the 32 KB L1.
     extern __shared__ float4 s_a[];
-    if constexpr (NCH >= 4) {
+    if constexpr (NCH >= 1) {
         const int c4 = g.C >> 2;
         for (int e = threadIdx.x; e < 36 * c4; e += 256) {
             const int r = e / c4, j = e - r * c4;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
 
 template <int NCH>
 static void launch_step(hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
-    const size_t lds = NCH >= 4 ? (size_t)36 * NCH * 16 * sizeof(float4) : 0;      // 6x6 pixels x C/4 float4
+    const size_t lds = NCH >= 1 ? (size_t)36 * NCH * 16 * sizeof(float4) : 0;      // 6x6 pixels x C/4 float4
     hipLaunchKernelGGL(k_pm_step<NCH>, dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
 }
 
