@@ -390,8 +390,10 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     hipLaunchKernelGGL(k_pcg_start_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
 
     // z = Vcycle(r): result in lv[0].x. Levels [0, tail0) run as grid-wide kernels, levels [tail0, nl) in the fused tail kernel.
+    // Measured (profiles/r1e): running the 44x44..6x6 levels inside ONE workgroup costs 157 us per cycle, more than the 12 separate
+    // ~5 us launches it replaces (a single CU is latency bound on the dependent stencil phases), so only the coarsest grid
+    // (registers + LDS, no global traffic in its 60 sweeps) stays in the tail kernel.
     int tail0 = nl - 1;
-    while (tail0 > 1 && lv[tail0 - 1].n <= 2048 && nl - (tail0 - 1) <= MG_TAIL_MAX) --tail0;
     LvlPack pack; pack.nl = nl - tail0;
     for (int l = tail0; l < nl; ++l) pack.lv[l - tail0] = lv[l];
     auto vcycle = [&]() -> int {

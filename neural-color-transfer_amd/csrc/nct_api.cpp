@@ -28,6 +28,7 @@ void* nct_ctx::alloc(size_t bytes) {
     return p;
 }
 void nct_ctx::release(void* p) {
+    if (defer_release) { deferred.push_back(p); return; }
     for (auto& b : blocks) if (b.p == p) { b.used = false; return; }
 }
 

@@ -32,6 +32,12 @@ struct nct_ctx {
     }
     void* alloc(size_t bytes);        // never returns null on success; sets err and returns null on failure
     void release(void* p);
+    // Arena blocks are recycled in stream order, which is only safe on ONE stream. While work is being enqueued on the side
+    // stream, set defer_release: blocks released meanwhile stay reserved until flush_deferred() is called after the main
+    // stream has been made to wait on the side stream's completion event.
+    bool defer_release = false;
+    std::vector<void*> deferred;
+    void flush_deferred() { for (void* p : deferred) for (auto& b : blocks) if (b.p == p) { b.used = false; break; } deferred.clear(); }
 };
 
 // RAII scratch buffer from the context arena

@@ -110,14 +110,41 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     NCT_HIP(hipStreamSynchronize(s));
     clk.lap(timing ? &timing->cluster_ms : nullptr);
 
+    // ---- K1 for all five levels on the side stream: the kNN graph of a level depends only on the level image of S and on the
+    // labels (main.cu:351-359), not on the correspondence, so it overlaps with PatchMatch / votes / solvers of the main stream
+    // (whose many small launches leave most CUs idle). Scratch released meanwhile stays reserved until the join (nct_internal.h).
+    std::vector<DevBuf<uint8_t>*> slab(5, nullptr);
+    std::vector<DevBuf<int>*> knn_ids(5, nullptr);
+    std::vector<DevBuf<double>*> knn_ws(5, nullptr);
+    struct Cleanup3 { std::vector<DevBuf<uint8_t>*>& a; std::vector<DevBuf<int>*>& b; std::vector<DevBuf<double>*>& c; nct_ctx* ctx;
+                      ~Cleanup3() { (void)hipStreamSynchronize(ctx->stream2); ctx->defer_release = false; ctx->flush_deferred();
+                                    for (auto* p : a) delete p; for (auto* p : b) delete p; for (auto* p : c) delete p; } } cleanup3{slab, knn_ids, knn_ws, ctx};
+    {
+        hipStream_t s2 = ctx->stream2;
+        NCT_HIP(hipEventRecord(ctx->ev_fork, s));
+        NCT_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+        for (int l = 0; l < 5; ++l) {
+            const size_t npx = (size_t)ah[l] * aw[l];
+            slab[l] = new DevBuf<uint8_t>(ctx, npx * 3); knn_ids[l] = new DevBuf<int>(ctx, npx * 8); knn_ws[l] = new DevBuf<double>(ctx, npx * 8);
+            if (!slab[l]->ok() || !knn_ids[l]->ok() || !knn_ws[l]->ok()) return NCT_ERR_HIP;
+        }
+        ctx->defer_release = true;
+        for (int l = 0; l < 5 && rc == 0; ++l) {
+            rc = nctk_bgr2lab(ctx, s2, simg[l], *slab[l], (size_t)ah[l] * aw[l]);
+            if (rc == 0) rc = nctk_knn_graph(ctx, s2, *slab[l], ah[l], aw[l], labels, ah[0], aw[0], nlabels, 1 << l, *knn_ids[l], *knn_ws[l]);
+        }
+        ctx->defer_release = false;
+        if (rc) return rc;
+        NCT_HIP(hipEventRecord(ctx->ev_join, s2));
+    }
+    bool knn_joined = false;
+
     // ---- level loop (main.cu:179-428)
     DevBuf<uint32_t> ann(ctx, N), bnn(ctx, (size_t)RH * RW), ann_prev(ctx, N), bnn_prev(ctx, (size_t)RH * RW);
     DevBuf<float> annd(ctx, N), bnnd(ctx, (size_t)RH * RW), err(ctx, N);
-    DevBuf<uint8_t> guide(ctx, N * 3), s_lab_l(ctx, N * 3), g_lab_l(ctx, N * 3), out_lab(ctx, N * 3);
-    DevBuf<int> knn_id(ctx, N * 8);
-    DevBuf<double> knn_w(ctx, N * 8);
-    if (!ann.ok() || !bnn.ok() || !ann_prev.ok() || !bnn_prev.ok() || !annd.ok() || !bnnd.ok() || !err.ok() || !guide.ok() || !s_lab_l.ok() ||
-        !g_lab_l.ok() || !out_lab.ok() || !knn_id.ok() || !knn_w.ok()) return NCT_ERR_HIP;
+    DevBuf<uint8_t> guide(ctx, N * 3), g_lab_l(ctx, N * 3), out_lab(ctx, N * 3);
+    if (!ann.ok() || !bnn.ok() || !ann_prev.ok() || !bnn_prev.ok() || !annd.ok() || !bnnd.ok() || !err.ok() || !guide.ok() ||
+        !g_lab_l.ok() || !out_lab.ok()) return NCT_ERR_HIP;
     if (!P->out) NCT_HIP(hipMalloc(&P->out, N * 3));
     nct_color_params cp{prm->eps, prm->nonlocal_weight, prm->local_weight, prm->wls_lambda_init, prm->wls_alpha, (double)prm->k_num};
 
@@ -146,10 +173,10 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         rc = nctk_normalize(ctx, s, voted, nvoted, nullptr, C, na_px); if (rc) return rc;
         rc = nctk_feature_distance(ctx, s, na, nvoted, err, C, na_px); if (rc) return rc;
         clk.lap(timing ? &timing->vote_ms : nullptr);
-        // kNN graph in Lab (main.cu:351-359)
-        rc = nctk_bgr2lab(ctx, s, simg[l], s_lab_l, na_px); if (rc) return rc;
+        // kNN graph in Lab (main.cu:351-359): computed on the side stream; join once before its first use
         rc = nctk_bgr2lab(ctx, s, guide, g_lab_l, na_px); if (rc) return rc;
-        rc = nctk_knn_graph(ctx, s, s_lab_l, ah[l], aw[l], labels, ah[0], aw[0], nlabels, 1 << l, knn_id, knn_w); if (rc) return rc;
+        if (!knn_joined) { NCT_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); ctx->flush_deferred(); knn_joined = true; }
+        const uint8_t* s_lab_l = *slab[l]; const int* knn_id = *knn_ids[l]; const double* knn_w = *knn_ws[l];
         clk.lap(timing ? &timing->knn_ms : nullptr);
         // local colour transfer (main.cu:368-380)
         nct_color_debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
