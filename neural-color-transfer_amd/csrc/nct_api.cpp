@@ -58,6 +58,8 @@ int nct_create(int device, nct_ctx** out) {
         g_create_err = std::string("stream/event creation: ") + hipGetErrorString(e);
         delete c; return NCT_ERR_HIP;
     }
+    for (int l = 0; l < 5; ++l)
+        if ((e = hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     *out = c;
     return NCT_OK;
 }
@@ -79,6 +81,7 @@ void nct_destroy(nct_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (int l = 0; l < 5; ++l) if (ctx->ev_level[l]) (void)hipEventDestroy(ctx->ev_level[l]);
     delete ctx;
 }
 

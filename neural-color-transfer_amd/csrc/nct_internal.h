@@ -15,6 +15,7 @@ struct nct_ctx {
     hipStream_t stream = nullptr;     // main stream (S->R direction, VGG, colour stage)
     hipStream_t stream2 = nullptr;    // second stream (R->S direction runs concurrently)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_level[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // side-stream completion of level l's kNN graph
     std::string err;
     std::vector<nct_block> blocks;    // cached device allocations, reused across calls and pairs
     size_t bytes_allocated = 0;

@@ -132,12 +132,11 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         for (int l = 0; l < 5 && rc == 0; ++l) {
             rc = nctk_bgr2lab(ctx, s2, simg[l], *slab[l], (size_t)ah[l] * aw[l]);
             if (rc == 0) rc = nctk_knn_graph(ctx, s2, *slab[l], ah[l], aw[l], labels, ah[0], aw[0], nlabels, 1 << l, *knn_ids[l], *knn_ws[l]);
+            if (rc == 0 && hipEventRecord(ctx->ev_level[l], s2) != hipSuccess) rc = ctx->fail(NCT_ERR_HIP, "hipEventRecord failed");
         }
         ctx->defer_release = false;
         if (rc) return rc;
-        NCT_HIP(hipEventRecord(ctx->ev_join, s2));
     }
-    bool knn_joined = false;
 
     // ---- level loop (main.cu:179-428)
     DevBuf<uint32_t> ann(ctx, N), bnn(ctx, (size_t)RH * RW), ann_prev(ctx, N), bnn_prev(ctx, (size_t)RH * RW);
@@ -175,7 +174,8 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         clk.lap(timing ? &timing->vote_ms : nullptr);
         // kNN graph in Lab (main.cu:351-359): computed on the side stream; join once before its first use
         rc = nctk_bgr2lab(ctx, s, guide, g_lab_l, na_px); if (rc) return rc;
-        if (!knn_joined) { NCT_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); ctx->flush_deferred(); knn_joined = true; }
+        NCT_HIP(hipStreamWaitEvent(s, ctx->ev_level[l], 0));          // level l's graph only: the fine levels keep overlapping
+        if (l == 4) ctx->flush_deferred();
         const uint8_t* s_lab_l = *slab[l]; const int* knn_id = *knn_ids[l]; const double* knn_w = *knn_ws[l];
         clk.lap(timing ? &timing->knn_ms : nullptr);
         // local colour transfer (main.cu:368-380)
