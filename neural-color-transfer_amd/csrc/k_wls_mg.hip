@@ -197,69 +197,142 @@ __global__ __launch_bounds__(256) void k_mg_smooth(Lvl L, const double* __restri
     if (DOT) mg_block_reduce<NQ>(acc, partial);
 }
 
-// Fused tail of the V-cycle: every level with <= 2048 pixels (44x44 and below at 700x700) plus the coarsest-grid solve run in ONE
-// 1024-thread workgroup — these grids cannot fill more than a few CUs anyway and each separate launch costs ~5 us of latency.
-// lv[0] is the first tail level (its rhs lv[0].b was written by the restriction of the level above; the result goes to lv[0].x).
-constexpr int MG_TAIL_MAX = 8;
-struct LvlPack { Lvl lv[MG_TAIL_MAX]; int nl; };
-__global__ __launch_bounds__(1024) void k_mg_tail(LvlPack P, int sweeps) {
-    const int tid = threadIdx.x;
-    __shared__ double s_x[2][256 * NQ];
-    for (int l = 0; l < P.nl - 1; ++l) {
-        const Lvl& L = P.lv[l]; const Lvl& C = P.lv[l + 1];
-        for (int i = tid; i < L.n; i += 1024) pre2_px(L, L.b, L.x, i);
-        __syncthreads();
-        for (int I = tid; I < C.n; I += 1024) restrict_px(L, L.b, L.x, C, C.b, I);
-        __syncthreads();
-    }
-    {   // coarsest grid: `sweeps` damped-Jacobi sweeps from zero; coefficients and rhs in registers, iterates in LDS (n <= 256)
-        const Lvl& L = P.lv[P.nl - 1];
-        const int n = L.n, i = tid;
-        const bool live = i < n;
-        double bq[NQ], d = 0, dv = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        int r = 0, c = 0;
-        if (live) {
-            r = i / L.W; c = i - r * L.W;
+// ---- tile-fused V-cycle legs. Same per-pixel expressions as the kernels above (bit-identical results), but the intermediate
+// iterate of a leg lives in LDS for a TX x TY fine tile plus a 1-pixel halo (recomputed by the neighbouring tiles) instead of
+// making a round trip through global memory and a second launch:
+//   down = two pre-smoothing sweeps + residual + restriction          (k_mg_pre2 + k_mg_restrict)
+//   up   = prolongation + two post-smoothing sweeps                   (k_mg_prolong_smooth + k_mg_smooth)
+template <typename F>
+__device__ __forceinline__ void lvl_op_rc(const Lvl& L, int r, int c, F&& val /* val(r, c, q) */, double (&y)[NQ]) {
+    const int W = L.W, H = L.H, i = r * W + c;
+    const double d = L.diag[i];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) bq[q] = L.b[(size_t)q * n + i];
-            d = L.diag[i]; dv = L.dinv[i];
-            if (c + 1 < L.W) w0 = L.wx[i];
-            if (c > 0) w1 = L.wx[i - 1];
-            if (r + 1 < L.H) w2 = L.wy[i];
-            if (r > 0) w3 = L.wy[i - L.W];
+    for (int q = 0; q < NQ; ++q) y[q] = d * val(r, c, q);
+    if (c + 1 < W) { const double w = L.wx[i];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) s_x[0][q * n + i] = 0.0;
+        for (int q = 0; q < NQ; ++q) y[q] -= w * val(r, c + 1, q); }
+    if (c > 0) { const double w = L.wx[i - 1];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= w * val(r, c - 1, q); }
+    if (r + 1 < H) { const double w = L.wy[i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= w * val(r + 1, c, q); }
+    if (r > 0) { const double w = L.wy[i - W];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= w * val(r - 1, c, q); }
+}
+template <int TX, int TY>
+__global__ __launch_bounds__(256) void k_mg_down(Lvl F, const double* __restrict__ b, double* __restrict__ x, Lvl C, double* __restrict__ bc) {
+    constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
+    __shared__ double s_x[NQ * LN];
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    for (int p = threadIdx.x; p < LN; p += 256) {
+        const int ly = p / LW, lx = p - ly * LW;
+        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+        if (gy < 0 || gy >= F.H || gx < 0 || gx >= F.W) continue;
+        const int i = gy * F.W + gx;
+        auto x1 = [&](int j, int q) { return b[(size_t)q * F.n + j] * F.dinv[j]; };
+        double y[NQ]; lvl_op(F, i, x1, y);
+        const double d = F.dinv[i];
+        const bool interior = lx >= 1 && lx <= TX && ly >= 1 && ly <= TY;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double v = x1(i, q) + (b[(size_t)q * F.n + i] - y[q]) * d;
+            s_x[q * LN + p] = v;
+            if (interior) x[(size_t)q * F.n + i] = v;
         }
-        __syncthreads();
-        int cur = 0;
-        for (int s = 0; s < sweeps; ++s) {
-            if (live) {
+    }
+    __syncthreads();
+    auto xv = [&](int r, int c, int q) { return s_x[q * LN + (r - y0 + 1) * LW + (c - x0 + 1)]; };
+    for (int p = threadIdx.x; p < (TX / 2) * (TY / 2); p += 256) {
+        const int cy = p / (TX / 2), cx = p - cy * (TX / 2);
+        const int Y = y0 / 2 + cy, X = x0 / 2 + cx;
+        if (Y >= C.H || X >= C.W) continue;
+        double acc[NQ];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const double* xc = &s_x[cur][q * n];
-                    double y = d * xc[i];                                   // same operation order as lvl_op: +x, -x, +y, -y
-                    if (c + 1 < L.W) y -= w0 * xc[i + 1];
-                    if (c > 0) y -= w1 * xc[i - 1];
-                    if (r + 1 < L.H) y -= w2 * xc[i + L.W];
-                    if (r > 0) y -= w3 * xc[i - L.W];
-                    s_x[cur ^ 1][q * n + i] = xc[i] + (bq[q] - y) * dv;
-                }
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int yy = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
+            if (yy < F.H && xx < F.W) {
+                double yv[NQ]; lvl_op_rc(F, yy, xx, xv, yv);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] += b[(size_t)q * F.n + yy * F.W + xx] - yv[q];
             }
-            __syncthreads();
-            cur ^= 1;
         }
-        if (live)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) L.x[(size_t)q * n + i] = s_x[cur][q * n + i];
-        __syncthreads();
+        for (int q = 0; q < NQ; ++q) bc[(size_t)q * C.n + Y * C.W + X] = acc[q];
     }
-    for (int l = P.nl - 2; l >= 0; --l) {
-        const Lvl& L = P.lv[l]; const Lvl& C = P.lv[l + 1];
-        for (int i = tid; i < L.n; i += 1024) prolong_px(L, L.b, L.x, C.W, C.n, C.x, L.x2, i);
-        __syncthreads();
-        for (int i = tid; i < L.n; i += 1024) { double acc[NQ]; smooth_px(L, L.b, L.x2, L.x, i, acc); }
-        __syncthreads();
+}
+// xo must not alias x (neighbouring tiles still read x for their halo)
+template <int TX, int TY>
+__global__ __launch_bounds__(256) void k_mg_up(Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc, const double* __restrict__ ec,
+                                               double* __restrict__ xo) {
+    constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
+    __shared__ double s_x[NQ * LN];
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    for (int p = threadIdx.x; p < LN; p += 256) {
+        const int ly = p / LW, lx = p - ly * LW;
+        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+        if (gy < 0 || gy >= L.H || gx < 0 || gx >= L.W) continue;
+        auto xe = [&](int r, int c, int q) { return x[(size_t)q * L.n + r * L.W + c] + ec[(size_t)q * nc + ((r >> 1) * Wc + (c >> 1))]; };
+        double y[NQ]; lvl_op_rc(L, gy, gx, xe, y);
+        const int i = gy * L.W + gx;
+        const double d = L.dinv[i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s_x[q * LN + p] = xe(gy, gx, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
     }
+    __syncthreads();
+    auto xv = [&](int r, int c, int q) { return s_x[q * LN + (r - y0 + 1) * LW + (c - x0 + 1)]; };
+    for (int p = threadIdx.x; p < TX * TY; p += 256) {
+        const int ly = p / TX, lx = p - ly * TX;
+        const int gy = y0 + ly, gx = x0 + lx;
+        if (gy >= L.H || gx >= L.W) continue;
+        double y[NQ]; lvl_op_rc(L, gy, gx, xv, y);
+        const int i = gy * L.W + gx;
+        const double d = L.dinv[i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xv(gy, gx, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
+    }
+}
+// r.z partial sums in the canonical block order (256 consecutive pixels per block)
+__global__ __launch_bounds__(256) void k_pcg_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = i < n ? a[(size_t)q * n + i] * b[(size_t)q * n + i] : 0.0;
+    mg_block_reduce<NQ>(acc, partial);
+}
+
+// Coarsest grid (n <= 64 unknowns): `sweeps` damped-Jacobi sweeps from a zero initial guess. One wave per right-hand side, one lane
+// per unknown, the iterate stays in a register and the four neighbours come through ds_bpermute — no LDS round trips, no
+// barriers (the six right-hand sides are independent). Same operation order as lvl_op: +x, -x, +y, -y.
+// (A 1024-thread LDS version of this took 82 us per cycle, 20 % of the whole V-cycle: profiles/r1f_e2e_kernels.md.)
+__global__ __launch_bounds__(64 * NQ) void k_mg_coarsest(Lvl L, int sweeps) {
+    const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
+    const int n = L.n, W = L.W, H = L.H;
+    const bool live = i < n;
+    const int r = live ? i / W : 0, c = live ? i - r * W : 0;
+    double bq = 0, d = 0, dv = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    const bool has_r = live && c + 1 < W, has_l = live && c > 0, has_d = live && r + 1 < H, has_u = live && r > 0;
+    if (live) {
+        bq = L.b[(size_t)q * n + i]; d = L.diag[i]; dv = L.dinv[i];
+        if (has_r) w0 = L.wx[i];
+        if (has_l) w1 = L.wx[i - 1];
+        if (has_d) w2 = L.wy[i];
+        if (has_u) w3 = L.wy[i - W];
+    }
+    double x = 0.0;
+    for (int s = 0; s < sweeps; ++s) {
+        const double xr = __shfl(x, (i + 1) & 63), xl = __shfl(x, (i - 1) & 63), xd = __shfl(x, (i + W) & 63), xu = __shfl(x, (i - W) & 63);
+        double y = d * x;
+        if (has_r) y -= w0 * xr;
+        if (has_l) y -= w1 * xl;
+        if (has_d) y -= w2 * xd;
+        if (has_u) y -= w3 * xu;
+        if (live) x = x + (bq - y) * dv;
+    }
+    if (live) L.x[(size_t)q * n + i] = x;
 }
 
 // ---- PCG pieces at the fine level
@@ -373,7 +446,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             if (L.n <= 64 || (h <= 8 && w <= 8) || lv.size() >= 16) break;
             h = (h + 1) / 2; w = (w + 1) / 2;
         }
-        if (lv.back().n > 256 || lv.size() < 2) return ctx->fail(NCT_ERR_INVALID, "wls: unsupported grid %dx%d (coarsest level %d)", W, H, lv.back().n);
+        if (lv.back().n > 64 || lv.size() < 2) return ctx->fail(NCT_ERR_INVALID, "wls: unsupported grid %dx%d (coarsest level %d)", W, H, lv.back().n);
     }
     const int nl = (int)lv.size();
     for (int l = 0; l < nl; ++l) {
@@ -389,29 +462,28 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     hipLaunchKernelGGL(k_pcg_start, dim3(nb), dim3(256), 0, s, F, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
     hipLaunchKernelGGL(k_pcg_start_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
 
-    // z = Vcycle(r): result in lv[0].x. Levels [0, tail0) run as grid-wide kernels, levels [tail0, nl) in the fused tail kernel.
-    // Measured (profiles/r1e): running the 44x44..6x6 levels inside ONE workgroup costs 157 us per cycle, more than the 12 separate
-    // ~5 us launches it replaces (a single CU is latency bound on the dependent stencil phases), so only the coarsest grid
-    // (registers + LDS, no global traffic in its 60 sweeps) stays in the tail kernel.
-    int tail0 = nl - 1;
-    LvlPack pack; pack.nl = nl - tail0;
-    for (int l = tail0; l < nl; ++l) pack.lv[l - tail0] = lv[l];
+    // z = Vcycle(r). Levels 0..nl-2 run the tile-fused down/up legs (2 launches per level), the coarsest grid one 6-wave kernel.
+    // res[l] = where level l's correction ends up (the up leg cannot write in place: neighbouring tiles still read lv[l].x).
+    // Measured (profiles/r1e): running the 44x44..6x6 levels inside ONE workgroup cost 157 us per cycle, more than the separate
+    // ~5 us launches it replaced (a single CU is latency bound on the dependent stencil phases), so every level keeps its own grid.
+    const int tail0 = nl - 1;
+    constexpr int TX = 32, TY = 16;
+    auto tiles = [&](const Lvl& L) { return dim3(cdiv(L.W, TX), cdiv(L.H, TY)); };
     auto vcycle = [&]() -> int {
         for (int l = 0; l < tail0; ++l) {
             const double* b = l == 0 ? (const double*)r : lv[l].b;
-            hipLaunchKernelGGL(k_mg_pre2, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, lv[l].x); LCHK();
-            hipLaunchKernelGGL(k_mg_restrict, dim3(cdiv(lv[l + 1].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1], lv[l + 1].b); LCHK();
+            hipLaunchKernelGGL((k_mg_down<TX, TY>), tiles(lv[l]), dim3(256), 0, s, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b); LCHK();
         }
-        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, s, pack, 60); LCHK();
+        hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(64 * NQ), 0, s, lv[nl - 1], 60); LCHK();
         for (int l = tail0 - 1; l >= 0; --l) {
             const double* b = l == 0 ? (const double*)r : lv[l].b;
-            hipLaunchKernelGGL(k_mg_prolong_smooth, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, (const double*)lv[l + 1].x, lv[l].x2); LCHK();
-            if (l == 0) hipLaunchKernelGGL(k_mg_smooth<true>, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x2, lv[l].x, (double*)partial);
-            else        hipLaunchKernelGGL(k_mg_smooth<false>, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x2, lv[l].x, (double*)nullptr);
-            LCHK();
+            const double* ec = l + 1 == nl - 1 ? lv[l + 1].x : lv[l + 1].x2;
+            hipLaunchKernelGGL((k_mg_up<TX, TY>), tiles(lv[l]), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2); LCHK();
         }
+        hipLaunchKernelGGL(k_pcg_dot, dim3(nb), dim3(256), 0, s, N, (const double*)r, (const double*)lv[0].x2, (double*)partial); LCHK();
         return 0;
     };
+    const double* z = lv[0].x2;
     const int maxit = 5000, check_every = 8;
     PState hst; memset(&hst, 0, sizeof hst);
     int it = 0; bool done = false;
@@ -423,7 +495,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
         for (int k = 0; k < check_every; ++k, ++it) {
             int rc = vcycle(); if (rc) return rc;
             hipLaunchKernelGGL(k_pcg_rz_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, it == 0 ? 1 : 0); LCHK();
-            hipLaunchKernelGGL(k_pcg_dir, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const PState*)st, (const double*)F.x, (double*)p, it == 0 ? 1 : 0); LCHK();
+            hipLaunchKernelGGL(k_pcg_dir, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const PState*)st, z, (double*)p, it == 0 ? 1 : 0); LCHK();
             hipLaunchKernelGGL(k_pcg_apply, dim3(nb), dim3(256), 0, s, F, (const double*)p, (double*)Ap, (double*)partial); LCHK();
             hipLaunchKernelGGL(k_pcg_alpha_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st); LCHK();
             hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(256), 0, s, N, (const PState*)st, (const double*)p, (const double*)Ap, (double*)x6, (double*)r, (double*)partial); LCHK();
