@@ -23,6 +23,10 @@
 namespace {
 constexpr double OMEGA = 0.8;
 constexpr int NQ = 6;
+#ifndef NCT_MG_TXB
+#define NCT_MG_TXB 30
+#define NCT_MG_TYB 14
+#endif
 
 struct Lvl { int H, W, n; double *r, *wx, *wy, *diag, *dinv, *b, *x, *x2; };   // dinv = omega / diag (one division per pixel per solve)
 
@@ -123,85 +127,13 @@ __global__ void k_mg_diag(Lvl L) {
     L.dinv[i] = OMEGA / a00;
 }
 
-// ---- V-cycle pieces (vectors planar [6][n]); per-pixel bodies shared by the per-level kernels and the fused tail kernel
-// two damped-Jacobi sweeps from a zero initial guess: x1 = b*dinv ; x = x1 + (b - M x1)*dinv   (dinv = omega/diag)
-__device__ __forceinline__ void pre2_px(const Lvl& L, const double* __restrict__ b, double* __restrict__ x, int i) {
-    auto x1 = [&](int j, int q) { return b[(size_t)q * L.n + j] * L.dinv[j]; };
-    double y[NQ]; lvl_op(L, i, x1, y);
-    const double d = L.dinv[i];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) x[(size_t)q * L.n + i] = x1(i, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
-}
-// coarse rhs = sum over the aggregate of (b - M x), fine pixels in the order (0,0),(0,1),(1,0),(1,1)
-__device__ __forceinline__ void restrict_px(const Lvl& F, const double* __restrict__ b, const double* __restrict__ x, const Lvl& C, double* __restrict__ bc, int I) {
-    const int Y = I / C.W, X = I - Y * C.W;
-    double acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-    auto xv = [&](int j, int q) { return x[(size_t)q * F.n + j]; };
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int y = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
-        if (y < F.H && xx < F.W) {
-            const int i = y * F.W + xx;
-            double yv[NQ]; lvl_op(F, i, xv, yv);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] += b[(size_t)q * F.n + i] - yv[q];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) bc[(size_t)q * C.n + I] = acc[q];
-}
-// xo = xe + (b - M xe)*dinv with xe = x + e_coarse(parent)   (prolongation fused with the first post-smoothing sweep)
-__device__ __forceinline__ void prolong_px(const Lvl& L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc, const double* __restrict__ ec,
-                                           double* __restrict__ xo, int i) {
-    auto xe = [&](int j, int q) { const int y = j / L.W, xx = j - y * L.W; return x[(size_t)q * L.n + j] + ec[(size_t)q * nc + ((y >> 1) * Wc + (xx >> 1))]; };
-    double y[NQ]; lvl_op(L, i, xe, y);
-    const double d = L.dinv[i];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xe(i, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
-}
-// plain sweep xo = x + (b - M x)*dinv ; returns b.xo per q in acc (for r.z at level 0)
-__device__ __forceinline__ void smooth_px(const Lvl& L, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xo, int i, double (&acc)[NQ]) {
-    auto xv = [&](int j, int q) { return x[(size_t)q * L.n + j]; };
-    double y[NQ]; lvl_op(L, i, xv, y);
-    const double d = L.dinv[i];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const double bq = b[(size_t)q * L.n + i];
-        const double v = x[(size_t)q * L.n + i] + (bq - y[q]) * d;
-        xo[(size_t)q * L.n + i] = v;
-        acc[q] = bq * v;
-    }
-}
-
-__global__ void k_mg_pre2(Lvl L, const double* __restrict__ b, double* __restrict__ x) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < L.n) pre2_px(L, b, x, i);
-}
-__global__ void k_mg_restrict(Lvl F, const double* __restrict__ b, const double* __restrict__ x, Lvl C, double* __restrict__ bc) {
-    const int I = blockIdx.x * blockDim.x + threadIdx.x;
-    if (I < C.n) restrict_px(F, b, x, C, bc, I);
-}
-__global__ void k_mg_prolong_smooth(Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc, const double* __restrict__ ec, double* __restrict__ xo) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < L.n) prolong_px(L, b, x, Wc, nc, ec, xo, i);
-}
-template <bool DOT>
-__global__ __launch_bounds__(256) void k_mg_smooth(Lvl L, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xo, double* __restrict__ partial) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-    if (i < L.n) smooth_px(L, b, x, xo, i, acc);
-    if (DOT) mg_block_reduce<NQ>(acc, partial);
-}
-
-// ---- tile-fused V-cycle legs. Same per-pixel expressions as the kernels above (bit-identical results), but the intermediate
-// iterate of a leg lives in LDS for a TX x TY fine tile plus a 1-pixel halo (recomputed by the neighbouring tiles) instead of
-// making a round trip through global memory and a second launch:
-//   down = two pre-smoothing sweeps + residual + restriction          (k_mg_pre2 + k_mg_restrict)
-//   up   = prolongation + two post-smoothing sweeps                   (k_mg_prolong_smooth + k_mg_smooth)
+// ---- V-cycle (vectors planar [6][n])
+// ---- tile-fused V-cycle legs: the intermediate iterate of a leg lives in LDS for a TX x TY fine tile plus a 1-pixel halo
+// (recomputed by the neighbouring tiles with the same expressions, hence bit-identical) instead of making a round trip through
+// global memory and a second launch:
+//   down: x1 = b*dinv ; x = x1 + (b - M x1)*dinv (two damped-Jacobi sweeps from zero) ; coarse rhs = sum over the 2x2 aggregate
+//         of (b - M x), fine pixels in the order (0,0),(0,1),(1,0),(1,1)
+//   up:   xe = x + e_coarse(parent) ; x2 = xe + (b - M xe)*dinv ; xo = x2 + (b - M x2)*dinv
 template <typename F>
 __device__ __forceinline__ void lvl_op_rc(const Lvl& L, int r, int c, F&& val /* val(r, c, q) */, double (&y)[NQ]) {
     const int W = L.W, H = L.H, i = r * W + c;
@@ -467,19 +399,21 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     // Measured (profiles/r1e): running the 44x44..6x6 levels inside ONE workgroup cost 157 us per cycle, more than the separate
     // ~5 us launches it replaced (a single CU is latency bound on the dependent stencil phases), so every level keeps its own grid.
     const int tail0 = nl - 1;
-    constexpr int TX = 32, TY = 16;
-    auto tiles = [&](const Lvl& L) { return dim3(cdiv(L.W, TX), cdiv(L.H, TY)); };
+    // Tile shapes: bandwidth-bound levels use TXB x TYB tiles; below 100k pixels the legs are latency bound, so a 16x8 tile whose
+    // haloed footprint (18x10) fits one pass of the 256 threads keeps the dependent load chains short and spreads over more CUs.
+    constexpr int TXB = NCT_MG_TXB, TYB = NCT_MG_TYB;
+    auto down = [&](int l, const double* b) {
+        if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB>), dim3(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), dim3(256), 0, s, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b);
+        else                   hipLaunchKernelGGL((k_mg_down<16, 8>), dim3(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8)), dim3(256), 0, s, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b);
+    };
+    auto up = [&](int l, const double* b, const double* ec) {
+        if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB>), dim3(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2);
+        else                   hipLaunchKernelGGL((k_mg_up<16, 8>), dim3(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2);
+    };
     auto vcycle = [&]() -> int {
-        for (int l = 0; l < tail0; ++l) {
-            const double* b = l == 0 ? (const double*)r : lv[l].b;
-            hipLaunchKernelGGL((k_mg_down<TX, TY>), tiles(lv[l]), dim3(256), 0, s, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b); LCHK();
-        }
+        for (int l = 0; l < tail0; ++l) { down(l, l == 0 ? (const double*)r : lv[l].b); LCHK(); }
         hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(64 * NQ), 0, s, lv[nl - 1], 60); LCHK();
-        for (int l = tail0 - 1; l >= 0; --l) {
-            const double* b = l == 0 ? (const double*)r : lv[l].b;
-            const double* ec = l + 1 == nl - 1 ? lv[l + 1].x : lv[l + 1].x2;
-            hipLaunchKernelGGL((k_mg_up<TX, TY>), tiles(lv[l]), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2); LCHK();
-        }
+        for (int l = tail0 - 1; l >= 0; --l) { up(l, l == 0 ? (const double*)r : lv[l].b, l + 1 == nl - 1 ? lv[l + 1].x : lv[l + 1].x2); LCHK(); }
         hipLaunchKernelGGL(k_pcg_dot, dim3(nb), dim3(256), 0, s, N, (const double*)r, (const double*)lv[0].x2, (double*)partial); LCHK();
         return 0;
     };
