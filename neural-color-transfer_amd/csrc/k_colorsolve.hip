@@ -129,7 +129,7 @@ struct S1Sys {
     const double *daa, *dab, *dbb;          // [n][3]: (dw s)^2, (dw s) dw, dw^2
     const double *gx, *gy;                  // [n]
     const int* knn_id; const double* iw2;   // [n][8]
-    const int* rev_start; const unsigned* rev_edge;   // reverse adjacency: edges e = src*8+ki sorted by target
+    const int* rev_start; const int* rev_src; const double* rev_w;   // reverse adjacency (in-edges sorted by target, then by edge id src*8+ki): source pixel, iw2 of the edge
 };
 struct CGState { double r0[6], r1[6], va[6], vb[6]; int active[6]; int iters[6]; };
 
@@ -151,41 +151,65 @@ __global__ void k_s1_setup(int n, const double* __restrict__ weight, float dWeig
     for (int k = 0; k < 8; ++k) { const double iw = sqrt(knn_w[(size_t)i * 8 + k]) * nonlocalWeight; iw2[(size_t)i * 8 + k] = iw * iw; }
 }
 
-__device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__ p, int i, double (&ya)[3], double (&yb)[3]) {
-    const int n = S.n, w = S.w, h = S.h;
-    const int y = i / w, x = i - y * w;
-    // the gathered vector is interleaved [pixel][a0 a1 a2 b0 b1 b2]: one 48-byte read per neighbour instead of two 24-byte ones
-    (void)n;
-    double a[3], b[3];
+// y = Op(p) at pixel i (live = i < n). The in-degree of the kNN graph is mild (max 37 at 700x700, p99 19: scripts/knn_indegree.py),
+// so one thread per pixel walks its own in-edge list.
+__device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__ p, int i, bool live, double (&ya)[3], double (&yb)[3]) {
+    const int w = S.w, h = S.h;
+    double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+    int e0 = 0, e1 = 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { a[c] = p[(size_t)i * 6 + c]; b[c] = p[(size_t)i * 6 + 3 + c]; }
+    for (int c = 0; c < 3; ++c) { ya[c] = 0.0; yb[c] = 0.0; }
+    if (live) {
+        const int y = i / w, x = i - y * w;
+        // the gathered vector is interleaved [pixel][a0 a1 a2 b0 b1 b2]: one 48-byte read per neighbour instead of two 24-byte ones
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        ya[c] = S.daa[(size_t)i * 3 + c] * a[c] + S.dab[(size_t)i * 3 + c] * b[c];
-        yb[c] = S.dab[(size_t)i * 3 + c] * a[c] + S.dbb[(size_t)i * 3 + c] * b[c];
+        for (int c = 0; c < 3; ++c) { a[c] = p[(size_t)i * 6 + c]; b[c] = p[(size_t)i * 6 + 3 + c]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ya[c] = S.daa[(size_t)i * 3 + c] * a[c] + S.dab[(size_t)i * 3 + c] * b[c];
+            yb[c] = S.dab[(size_t)i * 3 + c] * a[c] + S.dbb[(size_t)i * 3 + c] * b[c];
+        }
+        auto edge = [&](int j, double wt) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { ya[c] += wt * (a[c] - p[(size_t)j * 6 + c]); yb[c] += wt * (b[c] - p[(size_t)j * 6 + 3 + c]); }
+        };
+        // local smoothness: every edge is entered twice in A (ColorTransfer.cpp:671-843)
+        if (x + 1 < w) { const double g = S.gx[i]; edge(i + 1, 2.0 * (g * g)); }
+        if (x > 0) { const double g = S.gx[i - 1]; edge(i - 1, 2.0 * (g * g)); }
+        if (y + 1 < h) { const double g = S.gy[i]; edge(i + w, 2.0 * (g * g)); }
+        if (y > 0) { const double g = S.gy[i - w]; edge(i - w, 2.0 * (g * g)); }
+        // nonlocal: out-edges, then in-edges
+#pragma unroll
+        for (int k = 0; k < 8; ++k) edge(S.knn_id[(size_t)i * 8 + k], S.iw2[(size_t)i * 8 + k]);
+        e0 = S.rev_start[i]; e1 = S.rev_start[i + 1];
+        {
+            // loads of four edges are issued together (the accumulation order stays the edge order)
+            int e = e0;
+            for (; e + 4 <= e1; e += 4) {
+                int j[4]; double wt[4], pv[4][6];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { j[u] = S.rev_src[e + u]; wt[u] = S.rev_w[e + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) pv[u][c] = p[(size_t)j[u] * 6 + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { ya[c] += wt[u] * (a[c] - pv[u][c]); yb[c] += wt[u] * (b[c] - pv[u][3 + c]); }
+            }
+            for (; e < e1; ++e) edge(S.rev_src[e], S.rev_w[e]);
+        }
     }
-    auto edge = [&](int j, double wt) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { ya[c] += wt * (a[c] - p[(size_t)j * 6 + c]); yb[c] += wt * (b[c] - p[(size_t)j * 6 + 3 + c]); }
-    };
-    // local smoothness: every edge is entered twice in A (ColorTransfer.cpp:671-843)
-    if (x + 1 < w) { const double g = S.gx[i]; edge(i + 1, 2.0 * (g * g)); }
-    if (x > 0) { const double g = S.gx[i - 1]; edge(i - 1, 2.0 * (g * g)); }
-    if (y + 1 < h) { const double g = S.gy[i]; edge(i + w, 2.0 * (g * g)); }
-    if (y > 0) { const double g = S.gy[i - w]; edge(i - w, 2.0 * (g * g)); }
-    // nonlocal: out-edges, then in-edges
-#pragma unroll
-    for (int k = 0; k < 8; ++k) edge(S.knn_id[(size_t)i * 8 + k], S.iw2[(size_t)i * 8 + k]);
-    for (int e = S.rev_start[i]; e < S.rev_start[i + 1]; ++e) { const unsigned ed = S.rev_edge[e]; edge((int)(ed >> 3), S.iw2[ed]); }
 }
 
 // r = rhs - Op(x0); partial r.r
 __global__ __launch_bounds__(256) void k_s1_residual(S1Sys S, const double* __restrict__ x, const double* __restrict__ rhs, double* __restrict__ r, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[3] = {0, 0, 0};
+    double ya[3], yb[3];
+    s1_op(S, x, i, i < S.n, ya, yb);
     if (i < S.n) {
-        double ya[3], yb[3];
-        s1_op(S, x, i, ya, yb);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double ra = rhs[(size_t)i * 3 + c] - ya[c], rb = rhs[(size_t)(S.n + i) * 3 + c] - yb[c];
@@ -198,9 +222,9 @@ __global__ __launch_bounds__(256) void k_s1_residual(S1Sys S, const double* __re
 __global__ __launch_bounds__(256) void k_s1_apply(S1Sys S, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[3] = {0, 0, 0};
+    double ya[3], yb[3];
+    s1_op(S, p, i, i < S.n, ya, yb);
     if (i < S.n) {
-        double ya[3], yb[3];
-        s1_op(S, p, i, ya, yb);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             Ap[(size_t)i * 3 + c] = ya[c]; Ap[(size_t)(S.n + i) * 3 + c] = yb[c];
@@ -266,6 +290,12 @@ __global__ void k_edge_keys(const int* __restrict__ knn_id, int m, unsigned* __r
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m) return;
     keys[e] = (unsigned)knn_id[e]; vals[e] = (unsigned)e;
+}
+__global__ void k_rev_edges(const unsigned* __restrict__ sorted_edge, const double* __restrict__ iw2, int m, int* __restrict__ rev_src, double* __restrict__ rev_w) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const unsigned ed = sorted_edge[e];
+    rev_src[e] = (int)(ed >> 3); rev_w[e] = iw2[ed];
 }
 __global__ void k_seg_starts(const unsigned* __restrict__ keys, int m, int* __restrict__ start, int n) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,10 +367,11 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         DevBuf<double> gx(ctx, n), gy(ctx, n), daa(ctx, (size_t)3 * n), dab(ctx, (size_t)3 * n), dbb(ctx, (size_t)3 * n), rhs(ctx, (size_t)6 * n), iw2(ctx, (size_t)8 * n);
         DevBuf<double> r(ctx, (size_t)6 * n), p(ctx, (size_t)6 * n), Ap(ctx, (size_t)6 * n), partial(ctx, (size_t)nbl * 3);
         DevBuf<unsigned> ek(ctx, (size_t)8 * n), ev(ctx, (size_t)8 * n), eks(ctx, (size_t)8 * n), evs(ctx, (size_t)8 * n);
-        DevBuf<int> rstart(ctx, n + 1);
+        DevBuf<int> rstart(ctx, n + 1), rev_src(ctx, (size_t)8 * n);
+        DevBuf<double> rev_w(ctx, (size_t)8 * n);
         DevBuf<CGState> st(ctx, 1);
         if (!gx.ok() || !gy.ok() || !daa.ok() || !dab.ok() || !dbb.ok() || !rhs.ok() || !iw2.ok() || !r.ok() || !p.ok() || !Ap.ok() || !partial.ok() ||
-            !ek.ok() || !ev.ok() || !eks.ok() || !evs.ok() || !rstart.ok() || !st.ok()) return NCT_ERR_HIP;
+            !ek.ok() || !ev.ok() || !eks.ok() || !evs.ok() || !rstart.ok() || !rev_src.ok() || !rev_w.ok() || !st.ok()) return NCT_ERR_HIP;
         // lambda / alpha / dWeight arrive as float in the reference signature (ColorTransfer.cpp:548-550)
         const float lambda_f = (float)prm.local_weight, alpha_f = (float)prm.wls_alpha, dWeight_f = (float)normFactor;
         hipLaunchKernelGGL(k_gradient_weights, dim3(nbl), dim3(256), 0, s, s_lab_level, h, w, (double)lambda_f, (double)alpha_f, (double*)gx, (double*)gy); LCHK();
@@ -357,7 +388,8 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         if (!tmp.ok()) return NCT_ERR_HIP;
         NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)ek, (unsigned*)eks, (const unsigned*)ev, (unsigned*)evs, m, 0, end_bit, s));
         hipLaunchKernelGGL(k_seg_starts, dim3(cdiv(n + 1, 256)), dim3(256), 0, s, (const unsigned*)eks, m, (int*)rstart, n); LCHK();
-        S1Sys S{n, h, w, daa, dab, dbb, gx, gy, knn_id, iw2, rstart, evs};
+        hipLaunchKernelGGL(k_rev_edges, dim3(cdiv(m, 256)), dim3(256), 0, s, (const unsigned*)evs, (const double*)iw2, m, (int*)rev_src, (double*)rev_w); LCHK();
+        S1Sys S{n, h, w, daa, dab, dbb, gx, gy, knn_id, iw2, rstart, rev_src, rev_w};
         const double tol2 = 1e-6 * 1e-6;
         const int maxit = layer == 4 ? 50 : 100;                       // ColorTransfer.cpp:916-921
         hipLaunchKernelGGL(k_pack6, dim3(cdiv(6 * n, 256)), dim3(256), 0, s, n, (const double*)x, (double*)p); LCHK();
