@@ -30,6 +30,10 @@ constexpr int NQ = 6;
 
 struct Lvl { int H, W, n; double *r, *wx, *wy, *diag, *dinv, *b, *x, *x2; };   // dinv = omega / diag (one division per pixel per solve)
 
+// PCG state of the 6 right-hand sides. nactive = number of systems still iterating: the host polls it only every few iterations, and
+// every kernel of an iteration enqueued past convergence returns at once when it is 0.
+struct PState { double rz[6], rr[6], bb[6], al[6], be[6]; int active[6]; int iters[6]; int nactive; };
+
 template <int NV>
 __device__ __forceinline__ void mg_block_reduce(double (&v)[NV], double* __restrict__ partial) {
     __shared__ double s_red[256 * NV];
@@ -154,7 +158,8 @@ __device__ __forceinline__ void lvl_op_rc(const Lvl& L, int r, int c, F&& val /*
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(r - 1, c, q); }
 }
 template <int TX, int TY>
-__global__ __launch_bounds__(256) void k_mg_down(Lvl F, const double* __restrict__ b, double* __restrict__ x, Lvl C, double* __restrict__ bc) {
+__global__ __launch_bounds__(256) void k_mg_down(const PState* __restrict__ st, Lvl F, const double* __restrict__ b, double* __restrict__ x, Lvl C, double* __restrict__ bc) {
+    if (st->nactive == 0) return;
     constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
     __shared__ double s_x[NQ * LN];
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
@@ -198,8 +203,9 @@ __global__ __launch_bounds__(256) void k_mg_down(Lvl F, const double* __restrict
 }
 // xo must not alias x (neighbouring tiles still read x for their halo)
 template <int TX, int TY>
-__global__ __launch_bounds__(256) void k_mg_up(Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc, const double* __restrict__ ec,
-                                               double* __restrict__ xo) {
+__global__ __launch_bounds__(256) void k_mg_up(const PState* __restrict__ st, Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc,
+                                               const double* __restrict__ ec, double* __restrict__ xo) {
+    if (st->nactive == 0) return;
     constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
     __shared__ double s_x[NQ * LN];
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
@@ -228,7 +234,8 @@ __global__ __launch_bounds__(256) void k_mg_up(Lvl L, const double* __restrict__
     }
 }
 // r.z partial sums in the canonical block order (256 consecutive pixels per block)
-__global__ __launch_bounds__(256) void k_pcg_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_pcg_dot(const PState* __restrict__ st, int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ partial) {
+    if (st->nactive == 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[NQ];
 #pragma unroll
@@ -240,7 +247,8 @@ __global__ __launch_bounds__(256) void k_pcg_dot(int n, const double* __restrict
 // per unknown, the iterate stays in a register and the four neighbours come through ds_bpermute — no LDS round trips, no
 // barriers (the six right-hand sides are independent). Same operation order as lvl_op: +x, -x, +y, -y.
 // (A 1024-thread LDS version of this took 82 us per cycle, 20 % of the whole V-cycle: profiles/r1f_e2e_kernels.md.)
-__global__ __launch_bounds__(64 * NQ) void k_mg_coarsest(Lvl L, int sweeps) {
+__global__ __launch_bounds__(64 * NQ) void k_mg_coarsest(const PState* __restrict__ st, Lvl L, int sweeps) {
+    if (st->nactive == 0) return;
     const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
     const int n = L.n, W = L.W, H = L.H;
     const bool live = i < n;
@@ -268,7 +276,6 @@ __global__ __launch_bounds__(64 * NQ) void k_mg_coarsest(Lvl L, int sweeps) {
 }
 
 // ---- PCG pieces at the fine level
-struct PState { double rz[6], rr[6], bb[6], al[6], be[6]; int active[6]; int iters[6]; };
 
 // x6 = interleave(X); r = rough*x0 - M x0 ; partial: rr, bb (12)
 __global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restrict__ X /*[2][n][3]*/, double* __restrict__ x6, double* __restrict__ r, double* __restrict__ partial) {
@@ -295,20 +302,24 @@ __global__ void k_pcg_start_fin(const double* __restrict__ partial, int nb, PSta
     double s[12]; mg_final_reduce<12>(partial, nb, s);
     if (threadIdx.x < 6) { const int q = threadIdx.x; st->rr[q] = s[q]; st->bb[q] = s[6 + q]; st->rz[q] = 0; st->al[q] = 0; st->be[q] = 0; st->iters[q] = 0;
                            st->active[q] = (s[q] > rtol2 * s[6 + q]) ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) { int na = 0; for (int q = 0; q < 6; ++q) na += st->active[q]; st->nactive = na; }
 }
 // after the V-cycle: rz = r.z ; first iteration: p = z, else be = rz/rz_old, p = z + be p
 __global__ void k_pcg_rz_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, int first) {
+    if (st->nactive == 0) return;
     double s[6]; mg_final_reduce<6>(partial, nb, s);
     if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) { st->be[q] = first ? 0.0 : s[q] / st->rz[q]; st->rz[q] = s[q]; } }
 }
 __global__ void k_pcg_dir(int n, const PState* __restrict__ st, const double* __restrict__ z, double* __restrict__ p, int first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * NQ) return;
+    if (i >= n * NQ || st->nactive == 0) return;
     const int q = i / n;                      // planar [6][n]
     if (!st->active[q]) return;
     p[i] = first ? z[i] : z[i] + st->be[q] * p[i];
 }
-__global__ __launch_bounds__(256) void k_pcg_apply(Lvl L, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_pcg_apply(const PState* __restrict__ st, Lvl L, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
+    if (st->nactive == 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[NQ];
 #pragma unroll
@@ -322,11 +333,13 @@ __global__ __launch_bounds__(256) void k_pcg_apply(Lvl L, const double* __restri
     mg_block_reduce<NQ>(acc, partial);
 }
 __global__ void k_pcg_alpha_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st) {
+    if (st->nactive == 0) return;
     double s[6]; mg_final_reduce<6>(partial, nb, s);
     if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) st->al[q] = st->rz[q] / s[q]; }
 }
 __global__ __launch_bounds__(256) void k_pcg_update(int n, const PState* __restrict__ st, const double* __restrict__ p, const double* __restrict__ Ap,
                                                     double* __restrict__ x, double* __restrict__ r, double* __restrict__ partial) {
+    if (st->nactive == 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[NQ];
 #pragma unroll
@@ -345,8 +358,11 @@ __global__ __launch_bounds__(256) void k_pcg_update(int n, const PState* __restr
     mg_block_reduce<NQ>(acc, partial);
 }
 __global__ void k_pcg_rr_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, double rtol2) {
+    if (st->nactive == 0) return;
     double s[6]; mg_final_reduce<6>(partial, nb, s);
     if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) { st->rr[q] = s[q]; st->iters[q]++; st->active[q] = (s[q] > rtol2 * st->bb[q]) ? 1 : 0; } }
+    __syncthreads();
+    if (threadIdx.x == 0) { int na = 0; for (int q = 0; q < 6; ++q) na += st->active[q]; st->nactive = na; }
 }
 __global__ void k_pcg_finish(int n, const double* __restrict__ x6, double* __restrict__ X) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,18 +419,18 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     // haloed footprint (18x10) fits one pass of the 256 threads keeps the dependent load chains short and spreads over more CUs.
     constexpr int TXB = NCT_MG_TXB, TYB = NCT_MG_TYB;
     auto down = [&](int l, const double* b) {
-        if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB>), dim3(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), dim3(256), 0, s, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b);
-        else                   hipLaunchKernelGGL((k_mg_down<16, 8>), dim3(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8)), dim3(256), 0, s, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b);
+        if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB>), dim3(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), dim3(256), 0, s, (const PState*)st, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b);
+        else                   hipLaunchKernelGGL((k_mg_down<16, 8>), dim3(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8)), dim3(256), 0, s, (const PState*)st, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b);
     };
     auto up = [&](int l, const double* b, const double* ec) {
-        if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB>), dim3(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2);
-        else                   hipLaunchKernelGGL((k_mg_up<16, 8>), dim3(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8)), dim3(256), 0, s, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2);
+        if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB>), dim3(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), dim3(256), 0, s, (const PState*)st, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2);
+        else                   hipLaunchKernelGGL((k_mg_up<16, 8>), dim3(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8)), dim3(256), 0, s, (const PState*)st, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2);
     };
     auto vcycle = [&]() -> int {
         for (int l = 0; l < tail0; ++l) { down(l, l == 0 ? (const double*)r : lv[l].b); LCHK(); }
-        hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(64 * NQ), 0, s, lv[nl - 1], 60); LCHK();
+        hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(64 * NQ), 0, s, (const PState*)st, lv[nl - 1], 60); LCHK();
         for (int l = tail0 - 1; l >= 0; --l) { up(l, l == 0 ? (const double*)r : lv[l].b, l + 1 == nl - 1 ? lv[l + 1].x : lv[l + 1].x2); LCHK(); }
-        hipLaunchKernelGGL(k_pcg_dot, dim3(nb), dim3(256), 0, s, N, (const double*)r, (const double*)lv[0].x2, (double*)partial); LCHK();
+        hipLaunchKernelGGL(k_pcg_dot, dim3(nb), dim3(256), 0, s, (const PState*)st, N, (const double*)r, (const double*)lv[0].x2, (double*)partial); LCHK();
         return 0;
     };
     const double* z = lv[0].x2;
@@ -430,7 +446,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             int rc = vcycle(); if (rc) return rc;
             hipLaunchKernelGGL(k_pcg_rz_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, it == 0 ? 1 : 0); LCHK();
             hipLaunchKernelGGL(k_pcg_dir, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const PState*)st, z, (double*)p, it == 0 ? 1 : 0); LCHK();
-            hipLaunchKernelGGL(k_pcg_apply, dim3(nb), dim3(256), 0, s, F, (const double*)p, (double*)Ap, (double*)partial); LCHK();
+            hipLaunchKernelGGL(k_pcg_apply, dim3(nb), dim3(256), 0, s, (const PState*)st, F, (const double*)p, (double*)Ap, (double*)partial); LCHK();
             hipLaunchKernelGGL(k_pcg_alpha_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st); LCHK();
             hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(256), 0, s, N, (const PState*)st, (const double*)p, (const double*)Ap, (double*)x6, (double*)r, (double*)partial); LCHK();
             hipLaunchKernelGGL(k_pcg_rr_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
