@@ -24,11 +24,17 @@ namespace {
 constexpr double OMEGA = 0.8;
 constexpr int NQ = 6;
 #ifndef NCT_MG_TXB
-#define NCT_MG_TXB 30
-#define NCT_MG_TYB 14
+#define NCT_MG_TXB 32
+#define NCT_MG_TYB 16
 #endif
 
-struct Lvl { int H, W, n; double *r, *wx, *wy, *diag, *dinv, *b, *x, *x2; };   // dinv = omega / diag (one division per pixel per solve)
+// The PCG itself (and the hierarchy construction) is fp64; the V-cycle — a fixed linear preconditioner, whose accuracy does not
+// limit the accuracy of the solution — runs in fp32 on rounded copies of the level operators: half the bytes on the two
+// bandwidth-bound levels, same iteration counts (scripts/mg_convergence_experiments.py).
+typedef float vf;
+struct Lvl { int H, W, n; double *r, *wx, *wy, *diag;      // fp64 operator: data term, edge weights, diagonal
+             vf *fdiag, *fdinv, *fwx, *fwy;                // fp32 copies; fdinv = (float)(omega / diag)
+             vf *b, *x, *x2; };                            // V-cycle vectors, planar [6][n]
 
 // PCG state of the 6 right-hand sides. nactive = number of systems still iterating: the host polls it only every few iterations, and
 // every kernel of an iteration enqueued past convergence returns at once when it is 0.
@@ -128,53 +134,56 @@ __global__ void k_mg_diag(Lvl L) {
     if (y + 1 < L.H) a00 += L.wy[i];
     if (y > 0) a00 += L.wy[i - L.W];
     L.diag[i] = a00;
-    L.dinv[i] = OMEGA / a00;
+    L.fdiag[i] = (vf)a00; L.fdinv[i] = (vf)(OMEGA / a00); L.fwx[i] = (vf)L.wx[i]; L.fwy[i] = (vf)L.wy[i];
 }
 
-// ---- V-cycle (vectors planar [6][n])
-// ---- tile-fused V-cycle legs: the intermediate iterate of a leg lives in LDS for a TX x TY fine tile plus a 1-pixel halo
-// (recomputed by the neighbouring tiles with the same expressions, hence bit-identical) instead of making a round trip through
-// global memory and a second launch:
+// ---- V-cycle (fp32, vectors planar [6][n])
+// tile-fused legs: the intermediate iterate of a leg lives in LDS for a TX x TY fine tile plus a 1-pixel halo (recomputed by
+// the neighbouring tiles with the same expressions, hence bit-identical) instead of making a round trip through global memory
+// and a second launch:
 //   down: x1 = b*dinv ; x = x1 + (b - M x1)*dinv (two damped-Jacobi sweeps from zero) ; coarse rhs = sum over the 2x2 aggregate
 //         of (b - M x), fine pixels in the order (0,0),(0,1),(1,0),(1,1)
 //   up:   xe = x + e_coarse(parent) ; x2 = xe + (b - M xe)*dinv ; xo = x2 + (b - M x2)*dinv
+// y = M v at pixel (r, c): diag*v - sum_w w*v_nbr, neighbour order +x, -x, +y, -y (as lvl_op)
 template <typename F>
-__device__ __forceinline__ void lvl_op_rc(const Lvl& L, int r, int c, F&& val /* val(r, c, q) */, double (&y)[NQ]) {
+__device__ __forceinline__ void lvl_opf(const Lvl& L, int r, int c, F&& val /* val(r, c, q) */, vf (&y)[NQ]) {
     const int W = L.W, H = L.H, i = r * W + c;
-    const double d = L.diag[i];
+    const vf d = L.fdiag[i];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) y[q] = d * val(r, c, q);
-    if (c + 1 < W) { const double w = L.wx[i];
+    if (c + 1 < W) { const vf w = L.fwx[i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(r, c + 1, q); }
-    if (c > 0) { const double w = L.wx[i - 1];
+    if (c > 0) { const vf w = L.fwx[i - 1];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(r, c - 1, q); }
-    if (r + 1 < H) { const double w = L.wy[i];
+    if (r + 1 < H) { const vf w = L.fwy[i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(r + 1, c, q); }
-    if (r > 0) { const double w = L.wy[i - W];
+    if (r > 0) { const vf w = L.fwy[i - W];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(r - 1, c, q); }
 }
-template <int TX, int TY>
-__global__ __launch_bounds__(256) void k_mg_down(const PState* __restrict__ st, Lvl F, const double* __restrict__ b, double* __restrict__ x, Lvl C, double* __restrict__ bc) {
+// TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below
+template <int TX, int TY, typename TB>
+__global__ __launch_bounds__(256) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc) {
     if (st->nactive == 0) return;
     constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
-    __shared__ double s_x[NQ * LN];
+    __shared__ vf s_x[NQ * LN];
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    auto bv = [&](int j, int q) { return (vf)b[(size_t)q * F.n + j]; };
     for (int p = threadIdx.x; p < LN; p += 256) {
         const int ly = p / LW, lx = p - ly * LW;
         const int gy = y0 + ly - 1, gx = x0 + lx - 1;
         if (gy < 0 || gy >= F.H || gx < 0 || gx >= F.W) continue;
         const int i = gy * F.W + gx;
-        auto x1 = [&](int j, int q) { return b[(size_t)q * F.n + j] * F.dinv[j]; };
-        double y[NQ]; lvl_op(F, i, x1, y);
-        const double d = F.dinv[i];
+        auto x1 = [&](int r, int c, int q) { const int j = r * F.W + c; return bv(j, q) * F.fdinv[j]; };
+        vf y[NQ]; lvl_opf(F, gy, gx, x1, y);
+        const vf d = F.fdinv[i];
         const bool interior = lx >= 1 && lx <= TX && ly >= 1 && ly <= TY;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const double v = x1(i, q) + (b[(size_t)q * F.n + i] - y[q]) * d;
+            const vf v = x1(gy, gx, q) + (bv(i, q) - y[q]) * d;
             s_x[q * LN + p] = v;
             if (interior) x[(size_t)q * F.n + i] = v;
         }
@@ -185,16 +194,16 @@ __global__ __launch_bounds__(256) void k_mg_down(const PState* __restrict__ st, 
         const int cy = p / (TX / 2), cx = p - cy * (TX / 2);
         const int Y = y0 / 2 + cy, X = x0 / 2 + cx;
         if (Y >= C.H || X >= C.W) continue;
-        double acc[NQ];
+        vf acc[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int yy = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
             if (yy < F.H && xx < F.W) {
-                double yv[NQ]; lvl_op_rc(F, yy, xx, xv, yv);
+                vf yv[NQ]; lvl_opf(F, yy, xx, xv, yv);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[q] += b[(size_t)q * F.n + yy * F.W + xx] - yv[q];
+                for (int q = 0; q < NQ; ++q) acc[q] += bv(yy * F.W + xx, q) - yv[q];
             }
         }
 #pragma unroll
@@ -202,23 +211,24 @@ __global__ __launch_bounds__(256) void k_mg_down(const PState* __restrict__ st, 
     }
 }
 // xo must not alias x (neighbouring tiles still read x for their halo)
-template <int TX, int TY>
-__global__ __launch_bounds__(256) void k_mg_up(const PState* __restrict__ st, Lvl L, const double* __restrict__ b, const double* __restrict__ x, int Wc, int nc,
-                                               const double* __restrict__ ec, double* __restrict__ xo) {
+template <int TX, int TY, typename TB>
+__global__ __launch_bounds__(256) void k_mg_up(const PState* __restrict__ st, Lvl L, const TB* __restrict__ b, const vf* __restrict__ x, int Wc, int nc,
+                                               const vf* __restrict__ ec, vf* __restrict__ xo) {
     if (st->nactive == 0) return;
     constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
-    __shared__ double s_x[NQ * LN];
+    __shared__ vf s_x[NQ * LN];
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    auto bv = [&](int j, int q) { return (vf)b[(size_t)q * L.n + j]; };
     for (int p = threadIdx.x; p < LN; p += 256) {
         const int ly = p / LW, lx = p - ly * LW;
         const int gy = y0 + ly - 1, gx = x0 + lx - 1;
         if (gy < 0 || gy >= L.H || gx < 0 || gx >= L.W) continue;
         auto xe = [&](int r, int c, int q) { return x[(size_t)q * L.n + r * L.W + c] + ec[(size_t)q * nc + ((r >> 1) * Wc + (c >> 1))]; };
-        double y[NQ]; lvl_op_rc(L, gy, gx, xe, y);
+        vf y[NQ]; lvl_opf(L, gy, gx, xe, y);
         const int i = gy * L.W + gx;
-        const double d = L.dinv[i];
+        const vf d = L.fdinv[i];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) s_x[q * LN + p] = xe(gy, gx, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
+        for (int q = 0; q < NQ; ++q) s_x[q * LN + p] = xe(gy, gx, q) + (bv(i, q) - y[q]) * d;
     }
     __syncthreads();
     auto xv = [&](int r, int c, int q) { return s_x[q * LN + (r - y0 + 1) * LW + (c - x0 + 1)]; };
@@ -226,26 +236,26 @@ __global__ __launch_bounds__(256) void k_mg_up(const PState* __restrict__ st, Lv
         const int ly = p / TX, lx = p - ly * TX;
         const int gy = y0 + ly, gx = x0 + lx;
         if (gy >= L.H || gx >= L.W) continue;
-        double y[NQ]; lvl_op_rc(L, gy, gx, xv, y);
+        vf y[NQ]; lvl_opf(L, gy, gx, xv, y);
         const int i = gy * L.W + gx;
-        const double d = L.dinv[i];
+        const vf d = L.fdinv[i];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xv(gy, gx, q) + (b[(size_t)q * L.n + i] - y[q]) * d;
+        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xv(gy, gx, q) + (bv(i, q) - y[q]) * d;
     }
 }
-// r.z partial sums in the canonical block order (256 consecutive pixels per block)
-__global__ __launch_bounds__(256) void k_pcg_dot(const PState* __restrict__ st, int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ partial) {
+// r.z partial sums in the canonical block order (256 consecutive pixels per block); z = fp32 V-cycle output, widened exactly
+__global__ __launch_bounds__(256) void k_pcg_dot(const PState* __restrict__ st, int n, const double* __restrict__ a, const vf* __restrict__ z, double* __restrict__ partial) {
     if (st->nactive == 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = i < n ? a[(size_t)q * n + i] * b[(size_t)q * n + i] : 0.0;
+    for (int q = 0; q < NQ; ++q) acc[q] = i < n ? a[(size_t)q * n + i] * (double)z[(size_t)q * n + i] : 0.0;
     mg_block_reduce<NQ>(acc, partial);
 }
 
 // Coarsest grid (n <= 64 unknowns): `sweeps` damped-Jacobi sweeps from a zero initial guess. One wave per right-hand side, one lane
 // per unknown, the iterate stays in a register and the four neighbours come through ds_bpermute — no LDS round trips, no
-// barriers (the six right-hand sides are independent). Same operation order as lvl_op: +x, -x, +y, -y.
+// barriers (the six right-hand sides are independent). Same operation order as lvl_opf: +x, -x, +y, -y.
 // (A 1024-thread LDS version of this took 82 us per cycle, 20 % of the whole V-cycle: profiles/r1f_e2e_kernels.md.)
 __global__ __launch_bounds__(64 * NQ) void k_mg_coarsest(const PState* __restrict__ st, Lvl L, int sweeps) {
     if (st->nactive == 0) return;
@@ -253,19 +263,19 @@ __global__ __launch_bounds__(64 * NQ) void k_mg_coarsest(const PState* __restric
     const int n = L.n, W = L.W, H = L.H;
     const bool live = i < n;
     const int r = live ? i / W : 0, c = live ? i - r * W : 0;
-    double bq = 0, d = 0, dv = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    vf bq = 0, d = 0, dv = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     const bool has_r = live && c + 1 < W, has_l = live && c > 0, has_d = live && r + 1 < H, has_u = live && r > 0;
     if (live) {
-        bq = L.b[(size_t)q * n + i]; d = L.diag[i]; dv = L.dinv[i];
-        if (has_r) w0 = L.wx[i];
-        if (has_l) w1 = L.wx[i - 1];
-        if (has_d) w2 = L.wy[i];
-        if (has_u) w3 = L.wy[i - W];
+        bq = L.b[(size_t)q * n + i]; d = L.fdiag[i]; dv = L.fdinv[i];
+        if (has_r) w0 = L.fwx[i];
+        if (has_l) w1 = L.fwx[i - 1];
+        if (has_d) w2 = L.fwy[i];
+        if (has_u) w3 = L.fwy[i - W];
     }
-    double x = 0.0;
+    vf x = 0.0f;
     for (int s = 0; s < sweeps; ++s) {
-        const double xr = __shfl(x, (i + 1) & 63), xl = __shfl(x, (i - 1) & 63), xd = __shfl(x, (i + W) & 63), xu = __shfl(x, (i - W) & 63);
-        double y = d * x;
+        const vf xr = __shfl(x, (i + 1) & 63), xl = __shfl(x, (i - 1) & 63), xd = __shfl(x, (i + W) & 63), xu = __shfl(x, (i - W) & 63);
+        vf y = d * x;
         if (has_r) y -= w0 * xr;
         if (has_l) y -= w1 * xl;
         if (has_d) y -= w2 * xd;
@@ -311,12 +321,13 @@ __global__ void k_pcg_rz_fin(const double* __restrict__ partial, int nb, PState*
     double s[6]; mg_final_reduce<6>(partial, nb, s);
     if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) { st->be[q] = first ? 0.0 : s[q] / st->rz[q]; st->rz[q] = s[q]; } }
 }
-__global__ void k_pcg_dir(int n, const PState* __restrict__ st, const double* __restrict__ z, double* __restrict__ p, int first) {
+__global__ void k_pcg_dir(int n, const PState* __restrict__ st, const vf* __restrict__ z, double* __restrict__ p, int first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * NQ || st->nactive == 0) return;
     const int q = i / n;                      // planar [6][n]
     if (!st->active[q]) return;
-    p[i] = first ? z[i] : z[i] + st->be[q] * p[i];
+    const double zv = (double)z[i];
+    p[i] = first ? zv : zv + st->be[q] * p[i];
 }
 __global__ __launch_bounds__(256) void k_pcg_apply(const PState* __restrict__ st, Lvl L, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
     if (st->nactive == 0) return;
@@ -379,17 +390,19 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
                       double rtol, int* iters_out /*host[6], nullable*/) {
     // ---- hierarchy
     std::vector<Lvl> lv;
-    std::vector<DevBuf<double>*> bufs;
-    struct Cleanup { std::vector<DevBuf<double>*>& b; ~Cleanup() { for (auto* p : b) delete p; } } cleanup{bufs};
-    auto newbuf = [&](size_t n) -> double* { auto* b = new DevBuf<double>(ctx, n); bufs.push_back(b); return b->ok() ? (double*)*b : nullptr; };
+    std::vector<void*> owned;
+    struct Cleanup { nct_ctx* c; std::vector<void*>& v; ~Cleanup() { for (void* q : v) c->release(q); } } cleanup{ctx, owned};
+    auto newd = [&](size_t n) -> double* { void* q = ctx->alloc(n * sizeof(double)); if (q) owned.push_back(q); return (double*)q; };
+    auto newf = [&](size_t n) -> vf* { void* q = ctx->alloc(n * sizeof(vf)); if (q) owned.push_back(q); return (vf*)q; };
     {
         int h = H, w = W;
         for (int l = 0;; ++l) {
-            Lvl L{h, w, h * w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            Lvl L; memset(&L, 0, sizeof L); L.H = h; L.W = w; L.n = h * w;
             if (l == 0) { L.r = (double*)rough; L.wx = (double*)wx; L.wy = (double*)wy; }
-            else { L.r = newbuf(L.n); L.wx = newbuf(L.n); L.wy = newbuf(L.n); }
-            L.diag = newbuf(L.n); L.dinv = newbuf(L.n); L.b = newbuf((size_t)L.n * NQ); L.x = newbuf((size_t)L.n * NQ); L.x2 = newbuf((size_t)L.n * NQ);
-            if (!L.r || !L.wx || !L.wy || !L.diag || !L.dinv || !L.b || !L.x || !L.x2) return NCT_ERR_HIP;
+            else { L.r = newd(L.n); L.wx = newd(L.n); L.wy = newd(L.n); }
+            L.diag = newd(L.n); L.fdiag = newf(L.n); L.fdinv = newf(L.n); L.fwx = newf(L.n); L.fwy = newf(L.n);
+            L.b = l == 0 ? nullptr : newf((size_t)L.n * NQ); L.x = newf((size_t)L.n * NQ); L.x2 = newf((size_t)L.n * NQ);
+            if (!L.r || !L.wx || !L.wy || !L.diag || !L.fdiag || !L.fdinv || !L.fwx || !L.fwy || (l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
             lv.push_back(L);
             if (L.n <= 64 || (h <= 8 && w <= 8) || lv.size() >= 16) break;
             h = (h + 1) / 2; w = (w + 1) / 2;
@@ -418,22 +431,35 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     // Tile shapes: bandwidth-bound levels use TXB x TYB tiles; below 100k pixels the legs are latency bound, so a 16x8 tile whose
     // haloed footprint (18x10) fits one pass of the 256 threads keeps the dependent load chains short and spreads over more CUs.
     constexpr int TXB = NCT_MG_TXB, TYB = NCT_MG_TYB;
-    auto down = [&](int l, const double* b) {
-        if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB>), dim3(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), dim3(256), 0, s, (const PState*)st, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b);
-        else                   hipLaunchKernelGGL((k_mg_down<16, 8>), dim3(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8)), dim3(256), 0, s, (const PState*)st, lv[l], b, lv[l].x, lv[l + 1], lv[l + 1].b);
+    auto down = [&](int l) {
+        const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
+        if (l == 0) {
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, double>), gb, dim3(256), 0, s, (const PState*)st, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<16, 8, double>), gs, dim3(256), 0, s, (const PState*)st, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+        } else {
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, vf>), gb, dim3(256), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<16, 8, vf>), gs, dim3(256), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+        }
     };
-    auto up = [&](int l, const double* b, const double* ec) {
-        if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB>), dim3(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), dim3(256), 0, s, (const PState*)st, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2);
-        else                   hipLaunchKernelGGL((k_mg_up<16, 8>), dim3(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8)), dim3(256), 0, s, (const PState*)st, lv[l], b, (const double*)lv[l].x, lv[l + 1].W, lv[l + 1].n, ec, lv[l].x2);
+    auto up = [&](int l, const vf* ec) {
+        const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
+        const int Wc = lv[l + 1].W, nc = lv[l + 1].n;
+        if (l == 0) {
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, double>), gb, dim3(256), 0, s, (const PState*)st, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<16, 8, double>), gs, dim3(256), 0, s, (const PState*)st, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+        } else {
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, vf>), gb, dim3(256), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<16, 8, vf>), gs, dim3(256), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+        }
     };
     auto vcycle = [&]() -> int {
-        for (int l = 0; l < tail0; ++l) { down(l, l == 0 ? (const double*)r : lv[l].b); LCHK(); }
+        for (int l = 0; l < tail0; ++l) { down(l); LCHK(); }
         hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(64 * NQ), 0, s, (const PState*)st, lv[nl - 1], 60); LCHK();
-        for (int l = tail0 - 1; l >= 0; --l) { up(l, l == 0 ? (const double*)r : lv[l].b, l + 1 == nl - 1 ? lv[l + 1].x : lv[l + 1].x2); LCHK(); }
-        hipLaunchKernelGGL(k_pcg_dot, dim3(nb), dim3(256), 0, s, (const PState*)st, N, (const double*)r, (const double*)lv[0].x2, (double*)partial); LCHK();
+        for (int l = tail0 - 1; l >= 0; --l) { up(l, l + 1 == nl - 1 ? lv[l + 1].x : lv[l + 1].x2); LCHK(); }
+        hipLaunchKernelGGL(k_pcg_dot, dim3(nb), dim3(256), 0, s, (const PState*)st, N, (const double*)r, (const vf*)lv[0].x2, (double*)partial); LCHK();
         return 0;
     };
-    const double* z = lv[0].x2;
+    const vf* z = lv[0].x2;
     const int maxit = 5000, check_every = 8;
     PState hst; memset(&hst, 0, sizeof hst);
     int it = 0; bool done = false;

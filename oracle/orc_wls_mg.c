@@ -5,8 +5,10 @@
  * this solver converges to 1e-8 relative residual and is cross-checked against the exact solve (banded Cholesky / PARDISO
  * fixture) in tests/test_oracle_color.py. It exists in this exact arithmetic order so that the 8-bit result of the GPU
  * path can be compared bit-for-bit (see orc_color_canon.c for why that matters: S1 downstream is chaotic).
- * Hierarchy: 2x2 aggregation (coarse data term = sum of the 4 fine ones, coarse edge = sum of the crossing fine edges);
- * V(2,2) cycle, damped Jacobi (omega 0.8), 60 Jacobi sweeps on the coarsest grid; two-stage 256-wide tree reductions. */
+ * Hierarchy: 2x2 aggregation (coarse data term = sum of the 4 fine ones, coarse edge = sum of the crossing fine edges), built in
+ * fp64; V(2,2) cycle, damped Jacobi (omega 0.8), 60 Jacobi sweeps on the coarsest grid — the cycle runs in fp32 on rounded copies
+ * of the level operators (it is only the preconditioner; the CG recurrences, the operator and every dot product stay fp64);
+ * two-stage 256-wide tree reductions. */
 #include "orc_common.h"
 #include <stdio.h>
 
@@ -14,7 +16,7 @@ void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha,
 
 #define NQ 6
 static const double OMEGA = 0.8;
-typedef struct { int H, W, n; double *r, *wx, *wy, *diag, *dinv, *b, *x, *x2; } lvl_t;   /* dinv = omega / diag */
+typedef struct { int H, W, n; double *r, *wx, *wy, *diag; float *fdiag, *fdinv, *fwx, *fwy, *b, *x, *x2; } lvl_t;   /* fdinv = (float)(omega / diag) */
 
 static void tree256(double* s) { for (int off = 128; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) s[t] += s[t + off]; }
 static void canon_sum(const double* v, int n, int nq, double* out) {
@@ -44,70 +46,83 @@ static void canon_sum(const double* v, int n, int nq, double* out) {
     if (r_ + 1 < H_) { const double w_ = (L)->wy[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + W_, q); } \
     if (r_ > 0) { const double w_ = (L)->wy[(i) - W_]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - W_, q); } } while (0)
 
+/* fp32 stencil of a level; VAL(j,q) is a float expression giving v_j[q]; every operation is a float operation */
+#define LVL_OPF(L, i, VAL, y) do { \
+    const int W_ = (L)->W, H_ = (L)->H; const int r_ = (i) / W_, c_ = (i) - r_ * W_; const float d_ = (L)->fdiag[i]; \
+    for (int q = 0; q < NQ; ++q) (y)[q] = d_ * VAL((i), q); \
+    if (c_ + 1 < W_) { const float w_ = (L)->fwx[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + 1, q); } \
+    if (c_ > 0) { const float w_ = (L)->fwx[(i) - 1]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - 1, q); } \
+    if (r_ + 1 < H_) { const float w_ = (L)->fwy[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + W_, q); } \
+    if (r_ > 0) { const float w_ = (L)->fwy[(i) - W_]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - W_, q); } } while (0)
+
+/* z = lv[0].x (fp32) for the fp64 residual r0 (rounded to fp32 on load) */
 static void vcycle(lvl_t* lv, int nl, const double* r0) {
     for (int l = 0; l < nl - 1; ++l) {
         lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
-        const double* b = l == 0 ? r0 : L->b;
-#define X1(j, q) (b[(size_t)(j) * NQ + (q)] * L->dinv[j])
+#define BV(j, q) (l == 0 ? (float)r0[(size_t)(j) * NQ + (q)] : L->b[(size_t)(j) * NQ + (q)])
+#define X1(j, q) (BV(j, q) * L->fdinv[j])
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < L->n; ++i) {
-            double y[NQ]; LVL_OP(L, i, X1, y);
-            const double d = L->dinv[i];
-            for (int q = 0; q < NQ; ++q) L->x[(size_t)i * NQ + q] = X1(i, q) + (b[(size_t)i * NQ + q] - y[q]) * d;
+            float y[NQ]; LVL_OPF(L, i, X1, y);
+            const float d = L->fdinv[i];
+            for (int q = 0; q < NQ; ++q) { const float x1 = X1(i, q); const float t = BV(i, q) - y[q]; const float u = t * d; L->x[(size_t)i * NQ + q] = x1 + u; }
         }
 #undef X1
 #define XV(j, q) (L->x[(size_t)(j) * NQ + (q)])
 #pragma omp parallel for schedule(static)
         for (int I = 0; I < C->n; ++I) {
             const int Y = I / C->W, X = I - Y * C->W;
-            double acc[NQ] = {0, 0, 0, 0, 0, 0};
+            float acc[NQ] = {0, 0, 0, 0, 0, 0};
             for (int t = 0; t < 4; ++t) {
                 const int y = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
                 if (y < L->H && xx < L->W) {
                     const int i = y * L->W + xx;
-                    double yv[NQ]; LVL_OP(L, i, XV, yv);
-                    for (int q = 0; q < NQ; ++q) acc[q] += b[(size_t)i * NQ + q] - yv[q];
+                    float yv[NQ]; LVL_OPF(L, i, XV, yv);
+                    for (int q = 0; q < NQ; ++q) { const float t2 = BV(i, q) - yv[q]; acc[q] += t2; }
                 }
             }
             for (int q = 0; q < NQ; ++q) C->b[(size_t)I * NQ + q] = acc[q];
         }
 #undef XV
+#undef BV
     }
     {   /* coarsest: 60 Jacobi sweeps from zero */
         lvl_t* L = &lv[nl - 1];
-        double* cur = L->x; double* nxt = L->x2;
-        memset(cur, 0, sizeof(double) * (size_t)L->n * NQ);
+        float* cur = L->x; float* nxt = L->x2;
+        memset(cur, 0, sizeof(float) * (size_t)L->n * NQ);
         for (int s = 0; s < 60; ++s) {
 #define CV(j, q) (cur[(size_t)(j) * NQ + (q)])
             for (int i = 0; i < L->n; ++i) {
-                double y[NQ]; LVL_OP(L, i, CV, y);
-                const double d = L->dinv[i];
-                for (int q = 0; q < NQ; ++q) nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + (L->b[(size_t)i * NQ + q] - y[q]) * d;
+                float y[NQ]; LVL_OPF(L, i, CV, y);
+                const float d = L->fdinv[i];
+                for (int q = 0; q < NQ; ++q) { const float t = L->b[(size_t)i * NQ + q] - y[q]; const float u = t * d; nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + u; }
             }
 #undef CV
-            double* t = cur; cur = nxt; nxt = t;
+            float* t = cur; cur = nxt; nxt = t;
         }
+        /* 60 is even: the result is back in L->x */
     }
     for (int l = nl - 2; l >= 0; --l) {
         lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
-        const double* b = l == 0 ? r0 : L->b;
         const int Wc = C->W;
+#define BV(j, q) (l == 0 ? (float)r0[(size_t)(j) * NQ + (q)] : L->b[(size_t)(j) * NQ + (q)])
 #define XE(j, q) (L->x[(size_t)(j) * NQ + (q)] + C->x[(size_t)((((j) / L->W) >> 1) * Wc + ((((j) % L->W)) >> 1)) * NQ + (q)])
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < L->n; ++i) {
-            double y[NQ]; LVL_OP(L, i, XE, y);
-            const double d = L->dinv[i];
-            for (int q = 0; q < NQ; ++q) L->x2[(size_t)i * NQ + q] = XE(i, q) + (b[(size_t)i * NQ + q] - y[q]) * d;
+            float y[NQ]; LVL_OPF(L, i, XE, y);
+            const float d = L->fdinv[i];
+            for (int q = 0; q < NQ; ++q) { const float xe = XE(i, q); const float t = BV(i, q) - y[q]; const float u = t * d; L->x2[(size_t)i * NQ + q] = xe + u; }
         }
 #undef XE
 #define X2(j, q) (L->x2[(size_t)(j) * NQ + (q)])
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < L->n; ++i) {
-            double y[NQ]; LVL_OP(L, i, X2, y);
-            const double d = L->dinv[i];
-            for (int q = 0; q < NQ; ++q) L->x[(size_t)i * NQ + q] = L->x2[(size_t)i * NQ + q] + (b[(size_t)i * NQ + q] - y[q]) * d;
+            float y[NQ]; LVL_OPF(L, i, X2, y);
+            const float d = L->fdinv[i];
+            for (int q = 0; q < NQ; ++q) { const float t = BV(i, q) - y[q]; const float u = t * d; L->x[(size_t)i * NQ + q] = L->x2[(size_t)i * NQ + q] + u; }
         }
 #undef X2
+#undef BV
     }
 }
 
@@ -118,8 +133,9 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
       for (;;) {
           lvl_t* L = &lv[nl]; L->H = h; L->W = w; L->n = h * w;
           L->r = (double*)malloc(sizeof(double) * L->n); L->wx = (double*)malloc(sizeof(double) * L->n); L->wy = (double*)malloc(sizeof(double) * L->n);
-          L->diag = (double*)malloc(sizeof(double) * L->n); L->dinv = (double*)malloc(sizeof(double) * L->n);
-          L->b = (double*)malloc(sizeof(double) * (size_t)L->n * NQ); L->x = (double*)malloc(sizeof(double) * (size_t)L->n * NQ); L->x2 = (double*)malloc(sizeof(double) * (size_t)L->n * NQ);
+          L->diag = (double*)malloc(sizeof(double) * L->n);
+          L->fdiag = (float*)malloc(sizeof(float) * L->n); L->fdinv = (float*)malloc(sizeof(float) * L->n); L->fwx = (float*)malloc(sizeof(float) * L->n); L->fwy = (float*)malloc(sizeof(float) * L->n);
+          L->b = (float*)malloc(sizeof(float) * (size_t)L->n * NQ); L->x = (float*)malloc(sizeof(float) * (size_t)L->n * NQ); L->x2 = (float*)malloc(sizeof(float) * (size_t)L->n * NQ);
           ++nl;
           if (L->n <= 64 || (h <= 8 && w <= 8) || nl >= 16) break;
           h = (h + 1) / 2; w = (w + 1) / 2;
@@ -152,7 +168,8 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
             if (x > 0) a00 += L->wx[i - 1];
             if (y + 1 < L->H) a00 += L->wy[i];
             if (y > 0) a00 += L->wy[i - L->W];
-            L->diag[i] = a00; L->dinv[i] = OMEGA / a00;
+            L->diag[i] = a00;
+            L->fdiag[i] = (float)a00; L->fdinv[i] = (float)(OMEGA / a00); L->fwx[i] = (float)L->wx[i]; L->fwy[i] = (float)L->wy[i];
         }
     }
     lvl_t* F = &lv[0];
@@ -181,10 +198,10 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     const int maxit = 5000;
     while (any && it < maxit) {
         vcycle(lv, nl, r);                                             /* z = F->x */
-        for (int i = 0; i < n; ++i) for (int q = 0; q < NQ; ++q) acc[(size_t)i * NQ + q] = r[(size_t)i * NQ + q] * F->x[(size_t)i * NQ + q];
+        for (int i = 0; i < n; ++i) for (int q = 0; q < NQ; ++q) acc[(size_t)i * NQ + q] = r[(size_t)i * NQ + q] * (double)F->x[(size_t)i * NQ + q];
         canon_sum(acc, n, NQ, s);
         for (int q = 0; q < 6; ++q) if (active[q]) { be[q] = it == 0 ? 0.0 : s[q] / rz[q]; rz[q] = s[q]; }
-        for (size_t j = 0; j < (size_t)n * NQ; ++j) { const int q = (int)(j % NQ); if (active[q]) p[j] = it == 0 ? F->x[j] : F->x[j] + be[q] * p[j]; }
+        for (size_t j = 0; j < (size_t)n * NQ; ++j) { const int q = (int)(j % NQ); const double zv = (double)F->x[j]; if (active[q]) p[j] = it == 0 ? zv : zv + be[q] * p[j]; }
 #define PV(j, q) (p[(size_t)(j) * NQ + (q)])
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < n; ++i) {
@@ -212,7 +229,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     for (int i = 0; i < n; ++i) for (int q = 0; q < NQ; ++q) { if (q < 3) a[(size_t)i * 3 + q] = x6[(size_t)i * NQ + q]; else b[(size_t)i * 3 + q - 3] = x6[(size_t)i * NQ + q]; }
     if (iters_out) memcpy(iters_out, iters, sizeof iters);
     int mx = 0; for (int q = 0; q < 6; ++q) if (iters[q] > mx) mx = iters[q];
-    for (int l = 0; l < nl; ++l) { free(lv[l].r); free(lv[l].wx); free(lv[l].wy); free(lv[l].diag); free(lv[l].dinv); free(lv[l].b); free(lv[l].x); free(lv[l].x2); }
+    for (int l = 0; l < nl; ++l) { free(lv[l].r); free(lv[l].wx); free(lv[l].wy); free(lv[l].diag); free(lv[l].fdiag); free(lv[l].fdinv); free(lv[l].fwx); free(lv[l].fwy); free(lv[l].b); free(lv[l].x); free(lv[l].x2); }
     free(x6); free(r); free(p); free(Ap); free(acc);
     return any ? -1 : mx;
 }
