@@ -164,83 +164,93 @@ __device__ __forceinline__ void lvl_opf(const Lvl& L, int r, int c, F&& val /* v
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(r - 1, c, q); }
 }
-// TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below
+// TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below.
+// One thread per pixel of the haloed tile (mg_threads = (TX+2)(TY+2) rounded up to whole waves): every thread issues all of its
+// loads at once, so a leg costs one round of memory latency per phase instead of one per 256-pixel pass.
+constexpr int mg_threads(int TX, int TY) { return ((TX + 2) * (TY + 2) + 63) / 64 * 64; }
 template <int TX, int TY, typename TB>
-__global__ __launch_bounds__(256) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc) {
+__global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc) {
     if (st->nactive == 0) return;
     constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
-    __shared__ vf s_x[NQ * LN];
+    __shared__ vf s_x[2 * NQ * LN];                      // [0, NQ*LN): iterate x ; [NQ*LN, 2*NQ*LN): residual b - M x
+    vf* s_r = s_x + NQ * LN;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int p = threadIdx.x;
+    const int ly = p / LW, lx = p - ly * LW;
+    const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+    const bool valid = p < LN && gy >= 0 && gy < F.H && gx >= 0 && gx < F.W;
+    const bool interior = valid && lx >= 1 && lx <= TX && ly >= 1 && ly <= TY;
+    const int i = gy * F.W + gx;
     auto bv = [&](int j, int q) { return (vf)b[(size_t)q * F.n + j]; };
-    for (int p = threadIdx.x; p < LN; p += 256) {
-        const int ly = p / LW, lx = p - ly * LW;
-        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-        if (gy < 0 || gy >= F.H || gx < 0 || gx >= F.W) continue;
-        const int i = gy * F.W + gx;
+    vf bq[NQ];
+    if (valid) {
         auto x1 = [&](int r, int c, int q) { const int j = r * F.W + c; return bv(j, q) * F.fdinv[j]; };
         vf y[NQ]; lvl_opf(F, gy, gx, x1, y);
         const vf d = F.fdinv[i];
-        const bool interior = lx >= 1 && lx <= TX && ly >= 1 && ly <= TY;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const vf v = x1(gy, gx, q) + (bv(i, q) - y[q]) * d;
+            bq[q] = bv(i, q);
+            const vf v = x1(gy, gx, q) + (bq[q] - y[q]) * d;
             s_x[q * LN + p] = v;
             if (interior) x[(size_t)q * F.n + i] = v;
         }
     }
     __syncthreads();
-    auto xv = [&](int r, int c, int q) { return s_x[q * LN + (r - y0 + 1) * LW + (c - x0 + 1)]; };
-    for (int p = threadIdx.x; p < (TX / 2) * (TY / 2); p += 256) {
+    if (interior) {
+        auto xv = [&](int r, int c, int q) { return s_x[q * LN + (r - y0 + 1) * LW + (c - x0 + 1)]; };
+        vf yv[NQ]; lvl_opf(F, gy, gx, xv, yv);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s_r[q * LN + p] = bq[q] - yv[q];
+    }
+    __syncthreads();
+    if (p < (TX / 2) * (TY / 2)) {
         const int cy = p / (TX / 2), cx = p - cy * (TX / 2);
         const int Y = y0 / 2 + cy, X = x0 / 2 + cx;
-        if (Y >= C.H || X >= C.W) continue;
-        vf acc[NQ];
+        if (Y < C.H && X < C.W) {
+            vf acc[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
+            for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int yy = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
-            if (yy < F.H && xx < F.W) {
-                vf yv[NQ]; lvl_opf(F, yy, xx, xv, yv);
+            for (int t = 0; t < 4; ++t) {
+                const int yy = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
+                if (yy < F.H && xx < F.W) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[q] += bv(yy * F.W + xx, q) - yv[q];
+                    for (int q = 0; q < NQ; ++q) acc[q] += s_r[q * LN + (yy - y0 + 1) * LW + (xx - x0 + 1)];
+                }
             }
-        }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) bc[(size_t)q * C.n + Y * C.W + X] = acc[q];
+            for (int q = 0; q < NQ; ++q) bc[(size_t)q * C.n + Y * C.W + X] = acc[q];
+        }
     }
 }
 // xo must not alias x (neighbouring tiles still read x for their halo)
 template <int TX, int TY, typename TB>
-__global__ __launch_bounds__(256) void k_mg_up(const PState* __restrict__ st, Lvl L, const TB* __restrict__ b, const vf* __restrict__ x, int Wc, int nc,
-                                               const vf* __restrict__ ec, vf* __restrict__ xo) {
+__global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __restrict__ st, Lvl L, const TB* __restrict__ b, const vf* __restrict__ x, int Wc, int nc,
+                                                              const vf* __restrict__ ec, vf* __restrict__ xo) {
     if (st->nactive == 0) return;
     constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
     __shared__ vf s_x[NQ * LN];
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    auto bv = [&](int j, int q) { return (vf)b[(size_t)q * L.n + j]; };
-    for (int p = threadIdx.x; p < LN; p += 256) {
-        const int ly = p / LW, lx = p - ly * LW;
-        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-        if (gy < 0 || gy >= L.H || gx < 0 || gx >= L.W) continue;
+    const int p = threadIdx.x;
+    const int ly = p / LW, lx = p - ly * LW;
+    const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+    const bool valid = p < LN && gy >= 0 && gy < L.H && gx >= 0 && gx < L.W;
+    const bool interior = valid && lx >= 1 && lx <= TX && ly >= 1 && ly <= TY;
+    const int i = gy * L.W + gx;
+    vf bq[NQ], d = 0;
+    if (valid) {
         auto xe = [&](int r, int c, int q) { return x[(size_t)q * L.n + r * L.W + c] + ec[(size_t)q * nc + ((r >> 1) * Wc + (c >> 1))]; };
         vf y[NQ]; lvl_opf(L, gy, gx, xe, y);
-        const int i = gy * L.W + gx;
-        const vf d = L.fdinv[i];
+        d = L.fdinv[i];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) s_x[q * LN + p] = xe(gy, gx, q) + (bv(i, q) - y[q]) * d;
+        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * L.n + i]; s_x[q * LN + p] = xe(gy, gx, q) + (bq[q] - y[q]) * d; }
     }
     __syncthreads();
-    auto xv = [&](int r, int c, int q) { return s_x[q * LN + (r - y0 + 1) * LW + (c - x0 + 1)]; };
-    for (int p = threadIdx.x; p < TX * TY; p += 256) {
-        const int ly = p / TX, lx = p - ly * TX;
-        const int gy = y0 + ly, gx = x0 + lx;
-        if (gy >= L.H || gx >= L.W) continue;
+    if (interior) {
+        auto xv = [&](int r, int c, int q) { return s_x[q * LN + (r - y0 + 1) * LW + (c - x0 + 1)]; };
         vf y[NQ]; lvl_opf(L, gy, gx, xv, y);
-        const int i = gy * L.W + gx;
-        const vf d = L.fdinv[i];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xv(gy, gx, q) + (bv(i, q) - y[q]) * d;
+        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xv(gy, gx, q) + (bq[q] - y[q]) * d;
     }
 }
 // r.z partial sums in the canonical block order (256 consecutive pixels per block); z = fp32 V-cycle output, widened exactly
@@ -434,22 +444,22 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     auto down = [&](int l) {
         const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
         if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, double>), gb, dim3(256), 0, s, (const PState*)st, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
-            else                   hipLaunchKernelGGL((k_mg_down<16, 8, double>), gs, dim3(256), 0, s, (const PState*)st, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, (const PState*)st, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, (const PState*)st, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
         } else {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, vf>), gb, dim3(256), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
-            else                   hipLaunchKernelGGL((k_mg_down<16, 8, vf>), gs, dim3(256), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
         }
     };
     auto up = [&](int l, const vf* ec) {
         const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
         const int Wc = lv[l + 1].W, nc = lv[l + 1].n;
         if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, double>), gb, dim3(256), 0, s, (const PState*)st, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            else                   hipLaunchKernelGGL((k_mg_up<16, 8, double>), gs, dim3(256), 0, s, (const PState*)st, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, (const PState*)st, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, (const PState*)st, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
         } else {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, vf>), gb, dim3(256), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            else                   hipLaunchKernelGGL((k_mg_up<16, 8, vf>), gs, dim3(256), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
         }
     };
     auto vcycle = [&]() -> int {
