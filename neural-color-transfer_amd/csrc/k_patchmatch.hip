@@ -9,7 +9,7 @@
 //    tile so that neighbouring queries — whose candidate tiles overlap when the NNF is coherent — share L1/L2);
 //    lane v owns float4 channel chunks v, v+16, …; the 9*C-term dot product is one fmaf chain per lane followed
 //    by a 4-step DPP rotate-add (no LDS traffic, no bpermute);
-//  * for C <= 128 the query's own 3x3xC tile lives in registers for the whole step;
+//  * the 6x6xC region of A shared by the 16 queries of a workgroup is staged once per launch in LDS;
 //  * the racy single launch of the reference becomes 1 + iters*4 Jacobi steps on a double-buffered NNF
 //    (one launch per (iteration, jump)); random search is fused into the jump==1 step; RNG is counter based.
 //    => results are deterministic and bit-identical to oracle/orc_nnf.c.
@@ -19,6 +19,9 @@
 #include <cfloat>
 #include <climits>
 
+#ifndef NCT_PM_FAST_MAX
+#define NCT_PM_FAST_MAX 1
+#endif
 struct PMGeom { int C, ah, aw, bh, bw, tiles_x, tiles_y; };
 
 // ---- distance of query (ax,ay) to candidate (bx,by): -(sum over valid taps of <a,b>) / n_valid
@@ -26,6 +29,30 @@ template <int NCH, bool AREG>
 __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const PMGeom& g,
                                          const float4 (&areg)[9][NCH > 0 ? NCH : 1], int ax, int ay, unsigned amask,
                                          int bx, int by, int v, const float4* __restrict__ a_lds = nullptr, int lx = 0, int ly = 0) {
+    // Fast path: when every tap of the query AND of the candidate lies inside its image — for every query of the wave, so the
+    // branch is uniform — the nine B rows are the centre pointer plus wave-uniform offsets, the nine LDS rows are immediates,
+    // nothing is masked and n = 9: ~70 VALU instructions per evaluation instead of ~270 (clamps, validity tests, selects and 64-bit
+    // address arithmetic per tap). Same fmaf chain, same result. It buys only 6.5 % at C = 64 (profiles/r1l): the kernel is bound by
+    // the L2-miss traffic (5.3 TB/s on the fabric side, PMC FETCH_SIZE), not by issue slots; for C >= 128 the 18+ loads in flight
+    // cost more occupancy than the shorter instruction stream returns, so those instantiations keep the general loop.
+    if constexpr (NCH >= 1 && NCH <= NCT_PM_FAST_MAX && !AREG) {
+        const bool inside = amask == 0x1FFu && bx >= 1 && bx < g.bw - 1 && by >= 1 && by < g.bh - 1;
+        if (__builtin_amdgcn_ballot_w64(inside) == __builtin_amdgcn_ballot_w64(true)) {
+            constexpr int C4 = 16 * NCH;
+            const float4* pbc = reinterpret_cast<const float4*>(B) + (size_t)(unsigned)(by * g.bw + bx) * C4 + v;
+            const float4* pac = a_lds + ((ly + 1) * 6 + (lx + 1)) * C4 + v;
+            float facc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const float4* pb = pbc + (dy * g.bw + dx) * C4;
+                const float4* pa = pac + (dy * 6 + dx) * C4;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) facc = dot4_acc(pa[16 * k], pb[16 * k], facc);
+            }
+            return (-row16_sum(facc)) / 9.0f;
+        }
+    }
     float acc = 0.f;
     int n = 0;
     const int nchunk = g.C >> 2;
