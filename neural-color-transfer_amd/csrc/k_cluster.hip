@@ -169,7 +169,7 @@ constexpr unsigned KEY_SENTINEL = 1u << 19;   // sorts after every real key (16 
 __device__ __forceinline__ unsigned cell_key(int l, unsigned col) {
     return ((unsigned)l << 15) | (((col >> 16) & 255u) >> CELL_SHIFT) << 10 | (((col >> 8) & 255u) >> CELL_SHIFT) << 5 | ((col & 255u) >> CELL_SHIFT);
 }
-__global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* __restrict__ lab, int lw, int lh, int h, int w, int samples, int nlabels,
+__global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* __restrict__ lab, int lw, int lh, int h, int w, int samples, int nlabels_host, const int* __restrict__ nlabels_dev,
                               int* __restrict__ count, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= h * w) return;
@@ -177,6 +177,7 @@ __global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* 
     const int cx = min(x / samples, lw - 1), cy = min(y / samples, lh - 1);
     const unsigned m = mask[cy * lw + cx];
     const unsigned col = (unsigned)lab[(size_t)i * 3] | ((unsigned)lab[(size_t)i * 3 + 1] << 8) | ((unsigned)lab[(size_t)i * 3 + 2] << 16);
+    const int nlabels = nlabels_dev ? *nlabels_dev : nlabels_host;   // the pipeline passes the k-means result without a host round trip
     for (int l = 0; l < nlabels; ++l)
         if ((m >> l) & 1u) { const int pos = atomicAdd(count, 1); keys[pos] = cell_key(l, col); vals[pos] = (unsigned)i; }
 }
@@ -290,9 +291,9 @@ __global__ void k_knn_merge(int npix, const int* __restrict__ nslot, const doubl
     for (; lp < KNN_K; ++lp) { knn_id[(size_t)i * KNN_K + lp] = i; knn_w[(size_t)i * KNN_K + lp] = 0.0; }
 }
 
-int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, int w, const int* labels, int lh, int lw, int nlabels, int samples,
+int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, int w, const int* labels, int lh, int lw, int nlabels, const int* nlabels_dev, int samples,
                    int* knn_id, double* knn_w) {
-    NCT_REQUIRE(nlabels >= 1 && nlabels <= 16, "knn_graph: nlabels=%d out of range", nlabels);
+    NCT_REQUIRE(nlabels_dev || (nlabels >= 1 && nlabels <= 16), "knn_graph: nlabels=%d out of range", nlabels);
     const int n = h * w;
     const int cap = n * KNN_SLOTS, nkeys = 16 << 15;
     DevBuf<unsigned> mask(ctx, (size_t)lh * lw), keys(ctx, cap), vals(ctx, cap), keys_s(ctx, cap), vals_s(ctx, cap);
@@ -304,7 +305,7 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)(unsigned*)keys, (int)KEY_SENTINEL, cap, s));       // unused slots sort to the end
     hipLaunchKernelGGL(k_cell_masks, dim3(cdiv(lh * lw, 256)), dim3(256), 0, s, labels, lh, lw, (unsigned*)mask);
     NCT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_knn_entries, dim3(cdiv(n, 256)), dim3(256), 0, s, (const unsigned*)mask, lab_u8, lw, lh, h, w, samples, nlabels,
+    hipLaunchKernelGGL(k_knn_entries, dim3(cdiv(n, 256)), dim3(256), 0, s, (const unsigned*)mask, lab_u8, lw, lh, h, w, samples, nlabels, nlabels_dev,
                        (int*)count, (unsigned*)keys, (unsigned*)vals);
     NCT_LAUNCH_CHECK();
     size_t tmp_bytes = 0;

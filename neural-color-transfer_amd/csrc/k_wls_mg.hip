@@ -470,29 +470,42 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
         return 0;
     };
     const vf* z = lv[0].x2;
-    const int maxit = 5000, check_every = 8;
-    PState hst; memset(&hst, 0, sizeof hst);
-    int it = 0; bool done = false;
-    // state may already be converged (x0 solves the system): check once
-    NCT_HIP(hipMemcpyAsync(&hst, (PState*)st, sizeof hst, hipMemcpyDeviceToHost, s));
-    NCT_HIP(hipStreamSynchronize(s));
-    done = true; for (int q = 0; q < 6; ++q) if (hst.active[q]) done = false;
-    while (!done && it < maxit) {
-        for (int k = 0; k < check_every; ++k, ++it) {
-            int rc = vcycle(); if (rc) return rc;
-            hipLaunchKernelGGL(k_pcg_rz_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, it == 0 ? 1 : 0); LCHK();
-            hipLaunchKernelGGL(k_pcg_dir, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const PState*)st, z, (double*)p, it == 0 ? 1 : 0); LCHK();
-            hipLaunchKernelGGL(k_pcg_apply, dim3(nb), dim3(256), 0, s, (const PState*)st, F, (const double*)p, (double*)Ap, (double*)partial); LCHK();
-            hipLaunchKernelGGL(k_pcg_alpha_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st); LCHK();
-            hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(256), 0, s, N, (const PState*)st, (const double*)p, (const double*)Ap, (double*)x6, (double*)r, (double*)partial); LCHK();
-            hipLaunchKernelGGL(k_pcg_rr_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
-        }
-        NCT_HIP(hipMemcpyAsync(&hst, (PState*)st, sizeof hst, hipMemcpyDeviceToHost, s));
-        NCT_HIP(hipStreamSynchronize(s));
-        done = true; for (int q = 0; q < 6; ++q) if (hst.active[q]) done = false;
+    // Convergence is polled without draining the stream: after every batch of `batch` iterations the solver state is copied to
+    // page-locked host memory and an event is recorded; the host then enqueues the NEXT batch before it waits for that event, so
+    // the GPU always has a batch queued. The batch enqueued past convergence costs only empty launches (nactive == 0).
+    const int maxit = 5000, batch = 4;
+    PState* hst = (PState*)ctx->pinned;                   // two slots
+    static_assert(2 * sizeof(PState) <= 4096, "pinned read-back area too small");
+    auto iteration = [&](int it) -> int {
+        int rc = vcycle(); if (rc) return rc;
+        hipLaunchKernelGGL(k_pcg_rz_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, it == 0 ? 1 : 0); LCHK();
+        hipLaunchKernelGGL(k_pcg_dir, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const PState*)st, z, (double*)p, it == 0 ? 1 : 0); LCHK();
+        hipLaunchKernelGGL(k_pcg_apply, dim3(nb), dim3(256), 0, s, (const PState*)st, F, (const double*)p, (double*)Ap, (double*)partial); LCHK();
+        hipLaunchKernelGGL(k_pcg_alpha_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st); LCHK();
+        hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(256), 0, s, N, (const PState*)st, (const double*)p, (const double*)Ap, (double*)x6, (double*)r, (double*)partial); LCHK();
+        hipLaunchKernelGGL(k_pcg_rr_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
+        return 0;
+    };
+    auto snapshot = [&](int slot) -> int {
+        NCT_HIP(hipMemcpyAsync(&hst[slot], (PState*)st, sizeof(PState), hipMemcpyDeviceToHost, s));
+        NCT_HIP(hipEventRecord(ctx->ev_poll[slot], s));
+        return 0;
+    };
+    int it = 0, slot = 0; bool done = false;
+    { int rc = snapshot(slot); if (rc) return rc; }        // state after the start kernel (x0 may already solve the system)
+    PState fin; memset(&fin, 0, sizeof fin);
+    while (true) {
+        if (it < maxit) { for (int k = 0; k < batch; ++k, ++it) { int rc = iteration(it); if (rc) return rc; } }
+        { int rc = snapshot(slot ^ 1); if (rc) return rc; }
+        NCT_HIP(hipEventSynchronize(ctx->ev_poll[slot]));  // the snapshot taken BEFORE the batch just enqueued
+        fin = hst[slot];
+        if (fin.nactive == 0) { done = true; break; }
+        if (it >= maxit + batch) break;
+        slot ^= 1;
     }
+    // iterations enqueued after `fin` was taken leave the state untouched (nactive == 0), so fin is final
     if (!done) return ctx->fail(NCT_ERR_HIP, "WLS MG-PCG did not converge in %d iterations", maxit);
     hipLaunchKernelGGL(k_pcg_finish, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const double*)x6, X); LCHK();
-    if (iters_out) for (int q = 0; q < 6; ++q) iters_out[q] = hst.iters[q];
+    if (iters_out) for (int q = 0; q < 6; ++q) iters_out[q] = fin.iters[q];
     return 0;
 }

@@ -60,6 +60,9 @@ int nct_create(int device, nct_ctx** out) {
     }
     for (int l = 0; l < 5; ++l)
         if ((e = hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
+    for (int l = 0; l < 2; ++l)
+        if ((e = hipEventCreateWithFlags(&c->ev_poll[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
+    if ((e = hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault)) != hipSuccess) { g_create_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     *out = c;
     return NCT_OK;
 }
@@ -82,6 +85,8 @@ void nct_destroy(nct_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (int l = 0; l < 5; ++l) if (ctx->ev_level[l]) (void)hipEventDestroy(ctx->ev_level[l]);
+    for (int l = 0; l < 2; ++l) if (ctx->ev_poll[l]) (void)hipEventDestroy(ctx->ev_poll[l]);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
 }
 

@@ -86,7 +86,7 @@ int nct_knn_graph(nct_ctx* ctx, const uint8_t* lab_u8, int h, int w, const int* 
     DevBuf<double> kw(ctx, (size_t)n * 8);
     if (!l.ok() || !lb.ok() || !id.ok() || !kw.ok()) return NCT_ERR_HIP;
     H2D(l, lab_u8, (size_t)n * 3); H2D(lb, labels, sizeof(int) * lh * lw);
-    RC(nctk_knn_graph(ctx, ctx->stream, l, h, w, lb, lh, lw, nlabels, samples, id, kw));
+    RC(nctk_knn_graph(ctx, ctx->stream, l, h, w, lb, lh, lw, nlabels, nullptr, samples, id, kw));
     D2H(knn_id, id, sizeof(int) * n * 8); D2H(knn_w, kw, sizeof(double) * n * 8); SYNC();
     return NCT_OK;
 }

@@ -16,6 +16,8 @@ struct nct_ctx {
     hipStream_t stream2 = nullptr;    // second stream (R->S direction runs concurrently)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_level[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // side-stream completion of level l's kNN graph
+    hipEvent_t ev_poll[2] = {nullptr, nullptr};   // completion of the two in-flight solver-state read-backs (k_wls_mg.hip)
+    void* pinned = nullptr;                        // 4 KB of page-locked host memory for those read-backs
     std::string err;
     std::vector<nct_block> blocks;    // cached device allocations, reused across calls and pairs
     size_t bytes_allocated = 0;
@@ -82,7 +84,7 @@ void nct_cvt_free(nct_ctx* ctx);
 void nct_pair_free(nct_ctx* ctx);   // nct_pipeline.cpp
 // k_cluster.hip
 int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat_hwc_norm, int n, int C, int K, int iters, uint64_t seed, int* labels, int* nlabels_dev);
-int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, int w, const int* labels, int lh, int lw, int nlabels, int samples,
+int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, int w, const int* labels, int lh, int lw, int nlabels, const int* nlabels_dev /*nullable: overrides nlabels*/, int samples,
                    int* knn_id, double* knn_w);
 // k_colorsolve.hip
 struct nct_color_params { double eps, nonlocal_weight, local_weight, wls_lambda_init, wls_alpha, k_num; };

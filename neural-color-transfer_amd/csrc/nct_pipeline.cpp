@@ -105,9 +105,8 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     if (!labels.ok() || !nlab_dev.ok() || !na.ok() || !nb.ok() || !voted.ok() || !nvoted.ok()) return NCT_ERR_HIP;
     rc = nctk_normalize(ctx, s, sfeat, na, nullptr, 512, ah[0] * aw[0]); if (rc) return rc;
     rc = nctk_kmeans_labels(ctx, s, na, ah[0] * aw[0], 512, prm->cluster_num, 11, (uint64_t)prm->seed, labels, nlab_dev); if (rc) return rc;
-    int nlabels = 0;
-    NCT_HIP(hipMemcpyAsync(&nlabels, (int*)nlab_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-    NCT_HIP(hipStreamSynchronize(s));
+    // the number of labels (1 if k-means degenerated, else K) stays on the device: reading it back would stall the host — and with it
+    // the enqueueing of everything below — until the VGG forwards and k-means have finished
     clk.lap(timing ? &timing->cluster_ms : nullptr);
 
     // ---- K1 for all five levels on the side stream: the kNN graph of a level depends only on the level image of S and on the
@@ -131,7 +130,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         ctx->defer_release = true;
         for (int l = 0; l < 5 && rc == 0; ++l) {
             rc = nctk_bgr2lab(ctx, s2, simg[l], *slab[l], (size_t)ah[l] * aw[l]);
-            if (rc == 0) rc = nctk_knn_graph(ctx, s2, *slab[l], ah[l], aw[l], labels, ah[0], aw[0], nlabels, 1 << l, *knn_ids[l], *knn_ws[l]);
+            if (rc == 0) rc = nctk_knn_graph(ctx, s2, *slab[l], ah[l], aw[l], labels, ah[0], aw[0], 0, nlab_dev, 1 << l, *knn_ids[l], *knn_ws[l]);
             if (rc == 0 && hipEventRecord(ctx->ev_level[l], s2) != hipSuccess) rc = ctx->fail(NCT_ERR_HIP, "hipEventRecord failed");
         }
         ctx->defer_release = false;
