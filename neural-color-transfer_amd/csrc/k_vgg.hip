@@ -33,51 +33,51 @@ __global__ void k_vgg_preprocess(const uint8_t* __restrict__ bgr, int stride, fl
 }
 
 // ---------------------------------------------------------------- conv3x3 pad1 stride1 + bias + ReLU
-// TW: pixel-tile width (32 or 16). A 32-pixel MFMA column tile is TW x (32/TW) pixels; a wave owns two of them
-// stacked vertically plus two 32-cout row tiles. Workgroup = 4 waves = WN pixel-tile pairs x (4/WN) cout-tile pairs.
-struct ConvGeom { int Cin, Cout, H, W, tiles_x, tiles_y, nblk_n; };
+// Pixels are tiled in 1-D (row-major pixel index p = y*W + x): a 32-pixel MFMA column tile is 32 consecutive pixels (it may wrap
+// over a row end — validity is per lane anyway), a wave owns two consecutive ones plus two 32-cout row tiles, a workgroup =
+// 4 waves = WCO along cout x (4/WCO) along pixels. 1-D tiling wastes no lanes on ragged 2-D tile edges: conv4_x at 88x88 needs
+// 61 x 4 = 244 workgroups (one per CU, one round) where 16x8 tiles needed 264 — 8 CUs with two workgroups doubled the layer time.
+struct ConvGeom { int Cin, Cout, H, W, npx_blocks, nblk_n; };
 
-template <int TW, int WCO>   // WCO = waves along cout (1 => block covers 64 cout x 256 px; 2 => 128 cout x 128 px)
+template <int WCO>   // WCO = waves along cout (1 => block covers 64 cout x 256 px; 2 => 128 cout x 128 px)
 __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ in, const float* __restrict__ wp /*[Cin*9][Cout]*/,
                                                       const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int relu) {
-    constexpr int TH = 32 / TW;              // rows per MFMA pixel tile
     constexpr int WPX = 4 / WCO;             // waves along pixels
-    constexpr int BLK_ROWS = WPX * 2 * TH;   // pixel rows covered by a workgroup
+    constexpr int BLK_PX = WPX * 64;         // pixels covered by a workgroup
     const int HW = g.H * g.W;
-    // block -> (pixel tile, cout block); blocks of one pixel tile differ by multiples of 8 => same XCD/L2
+    // block -> (pixel block, cout block); blocks of one pixel block differ by multiples of 8 => same XCD/L2
     int bid = blockIdx.x;
-    const int np = g.tiles_x * g.tiles_y;
+    const int np = g.npx_blocks;
     int pt, nb;
     {
         const int grp = bid / (8 * g.nblk_n), rem = bid - grp * 8 * g.nblk_n;
         nb = rem >> 3; pt = grp * 8 + (rem & 7);
     }
     if (pt >= np) return;
-    const int ty = pt / g.tiles_x, tx = pt - ty * g.tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, l31 = lane & 31;
     const int wco = wave % WCO, wpx = wave / WCO;
     const int m0 = nb * (64 * WCO) + wco * 64;                 // first cout of this wave
-    const int x = tx * TW + (l31 % TW);
-    const int yb = ty * BLK_ROWS + wpx * 2 * TH + (l31 / TW);  // row of pixel tile 0; tile 1 is TH rows below
+    const int p0 = pt * BLK_PX + wpx * 64 + l31, p1 = p0 + 32; // this lane's pixel in tile 0 / tile 1
+    const bool live0 = p0 < HW, live1 = p1 < HW;
+    const int pc0 = live0 ? p0 : HW - 1, pc1 = live1 ? p1 : HW - 1;
+    const int y0 = pc0 / g.W, x0 = pc0 - y0 * g.W, y1 = pc1 / g.W, x1 = pc1 - y1 * g.W;
 
     // per-lane tap tables for the 9 k-steps of a channel pair (k = 2s + half within 18)
-    // out-of-image taps read the (in-bounds) tile origin instead and are zeroed by a select: no divergent branches in the K loop
+    // out-of-image taps read the (in-bounds) own pixel instead and are zeroed by a select: no divergent branches in the K loop
     int off0[9], off1[9]; unsigned vm0 = 0, vm1 = 0;
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         const int k = 2 * s + half;
         const int ci = k / 9, tap = k - 9 * ci, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const int boff = ci * HW + dy * g.W + dx;
-        const bool xo = (x + dx) >= 0 && (x + dx) < g.W;
-        const int y0 = yb + dy, y1 = yb + TH + dy;
-        const bool v0 = xo && y0 >= 0 && y0 < g.H, v1 = xo && y1 >= 0 && y1 < g.H;
+        const bool v0 = live0 && (x0 + dx) >= 0 && (x0 + dx) < g.W && (y0 + dy) >= 0 && (y0 + dy) < g.H;
+        const bool v1 = live1 && (x1 + dx) >= 0 && (x1 + dx) < g.W && (y1 + dy) >= 0 && (y1 + dy) < g.H;
         vm0 |= (unsigned)v0 << s; vm1 |= (unsigned)v1 << s;
         off0[s] = v0 ? boff : ci * HW; off1[s] = v1 ? boff : ci * HW;
     }
-    const int xc = min(x, g.W - 1);
-    const float* b0p = in + (size_t)min(yb, g.H - 1) * g.W + xc;
-    const float* b1p = in + (size_t)min(yb + TH, g.H - 1) * g.W + xc;
+    const float* b0p = in + pc0;
+    const float* b1p = in + pc1;
     const float* ap = wp + (size_t)half * g.Cout + m0 + l31;
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};   // [cout tile][pixel tile]
@@ -115,8 +115,6 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
     }
 
     // epilogue: D row (cout) = (r&3) + 8*(r>>2) + 4*half, D col (pixel) = l31
-    const bool xok = x < g.W;
-    const int y0 = yb, y1 = yb + TH;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -124,28 +122,20 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
         const float bb0 = bias[co0], bb1 = bias[co1];
         float v00 = acc00[r] + bb0, v01 = acc01[r] + bb0, v10 = acc10[r] + bb1, v11 = acc11[r] + bb1;
         if (relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
-        if (xok && y0 < g.H) { out[(size_t)co0 * HW + (size_t)y0 * g.W + x] = v00; out[(size_t)co1 * HW + (size_t)y0 * g.W + x] = v10; }
-        if (xok && y1 < g.H) { out[(size_t)co0 * HW + (size_t)y1 * g.W + x] = v01; out[(size_t)co1 * HW + (size_t)y1 * g.W + x] = v11; }
+        if (live0) { out[(size_t)co0 * HW + p0] = v00; out[(size_t)co1 * HW + p0] = v10; }
+        if (live1) { out[(size_t)co0 * HW + p1] = v01; out[(size_t)co1 * HW + p1] = v11; }
     }
 }
 
 int nctk_conv3x3(nct_ctx* ctx, hipStream_t s, const float* in, const float* wp, const float* bias, float* out,
                  int Cin, int Cout, int H, int W, int relu) {
     NCT_REQUIRE((Cin & 1) == 0 && (Cout & 63) == 0, "conv3x3: Cin=%d must be even (pad) and Cout=%d a multiple of 64", Cin, Cout);
-    const bool wide = W > 176;
-    const int TW = wide ? 32 : 16, TH = 32 / TW;
     const int WCO = (Cout % 128 == 0) ? 2 : 1;
-    const int blk_rows = (4 / WCO) * 2 * TH;
-    ConvGeom g{Cin, Cout, H, W, cdiv(W, TW), cdiv(H, blk_rows), Cout / (64 * WCO)};
-    const int np = g.tiles_x * g.tiles_y;
-    const int nblocks = cdiv(np, 8) * 8 * g.nblk_n;
-    if (wide) {
-        if (WCO == 2) hipLaunchKernelGGL((k_conv3x3_mfma<32, 2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
-        else          hipLaunchKernelGGL((k_conv3x3_mfma<32, 1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
-    } else {
-        if (WCO == 2) hipLaunchKernelGGL((k_conv3x3_mfma<16, 2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
-        else          hipLaunchKernelGGL((k_conv3x3_mfma<16, 1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
-    }
+    const int blk_px = (4 / WCO) * 64;
+    ConvGeom g{Cin, Cout, H, W, cdiv(H * W, blk_px), Cout / (64 * WCO)};
+    const int nblocks = cdiv(g.npx_blocks, 8) * 8 * g.nblk_n;
+    if (WCO == 2) hipLaunchKernelGGL((k_conv3x3_mfma<2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+    else          hipLaunchKernelGGL((k_conv3x3_mfma<1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
     NCT_LAUNCH_CHECK();
     return 0;
 }
