@@ -203,7 +203,15 @@ __device__ __forceinline__ double lab_dist(unsigned p, unsigned q) {
 // One thread per (cluster, member) entry. Exact k+1 nearest by (dist, id) inside the cluster: colour cells are visited in
 // Chebyshev rings around the query's cell; every point outside ring r differs by at least r*8+1 Lab units in some channel,
 // so the search stops as soon as the current (k+1)-th best squared distance is < (r*8+1)^2 (strict: ties cannot hide outside).
-__global__ __launch_bounds__(256) void k_knn_grid(const uint8_t* __restrict__ lab, const int* __restrict__ count, const unsigned* __restrict__ keys,
+// packed Lab colour of every sorted entry: the ring search then streams colours in entry order instead of gathering three bytes per
+// scanned point through the pixel id (that gather was ~3/4 of the search time: profiles/r1m)
+__global__ void k_knn_entry_colours(const uint8_t* __restrict__ lab, const int* __restrict__ count, const unsigned* __restrict__ vals, unsigned* __restrict__ cols) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *count) return;
+    const size_t id = vals[e];
+    cols[e] = (unsigned)lab[id * 3] | ((unsigned)lab[id * 3 + 1] << 8) | ((unsigned)lab[id * 3 + 2] << 16);
+}
+__global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ cols, const int* __restrict__ count, const unsigned* __restrict__ keys,
                                                   const unsigned* __restrict__ vals, const int* __restrict__ start,
                                                   int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -212,17 +220,17 @@ __global__ __launch_bounds__(256) void k_knn_grid(const uint8_t* __restrict__ la
     const int id = (int)vals[e];
     const int l = (int)(key >> 15);
     const int cz = (int)((key >> 10) & 31u), cy = (int)((key >> 5) & 31u), cx = (int)(key & 31u);
-    const unsigned pc = (unsigned)lab[(size_t)id * 3] | ((unsigned)lab[(size_t)id * 3 + 1] << 8) | ((unsigned)lab[(size_t)id * 3 + 2] << 16);
+    const unsigned pc = cols[e];
     double bd[KNN_K + 1]; int bi[KNN_K + 1]; int bq[KNN_K + 1];
 #pragma unroll
     for (int t = 0; t <= KNN_K; ++t) { bd[t] = 1e300; bi[t] = 0x7fffffff; bq[t] = 0x7fffffff; }
     auto scan = [&](int b0, int b1) {
         for (int t = b0; t < b1; ++t) {
-            const int jd = (int)vals[t];
-            const unsigned qc = (unsigned)lab[(size_t)jd * 3] | ((unsigned)lab[(size_t)jd * 3 + 1] << 8) | ((unsigned)lab[(size_t)jd * 3 + 2] << 16);
+            const unsigned qc = cols[t];
             const int e0 = (int)(pc & 255u) - (int)(qc & 255u), e1 = (int)((pc >> 8) & 255u) - (int)((qc >> 8) & 255u), e2 = (int)((pc >> 16) & 255u) - (int)((qc >> 16) & 255u);
             const int q2 = e0 * e0 + e1 * e1 + e2 * e2;
             if (q2 > bq[KNN_K]) continue;
+            const int jd = (int)vals[t];
             const double d = lab_dist(pc, qc);
             if (!ent_less(d, jd, bd[KNN_K], bi[KNN_K])) continue;
             bd[KNN_K] = d; bi[KNN_K] = jd; bq[KNN_K] = q2;
@@ -297,9 +305,10 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     const int n = h * w;
     const int cap = n * KNN_SLOTS, nkeys = 16 << 15;
     DevBuf<unsigned> mask(ctx, (size_t)lh * lw), keys(ctx, cap), vals(ctx, cap), keys_s(ctx, cap), vals_s(ctx, cap);
+    DevBuf<unsigned> cols(ctx, cap);
     DevBuf<int> count(ctx, 1), start(ctx, nkeys + 2), nslot(ctx, n), cand_id(ctx, (size_t)n * KNN_SLOTS * KNN_K);
     DevBuf<double> cand_d(ctx, (size_t)n * KNN_SLOTS * KNN_K);
-    if (!mask.ok() || !keys.ok() || !vals.ok() || !keys_s.ok() || !vals_s.ok() || !count.ok() || !start.ok() || !nslot.ok() || !cand_id.ok() || !cand_d.ok()) return NCT_ERR_HIP;
+    if (!mask.ok() || !keys.ok() || !vals.ok() || !keys_s.ok() || !vals_s.ok() || !cols.ok() || !count.ok() || !start.ok() || !nslot.ok() || !cand_id.ok() || !cand_d.ok()) return NCT_ERR_HIP;
     NCT_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
     NCT_HIP(hipMemsetAsync(nslot, 0, sizeof(int) * n, s));
     NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)(unsigned*)keys, (int)KEY_SENTINEL, cap, s));       // unused slots sort to the end
@@ -315,7 +324,9 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 20, s));
     hipLaunchKernelGGL(k_knn_cell_starts, dim3(cdiv(nkeys + 1, 256)), dim3(256), 0, s, (const unsigned*)keys_s, cap, (int*)start, nkeys);
     NCT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_knn_grid, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
+    hipLaunchKernelGGL(k_knn_entry_colours, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, (const int*)count, (const unsigned*)vals_s, (unsigned*)cols);
+    NCT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_knn_grid, dim3(cdiv(cap, 256)), dim3(256), 0, s, (const unsigned*)cols, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
                        (const int*)start, (int*)nslot, (double*)cand_d, (int*)cand_id);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_merge, dim3(cdiv(n, 256)), dim3(256), 0, s, n, (const int*)nslot, (const double*)cand_d, (const int*)cand_id, knn_id, knn_w);
