@@ -162,14 +162,14 @@ __global__ void k_cell_masks(const int* __restrict__ labels, int lh, int lw, uns
     mask[i] = m;
 }
 
-// ---- (cluster, colour-cell) membership entries: key = cluster << 15 | cell(L,a,b) with 8-unit cells (32^3), value = pixel id
-constexpr int CELL_SHIFT = 3;                 // 8 Lab units per cell
-constexpr int CELLS = 32;                     // per axis
-constexpr unsigned KEY_SENTINEL = 1u << 19;   // sorts after every real key (16 clusters x 32768 cells)
-__device__ __forceinline__ unsigned cell_key(int l, unsigned col) {
-    return ((unsigned)l << 15) | (((col >> 16) & 255u) >> CELL_SHIFT) << 10 | (((col >> 8) & 255u) >> CELL_SHIFT) << 5 | ((col & 255u) >> CELL_SHIFT);
+// ---- (cluster, colour-cell) membership entries: key = cluster << 3*cb | cell(L,a,b), value = pixel id. The cell edge is 2^cs Lab
+// units (cb = 8 - cs bits per axis): 8-unit cells (32^3) for the sparse coarse levels, 4-unit cells (64^3) from 100k pixels on, where
+// an 8-unit cell already holds dozens of points and rings 0-1 (always visited) would scan 8x more of them than needed.
+__device__ __forceinline__ unsigned cell_key(int l, unsigned col, int cs) {
+    const int cb = 8 - cs;
+    return ((unsigned)l << (3 * cb)) | (((col >> 16) & 255u) >> cs) << (2 * cb) | (((col >> 8) & 255u) >> cs) << cb | ((col & 255u) >> cs);
 }
-__global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* __restrict__ lab, int lw, int lh, int h, int w, int samples, int nlabels_host, const int* __restrict__ nlabels_dev,
+__global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* __restrict__ lab, int lw, int lh, int h, int w, int samples, int nlabels_host, const int* __restrict__ nlabels_dev, int cs,
                               int* __restrict__ count, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= h * w) return;
@@ -179,7 +179,7 @@ __global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* 
     const unsigned col = (unsigned)lab[(size_t)i * 3] | ((unsigned)lab[(size_t)i * 3 + 1] << 8) | ((unsigned)lab[(size_t)i * 3 + 2] << 16);
     const int nlabels = nlabels_dev ? *nlabels_dev : nlabels_host;   // the pipeline passes the k-means result without a host round trip
     for (int l = 0; l < nlabels; ++l)
-        if ((m >> l) & 1u) { const int pos = atomicAdd(count, 1); keys[pos] = cell_key(l, col); vals[pos] = (unsigned)i; }
+        if ((m >> l) & 1u) { const int pos = atomicAdd(count, 1); keys[pos] = cell_key(l, col, cs); vals[pos] = (unsigned)i; }
 }
 // start[k] = first sorted entry with key >= k, k in [0, nkeys]
 __global__ void k_knn_cell_starts(const unsigned* __restrict__ keys, int m, int* __restrict__ start, int nkeys) {
@@ -212,14 +212,15 @@ __global__ void k_knn_entry_colours(const uint8_t* __restrict__ lab, const int* 
     cols[e] = (unsigned)lab[id * 3] | ((unsigned)lab[id * 3 + 1] << 8) | ((unsigned)lab[id * 3 + 2] << 16);
 }
 __global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ cols, const int* __restrict__ count, const unsigned* __restrict__ keys,
-                                                  const unsigned* __restrict__ vals, const int* __restrict__ start,
+                                                  const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
                                                   int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
+    const int cb = 8 - cs, CELLS = 1 << cb; const unsigned cmask = (unsigned)CELLS - 1u;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= *count) return;
     const unsigned key = keys[e];
     const int id = (int)vals[e];
-    const int l = (int)(key >> 15);
-    const int cz = (int)((key >> 10) & 31u), cy = (int)((key >> 5) & 31u), cx = (int)(key & 31u);
+    const int l = (int)(key >> (3 * cb));
+    const int cz = (int)((key >> (2 * cb)) & cmask), cy = (int)((key >> cb) & cmask), cx = (int)(key & cmask);
     const unsigned pc = cols[e];
     double bd[KNN_K + 1]; int bi[KNN_K + 1]; int bq[KNN_K + 1];
 #pragma unroll
@@ -243,14 +244,14 @@ __global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ c
                 }
         }
     };
-    const int base = l << 15;
+    const int base = l << (3 * cb);
     for (int r = 0; r < CELLS; ++r) {
-        if (r > 0) { const int bound = (r - 1) * (1 << CELL_SHIFT) + 1; if (bq[KNN_K] < bound * bound) break; }
+        if (r > 0) { const int bound = (r - 1) * (1 << cs) + 1; if (bq[KNN_K] < bound * bound) break; }
         for (int dz = -r; dz <= r; ++dz) {
             const int z = cz + dz; if (z < 0 || z >= CELLS) continue;
             for (int dy = -r; dy <= r; ++dy) {
                 const int yy = cy + dy; if (yy < 0 || yy >= CELLS) continue;
-                const int row = base | (z << 10) | (yy << 5);
+                const int row = base | (z << (2 * cb)) | (yy << cb);
                 if (max(abs(dz), abs(dy)) == r) {                       // full x range of the shell face
                     const int x0 = max(cx - r, 0), x1 = min(cx + r, CELLS - 1);
                     scan(start[row | x0], start[(row | x1) + 1]);
@@ -303,7 +304,9 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
                    int* knn_id, double* knn_w) {
     NCT_REQUIRE(nlabels_dev || (nlabels >= 1 && nlabels <= 16), "knn_graph: nlabels=%d out of range", nlabels);
     const int n = h * w;
-    const int cap = n * KNN_SLOTS, nkeys = 16 << 15;
+    const int cs = n >= 100000 ? 2 : 3, cb = 8 - cs;
+    const int cap = n * KNN_SLOTS, nkeys = 16 << (3 * cb);
+    const unsigned key_sentinel = 1u << (3 * cb + 4);      // sorts after every real key (16 clusters x cells)
     DevBuf<unsigned> mask(ctx, (size_t)lh * lw), keys(ctx, cap), vals(ctx, cap), keys_s(ctx, cap), vals_s(ctx, cap);
     DevBuf<unsigned> cols(ctx, cap);
     DevBuf<int> count(ctx, 1), start(ctx, nkeys + 2), nslot(ctx, n), cand_id(ctx, (size_t)n * KNN_SLOTS * KNN_K);
@@ -311,23 +314,23 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     if (!mask.ok() || !keys.ok() || !vals.ok() || !keys_s.ok() || !vals_s.ok() || !cols.ok() || !count.ok() || !start.ok() || !nslot.ok() || !cand_id.ok() || !cand_d.ok()) return NCT_ERR_HIP;
     NCT_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
     NCT_HIP(hipMemsetAsync(nslot, 0, sizeof(int) * n, s));
-    NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)(unsigned*)keys, (int)KEY_SENTINEL, cap, s));       // unused slots sort to the end
+    NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)(unsigned*)keys, (int)key_sentinel, cap, s));       // unused slots sort to the end
     hipLaunchKernelGGL(k_cell_masks, dim3(cdiv(lh * lw, 256)), dim3(256), 0, s, labels, lh, lw, (unsigned*)mask);
     NCT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_knn_entries, dim3(cdiv(n, 256)), dim3(256), 0, s, (const unsigned*)mask, lab_u8, lw, lh, h, w, samples, nlabels, nlabels_dev,
+    hipLaunchKernelGGL(k_knn_entries, dim3(cdiv(n, 256)), dim3(256), 0, s, (const unsigned*)mask, lab_u8, lw, lh, h, w, samples, nlabels, nlabels_dev, cs,
                        (int*)count, (unsigned*)keys, (unsigned*)vals);
     NCT_LAUNCH_CHECK();
     size_t tmp_bytes = 0;
-    NCT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 20, s));
+    NCT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 3 * cb + 5, s));
     DevBuf<char> tmp(ctx, tmp_bytes ? tmp_bytes : 16);
     if (!tmp.ok()) return NCT_ERR_HIP;
-    NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 20, s));
+    NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 3 * cb + 5, s));
     hipLaunchKernelGGL(k_knn_cell_starts, dim3(cdiv(nkeys + 1, 256)), dim3(256), 0, s, (const unsigned*)keys_s, cap, (int*)start, nkeys);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_entry_colours, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, (const int*)count, (const unsigned*)vals_s, (unsigned*)cols);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_grid, dim3(cdiv(cap, 256)), dim3(256), 0, s, (const unsigned*)cols, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
-                       (const int*)start, (int*)nslot, (double*)cand_d, (int*)cand_id);
+                       (const int*)start, cs, (int*)nslot, (double*)cand_d, (int*)cand_id);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_merge, dim3(cdiv(n, 256)), dim3(256), 0, s, n, (const int*)nslot, (const double*)cand_d, (const int*)cand_id, knn_id, knn_w);
     NCT_LAUNCH_CHECK();
