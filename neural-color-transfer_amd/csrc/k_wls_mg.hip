@@ -24,8 +24,8 @@ namespace {
 constexpr double OMEGA = 0.8;
 constexpr int NQ = 6;
 #ifndef NCT_MG_TXB
-#define NCT_MG_TXB 32
-#define NCT_MG_TYB 16
+#define NCT_MG_TXB 48
+#define NCT_MG_TYB 8
 #endif
 
 // The PCG itself (and the hierarchy construction) is fp64; the V-cycle — a fixed linear preconditioner, whose accuracy does not
@@ -138,69 +138,79 @@ __global__ void k_mg_diag(Lvl L) {
 }
 
 // ---- V-cycle (fp32, vectors planar [6][n])
-// tile-fused legs: the intermediate iterate of a leg lives in LDS for a TX x TY fine tile plus a 1-pixel halo (recomputed by
-// the neighbouring tiles with the same expressions, hence bit-identical) instead of making a round trip through global memory
-// and a second launch:
+// tile-fused legs: every intermediate iterate of a leg lives in LDS for a TX x TY fine tile plus a halo (recomputed by the
+// neighbouring tiles with the same expressions, hence bit-identical) instead of making a round trip through global memory and a
+// launch per sweep:
 //   down: x1 = b*dinv ; x = x1 + (b - M x1)*dinv (two damped-Jacobi sweeps from zero) ; coarse rhs = sum over the 2x2 aggregate
 //         of (b - M x), fine pixels in the order (0,0),(0,1),(1,0),(1,1)
 //   up:   xe = x + e_coarse(parent) ; x2 = xe + (b - M xe)*dinv ; xo = x2 + (b - M x2)*dinv
-// y = M v at pixel (r, c): diag*v - sum_w w*v_nbr, neighbour order +x, -x, +y, -y (as lvl_op)
-template <typename F>
-__device__ __forceinline__ void lvl_opf(const Lvl& L, int r, int c, F&& val /* val(r, c, q) */, vf (&y)[NQ]) {
-    const int W = L.W, H = L.H, i = r * W + c;
-    const vf d = L.fdiag[i];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) y[q] = d * val(r, c, q);
-    if (c + 1 < W) { const vf w = L.fwx[i];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= w * val(r, c + 1, q); }
-    if (c > 0) { const vf w = L.fwx[i - 1];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= w * val(r, c - 1, q); }
-    if (r + 1 < H) { const vf w = L.fwy[i];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= w * val(r + 1, c, q); }
-    if (r > 0) { const vf w = L.fwy[i - W];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= w * val(r - 1, c, q); }
+// One thread per pixel of the tile + 2-pixel halo: it loads ITS pixel's right-hand side, coefficients and inputs once (all loads of
+// a leg are issued in the first phase), the first iterate is exchanged through LDS on the halo-2 grid, the second on the halo-1
+// grid, the result is produced on the tile. (Recomputing the first iterate at the 5 stencil points from global memory instead
+// cost 40-75 loads per thread and ~28 us per leg at 700x700.)
+struct PxCoef { vf d, dinv, w0, w1, w2, w3; bool r, l, dn, up; };    // diag, omega/diag, weights to +x, -x, +y, -y and their existence
+__device__ __forceinline__ PxCoef px_coef(const Lvl& L, int gy, int gx) {
+    const int i = gy * L.W + gx;
+    PxCoef c;
+    c.r = gx + 1 < L.W; c.l = gx > 0; c.dn = gy + 1 < L.H; c.up = gy > 0;
+    c.d = L.fdiag[i]; c.dinv = L.fdinv[i];
+    c.w0 = c.r ? L.fwx[i] : 0.f; c.w1 = c.l ? L.fwx[i - 1] : 0.f; c.w2 = c.dn ? L.fwy[i] : 0.f; c.w3 = c.up ? L.fwy[i - L.W] : 0.f;
+    return c;
 }
+// y = M v at the pixel stored at LDS position p of a grid with row pitch LW (same operation order as lvl_op: +x, -x, +y, -y)
+template <int LW, int LN>
+__device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s_v, int p, vf (&y)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) y[q] = c.d * s_v[q * LN + p];
+    if (c.r) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= c.w0 * s_v[q * LN + p + 1]; }
+    if (c.l) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= c.w1 * s_v[q * LN + p - 1]; }
+    if (c.dn) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= c.w2 * s_v[q * LN + p + LW]; }
+    if (c.up) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= c.w3 * s_v[q * LN + p - LW]; }
+}
+constexpr int mg_threads(int TX, int TY) { return ((TX + 4) * (TY + 4) + 63) / 64 * 64; }
 // TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below.
-// One thread per pixel of the haloed tile (mg_threads = (TX+2)(TY+2) rounded up to whole waves): every thread issues all of its
-// loads at once, so a leg costs one round of memory latency per phase instead of one per 256-pixel pass.
-constexpr int mg_threads(int TX, int TY) { return ((TX + 2) * (TY + 2) + 63) / 64 * 64; }
 template <int TX, int TY, typename TB>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc) {
     if (st->nactive == 0) return;
-    constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
-    __shared__ vf s_x[2 * NQ * LN];                      // [0, NQ*LN): iterate x ; [NQ*LN, 2*NQ*LN): residual b - M x
-    vf* s_r = s_x + NQ * LN;
+    constexpr int LW = TX + 4, LH = TY + 4, LN = LW * LH;
+    __shared__ vf s_a[NQ * LN], s_b[NQ * LN];            // s_a: x1, later the residual b - M x ; s_b: x
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const int p = threadIdx.x;
     const int ly = p / LW, lx = p - ly * LW;
-    const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+    const int gy = y0 + ly - 2, gx = x0 + lx - 2;
     const bool valid = p < LN && gy >= 0 && gy < F.H && gx >= 0 && gx < F.W;
-    const bool interior = valid && lx >= 1 && lx <= TX && ly >= 1 && ly <= TY;
+    const bool ring1 = valid && lx >= 1 && lx <= TX + 2 && ly >= 1 && ly <= TY + 2;     // tile + 1-pixel halo
+    const bool interior = valid && lx >= 2 && lx <= TX + 1 && ly >= 2 && ly <= TY + 1;
     const int i = gy * F.W + gx;
-    auto bv = [&](int j, int q) { return (vf)b[(size_t)q * F.n + j]; };
-    vf bq[NQ];
+    vf bq[NQ], x1[NQ]; PxCoef c;
     if (valid) {
-        auto x1 = [&](int r, int c, int q) { const int j = r * F.W + c; return bv(j, q) * F.fdinv[j]; };
-        vf y[NQ]; lvl_opf(F, gy, gx, x1, y);
-        const vf d = F.fdinv[i];
+        c = px_coef(F, gy, gx);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * F.n + i]; x1[q] = bq[q] * c.dinv; s_a[q * LN + p] = x1[q]; }
+    }
+    __syncthreads();
+    if (ring1) {
+        vf y[NQ]; lds_op<LW, LN>(c, s_a, p, y);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            bq[q] = bv(i, q);
-            const vf v = x1(gy, gx, q) + (bq[q] - y[q]) * d;
-            s_x[q * LN + p] = v;
+            const vf v = x1[q] + (bq[q] - y[q]) * c.dinv;
+            s_b[q * LN + p] = v;
             if (interior) x[(size_t)q * F.n + i] = v;
         }
     }
     __syncthreads();
     if (interior) {
-        auto xv = [&](int r, int c, int q) { return s_x[q * LN + (r - y0 + 1) * LW + (c - x0 + 1)]; };
-        vf yv[NQ]; lvl_opf(F, gy, gx, xv, yv);
+        vf yv[NQ]; lds_op<LW, LN>(c, s_b, p, yv);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) s_r[q * LN + p] = bq[q] - yv[q];
+        for (int q = 0; q < NQ; ++q) s_a[q * LN + p] = bq[q] - yv[q];
     }
     __syncthreads();
     if (p < (TX / 2) * (TY / 2)) {
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
                 const int yy = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
                 if (yy < F.H && xx < F.W) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) acc[q] += s_r[q * LN + (yy - y0 + 1) * LW + (xx - x0 + 1)];
+                    for (int q = 0; q < NQ; ++q) acc[q] += s_a[q * LN + (yy - y0 + 2) * LW + (xx - x0 + 2)];
                 }
             }
 #pragma unroll
@@ -228,29 +238,35 @@ template <int TX, int TY, typename TB>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __restrict__ st, Lvl L, const TB* __restrict__ b, const vf* __restrict__ x, int Wc, int nc,
                                                               const vf* __restrict__ ec, vf* __restrict__ xo) {
     if (st->nactive == 0) return;
-    constexpr int LW = TX + 2, LH = TY + 2, LN = LW * LH;
-    __shared__ vf s_x[NQ * LN];
+    constexpr int LW = TX + 4, LH = TY + 4, LN = LW * LH;
+    __shared__ vf s_a[NQ * LN], s_b[NQ * LN];            // s_a: xe ; s_b: x2
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const int p = threadIdx.x;
     const int ly = p / LW, lx = p - ly * LW;
-    const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+    const int gy = y0 + ly - 2, gx = x0 + lx - 2;
     const bool valid = p < LN && gy >= 0 && gy < L.H && gx >= 0 && gx < L.W;
-    const bool interior = valid && lx >= 1 && lx <= TX && ly >= 1 && ly <= TY;
+    const bool ring1 = valid && lx >= 1 && lx <= TX + 2 && ly >= 1 && ly <= TY + 2;
+    const bool interior = valid && lx >= 2 && lx <= TX + 1 && ly >= 2 && ly <= TY + 1;
     const int i = gy * L.W + gx;
-    vf bq[NQ], d = 0;
+    vf bq[NQ], xe[NQ]; PxCoef c;
     if (valid) {
-        auto xe = [&](int r, int c, int q) { return x[(size_t)q * L.n + r * L.W + c] + ec[(size_t)q * nc + ((r >> 1) * Wc + (c >> 1))]; };
-        vf y[NQ]; lvl_opf(L, gy, gx, xe, y);
-        d = L.fdinv[i];
+        c = px_coef(L, gy, gx);
+        const int ip = (gy >> 1) * Wc + (gx >> 1);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * L.n + i]; s_x[q * LN + p] = xe(gy, gx, q) + (bq[q] - y[q]) * d; }
+        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * L.n + i]; xe[q] = x[(size_t)q * L.n + i] + ec[(size_t)q * nc + ip]; s_a[q * LN + p] = xe[q]; }
+    }
+    __syncthreads();
+    vf x2[NQ];
+    if (ring1) {
+        vf y[NQ]; lds_op<LW, LN>(c, s_a, p, y);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { x2[q] = xe[q] + (bq[q] - y[q]) * c.dinv; s_b[q * LN + p] = x2[q]; }
     }
     __syncthreads();
     if (interior) {
-        auto xv = [&](int r, int c, int q) { return s_x[q * LN + (r - y0 + 1) * LW + (c - x0 + 1)]; };
-        vf y[NQ]; lvl_opf(L, gy, gx, xv, y);
+        vf y[NQ]; lds_op<LW, LN>(c, s_b, p, y);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = xv(gy, gx, q) + (bq[q] - y[q]) * d;
+        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = x2[q] + (bq[q] - y[q]) * c.dinv;
     }
 }
 // r.z partial sums in the canonical block order (256 consecutive pixels per block); z = fp32 V-cycle output, widened exactly
