@@ -279,36 +279,156 @@ __global__ __launch_bounds__(256) void k_pcg_dot(const PState* __restrict__ st, 
     mg_block_reduce<NQ>(acc, partial);
 }
 
-// Coarsest grid (n <= 64 unknowns): `sweeps` damped-Jacobi sweeps from a zero initial guess. One wave per right-hand side, one lane
-// per unknown, the iterate stays in a register and the four neighbours come through ds_bpermute — no LDS round trips, no
-// barriers (the six right-hand sides are independent). Same operation order as lvl_opf: +x, -x, +y, -y.
-// (A 1024-thread LDS version of this took 82 us per cycle, 20 % of the whole V-cycle: profiles/r1f_e2e_kernels.md.)
-__global__ __launch_bounds__(64 * NQ) void k_mg_coarsest(const PState* __restrict__ st, Lvl L, int sweeps) {
+// Tail of the V-cycle: every level with <= 512 pixels (22x22, 11x11, 6x6 at 700x700) in ONE 512-thread workgroup. Thread t owns
+// pixel t of each tail level; iterates travel through LDS (whole grids, no halos), each thread keeps its rhs / pre-smoothed
+// iterate / coefficients of every tail level in registers for the way back up. Replaces 2 launches per level (~4.8 us each, pure
+// latency) by a few barrier-separated LDS phases. The coarsest grid (n <= 64) is solved by `sweeps` damped-Jacobi sweeps from zero
+// with one wave per right-hand side and one lane per unknown: the iterate stays in a register, the neighbours come through
+// ds_bpermute, no barriers (a 1024-thread LDS version of that solve alone took 82 us per cycle: profiles/r1f_e2e_kernels.md).
+// Same expressions and operation order (+x, -x, +y, -y) as k_mg_down / k_mg_up. lv[0] is the first tail level: its rhs lv[0].b
+// was written by the restriction above it, its correction goes to lv[0].x2.
+constexpr int TAIL_N = 512, TAIL_LV = 4;
+struct TailPack { Lvl lv[TAIL_LV]; int nl; };
+__device__ __forceinline__ void tail_op(const PxCoef& c, const vf* __restrict__ s_v, int p, int pitch, vf (&y)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) y[q] = c.d * s_v[q * TAIL_N + p];
+    if (c.r) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= c.w0 * s_v[q * TAIL_N + p + 1]; }
+    if (c.l) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= c.w1 * s_v[q * TAIL_N + p - 1]; }
+    if (c.dn) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= c.w2 * s_v[q * TAIL_N + p + pitch]; }
+    if (c.up) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] -= c.w3 * s_v[q * TAIL_N + p - pitch]; }
+}
+__global__ __launch_bounds__(TAIL_N) void k_mg_tail(const PState* __restrict__ st, TailPack P, int sweeps) {
     if (st->nactive == 0) return;
-    const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
-    const int n = L.n, W = L.W, H = L.H;
-    const bool live = i < n;
-    const int r = live ? i / W : 0, c = live ? i - r * W : 0;
-    vf bq = 0, d = 0, dv = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    const bool has_r = live && c + 1 < W, has_l = live && c > 0, has_d = live && r + 1 < H, has_u = live && r > 0;
-    if (live) {
-        bq = L.b[(size_t)q * n + i]; d = L.fdiag[i]; dv = L.fdinv[i];
-        if (has_r) w0 = L.fwx[i];
-        if (has_l) w1 = L.fwx[i - 1];
-        if (has_d) w2 = L.fwy[i];
-        if (has_u) w3 = L.fwy[i - W];
+    __shared__ vf sA[NQ * TAIL_N], sB[NQ * TAIL_N], sC[NQ * TAIL_N];
+    const int t = threadIdx.x;
+    const int nl = P.nl;
+    vf bs[TAIL_LV][NQ], xs[TAIL_LV][NQ]; PxCoef cs[TAIL_LV];
+    // ---- down
+    {
+        const Lvl& L0 = P.lv[0];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) bs[0][q] = t < L0.n ? L0.b[(size_t)q * L0.n + t] : 0.f;
     }
-    vf x = 0.0f;
-    for (int s = 0; s < sweeps; ++s) {
-        const vf xr = __shfl(x, (i + 1) & 63), xl = __shfl(x, (i - 1) & 63), xd = __shfl(x, (i + W) & 63), xu = __shfl(x, (i - W) & 63);
-        vf y = d * x;
-        if (has_r) y -= w0 * xr;
-        if (has_l) y -= w1 * xl;
-        if (has_d) y -= w2 * xd;
-        if (has_u) y -= w3 * xu;
-        if (live) x = x + (bq - y) * dv;
+#pragma unroll
+    for (int l = 0; l < TAIL_LV - 1; ++l) {
+        if (l < nl - 1) {                                                  // the coarsest level (nl - 1) is solved below
+            const Lvl& L = P.lv[l]; const Lvl& C = P.lv[l + 1];
+            const bool live = t < L.n;
+            const int gy = live ? t / L.W : 0, gx = live ? t - gy * L.W : 0;
+            if (live) {
+                cs[l] = px_coef(L, gy, gx);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) sA[q * TAIL_N + t] = bs[l][q] * cs[l].dinv;
+            }
+            __syncthreads();
+            if (live) {
+                vf y[NQ]; tail_op(cs[l], sA, t, L.W, y);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { const vf x1 = bs[l][q] * cs[l].dinv; xs[l][q] = x1 + (bs[l][q] - y[q]) * cs[l].dinv; sB[q * TAIL_N + t] = xs[l][q]; }
+            }
+            __syncthreads();
+            if (live) {
+                vf yv[NQ]; tail_op(cs[l], sB, t, L.W, yv);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) sA[q * TAIL_N + t] = bs[l][q] - yv[q];
+            }
+            __syncthreads();
+            const bool livec = t < C.n;
+            const int Y = livec ? t / C.W : 0, X = livec ? t - Y * C.W : 0;
+            vf acc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
+            if (livec) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int yy = 2 * Y + (k >> 1), xx = 2 * X + (k & 1);
+                    if (yy < L.H && xx < L.W) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) acc[q] += sA[q * TAIL_N + yy * L.W + xx];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) bs[l + 1][q] = acc[q];
+            __syncthreads();
+        }
     }
-    if (live) L.x[(size_t)q * n + i] = x;
+    // ---- coarsest grid
+    {
+        const Lvl& L = P.lv[nl - 1];
+        const int n = L.n, W = L.W, H = L.H;
+#pragma unroll
+        for (int l = 0; l < TAIL_LV; ++l)
+            if (l == nl - 1 && t < n) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) sA[q * TAIL_N + t] = bs[l][q];
+            }
+        __syncthreads();
+        if (t < 64 * NQ) {
+            const int q = t >> 6, i = t & 63;
+            const bool live = i < n;
+            const int r = live ? i / W : 0, c = live ? i - r * W : 0;
+            vf bq = 0, d = 0, dv = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            const bool has_r = live && c + 1 < W, has_l = live && c > 0, has_d = live && r + 1 < H, has_u = live && r > 0;
+            if (live) {
+                bq = sA[q * TAIL_N + i]; d = L.fdiag[i]; dv = L.fdinv[i];
+                if (has_r) w0 = L.fwx[i];
+                if (has_l) w1 = L.fwx[i - 1];
+                if (has_d) w2 = L.fwy[i];
+                if (has_u) w3 = L.fwy[i - W];
+            }
+            vf x = 0.0f;
+            for (int s = 0; s < sweeps; ++s) {
+                const vf xr = __shfl(x, (i + 1) & 63), xl = __shfl(x, (i - 1) & 63), xd = __shfl(x, (i + W) & 63), xu = __shfl(x, (i - W) & 63);
+                vf y = d * x;
+                if (has_r) y -= w0 * xr;
+                if (has_l) y -= w1 * xl;
+                if (has_d) y -= w2 * xd;
+                if (has_u) y -= w3 * xu;
+                if (live) x = x + (bq - y) * dv;
+            }
+            if (live) { if (nl == 1) L.x2[(size_t)q * n + i] = x; else sC[q * TAIL_N + i] = x; }
+        }
+        __syncthreads();
+    }
+    // ---- up
+#pragma unroll
+    for (int l = TAIL_LV - 2; l >= 0; --l) {
+        if (l >= nl - 1) continue;
+        const Lvl& L = P.lv[l]; const Lvl& C = P.lv[l + 1];
+        const bool live = t < L.n;
+        const int gy = live ? t / L.W : 0, gx = live ? t - gy * L.W : 0;
+        vf xe[NQ], x2[NQ];
+        if (live) {
+            const int ip = (gy >> 1) * C.W + (gx >> 1);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { xe[q] = xs[l][q] + sC[q * TAIL_N + ip]; sA[q * TAIL_N + t] = xe[q]; }
+        }
+        __syncthreads();
+        if (live) {
+            vf y[NQ]; tail_op(cs[l], sA, t, L.W, y);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { x2[q] = xe[q] + (bs[l][q] - y[q]) * cs[l].dinv; sB[q * TAIL_N + t] = x2[q]; }
+        }
+        __syncthreads();
+        if (live) {
+            vf y[NQ]; tail_op(cs[l], sB, t, L.W, y);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const vf v = x2[q] + (bs[l][q] - y[q]) * cs[l].dinv;
+                if (l == 0) L.x2[(size_t)q * L.n + t] = v; else sC[q * TAIL_N + t] = v;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // ---- PCG pieces at the fine level
@@ -451,9 +571,13 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
 
     // z = Vcycle(r). Levels 0..nl-2 run the tile-fused down/up legs (2 launches per level), the coarsest grid one 6-wave kernel.
     // res[l] = where level l's correction ends up (the up leg cannot write in place: neighbouring tiles still read lv[l].x).
-    // Measured (profiles/r1e): running the 44x44..6x6 levels inside ONE workgroup cost 157 us per cycle, more than the separate
-    // ~5 us launches it replaced (a single CU is latency bound on the dependent stencil phases), so every level keeps its own grid.
-    const int tail0 = nl - 1;
+    // The deepest levels (<= 512 pixels) run inside one workgroup (k_mg_tail); 44x44 and up keep their own grids — a single CU doing
+    // the 44x44 level as well was slower than the two ~5 us launches it replaced (profiles/r1e).
+    // tail0 = first level of the single-workgroup tail: the deepest run of levels with <= TAIL_N pixels (at most TAIL_LV of them)
+    int tail0 = nl - 1;
+    while (tail0 > 1 && lv[tail0 - 1].n <= TAIL_N && nl - (tail0 - 1) <= TAIL_LV) --tail0;
+    TailPack pack; memset(&pack, 0, sizeof pack); pack.nl = nl - tail0;
+    for (int l = tail0; l < nl; ++l) pack.lv[l - tail0] = lv[l];
     // Tile shapes: bandwidth-bound levels use TXB x TYB tiles; below 100k pixels the legs are latency bound, so a 16x8 tile whose
     // haloed footprint (18x10) fits one pass of the 256 threads keeps the dependent load chains short and spreads over more CUs.
     constexpr int TXB = NCT_MG_TXB, TYB = NCT_MG_TYB;
@@ -480,8 +604,8 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     };
     auto vcycle = [&]() -> int {
         for (int l = 0; l < tail0; ++l) { down(l); LCHK(); }
-        hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(64 * NQ), 0, s, (const PState*)st, lv[nl - 1], 60); LCHK();
-        for (int l = tail0 - 1; l >= 0; --l) { up(l, l + 1 == nl - 1 ? lv[l + 1].x : lv[l + 1].x2); LCHK(); }
+        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(TAIL_N), 0, s, (const PState*)st, pack, 60); LCHK();
+        for (int l = tail0 - 1; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
         hipLaunchKernelGGL(k_pcg_dot, dim3(nb), dim3(256), 0, s, (const PState*)st, N, (const double*)r, (const vf*)lv[0].x2, (double*)partial); LCHK();
         return 0;
     };
