@@ -258,6 +258,68 @@ __global__ void k_s1_dir(int n, const CGState* __restrict__ st, const double* __
     const size_t j = (size_t)px * 6 + part * 3 + c;            // p is interleaved [pixel][6]; r stays [part][pixel][3]
     p[j] = first ? r[i] : st->vb[c] * p[j] + r[i];
 }
+// ---- fused variants for levels with few partial sums (nb <= S1_FUSE_NB): the two single-workgroup kernels of an iteration
+// (k_cg_alpha, k_cg_beta: ~5 us each, pure latency) disappear — EVERY workgroup of the following vector kernel repeats the
+// fixed-order final reduction of the nb x 3 partials (a few KB out of L2) and derives the scalars itself. Same reductions, same
+// order, same values. The state is double buffered (a workgroup may not overwrite scalars its neighbours still read) and the two
+// dot products use separate partial arrays.
+constexpr int S1_FUSE_NB = 512;
+// beta step + direction update, thread per pixel: state_out = beta(state_in, partial_rr); p = r + vb p   (first: state_out = state_in, p = r)
+__global__ __launch_bounds__(256) void k_s1_dir_f(int n, int nb, const double* __restrict__ partial_rr, const CGState* __restrict__ sin, CGState* __restrict__ sout,
+                                                  double tol2, const double* __restrict__ r, double* __restrict__ p, int first) {
+    double vb[3]; int act[3];
+    if (first) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { vb[c] = 0.0; act[c] = sin->active[c]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = *sin;
+    } else {
+        double sm[3]; final_reduce<3>(partial_rr, nb, sm);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool a = sin->active[c] != 0;
+            vb[c] = a ? sm[c] / sin->r1[c] : sin->vb[c];
+            act[c] = a ? (sm[c] > tol2 ? 1 : 0) : 0;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 3) {
+            const int c = threadIdx.x; const bool a = sin->active[c] != 0;
+            sout->r0[c] = a ? sin->r1[c] : sin->r0[c]; sout->r1[c] = a ? sm[c] : sin->r1[c]; sout->va[c] = sin->va[c]; sout->vb[c] = vb[c];
+            sout->iters[c] = sin->iters[c] + (a ? 1 : 0); sout->active[c] = act[c];
+        }
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (!act[c]) continue;
+            const size_t j = (size_t)i * 6 + part * 3 + c;
+            const double rv = r[((size_t)part * n + i) * 3 + c];
+            p[j] = first ? rv : vb[c] * p[j] + rv;
+        }
+}
+// alpha step + solution/residual update: va = r1 / (p.Ap) from partial_pap ; x += va p ; r -= va Ap ; partial_rr = r.r
+__global__ __launch_bounds__(256) void k_s1_update_f(int n, int nb, const double* __restrict__ partial_pap, const CGState* __restrict__ st, const double* __restrict__ p,
+                                                     const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r, double* __restrict__ partial_rr) {
+    double sm[3]; final_reduce<3>(partial_pap, nb, sm);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[3] = {0, 0, 0};
+    if (i < n) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (!st->active[c]) continue;
+            const double va = st->r1[c] / sm[c];
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const size_t j = ((size_t)part * n + i) * 3 + c;
+                x[j] += va * p[(size_t)i * 6 + part * 3 + c];
+                const double rn = r[j] - va * Ap[j];
+                r[j] = rn; acc[c] += rn * rn;
+            }
+        }
+    }
+    block_reduce_store<3>(acc, partial_rr);
+}
 // [part][n][3] -> [n][6]
 __global__ void k_pack6(int n, const double* __restrict__ x, double* __restrict__ x6) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,9 +431,10 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         DevBuf<unsigned> ek(ctx, (size_t)8 * n), ev(ctx, (size_t)8 * n), eks(ctx, (size_t)8 * n), evs(ctx, (size_t)8 * n);
         DevBuf<int> rstart(ctx, n + 1), rev_src(ctx, (size_t)8 * n);
         DevBuf<double> rev_w(ctx, (size_t)8 * n);
-        DevBuf<CGState> st(ctx, 1);
+        DevBuf<CGState> st(ctx, 2);
+        DevBuf<double> partial2(ctx, (size_t)nbl * 3);
         if (!gx.ok() || !gy.ok() || !daa.ok() || !dab.ok() || !dbb.ok() || !rhs.ok() || !iw2.ok() || !r.ok() || !p.ok() || !Ap.ok() || !partial.ok() ||
-            !ek.ok() || !ev.ok() || !eks.ok() || !evs.ok() || !rstart.ok() || !rev_src.ok() || !rev_w.ok() || !st.ok()) return NCT_ERR_HIP;
+            !ek.ok() || !ev.ok() || !eks.ok() || !evs.ok() || !rstart.ok() || !rev_src.ok() || !rev_w.ok() || !st.ok() || !partial2.ok()) return NCT_ERR_HIP;
         // lambda / alpha / dWeight arrive as float in the reference signature (ColorTransfer.cpp:548-550)
         const float lambda_f = (float)prm.local_weight, alpha_f = (float)prm.wls_alpha, dWeight_f = (float)normFactor;
         hipLaunchKernelGGL(k_gradient_weights, dim3(nbl), dim3(256), 0, s, s_lab_level, h, w, (double)lambda_f, (double)alpha_f, (double*)gx, (double*)gy); LCHK();
@@ -394,17 +457,33 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         const int maxit = layer == 4 ? 50 : 100;                       // ColorTransfer.cpp:916-921
         hipLaunchKernelGGL(k_pack6, dim3(cdiv(6 * n, 256)), dim3(256), 0, s, n, (const double*)x, (double*)p); LCHK();
         hipLaunchKernelGGL(k_s1_residual, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (const double*)rhs, (double*)r, (double*)partial); LCHK();
-        hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2, 3); LCHK();
-        for (int k = 1; k <= maxit; ++k) {
-            hipLaunchKernelGGL(k_s1_dir, dim3(cdiv(6 * n, 256)), dim3(256), 0, s, n, (const CGState*)st, (const double*)r, (double*)p, k == 1 ? 1 : 0); LCHK();
-            hipLaunchKernelGGL(k_s1_apply, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial); LCHK();
-            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st); LCHK();
-            hipLaunchKernelGGL(k_s1_update, dim3(nbl), dim3(256), 0, s, n, (const CGState*)st, (const double*)p, (const double*)Ap, (double*)x, (double*)r, (double*)partial); LCHK();
-            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2); LCHK();
+        CGState* st_final = (CGState*)st;
+        if (nbl <= S1_FUSE_NB) {
+            // 3 launches per iteration; state ping-pongs between S[0] and S[1] (iteration k reads S[k&1], writes S[(k+1)&1])
+            CGState* S2[2] = {(CGState*)st, (CGState*)st + 1};
+            hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, S2[1], tol2, 3); LCHK();
+            for (int k = 1; k <= maxit; ++k) {
+                hipLaunchKernelGGL(k_s1_dir_f, dim3(nbl), dim3(256), 0, s, n, nbl, (const double*)partial2, (const CGState*)S2[k & 1], S2[(k + 1) & 1], tol2,
+                                   (const double*)r, (double*)p, k == 1 ? 1 : 0); LCHK();
+                hipLaunchKernelGGL(k_s1_apply, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial); LCHK();
+                hipLaunchKernelGGL(k_s1_update_f, dim3(nbl), dim3(256), 0, s, n, nbl, (const double*)partial, (const CGState*)S2[(k + 1) & 1], (const double*)p, (const double*)Ap,
+                                   (double*)x, (double*)r, (double*)partial2); LCHK();
+            }
+            st_final = S2[(maxit + 1) & 1];
+            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, s, (const double*)partial2, nbl, st_final, tol2); LCHK();   // the last beta step (iteration count, final r.r)
+        } else {
+            hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2, 3); LCHK();
+            for (int k = 1; k <= maxit; ++k) {
+                hipLaunchKernelGGL(k_s1_dir, dim3(cdiv(6 * n, 256)), dim3(256), 0, s, n, (const CGState*)st, (const double*)r, (double*)p, k == 1 ? 1 : 0); LCHK();
+                hipLaunchKernelGGL(k_s1_apply, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial); LCHK();
+                hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st); LCHK();
+                hipLaunchKernelGGL(k_s1_update, dim3(nbl), dim3(256), 0, s, n, (const CGState*)st, (const double*)p, (const double*)Ap, (double*)x, (double*)r, (double*)partial); LCHK();
+                hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2); LCHK();
+            }
         }
         if (dbg && dbg->cg_iters) {
             CGState hst;
-            NCT_HIP(hipMemcpyAsync(&hst, (CGState*)st, sizeof hst, hipMemcpyDeviceToHost, s));
+            NCT_HIP(hipMemcpyAsync(&hst, st_final, sizeof hst, hipMemcpyDeviceToHost, s));
             NCT_HIP(hipStreamSynchronize(s));
             for (int c = 0; c < 3; ++c) dbg->cg_iters[c] = hst.iters[c];
         }
