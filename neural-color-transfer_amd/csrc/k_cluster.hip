@@ -49,6 +49,7 @@ __device__ float l2_ff(const float* __restrict__ a, const float* __restrict__ b,
 }
 
 constexpr int KM_MAXK = 16;
+constexpr int KM_LDS_PERM = 4096;
 struct KMState { int cidx[KM_MAXK]; int count[KM_MAXK]; unsigned radius[KM_MAXK]; int nc, changed, done; };
 
 // centre selection (chooseCentersRandom with a SplitMix64 Fisher-Yates permutation) — one thread, ~n steps
@@ -58,9 +59,13 @@ __global__ void k_km_init(const float* __restrict__ feat, int n, int C, int K, u
     st->nc = 0; st->changed = 0; st->done = 0;
     for (int i = 0; i < KM_MAXK; ++i) { st->count[i] = 0; st->radius[i] = 0u; }
     if (n < K) { st->done = 1; return; }
-    for (int i = 0; i < n; ++i) perm[i] = i;
+    // the shuffle is inherently serial (n dependent swaps); in LDS a swap costs ~50 ns instead of two global round trips
+    __shared__ int s_perm[KM_LDS_PERM];
+    int* pm = n <= KM_LDS_PERM ? s_perm : perm;
+    for (int i = 0; i < n; ++i) pm[i] = i;
     uint64_t sd = seed;
-    for (int i = n - 1; i > 0; --i) { const int j = (int)(sm64(sd) % (uint64_t)(i + 1)); const int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
+    for (int i = n - 1; i > 0; --i) { const int j = (int)(sm64(sd) % (uint64_t)(i + 1)); const int t = pm[i]; pm[i] = pm[j]; pm[j] = t; }
+    if (pm != perm) for (int i = 0; i < n; ++i) perm[i] = pm[i];
     int pos = 0, nc = 0; bool out = false;
     for (int index = 0; index < K && !out; ++index) {
         bool dup = true;
@@ -83,8 +88,17 @@ __global__ void k_km_centres(const float* __restrict__ feat, int n, int C, int K
     if (i >= K * C) return;
     const int c = i / C, k = i - c * C;
     if (first) { dc[i] = (double)feat[(size_t)st->cidx[c] * C + k]; return; }
+    // members are added in point order (that order defines the fp64 sum); the loads of eight points are issued together
     double s = 0.0;
-    for (int p = 0; p < n; ++p) if (labels[p] == c) s += (double)feat[(size_t)p * C + k];
+    int p = 0;
+    for (; p + 8 <= n; p += 8) {
+        int lb[8]; float f[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { lb[u] = labels[p + u]; f[u] = feat[(size_t)(p + u) * C + k]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (lb[u] == c) s += (double)f[u];
+    }
+    for (; p < n; ++p) if (labels[p] == c) s += (double)feat[(size_t)p * C + k];
     dc[i] = s / (double)st->count[c];
 }
 __global__ void k_km_dist(const float* __restrict__ feat, int n, int C, int K, const double* __restrict__ dc, const KMState* __restrict__ st, float* __restrict__ dist) {
