@@ -172,14 +172,16 @@ def patchmatch_roofline(nct, synth, device, S):
     # HBM/fabric-side bytes per launch come from the recorded, calibrated PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     # cannot run inside this process); they apply to the 700x700 workload only.
     traffic = None
-    pmc = os.path.join(REPO, "profiles", "r1_pmc_patchmatch.json")
+    pmc = os.path.join(REPO, "profiles", "r1s_pmc_patchmatch.json")
     if S == 700 and os.path.exists(pmc):
         traffic = json.load(open(pmc))["corrected_bytes_per_launch"]["total"]
+    traffic_gbs = None if traffic is None else traffic / (ms / n_launch * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": f"k_pm_step<1> (C=64, {S}x{S}, one direction per launch, 10 iters x 2 directions)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launch,
             "avg_launch_ms": ms / n_launch, "algorithmic_bytes_per_launch": alg / n_launch, "evals": evals,
+            "traffic_GBs": traffic_gbs, "traffic_frac_of_peak": None if traffic_gbs is None else traffic_gbs / HBM_PEAK_GBS,
             "note": "algorithmic bytes (SURVEY 8d) exceed the memory-side traffic: overlapping candidate tiles are served by L1/L2 "
-                    "(traffic = FETCH_SIZE x2 (gfx950 correction, calibrated) + WRITE_SIZE per launch, profiles/r1_pmc_patchmatch.json)"}
+                    "(traffic = FETCH_SIZE x2 (gfx950 correction, calibrated) + WRITE_SIZE per launch, profiles/r1s_pmc_patchmatch.json; traffic_GBs = that traffic over this run's launch time)"}
 
 
 def vgg_mfma(S, vgg_ms):
