@@ -291,25 +291,33 @@ __global__ void k_knn_merge(int npix, const int* __restrict__ nslot, const doubl
                             int* __restrict__ knn_id, double* __restrict__ knn_w) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
-    const int total = nslot[i] * KNN_K;
+    // every slot list is already sorted by (dist, id) with -1 padding at the end: a <=5-way merge with the heads in registers
+    // emits the unique entries in ascending (dist, id) order (= sort + dedupe of the reference; equal ids carry equal distances)
+    const int ns = nslot[i];
     const double* cd = cand_d + (size_t)i * KNN_SLOTS * KNN_K;
     const int* ci = cand_id + (size_t)i * KNN_SLOTS * KNN_K;
-    double last_d = -1.0; int last_id = -1, lp = 0;
-    // selection by repeated minimum over <= 40 entries strictly greater than the last emitted (dist,id)
+    double hd[KNN_SLOTS]; int hi[KNN_SLOTS], pos[KNN_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < KNN_SLOTS; ++sl) {
+        pos[sl] = 0; hi[sl] = -1; hd[sl] = 1e300;
+        if (sl < ns) { hi[sl] = ci[sl * KNN_K]; hd[sl] = cd[sl * KNN_K]; }
+    }
+    int lp = 0;
     while (lp < KNN_K) {
         double bd = 1e300; int bid = -1;
-        for (int t = 0; t < total; ++t) {
-            const int id = ci[t];
-            if (id < 0) continue;
-            const double d = cd[t];
-            const bool after = (last_id < 0) || ent_less(last_d, last_id, d, id);
-            if (after && (bid < 0 || ent_less(d, id, bd, bid))) { bd = d; bid = id; }
-        }
+#pragma unroll
+        for (int sl = 0; sl < KNN_SLOTS; ++sl)
+            if (hi[sl] >= 0 && (bid < 0 || ent_less(hd[sl], hi[sl], bd, bid))) { bd = hd[sl]; bid = hi[sl]; }
         if (bid < 0) break;
-        // the reference dedupes on consecutive equal ids after sorting by (dist,id): equal ids have equal distances
         knn_id[(size_t)i * KNN_K + lp] = bid;
         knn_w[(size_t)i * KNN_K + lp] = nct_exp(1.0 - bd / 3.0);
-        last_d = bd; last_id = bid; ++lp;
+        ++lp;
+#pragma unroll
+        for (int sl = 0; sl < KNN_SLOTS; ++sl)
+            if (hi[sl] == bid) {
+                ++pos[sl];
+                if (pos[sl] < KNN_K) { hi[sl] = ci[sl * KNN_K + pos[sl]]; hd[sl] = cd[sl * KNN_K + pos[sl]]; } else hi[sl] = -1;
+            }
     }
     for (; lp < KNN_K; ++lp) { knn_id[(size_t)i * KNN_K + lp] = i; knn_w[(size_t)i * KNN_K + lp] = 0.0; }
 }
