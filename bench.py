@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=700, help="image side (BASELINE config 2 = 700)")
     ap.add_argument("--inflight", type=int, default=2, help="independent pairs in flight per GPU per step (batch size)")
+    ap.add_argument("--dist-backend", default="nccl", help="[test hook] torch.distributed backend (gloo exercises the N>1 path on a 1-GPU box)")
+    ap.add_argument("--device-override", type=int, default=-1, help="[test hook] run every rank on this device instead of LOCAL_RANK")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -51,12 +53,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.device_override >= 0:
+        local_rank = args.device_override
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.dist_backend)
 
     import nct
     import synth
@@ -108,7 +115,7 @@ def main():
             t.join()
 
     elapsed = timed_region(step, args.steps, args.warmup, dist=dist, sync=sync,
-                           device=torch.device("cuda", local_rank) if dist is not None else None)
+                           device=torch.device("cuda", local_rank) if (dist is not None and args.dist_backend == "nccl") else None)
 
     # single-pair latency (nothing else on the GPU), host-in -> host-out rate for DESIGN.md (never `value`), per-stage times
     t1 = time.perf_counter()
