@@ -83,36 +83,59 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};   // [cout tile][pixel tile]
     // Software pipeline in registers: the 36 operands of channel pair c2+2 are requested before the 36 MFMAs of pair c2 issue
     // (36 x 64 = 2304 cycles of matrix work cover the L1/L2 latency of the next pair even at one wave per SIMD).
-    float a0c[9], a1c[9], b0c[9], b1c[9], a0n[9], a1n[9], b0n[9], b1n[9];
+    // Two register sets in ping-pong, no copies: while the 36 MFMAs of one channel pair issue (36 x 64 = 2304 cycles of matrix work),
+    // the 36 operand loads of the next pair are in flight. load_pair only ISSUES loads (raw values); the out-of-image select is
+    // applied right before each MFMA group, so the only s_waitcnt in front of an MFMA block is for loads issued a whole block
+    // earlier. (Selects or register copies directly behind the loads put the full L2 latency in front of every block: the conv
+    // layers ran at 55-60 % MFMA utilisation that way.)
+    float a0x[9], a1x[9], b0x[9], b1x[9], a0y[9], a1y[9], b0y[9], b1y[9];
     auto load_pair = [&](float (&a0)[9], float (&a1)[9], float (&b0)[9], float (&b1)[9]) {
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             a0[s] = ap[(size_t)(2 * s) * g.Cout];
             a1[s] = ap[(size_t)(2 * s) * g.Cout + 32];
-            const float t0 = b0p[off0[s]], t1 = b1p[off1[s]];
-            b0[s] = ((vm0 >> s) & 1u) ? t0 : 0.f;
-            b1[s] = ((vm1 >> s) & 1u) ? t1 : 0.f;
+            b0[s] = b0p[off0[s]];
+            b1[s] = b1p[off1[s]];
         }
         ap += (size_t)18 * g.Cout;
         b0p += (size_t)2 * HW;
         b1p += (size_t)2 * HW;
     };
-    load_pair(a0c, a1c, b0c, b1c);
-    for (int c2 = 0; c2 < g.Cin; c2 += 2) {
-        const bool more = c2 + 2 < g.Cin;
-        if (more) load_pair(a0n, a1n, b0n, b1n);
+    auto mma_pair = [&](const float (&a0)[9], const float (&a1)[9], const float (&b0)[9], const float (&b1)[9]) {
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c[s], b0c[s], acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c[s], b1c[s], acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c[s], b0c[s], acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c[s], b1c[s], acc11, 0, 0, 0);
+            const float x0 = ((vm0 >> s) & 1u) ? b0[s] : 0.f, x1 = ((vm1 >> s) & 1u) ? b1[s] : 0.f;
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], x0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], x1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x1, acc11, 0, 0, 0);
         }
-        if (more) {
+    };
+    // schedule of one half iteration: MFMA, load, MFMA, load, ... — the 36 loads ride in the shadow of the 36 MFMAs instead of
+    // draining the matrix pipe while they issue in one burst
+    auto interleave = [] {
 #pragma unroll
-            for (int s = 0; s < 9; ++s) { a0c[s] = a0n[s]; a1c[s] = a1n[s]; b0c[s] = b0n[s]; b1c[s] = b1n[s]; }
+        for (int i = 0; i < 36; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one VMEM read
         }
+    };
+    load_pair(a0x, a1x, b0x, b1x);
+    int c2 = 0;
+    for (; c2 + 4 <= g.Cin; c2 += 4) {
+        load_pair(a0y, a1y, b0y, b1y);                            // channels c2+2, c2+3
+        mma_pair(a0x, a1x, b0x, b1x);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        // channels c2+4, c2+5 — unconditionally: a branch around these loads makes the waitcnt pass assume they were NOT issued and
+        // drain everything inside the next MFMA block. Past the last pair the pointers are rewound and the (unused) loads re-read it.
+        if (c2 + 4 >= g.Cin) { ap -= (size_t)18 * g.Cout; b0p -= (size_t)2 * HW; b1p -= (size_t)2 * HW; }
+        load_pair(a0x, a1x, b0x, b1x);
+        mma_pair(a0y, a1y, b0y, b1y);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (c2 < g.Cin) mma_pair(a0x, a1x, b0x, b1x);                 // odd number of channel pairs
 
     // epilogue: D row (cout) = (r&3) + 8*(r>>2) + 4*half, D col (pixel) = l31
 #pragma unroll
