@@ -20,7 +20,7 @@
 #include <climits>
 
 #ifndef NCT_PM_FAST_MAX
-#define NCT_PM_FAST_MAX 1
+#define NCT_PM_FAST_MAX 2
 #endif
 struct PMGeom { int C, ah, aw, bh, bw, tiles_x, tiles_y; };
 
@@ -42,13 +42,25 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
             const float4* pbc = reinterpret_cast<const float4*>(B) + (size_t)(unsigned)(by * g.bw + bx) * C4 + v;
             const float4* pac = a_lds + ((ly + 1) * 6 + (lx + 1)) * C4 + v;
             float facc = 0.f;
+            if constexpr (NCH == 1) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = t / 3 - 1, dx = t % 3 - 1;
-                const float4* pb = pbc + (dy * g.bw + dx) * C4;
-                const float4* pa = pac + (dy * 6 + dx) * C4;
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3 - 1, dx = t % 3 - 1;
+                    const float4* pb = pbc + (dy * g.bw + dx) * C4;
+                    const float4* pa = pac + (dy * 6 + dx) * C4;
+                    facc = dot4_acc(pa[0], pb[0], facc);
+                }
+            } else {
+                // one patch row (3 taps x NCH chunks) at a time: bounds the loads in flight, and with them the register count
+#pragma unroll 1
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const float4* pbr = pbc + dy * g.bw * C4;
+                    const float4* par = pac + dy * 6 * C4;
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) facc = dot4_acc(pa[16 * k], pb[16 * k], facc);
+                    for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) facc = dot4_acc(par[dx * C4 + 16 * k], pbr[dx * C4 + 16 * k], facc);
+                }
             }
             return (-row16_sum(facc)) / 9.0f;
         }
