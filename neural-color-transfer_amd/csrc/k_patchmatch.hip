@@ -32,9 +32,10 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
     // Fast path: when every tap of the query AND of the candidate lies inside its image — for every query of the wave, so the
     // branch is uniform — the nine B rows are the centre pointer plus wave-uniform offsets, the nine LDS rows are immediates,
     // nothing is masked and n = 9: ~70 VALU instructions per evaluation instead of ~270 (clamps, validity tests, selects and 64-bit
-    // address arithmetic per tap). Same fmaf chain, same result. It buys only 6.5 % at C = 64 (profiles/r1l): the kernel is bound by
-    // the L2-miss traffic (5.3 TB/s on the fabric side, PMC FETCH_SIZE), not by issue slots; for C >= 128 the 18+ loads in flight
-    // cost more occupancy than the shorter instruction stream returns, so those instantiations keep the general loop.
+    // address arithmetic per tap). Same fmaf chain, same result. It buys 6.5 % at C = 64 and ~20 % at C = 128 (one patch row at a time,
+    // to bound the loads in flight): the kernel is bound by the L2-miss traffic (5.4 TB/s on the fabric side, PMC FETCH_SIZE), not by
+    // issue slots; for C >= 256 the fast path measured slower (the LDS-staged 36-73 KB query regions already limit occupancy), so
+    // those instantiations keep the general loop.
     if constexpr (NCH >= 1 && NCH <= NCT_PM_FAST_MAX && !AREG) {
         const bool inside = amask == 0x1FFu && bx >= 1 && bx < g.bw - 1 && by >= 1 && by < g.bh - 1;
         if (__builtin_amdgcn_ballot_w64(inside) == __builtin_amdgcn_ballot_w64(true)) {
