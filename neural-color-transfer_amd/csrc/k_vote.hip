@@ -147,13 +147,8 @@ __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restric
     if (pw_out && v == 0) pw_out[pix] = pw;
 }
 
-int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, const uint32_t* bnn, const float* pin_hwc, float* pout_hwc, float* pw,
-                           int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp) {
-    NCT_REQUIRE(C > 0 && (C & 3) == 0 && C <= 512, "bds_vote_features: C=%d must be a multiple of 4 and <= 512", C);
-    InvMap inv(ctx, bh * bw, ah * aw);
-    if (!inv.ok()) return NCT_ERR_HIP;
-    int rc = build_inverse(ctx, s, bnn, bh, bw, ah, aw, inv);
-    if (rc) return rc;
+static int launch_vote_features(nct_ctx* ctx, hipStream_t s, const InvMap& inv, const uint32_t* ann, const float* pin_hwc, float* pout_hwc, float* pw,
+                                int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp) {
     const double wa = w_coh / (double)(aw * ah);
     const double wb = w_comp / (double)(bw * bh);
     dim3 grid(cdiv(ah * aw, 16)), block(256);
@@ -169,6 +164,15 @@ int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, con
 #undef NCT_VOTE_LAUNCH
     NCT_LAUNCH_CHECK();
     return 0;
+}
+int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, const uint32_t* bnn, const float* pin_hwc, float* pout_hwc, float* pw,
+                           int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp) {
+    NCT_REQUIRE(C > 0 && (C & 3) == 0 && C <= 512, "bds_vote_features: C=%d must be a multiple of 4 and <= 512", C);
+    InvMap inv(ctx, bh * bw, ah * aw);
+    if (!inv.ok()) return NCT_ERR_HIP;
+    int rc = build_inverse(ctx, s, bnn, bh, bw, ah, aw, inv);
+    if (rc) return rc;
+    return launch_vote_features(ctx, s, inv, ann, pin_hwc, pout_hwc, pw, C, ah, aw, bh, bw, w_coh, w_comp);
 }
 
 // ---------------------------------------------------------------- B1 image vote (one thread per S pixel; integer sums)
@@ -202,16 +206,32 @@ __global__ void k_vote_image(const uint8_t* __restrict__ b, const uint32_t* __re
     out[(size_t)pix * 3 + 2] = (uint8_t)((a2 * wa + b2 * wb) / den);
 }
 
-int nctk_bds_vote_image(nct_ctx* ctx, hipStream_t s, const uint8_t* b_bgr, const uint32_t* ann, const uint32_t* bnn,
-                        int ah, int aw, int bh, int bw, double w_coh, double w_comp, uint8_t* out_bgr) {
-    InvMap inv(ctx, bh * bw, ah * aw);
-    if (!inv.ok()) return NCT_ERR_HIP;
-    int rc = build_inverse(ctx, s, bnn, bh, bw, ah, aw, inv);
-    if (rc) return rc;
+static int launch_vote_image(nct_ctx* ctx, hipStream_t s, const InvMap& inv, const uint8_t* b_bgr, const uint32_t* ann,
+                             int ah, int aw, int bh, int bw, double w_coh, double w_comp, uint8_t* out_bgr) {
     const double wa = w_coh / (double)(aw * ah);
     const double wb = w_comp / (double)(bw * bh);
     hipLaunchKernelGGL(k_vote_image, dim3(cdiv(ah * aw, 256)), dim3(256), 0, s, b_bgr, ann, (const uint32_t*)inv.vals_s, (const int*)inv.start,
                        ah, aw, bh, bw, wa, wb, out_bgr);
     NCT_LAUNCH_CHECK();
     return 0;
+}
+int nctk_bds_vote_image(nct_ctx* ctx, hipStream_t s, const uint8_t* b_bgr, const uint32_t* ann, const uint32_t* bnn,
+                        int ah, int aw, int bh, int bw, double w_coh, double w_comp, uint8_t* out_bgr) {
+    InvMap inv(ctx, bh * bw, ah * aw);
+    if (!inv.ok()) return NCT_ERR_HIP;
+    int rc = build_inverse(ctx, s, bnn, bh, bw, ah, aw, inv);
+    if (rc) return rc;
+    return launch_vote_image(ctx, s, inv, b_bgr, ann, ah, aw, bh, bw, w_coh, w_comp, out_bgr);
+}
+// both votes of a level (main.cu:291 and :303-318) from ONE inversion of the R->S field
+int nctk_bds_vote_both(nct_ctx* ctx, hipStream_t s, const uint8_t* b_bgr, const float* pin_hwc, const uint32_t* ann, const uint32_t* bnn, int C,
+                       int ah, int aw, int bh, int bw, double w_coh, double w_comp, uint8_t* out_bgr, float* pout_hwc) {
+    NCT_REQUIRE(C > 0 && (C & 3) == 0 && C <= 512, "bds_vote: C=%d must be a multiple of 4 and <= 512", C);
+    InvMap inv(ctx, bh * bw, ah * aw);
+    if (!inv.ok()) return NCT_ERR_HIP;
+    int rc = build_inverse(ctx, s, bnn, bh, bw, ah, aw, inv);
+    if (rc) return rc;
+    rc = launch_vote_image(ctx, s, inv, b_bgr, ann, ah, aw, bh, bw, w_coh, w_comp, out_bgr);
+    if (rc) return rc;
+    return launch_vote_features(ctx, s, inv, ann, pin_hwc, pout_hwc, nullptr, C, ah, aw, bh, bw, (float)w_coh, (float)w_comp);
 }

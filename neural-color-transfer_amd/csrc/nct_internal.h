@@ -102,3 +102,5 @@ int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, con
                            int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp);
 int nctk_bds_vote_image(nct_ctx* ctx, hipStream_t s, const uint8_t* b_bgr, const uint32_t* ann, const uint32_t* bnn,
                         int ah, int aw, int bh, int bw, double w_coh, double w_comp, uint8_t* out_bgr);
+int nctk_bds_vote_both(nct_ctx* ctx, hipStream_t s, const uint8_t* b_bgr, const float* pin_hwc, const uint32_t* ann, const uint32_t* bnn, int C,
+                       int ah, int aw, int bh, int bw, double w_coh, double w_comp, uint8_t* out_bgr, float* pout_hwc);

@@ -166,8 +166,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         rc = nctk_patchmatch_bidir(ctx, s, na, nb, C, ah[l], aw[l], bh[l], bw[l], prm->pm_iters, rs_range[l], seed_ab, seed_ba, ann, annd, bnn, bnnd); if (rc) return rc;
         clk.lap(timing ? &timing->patchmatch_ms : nullptr);
         // BDS votes: guidance image (main.cu:291) and features + matching error (main.cu:303-318)
-        rc = nctk_bds_vote_image(ctx, s, rimg[l], ann, bnn, ah[l], aw[l], bh[l], bw[l], 1.0, prm->bds_weight, guide); if (rc) return rc;
-        rc = nctk_bds_vote_features(ctx, s, ann, bnn, *rfeat[l], voted, nullptr, C, ah[l], aw[l], bh[l], bw[l], 1.f, (float)prm->bds_weight); if (rc) return rc;
+        rc = nctk_bds_vote_both(ctx, s, rimg[l], *rfeat[l], ann, bnn, C, ah[l], aw[l], bh[l], bw[l], 1.0, prm->bds_weight, guide, voted); if (rc) return rc;
         rc = nctk_normalize(ctx, s, voted, nvoted, nullptr, C, na_px); if (rc) return rc;
         rc = nctk_feature_distance(ctx, s, na, nvoted, err, C, na_px); if (rc) return rc;
         clk.lap(timing ? &timing->vote_ms : nullptr);
