@@ -25,10 +25,9 @@
 struct PMGeom { int C, ah, aw, bh, bw, tiles_x, tiles_y; };
 
 // ---- distance of query (ax,ay) to candidate (bx,by): -(sum over valid taps of <a,b>) / n_valid
-template <int NCH, bool AREG>
-__device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const PMGeom& g,
-                                         const float4 (&areg)[9][NCH > 0 ? NCH : 1], int ax, int ay, unsigned amask,
-                                         int bx, int by, int v, const float4* __restrict__ a_lds = nullptr, int lx = 0, int ly = 0) {
+template <int NCH>
+__device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const PMGeom& g, int ax, int ay, unsigned amask,
+                                         int bx, int by, int v, const float4* __restrict__ a_lds, int lx, int ly) {
     // Fast path: when every tap of the query AND of the candidate lies inside its image — for every query of the wave, so the
     // branch is uniform — the nine B rows are the centre pointer plus wave-uniform offsets, the nine LDS rows are immediates,
     // nothing is masked and n = 9: ~70 VALU instructions per evaluation instead of ~270 (clamps, validity tests, selects and 64-bit
@@ -36,7 +35,7 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
     // to bound the loads in flight): the kernel is bound by the L2-miss traffic (5.4 TB/s on the fabric side, PMC FETCH_SIZE), not by
     // issue slots; for C >= 256 the fast path measured slower (the LDS-staged 36-73 KB query regions already limit occupancy), so
     // those instantiations keep the general loop.
-    if constexpr (NCH >= 1 && NCH <= NCT_PM_FAST_MAX && !AREG) {
+    if constexpr (NCH >= 1 && NCH <= NCT_PM_FAST_MAX) {
         const bool inside = amask == 0x1FFu && bx >= 1 && bx < g.bw - 1 && by >= 1 && by < g.bh - 1;
         if (__builtin_amdgcn_ballot_w64(inside) == __builtin_amdgcn_ballot_w64(true)) {
             constexpr int C4 = 16 * NCH;
@@ -77,33 +76,24 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
         const int yc = clampi(yy, 0, g.bh - 1), xc = clampi(xx, 0, g.bw - 1);
         const float4* pb = reinterpret_cast<const float4*>(B + ((size_t)yc * g.bw + xc) * g.C);
         n += valid ? 1 : 0;
-        if constexpr (AREG) {
+        const int yac = clampi(ay + dy, 0, g.ah - 1), xac = clampi(ax + dx, 0, g.aw - 1);
+        // C = 64*NCH: the workgroup's 6x6xC query region sits in LDS (a_lds); generic C reads the query tile through L1
+        const float4* pa = (NCH >= 1) ? a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * (g.C >> 2)
+                                      : reinterpret_cast<const float4*>(A + ((size_t)yac * g.aw + xac) * g.C);
+        if constexpr (NCH > 0) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
+                float4 a = pa[v + 16 * k];
                 float4 b = pb[v + 16 * k];
                 if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);     // adding +0 products == skipping the tap
-                acc = dot4_acc(areg[t][k], b, acc);
+                acc = dot4_acc(a, b, acc);
             }
         } else {
-            const int yac = clampi(ay + dy, 0, g.ah - 1), xac = clampi(ax + dx, 0, g.aw - 1);
-            // C >= 256: the workgroup's 6x6xC query region sits in LDS (a_lds); otherwise read the query tile through L1
-            const float4* pa = (NCH >= 1) ? a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * (g.C >> 2)
-                                          : reinterpret_cast<const float4*>(A + ((size_t)yac * g.aw + xac) * g.C);
-            if constexpr (NCH > 0) {
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) {
-                    float4 a = pa[v + 16 * k];
-                    float4 b = pb[v + 16 * k];
-                    if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);
-                    acc = dot4_acc(a, b, acc);
-                }
-            } else {
-                for (int j = v; j < nchunk; j += 16) {
-                    float4 a = pa[j];
-                    float4 b = pb[j];
-                    if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);
-                    acc = dot4_acc(a, b, acc);
-                }
+            for (int j = v; j < nchunk; j += 16) {
+                float4 a = pa[j];
+                float4 b = pb[j];
+                if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = dot4_acc(a, b, acc);
             }
         }
     }
@@ -120,7 +110,6 @@ struct PMJob { const float* A; const float* B; const uint32_t* nnf_in; const flo
 template <int NCH>
 __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
                                                  unsigned long long* __restrict__ counter) {
-    constexpr bool AREG = false;   // experiment: query region always in LDS
     const bool second = (int)blockIdx.x >= nblk0;
     const PMJob& J = second ? j1 : j0;
     const float* __restrict__ A = J.A; const float* __restrict__ B = J.B;
@@ -143,9 +132,8 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
     const int qi = ay * g.aw + ax;
     const int lx = ax - tx * 4, ly = ay - ty * 4;       // position inside the 4x4 query tile (clamped queries stay inside the region)
 
-    // C >= 256: stage the 6x6xC region of A that the 16 queries of this workgroup read (their 3x3 tiles overlap) into LDS once
-    // per launch: 36 KB (C=256) / 72 KB (C=512). Without it every evaluation re-reads its 9*C*4-byte query tile and four such
-    // tiles per wave overflow the 32 KB L1.
+    // stage the 6x6xC region of A that the 16 queries of this workgroup read (their 3x3 tiles overlap) into LDS once per launch:
+    // 9 KB (C=64) ... 72 KB (C=512). Without it every evaluation re-reads its 9*C*4-byte query tile through L1.
     extern __shared__ float4 s_a[];
     if constexpr (NCH >= 1) {
         const int c4 = g.C >> 2;
@@ -157,21 +145,13 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
         __syncthreads();
     }
 
-    // validity of the query's own taps + (optionally) its tile in registers
+    // validity of the query's own taps
     unsigned amask = 0;
-    float4 areg[9][NCH > 0 ? NCH : 1];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int dy = t / 3 - 1, dx = t % 3 - 1;
         const int yy = ay + dy, xx = ax + dx;
-        const bool va = yy >= 0 && yy < g.ah && xx >= 0 && xx < g.aw;
-        amask |= (va ? 1u : 0u) << t;
-        if constexpr (AREG) {
-            const int yc = clampi(yy, 0, g.ah - 1), xc = clampi(xx, 0, g.aw - 1);
-            const float4* pa = reinterpret_cast<const float4*>(A + ((size_t)yc * g.aw + xc) * g.C);
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) areg[t][k] = pa[v + 16 * k];
-        }
+        amask |= ((yy >= 0 && yy < g.ah && xx >= 0 && xx < g.aw) ? 1u : 0u) << t;
     }
 
     uint32_t vbest = nnf_in[qi];
@@ -180,7 +160,7 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
     unsigned nevals = 0;
 
     if (mode == 0) {
-        dbest = pm_dist<NCH, AREG>(A, B, g, areg, ax, ay, amask, xbest, ybest, v, s_a, lx, ly);
+        dbest = pm_dist<NCH>(A, B, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly);
         float cut = (float)INT_MAX;                 // dist_single default cutoff
         if (dbest >= cut) dbest = cut;
         nevals = 1;
@@ -214,7 +194,7 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
                 valid = true; rr = FLT_MIN;
             }
             if (valid) {
-                float d = pm_dist<NCH, AREG>(A, B, g, areg, ax, ay, amask, xp, yp, v, s_a, lx, ly);
+                float d = pm_dist<NCH>(A, B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly);
                 if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
                 if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; }
                 ++nevals;
