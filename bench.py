@@ -3,10 +3,10 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 A "step" = one full pass of the hot path (VGG19 features, k-means, L=5->1 PatchMatch both ways, BDS votes, kNN graph,
-nonlocal + WLS colour solves, re-predicts) over one batch of `--inflight` (default 2) synthetic 700x700 source/reference pairs
+nonlocal + WLS colour solves, re-predicts) over one batch of `--inflight` (default 4) synthetic 700x700 source/reference pairs
 per GPU — BASELINE config 2. The pairs of a batch are independent jobs (own context, streams, arena, host thread) that run
-concurrently on the GPU: the launch-latency-bound phases of one overlap the heavy kernels of the other (+20 % pairs/s at 2,
-+27 % at 4 in flight; `--inflight 1` gives the single-pair latency, reported as `single_pair_ms` either way).
+concurrently on the GPU: the launch-latency-bound phases of one overlap the heavy kernels of the others (+17 % pairs/s at 2,
++24 % at 4 in flight, ~2.6 GB of HBM each; `--inflight 1` gives the single-pair latency, reported as `single_pair_ms` either way).
 `value` = pairs/s summed over ranks, inputs resident in HBM when the timed region starts (nct_pair_run only).
 
 Extra objects:
@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=700, help="image side (BASELINE config 2 = 700)")
-    ap.add_argument("--inflight", type=int, default=2, help="independent pairs in flight per GPU per step (batch size)")
+    ap.add_argument("--inflight", type=int, default=4, help="independent pairs in flight per GPU per step (batch size)")
     ap.add_argument("--dist-backend", default="nccl", help="[test hook] torch.distributed backend (gloo exercises the N>1 path on a 1-GPU box)")
     ap.add_argument("--device-override", type=int, default=-1, help="[test hook] run every rank on this device instead of LOCAL_RANK")
     ap.add_argument("--no-cpu-baseline", action="store_true")
