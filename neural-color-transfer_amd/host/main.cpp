@@ -161,9 +161,12 @@ int main(int argc, char** argv) {
         if (nct_vgg19_load_caffemodel(ctxs[j], model.c_str()) != NCT_OK) { printf("Error: %s\n", nct_last_error(ctxs[j])); return -1; }
     }
     const auto t0 = std::chrono::steady_clock::now();
+    // pairs are independent and of mixed sizes: every worker takes the next unprocessed pair from a shared counter (work stealing
+    // inside the node, BASELINE config 5); which worker runs a pair has no influence on its result
+    std::atomic<size_t> next{0};
     std::vector<std::thread> workers;
     for (int j = 0; j < nworkers; ++j)
-        workers.emplace_back([&, j] { for (size_t i = j; i < pairs.size(); i += nworkers) process(ctxs[j], cfg, pairs[i]); });   // static i mod workers
+        workers.emplace_back([&, j] { for (size_t i; (i = next.fetch_add(1)) < pairs.size();) process(ctxs[j], cfg, pairs[i]); });
     for (auto& t : workers) t.join();
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("Processed %zu pair(s) on %d GPU(s), %d in flight each, in %.3f sec (%.3f pairs/sec).\n", pairs.size(), ngpus, inflight, sec, pairs.empty() ? 0.0 : pairs.size() / sec);

@@ -96,3 +96,29 @@ def test_cli_batch_matches_library(tmp_path, ctx):
         exp = ctx.process_pair(s, rf, prm)
         got = np.asarray(Image.open(out / name).convert("RGB"))[..., ::-1]
         assert np.array_equal(got, exp)
+
+
+@pytest.mark.gpu
+def test_cli_inflight_workers_give_identical_files(tmp_path):
+    """`-inflight K`: K contexts + host threads per GPU take pairs from a shared counter; the files must not depend on K."""
+    from caffemodel_io import synthetic_vgg19, write_caffemodel
+    ws, bs = synthetic_vgg19(19)
+    (tmp_path / "model" / "vgg19").mkdir(parents=True)
+    write_caffemodel(str(tmp_path / "model" / "vgg19" / "VGG_ILSVRC_19_layers.caffemodel"), ws, bs)
+    inp = tmp_path / "in"; inp.mkdir()
+    lines = []
+    for i, (h, w) in enumerate([(64, 64), (72, 56), (48, 80), (96, 64), (64, 96)]):
+        Image.fromarray(synth.image(10 + i, h, w)[..., ::-1].copy()).save(inp / f"s{i}.png")
+        Image.fromarray(synth.image(20 + i, w, h)[..., ::-1].copy()).save(inp / f"r{i}.png")
+        lines.append(f"s{i}.png r{i}.png 2.0\n")
+    (inp / "pairs.txt").write_text("".join(lines))
+    outs = {}
+    for k in (1, 3):
+        out = tmp_path / f"out{k}"
+        r = run("-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(out), "-g", "0", "-inflight", str(k))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"{k} in flight each" in r.stdout
+        outs[k] = {n: np.asarray(Image.open(out / n)) for n in sorted(os.listdir(out))}
+    assert list(outs[1]) == list(outs[3]) and len(outs[1]) == 5
+    for n in outs[1]:
+        assert np.array_equal(outs[1][n], outs[3][n]), n
