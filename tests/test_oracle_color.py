@@ -234,3 +234,35 @@ def test_canonical_wls_matches_exact_solve(oracle):
     assert np.allclose(s1["ab_wls"], s2["ab_wls"], rtol=2e-5, atol=2e-6)
     d = np.abs(o1.astype(int) - o2.astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_knn_matches_reference_nanoflann(oracle):
+    """K1 pinned by the reference's own KD-tree library: tests/golden/knn_nanoflann.npz holds what the vendored nanoflann.hpp
+    (driven as in ColorTransfer::findSubKNNs: one cluster, k+1 results, Euclidean kdtree_distance) returns for two seeded Lab images
+    — one smooth, one quantised to force exact ties and duplicate points (generator: tests/golden/gen_knn_nanoflann.py, driver
+    oracle/ref_nanoflann_knn.cpp). The oracle's (dist, id) brute force must give the same distances bit for bit, and the same
+    neighbour wherever the distance is not tied (tie order is the KD-tree's traversal order in the reference; ours is by id)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "knn_nanoflann.npz"))
+    K = 8
+    for name in ("smooth", "flat"):
+        lab, rid, rd = g[name + "_lab"], g[name + "_ids"], g[name + "_dist"]
+        h, w = lab.shape[:2]
+        n = h * w
+        ids, ws = oracle.knn_graph(lab, np.zeros((2, 2), np.int32), 1, samples=max(h, w))      # one cluster, every pixel in it
+        exact_ids = checked = 0
+        for i in range(n):
+            # findSubKNNs: drop the query itself from the k+1 results, keep the first k
+            keep = [(rd[i, t], rid[i, t]) for t in range(K + 1) if rid[i, t] >= 0 and rid[i, t] != i][:K]
+            ref_d = np.array([d for d, _ in keep])
+            ref_w = np.exp(1.0 - ref_d / 3.0)
+            assert len(keep) == K
+            # weights come from orc_exp (IEEE-basic-op exp, <= 1 ulp from libm); distances are compared through them
+            assert np.allclose(ws[i], ref_w, rtol=4e-16, atol=0), (name, i)
+            for t in range(K):
+                d = keep[t][0]
+                tied = (t > 0 and keep[t - 1][0] == d) or (t + 1 < K and keep[t + 1][0] == d) or (t == K - 1 and rd[i, K] == d)
+                if not tied:
+                    checked += 1
+                    exact_ids += int(ids[i, t] == keep[t][1])
+        assert exact_ids == checked and checked > (n if name == "smooth" else 100), (name, exact_ids, checked)
