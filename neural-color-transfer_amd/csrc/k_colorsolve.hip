@@ -151,8 +151,18 @@ __global__ void k_s1_setup(int n, const double* __restrict__ weight, float dWeig
     for (int k = 0; k < 8; ++k) { const double iw = sqrt(knn_w[(size_t)i * 8 + k]) * nonlocalWeight; iw2[(size_t)i * 8 + k] = iw * iw; }
 }
 
-// y = Op(p) at pixel i (live = i < n). The in-degree of the kNN graph is mild (max 37 at 700x700, p99 19: scripts/knn_indegree.py),
-// so one thread per pixel walks its own in-edge list.
+// y = Op(p) at pixel i (live = i < n); must be called by every thread of a 256-thread workgroup whose threads own consecutive
+// pixels. The in-degree of the kNN graph is mild on average (8) but uneven (p99 19, max 37 at 700x700: scripts/knn_indegree.py),
+// and an in-edge is a dependent random 48-byte gather: with one thread walking its own list a wave waits for its longest list
+// (a uniform-degree graph runs the whole stage 20 % faster: scripts/s1_locality_probe.py). So the gathers are shared: the in-edges of
+// a workgroup's 256 consecutive pixels are ONE contiguous range of the target-sorted edge arrays; the threads fetch it edge-parallel
+// into LDS in chunks of S1_CHUNK edges, then every thread adds ITS edges from LDS in edge order — the per-pixel operation order
+// (local, out-edges, in-edges ascending) and therefore every bit of the result is unchanged.
+#ifndef NCT_S1_CHUNK
+#define NCT_S1_CHUNK 1024
+#endif
+constexpr int S1_CHUNK = NCT_S1_CHUNK;
+template <bool COOP>
 __device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__ p, int i, bool live, double (&ya)[3], double (&yb)[3]) {
     const int w = S.w, h = S.h;
     double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
@@ -178,12 +188,14 @@ __device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__
         if (x > 0) { const double g = S.gx[i - 1]; edge(i - 1, 2.0 * (g * g)); }
         if (y + 1 < h) { const double g = S.gy[i]; edge(i + w, 2.0 * (g * g)); }
         if (y > 0) { const double g = S.gy[i - w]; edge(i - w, 2.0 * (g * g)); }
-        // nonlocal: out-edges, then in-edges
+        // nonlocal: out-edges (8 independent gathers per thread), then in-edges
 #pragma unroll
         for (int k = 0; k < 8; ++k) edge(S.knn_id[(size_t)i * 8 + k], S.iw2[(size_t)i * 8 + k]);
         e0 = S.rev_start[i]; e1 = S.rev_start[i + 1];
-        {
-            // loads of four edges are issued together (the accumulation order stays the edge order)
+    }
+    if constexpr (!COOP) {
+        // small levels (latency bound, few workgroups): every thread walks its own list, loads of four edges issued together
+        if (live) {
             int e = e0;
             for (; e + 4 <= e1; e += 4) {
                 int j[4]; double wt[4], pv[4][6];
@@ -198,17 +210,45 @@ __device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { ya[c] += wt[u] * (a[c] - pv[u][c]); yb[c] += wt[u] * (b[c] - pv[u][3 + c]); }
             }
-            for (; e < e1; ++e) edge(S.rev_src[e], S.rev_w[e]);
+            for (; e < e1; ++e) {
+                const int j = S.rev_src[e]; const double wt = S.rev_w[e];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { ya[c] += wt * (a[c] - p[(size_t)j * 6 + c]); yb[c] += wt * (b[c] - p[(size_t)j * 6 + 3 + c]); }
+            }
+        }
+    } else {
+        // in-edges of the workgroup's pixels [i0, i1): edge range [E0, E1)
+        __shared__ double s_pv[6 * S1_CHUNK];          // [c][edge]
+        __shared__ double s_wt[S1_CHUNK];
+        const int i0 = blockIdx.x * 256, i1 = min(i0 + 256, S.n);
+        const int E0 = S.rev_start[i0], E1 = S.rev_start[i1];
+        for (int base = E0; base < E1; base += S1_CHUNK) {
+            const int cnt = min(S1_CHUNK, E1 - base);
+            for (int t = threadIdx.x; t < cnt; t += 256) {
+                const int j = S.rev_src[base + t];
+                s_wt[t] = S.rev_w[base + t];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) s_pv[c * S1_CHUNK + t] = p[(size_t)j * 6 + c];
+            }
+            __syncthreads();
+            const int lo = max(e0, base) - base, hi = min(e1, base + cnt) - base;
+            for (int t = lo; t < hi; ++t) {
+                const double wt = s_wt[t];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { ya[c] += wt * (a[c] - s_pv[c * S1_CHUNK + t]); yb[c] += wt * (b[c] - s_pv[(3 + c) * S1_CHUNK + t]); }
+            }
+            __syncthreads();
         }
     }
 }
 
 // r = rhs - Op(x0); partial r.r
+template <bool COOP>
 __global__ __launch_bounds__(256) void k_s1_residual(S1Sys S, const double* __restrict__ x, const double* __restrict__ rhs, double* __restrict__ r, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[3] = {0, 0, 0};
     double ya[3], yb[3];
-    s1_op(S, x, i, i < S.n, ya, yb);
+    s1_op<COOP>(S, x, i, i < S.n, ya, yb);
     if (i < S.n) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -219,11 +259,12 @@ __global__ __launch_bounds__(256) void k_s1_residual(S1Sys S, const double* __re
     }
     block_reduce_store<3>(acc, partial);
 }
+template <bool COOP>
 __global__ __launch_bounds__(256) void k_s1_apply(S1Sys S, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[3] = {0, 0, 0};
     double ya[3], yb[3];
-    s1_op(S, p, i, i < S.n, ya, yb);
+    s1_op<COOP>(S, p, i, i < S.n, ya, yb);
     if (i < S.n) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -456,7 +497,10 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         const double tol2 = 1e-6 * 1e-6;
         const int maxit = layer == 4 ? 50 : 100;                       // ColorTransfer.cpp:916-921
         hipLaunchKernelGGL(k_pack6, dim3(cdiv(6 * n, 256)), dim3(256), 0, s, n, (const double*)x, (double*)p); LCHK();
-        hipLaunchKernelGGL(k_s1_residual, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (const double*)rhs, (double*)r, (double*)partial); LCHK();
+        const bool coop = n >= 100000;                                  // shared in-edge gathers pay off on the bandwidth-bound levels only
+        if (coop) hipLaunchKernelGGL(k_s1_residual<true>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (const double*)rhs, (double*)r, (double*)partial);
+        else      hipLaunchKernelGGL(k_s1_residual<false>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (const double*)rhs, (double*)r, (double*)partial);
+        LCHK();
         CGState* st_final = (CGState*)st;
         if (nbl <= S1_FUSE_NB) {
             // 3 launches per iteration; state ping-pongs between S[0] and S[1] (iteration k reads S[k&1], writes S[(k+1)&1])
@@ -465,7 +509,9 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
             for (int k = 1; k <= maxit; ++k) {
                 hipLaunchKernelGGL(k_s1_dir_f, dim3(nbl), dim3(256), 0, s, n, nbl, (const double*)partial2, (const CGState*)S2[k & 1], S2[(k + 1) & 1], tol2,
                                    (const double*)r, (double*)p, k == 1 ? 1 : 0); LCHK();
-                hipLaunchKernelGGL(k_s1_apply, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial); LCHK();
+                if (coop) hipLaunchKernelGGL(k_s1_apply<true>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial);
+                else      hipLaunchKernelGGL(k_s1_apply<false>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial);
+                LCHK();
                 hipLaunchKernelGGL(k_s1_update_f, dim3(nbl), dim3(256), 0, s, n, nbl, (const double*)partial, (const CGState*)S2[(k + 1) & 1], (const double*)p, (const double*)Ap,
                                    (double*)x, (double*)r, (double*)partial2); LCHK();
             }
@@ -475,7 +521,9 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
             hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2, 3); LCHK();
             for (int k = 1; k <= maxit; ++k) {
                 hipLaunchKernelGGL(k_s1_dir, dim3(cdiv(6 * n, 256)), dim3(256), 0, s, n, (const CGState*)st, (const double*)r, (double*)p, k == 1 ? 1 : 0); LCHK();
-                hipLaunchKernelGGL(k_s1_apply, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial); LCHK();
+                if (coop) hipLaunchKernelGGL(k_s1_apply<true>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial);
+                else      hipLaunchKernelGGL(k_s1_apply<false>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial);
+                LCHK();
                 hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st); LCHK();
                 hipLaunchKernelGGL(k_s1_update, dim3(nbl), dim3(256), 0, s, n, (const CGState*)st, (const double*)p, (const double*)Ap, (double*)x, (double*)r, (double*)partial); LCHK();
                 hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2); LCHK();
