@@ -4,17 +4,19 @@
 // and factorises it on the CPU with MKL PARDISO (SparseSolver_CPU.cpp:104-286), five times per pair (n = W*H = 490k @700^2).
 //
 // MI355X design: conjugate gradients preconditioned by one aggregation-multigrid V(2,2) cycle, all 6 right-hand sides in
-// lock step, everything in fp64 on the device.
+// lock step; CG recurrences, operator and dot products in fp64, the cycle (a fixed linear preconditioner) in fp32.
 //  * the hierarchy needs no Galerkin triple products: with 2x2 aggregates and piecewise-constant interpolation, P^T A P of a
 //    weighted 5-point graph Laplacian + diagonal is again one (coarse data term = sum of the 4 fine ones, coarse edge = sum of
 //    the fine edges crossing between the two aggregates);
-//  * smoother = damped Jacobi (omega 0.8) — order independent, so the result is reproducible; the first two pre-smoothing
-//    sweeps (zero initial guess) and "prolong + first post-smoothing sweep" are each fused into one kernel;
+//  * smoother = damped Jacobi (omega 0.8) — order independent, so the result is reproducible; one cycle is two tile-fused
+//    launches per level (k_mg_down / k_mg_up, iterates exchanged through LDS) and ONE workgroup for all levels <= 512 pixels;
 //  * vectors are planar [6][pixels]: on a regular 5-point stencil the neighbours of consecutive pixels are consecutive, so
-//    every load/store of a wave is one fully coalesced 512-B segment per right-hand side;
-//  * every dot product is the same two-stage fixed-tree reduction as in k_colorsolve.hip (mirrored by the oracle).
-// Jacobi-PCG needed 2633/1391/701/359/357 iterations on the five levels of a 700x700 pair (profiles/r1b); this needs ~100/80/65/60/60.
-// Roofline: HBM streaming at the fine level (~60 B/pixel/sweep), launch-latency bound below 175x175.
+//    every load/store of a wave is one fully coalesced segment per right-hand side;
+//  * every dot product is the same two-stage fixed-tree reduction as in k_colorsolve.hip (mirrored by the oracle);
+//  * the host never drains the stream: convergence is polled one batch behind through page-locked memory, kernels enqueued
+//    past convergence return on a device flag.
+// Jacobi-PCG needed 2633/1391/701/359/357 iterations (rtol 1e-10) on the five levels of a 700x700 pair (profiles/r1b); this needs
+// 74/56/42/34/34 (rtol 1e-6) at ~165 us each. Roofline: Infinity-Cache/HBM streaming at 700^2 and 350^2, launch latency below.
 #include "nct_internal.h"
 #include "nct_device.h"
 #include <vector>
