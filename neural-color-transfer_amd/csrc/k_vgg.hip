@@ -38,12 +38,17 @@ __global__ void k_vgg_preprocess(const uint8_t* __restrict__ bgr, int stride, fl
 // 4 waves = WCO along cout x (4/WCO) along pixels. 1-D tiling wastes no lanes on ragged 2-D tile edges: conv4_x at 88x88 needs
 // 61 x 4 = 244 workgroups (one per CU, one round) where 16x8 tiles needed 264 — 8 CUs with two workgroups doubled the layer time.
 struct ConvGeom { int Cin, Cout, H, W, npx_blocks, nblk_n; };
+#ifndef NCT_CONV_PT1_BELOW
+#define NCT_CONV_PT1_BELOW 128
+#endif
 
-template <int WCO>   // WCO = waves along cout (1 => block covers 64 cout x 256 px; 2 => 128 cout x 128 px)
+// WCO = waves along cout (1 => block covers 64 cout x 256 px; 2 => 128 cout x 128 px); PT = 32-pixel tiles per wave (2, or 1 for the
+// layers whose grid would otherwise leave SIMDs with a single wave: half the pixels per workgroup, twice the workgroups)
+template <int WCO, int PT>
 __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ in, const float* __restrict__ wp /*[Cin*9][Cout]*/,
                                                       const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int relu) {
     constexpr int WPX = 4 / WCO;             // waves along pixels
-    constexpr int BLK_PX = WPX * 64;         // pixels covered by a workgroup
+    constexpr int BLK_PX = WPX * 32 * PT;    // pixels covered by a workgroup
     const int HW = g.H * g.W;
     // block -> (pixel block, cout block); blocks of one pixel block differ by multiples of 8 => same XCD/L2
     int bid = blockIdx.x;
@@ -58,8 +63,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
     const int half = lane >> 5, l31 = lane & 31;
     const int wco = wave % WCO, wpx = wave / WCO;
     const int m0 = nb * (64 * WCO) + wco * 64;                 // first cout of this wave
-    const int p0 = pt * BLK_PX + wpx * 64 + l31, p1 = p0 + 32; // this lane's pixel in tile 0 / tile 1
-    const bool live0 = p0 < HW, live1 = p1 < HW;
+    const int p0 = pt * BLK_PX + wpx * 32 * PT + l31, p1 = p0 + 32; // this lane's pixel in tile 0 / tile 1
+    const bool live0 = p0 < HW, live1 = PT == 2 && p1 < HW;
     const int pc0 = live0 ? p0 : HW - 1, pc1 = live1 ? p1 : HW - 1;
     const int y0 = pc0 / g.W, x0 = pc0 - y0 * g.W, y1 = pc1 / g.W, x1 = pc1 - y1 * g.W;
 
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
             a0[s] = ap[(size_t)(2 * s) * g.Cout];
             a1[s] = ap[(size_t)(2 * s) * g.Cout + 32];
             b0[s] = b0p[off0[s]];
-            b1[s] = b1p[off1[s]];
+            if constexpr (PT == 2) b1[s] = b1p[off1[s]];
         }
         ap += (size_t)18 * g.Cout;
         b0p += (size_t)2 * HW;
@@ -104,20 +109,35 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
     auto mma_pair = [&](const float (&a0)[9], const float (&a1)[9], const float (&b0)[9], const float (&b1)[9]) {
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            const float x0 = ((vm0 >> s) & 1u) ? b0[s] : 0.f, x1 = ((vm1 >> s) & 1u) ? b1[s] : 0.f;
+            const float x0 = ((vm0 >> s) & 1u) ? b0[s] : 0.f;
             acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], x0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], x1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x1, acc11, 0, 0, 0);
+            if constexpr (PT == 2) {
+                const float x1 = ((vm1 >> s) & 1u) ? b1[s] : 0.f;
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], x1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x1, acc11, 0, 0, 0);
+            } else {
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x0, acc10, 0, 0, 0);
+            }
         }
     };
     // schedule of one half iteration: MFMA, load, MFMA, load, ... — the 36 loads ride in the shadow of the 36 MFMAs instead of
     // draining the matrix pipe while they issue in one burst
     auto interleave = [] {
+        if constexpr (PT == 2) {
 #pragma unroll
-        for (int i = 0; i < 36; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one VMEM read
+            for (int i = 0; i < 36; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one VMEM read
+            }
+        } else {                                                       // 18 MFMAs, 27 loads
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
         }
     };
     load_pair(a0x, a1x, b0x, b1x);
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
         float v00 = acc00[r] + bb0, v01 = acc01[r] + bb0, v10 = acc10[r] + bb1, v11 = acc11[r] + bb1;
         if (relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
         if (live0) { out[(size_t)co0 * HW + p0] = v00; out[(size_t)co1 * HW + p0] = v10; }
-        if (live1) { out[(size_t)co0 * HW + p1] = v01; out[(size_t)co1 * HW + p1] = v11; }
+        if constexpr (PT == 2) { if (live1) { out[(size_t)co0 * HW + p1] = v01; out[(size_t)co1 * HW + p1] = v11; } }
     }
 }
 
@@ -154,11 +174,16 @@ int nctk_conv3x3(nct_ctx* ctx, hipStream_t s, const float* in, const float* wp, 
                  int Cin, int Cout, int H, int W, int relu) {
     NCT_REQUIRE((Cin & 1) == 0 && (Cout & 63) == 0, "conv3x3: Cin=%d must be even (pad) and Cout=%d a multiple of 64", Cin, Cout);
     const int WCO = (Cout % 128 == 0) ? 2 : 1;
-    const int blk_px = (4 / WCO) * 64;
+    // two pixel tiles per wave (best operand reuse) unless that grid has fewer than 512 workgroups (two per CU): then one tile per wave
+    const int full_blocks = cdiv(H * W, (4 / WCO) * 64) * (Cout / (64 * WCO));
+    const int PT = full_blocks >= NCT_CONV_PT1_BELOW ? 2 : 1;
+    const int blk_px = (4 / WCO) * 32 * PT;
     ConvGeom g{Cin, Cout, H, W, cdiv(H * W, blk_px), Cout / (64 * WCO)};
     const int nblocks = cdiv(g.npx_blocks, 8) * 8 * g.nblk_n;
-    if (WCO == 2) hipLaunchKernelGGL((k_conv3x3_mfma<2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
-    else          hipLaunchKernelGGL((k_conv3x3_mfma<1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+    if (WCO == 2 && PT == 2)      hipLaunchKernelGGL((k_conv3x3_mfma<2, 2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+    else if (WCO == 2)            hipLaunchKernelGGL((k_conv3x3_mfma<2, 1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+    else if (PT == 2)             hipLaunchKernelGGL((k_conv3x3_mfma<1, 2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+    else                          hipLaunchKernelGGL((k_conv3x3_mfma<1, 1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
     NCT_LAUNCH_CHECK();
     return 0;
 }
