@@ -64,7 +64,19 @@ __global__ void k_km_init(const float* __restrict__ feat, int n, int C, int K, u
     int* pm = n <= KM_LDS_PERM ? s_perm : perm;
     for (int i = 0; i < n; ++i) pm[i] = i;
     uint64_t sd = seed;
-    for (int i = n - 1; i > 0; --i) { const int j = (int)(sm64(sd) % (uint64_t)(i + 1)); const int t = pm[i]; pm[i] = pm[j]; pm[j] = t; }
+    for (int i = n - 1; i > 0; --i) {
+        // j = sm64() mod (i+1). The generic 64-bit division is ~1000 cycles in one thread; for divisors < 2^16 the same remainder comes
+        // from four 32-bit ones: z = hi*2^32 + lo  =>  z mod d = ((hi mod d) * (2^32 mod d) + lo mod d) mod d   (products < 2^32)
+        const uint64_t z = sm64(sd);
+        const uint32_t d = (uint32_t)(i + 1);
+        int j;
+        if (d < 65536u) {
+            const uint32_t hi = (uint32_t)(z >> 32), lo = (uint32_t)z;
+            const uint32_t c = ((0xFFFFFFFFu % d) + 1u) % d;
+            j = (int)(((hi % d) * c + lo % d) % d);
+        } else j = (int)(z % (uint64_t)d);
+        const int t = pm[i]; pm[i] = pm[j]; pm[j] = t;
+    }
     if (pm != perm) for (int i = 0; i < n; ++i) perm[i] = pm[i];
     int pos = 0, nc = 0; bool out = false;
     for (int index = 0; index < K && !out; ++index) {
