@@ -18,6 +18,7 @@
 #include "nct_device.h"
 #include "nct_detmath.h"
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
 
 // ================================================================= C1: k-means
 __device__ __forceinline__ uint64_t sm64(uint64_t& s) {
@@ -173,6 +174,9 @@ int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat, int n, in
 }
 
 // ================================================================= K1: kNN graph
+#ifndef NCT_KNN_MAX_BLOCKS
+#define NCT_KNN_MAX_BLOCKS 1024
+#endif
 constexpr int KNN_K = 8;          // Config.h:68 m_kNum
 constexpr int KNN_SLOTS = 5;      // a pixel belongs to its own cluster + at most 4 neighbouring ones
 
@@ -189,8 +193,8 @@ __global__ void k_cell_masks(const int* __restrict__ labels, int lh, int lw, uns
 }
 
 // ---- (cluster, colour-cell) membership entries: key = cluster << 3*cb | cell(L,a,b), value = pixel id. The cell edge is 2^cs Lab
-// units (cb = 8 - cs bits per axis): 8-unit cells (32^3) for the sparse coarse levels, 4-unit cells (64^3) from 100k pixels on, where
-// an 8-unit cell already holds dozens of points and rings 0-1 (always visited) would scan 8x more of them than needed.
+// units (cb = 8 - cs bits per axis): 32-unit cells (8^3) below 3k pixels, 16-unit below 12k, 8-unit below 100k, 4-unit cells (64^3)
+// above, where an 8-unit cell already holds dozens of points and rings 0-1 (always visited) would scan 8x more than needed.
 __device__ __forceinline__ unsigned cell_key(int l, unsigned col, int cs) {
     const int cb = 8 - cs;
     return ((unsigned)l << (3 * cb)) | (((col >> 16) & 255u) >> cs) << (2 * cb) | (((col >> 8) & 255u) >> cs) << cb | ((col & 255u) >> cs);
@@ -237,12 +241,10 @@ __global__ void k_knn_entry_colours(const uint8_t* __restrict__ lab, const int* 
     const size_t id = vals[e];
     cols[e] = (unsigned)lab[id * 3] | ((unsigned)lab[id * 3 + 1] << 8) | ((unsigned)lab[id * 3 + 2] << 16);
 }
-__global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ cols, const int* __restrict__ count, const unsigned* __restrict__ keys,
-                                                  const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
-                                                  int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
+__device__ __forceinline__ void knn_grid_entry(int e, const unsigned* __restrict__ cols, const unsigned* __restrict__ keys,
+                                               const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
+                                               int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
     const int cb = 8 - cs, CELLS = 1 << cb; const unsigned cmask = (unsigned)CELLS - 1u;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= *count) return;
     const unsigned key = keys[e];
     const int id = (int)vals[e];
     const int l = (int)(key >> (3 * cb));
@@ -297,6 +299,15 @@ __global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ c
         if (bi[t] != id && bi[t] != 0x7fffffff && ni < KNN_K) { od[ni] = bd[t]; oi[ni] = bi[t]; ++ni; }
     for (; ni < KNN_K; ++ni) { od[ni] = 1e300; oi[ni] = -1; }
 }
+// Grid-stride over the entries with a BOUNDED grid: the searches are long-running and this kernel lives on the side stream; a grid
+// that fills every CU slot makes the short main-stream kernels wait until all of its workgroups have been dispatched.
+__global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ cols, const int* __restrict__ count, const unsigned* __restrict__ keys,
+                                                  const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
+                                                  int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
+    const int m = *count;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < m; e += gridDim.x * 256)
+        knn_grid_entry(e, cols, keys, vals, start, cs, nslot, cand_d, cand_id);
+}
 
 // sortMergeComputeWeight: sort by (dist,id), dedupe, keep k, w = exp(1 - d/3); pad with zero-weight self edges
 __global__ void k_knn_merge(int npix, const int* __restrict__ nslot, const double* __restrict__ cand_d, const int* __restrict__ cand_id,
@@ -338,7 +349,9 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
                    int* knn_id, double* knn_w) {
     NCT_REQUIRE(nlabels_dev || (nlabels >= 1 && nlabels <= 16), "knn_graph: nlabels=%d out of range", nlabels);
     const int n = h * w;
-    const int cs = n >= 100000 ? 2 : 3, cb = 8 - cs;
+    // cell edge 2^cs Lab units, chosen so that a cell holds a handful of points: sparse (coarse-level) point sets in fine cells make a
+    // query walk thousands of empty cells before it has seen k+1 points
+    const int cs = n >= 100000 ? 2 : n >= 12000 ? 3 : n >= 3000 ? 4 : 5, cb = 8 - cs;
     const int cap = n * KNN_SLOTS, nkeys = 16 << (3 * cb);
     const unsigned key_sentinel = 1u << (3 * cb + 4);      // sorts after every real key (16 clusters x cells)
     DevBuf<unsigned> mask(ctx, (size_t)lh * lw), keys(ctx, cap), vals(ctx, cap), keys_s(ctx, cap), vals_s(ctx, cap);
@@ -363,7 +376,7 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_entry_colours, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, (const int*)count, (const unsigned*)vals_s, (unsigned*)cols);
     NCT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_knn_grid, dim3(cdiv(cap, 256)), dim3(256), 0, s, (const unsigned*)cols, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
+    hipLaunchKernelGGL(k_knn_grid, dim3(std::min(cdiv(cap, 256), NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
                        (const int*)start, cs, (int*)nslot, (double*)cand_d, (int*)cand_id);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_merge, dim3(cdiv(n, 256)), dim3(256), 0, s, n, (const int*)nslot, (const double*)cand_d, (const int*)cand_id, knn_id, knn_w);

@@ -118,7 +118,11 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     struct Cleanup3 { std::vector<DevBuf<uint8_t>*>& a; std::vector<DevBuf<int>*>& b; std::vector<DevBuf<double>*>& c; nct_ctx* ctx;
                       ~Cleanup3() { (void)hipStreamSynchronize(ctx->stream2); ctx->defer_release = false; ctx->flush_deferred();
                                     for (auto* p : a) delete p; for (auto* p : b) delete p; for (auto* p : c) delete p; } } cleanup3{slab, knn_ids, knn_ws, ctx};
-    {
+    // enqueued from inside the level loop, AFTER the coarsest level's correspondence work has been submitted: the side stream's ~200
+    // small packets would otherwise sit in front of the main stream's and the main stream starts the level loop ~2.6 ms late
+    auto enqueue_knn = [&]() -> int {
+        // arena blocks are recycled in stream order: the side stream may reuse blocks the main stream released up to this point, so it
+        // starts behind everything enqueued on the main stream so far
         hipStream_t s2 = ctx->stream2;
         NCT_HIP(hipEventRecord(ctx->ev_fork, s));
         NCT_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
@@ -127,15 +131,16 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
             slab[l] = new DevBuf<uint8_t>(ctx, npx * 3); knn_ids[l] = new DevBuf<int>(ctx, npx * 8); knn_ws[l] = new DevBuf<double>(ctx, npx * 8);
             if (!slab[l]->ok() || !knn_ids[l]->ok() || !knn_ws[l]->ok()) return NCT_ERR_HIP;
         }
+        int rc2 = 0;
         ctx->defer_release = true;
-        for (int l = 0; l < 5 && rc == 0; ++l) {
-            rc = nctk_bgr2lab(ctx, s2, simg[l], *slab[l], (size_t)ah[l] * aw[l]);
-            if (rc == 0) rc = nctk_knn_graph(ctx, s2, *slab[l], ah[l], aw[l], labels, ah[0], aw[0], 0, nlab_dev, 1 << l, *knn_ids[l], *knn_ws[l]);
-            if (rc == 0 && hipEventRecord(ctx->ev_level[l], s2) != hipSuccess) rc = ctx->fail(NCT_ERR_HIP, "hipEventRecord failed");
+        for (int l = 0; l < 5 && rc2 == 0; ++l) {
+            rc2 = nctk_bgr2lab(ctx, s2, simg[l], *slab[l], (size_t)ah[l] * aw[l]);
+            if (rc2 == 0) rc2 = nctk_knn_graph(ctx, s2, *slab[l], ah[l], aw[l], labels, ah[0], aw[0], 0, nlab_dev, 1 << l, *knn_ids[l], *knn_ws[l]);
+            if (rc2 == 0 && hipEventRecord(ctx->ev_level[l], s2) != hipSuccess) rc2 = ctx->fail(NCT_ERR_HIP, "hipEventRecord failed");
         }
         ctx->defer_release = false;
-        if (rc) return rc;
-    }
+        return rc2;
+    };
 
     // ---- level loop (main.cu:179-428)
     DevBuf<uint32_t> ann(ctx, N), bnn(ctx, (size_t)RH * RW), ann_prev(ctx, N), bnn_prev(ctx, (size_t)RH * RW);
@@ -172,6 +177,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         clk.lap(timing ? &timing->vote_ms : nullptr);
         // kNN graph in Lab (main.cu:351-359): computed on the side stream; join once before its first use
         rc = nctk_bgr2lab(ctx, s, guide, g_lab_l, na_px); if (rc) return rc;
+        if (l == 0) { rc = enqueue_knn(); if (rc) return rc; }
         NCT_HIP(hipStreamWaitEvent(s, ctx->ev_level[l], 0));          // level l's graph only: the fine levels keep overlapping
         if (l == 4) ctx->flush_deferred();
         const uint8_t* s_lab_l = *slab[l]; const int* knn_id = *knn_ids[l]; const double* knn_w = *knn_ws[l];
