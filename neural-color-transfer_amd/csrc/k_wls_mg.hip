@@ -38,9 +38,10 @@ struct Lvl { int H, W, n; double *r, *wx, *wy, *diag;      // fp64 operator: dat
              vf *fdiag, *fdinv, *fwx, *fwy;                // fp32 copies; fdinv = (float)(omega / diag)
              vf *b, *x, *x2; };                            // V-cycle vectors, planar [6][n]
 
-// PCG state of the 6 right-hand sides. nactive = number of systems still iterating: the host polls it only every few iterations, and
-// every kernel of an iteration enqueued past convergence returns at once when it is 0.
-struct PState { double rz[6], rr[6], bb[6], al[6], be[6]; int active[6]; int iters[6]; int nactive; };
+// State of the 6 right-hand sides of the single-reduction (Chronopoulos-Gear) PCG, double buffered: the update kernel of iteration k
+// reads st[k & 1] and (workgroup 0) writes st[(k + 1) & 1]. nactive = number of systems still iterating: the host polls it only every
+// few iterations, and every kernel of an iteration enqueued past convergence returns at once when it is 0.
+struct PState { double gam[6], alp[6], bb[6]; int active[6]; int iters[6]; int nactive; };
 
 template <int NV>
 __device__ __forceinline__ void mg_block_reduce(double (&v)[NV], double* __restrict__ partial) {
@@ -78,6 +79,31 @@ __device__ __forceinline__ void mg_final_reduce(const double* __restrict__ parti
     }
 #pragma unroll
     for (int q = 0; q < NV; ++q) out[q] = s_fin[q * 256];
+    __syncthreads();
+}
+
+// same fixed order over one group of NV values inside records of `stride` doubles
+template <int NV>
+__device__ __forceinline__ void mg_final_reduce_strided(const double* __restrict__ partial, int nb, int stride, double (&out)[NV]) {
+    __shared__ double s_fin2[256 * NV];
+    const int t = threadIdx.x;
+    double acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = 0.0;
+    for (int b = t; b < nb; b += 256)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) acc[q] += partial[(size_t)b * stride + q];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) s_fin2[q * 256 + t] = acc[q];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) s_fin2[q * 256 + t] += s_fin2[q * 256 + t + off];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) out[q] = s_fin2[q * 256];
     __syncthreads();
 }
 
@@ -271,16 +297,6 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
         for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = x2[q] + (bq[q] - y[q]) * c.dinv;
     }
 }
-// r.z partial sums in the canonical block order (256 consecutive pixels per block); z = fp32 V-cycle output, widened exactly
-__global__ __launch_bounds__(256) void k_pcg_dot(const PState* __restrict__ st, int n, const double* __restrict__ a, const vf* __restrict__ z, double* __restrict__ partial) {
-    if (st->nactive == 0) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = i < n ? a[(size_t)q * n + i] * (double)z[(size_t)q * n + i] : 0.0;
-    mg_block_reduce<NQ>(acc, partial);
-}
-
 // Tail of the V-cycle: every level with <= 512 pixels (22x22, 11x11, 6x6 at 700x700) in ONE 512-thread workgroup. Thread t owns
 // pixel t of each tail level; iterates travel through LDS (whole grids, no halos), each thread keeps its rhs / pre-smoothed
 // iterate / coefficients of every tail level in registers for the way back up. Replaces 2 launches per level (~4.8 us each, pure
@@ -458,70 +474,77 @@ __global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restri
 }
 __global__ void k_pcg_start_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, double rtol2) {
     double s[12]; mg_final_reduce<12>(partial, nb, s);
-    if (threadIdx.x < 6) { const int q = threadIdx.x; st->rr[q] = s[q]; st->bb[q] = s[6 + q]; st->rz[q] = 0; st->al[q] = 0; st->be[q] = 0; st->iters[q] = 0;
+    if (threadIdx.x < 6) { const int q = threadIdx.x; st->bb[q] = s[6 + q]; st->gam[q] = 0; st->alp[q] = 0; st->iters[q] = 0;
                            st->active[q] = (s[q] > rtol2 * s[6 + q]) ? 1 : 0; }
     __syncthreads();
     if (threadIdx.x == 0) { int na = 0; for (int q = 0; q < 6; ++q) na += st->active[q]; st->nactive = na; }
 }
-// after the V-cycle: rz = r.z ; first iteration: p = z, else be = rz/rz_old, p = z + be p
-__global__ void k_pcg_rz_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, int first) {
-    if (st->nactive == 0) return;
-    double s[6]; mg_final_reduce<6>(partial, nb, s);
-    if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) { st->be[q] = first ? 0.0 : s[q] / st->rz[q]; st->rz[q] = s[q]; } }
-}
-__global__ void k_pcg_dir(int n, const PState* __restrict__ st, const vf* __restrict__ z, double* __restrict__ p, int first) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * NQ || st->nactive == 0) return;
-    const int q = i / n;                      // planar [6][n]
-    if (!st->active[q]) return;
-    const double zv = (double)z[i];
-    p[i] = first ? zv : zv + st->be[q] * p[i];
-}
-__global__ __launch_bounds__(256) void k_pcg_apply(const PState* __restrict__ st, Lvl L, const double* __restrict__ p, double* __restrict__ Ap, double* __restrict__ partial) {
+// Single-reduction PCG (Chronopoulos & Gear): per iteration  u = M^-1 r (the V-cycle, fp32) ; w = A u ; gamma = r.u, delta = w.u,
+// rho = r.r in ONE reduction ; beta = gamma/gamma_old, alpha = gamma / (delta - beta*gamma/alpha_old) ; p = u + beta p ; s = w + beta s
+// (= A p by recurrence) ; x += alpha p ; r -= alpha s. Same iterates as textbook PCG in exact arithmetic and the same iteration counts
+// in practice (scripts/mg_convergence_experiments.py), with 3 launches and one reduction per iteration instead of 7 and three.
+// w = A u with u = the V-cycle output widened exactly; partial sums of gamma, delta, rho (18 per 256-pixel block)
+__global__ __launch_bounds__(256) void k_cg_apply(const PState* __restrict__ st, Lvl L, const vf* __restrict__ z, const double* __restrict__ r,
+                                                  double* __restrict__ w, double* __restrict__ partial) {
     if (st->nactive == 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    double acc[NQ];
+    double acc[18];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+    for (int q = 0; q < 18; ++q) acc[q] = 0.0;
     if (i < L.n) {
-        auto pv = [&](int j, int q) { return p[(size_t)q * L.n + j]; };
-        double y[NQ]; lvl_op(L, i, pv, y);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { Ap[(size_t)q * L.n + i] = y[q]; acc[q] = p[(size_t)q * L.n + i] * y[q]; }
-    }
-    mg_block_reduce<NQ>(acc, partial);
-}
-__global__ void k_pcg_alpha_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st) {
-    if (st->nactive == 0) return;
-    double s[6]; mg_final_reduce<6>(partial, nb, s);
-    if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) st->al[q] = st->rz[q] / s[q]; }
-}
-__global__ __launch_bounds__(256) void k_pcg_update(int n, const PState* __restrict__ st, const double* __restrict__ p, const double* __restrict__ Ap,
-                                                    double* __restrict__ x, double* __restrict__ r, double* __restrict__ partial) {
-    if (st->nactive == 0) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-    if (i < n) {
+        auto uv = [&](int j, int q) { return (double)z[(size_t)q * L.n + j]; };
+        double y[NQ]; lvl_op(L, i, uv, y);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            if (!st->active[q]) continue;
-            const size_t j = (size_t)q * n + i;
-            const double al = st->al[q];
-            x[j] += al * p[j];
-            const double rv = r[j] - al * Ap[j];
-            r[j] = rv; acc[q] = rv * rv;
+            const double u = uv(i, q), rv = r[(size_t)q * L.n + i];
+            w[(size_t)q * L.n + i] = y[q];
+            acc[q] = rv * u; acc[6 + q] = y[q] * u; acc[12 + q] = rv * rv;
         }
     }
-    mg_block_reduce<NQ>(acc, partial);
+    mg_block_reduce<18>(acc, partial);
 }
-__global__ void k_pcg_rr_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, double rtol2) {
+// three workgroups: workgroup j reduces gamma (0), delta (1), rho (2) of all 6 systems in the fixed order
+__global__ void k_cg_fin(const PState* __restrict__ st, const double* __restrict__ partial, int nb, double* __restrict__ sums) {
     if (st->nactive == 0) return;
-    double s[6]; mg_final_reduce<6>(partial, nb, s);
-    if (threadIdx.x < 6) { const int q = threadIdx.x; if (st->active[q]) { st->rr[q] = s[q]; st->iters[q]++; st->active[q] = (s[q] > rtol2 * st->bb[q]) ? 1 : 0; } }
-    __syncthreads();
-    if (threadIdx.x == 0) { int na = 0; for (int q = 0; q < 6; ++q) na += st->active[q]; st->nactive = na; }
+    double s[6]; mg_final_reduce_strided<6>(partial + blockIdx.x * 6, nb, 18, s);
+    if (threadIdx.x < 6) sums[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x];
+}
+// scalars + all four vector recurrences; every workgroup derives the scalars itself, workgroup 0 publishes the next state
+__global__ __launch_bounds__(256) void k_cg_update(int n, const PState* __restrict__ sc, PState* __restrict__ sn, const double* __restrict__ sums, double rtol2, int first,
+                                                   const vf* __restrict__ z, const double* __restrict__ w, double* __restrict__ p, double* __restrict__ s,
+                                                   double* __restrict__ x, double* __restrict__ r) {
+    if (sc->nactive == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) *sn = *sc; return; }
+    double al[NQ], be[NQ]; bool act[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double gam = sums[q], del = sums[6 + q], rho = sums[12 + q];
+        act[q] = sc->active[q] != 0 && rho > rtol2 * sc->bb[q];
+        be[q] = first ? 0.0 : gam / sc->gam[q];
+        al[q] = first ? gam / del : gam / (del - be[q] * gam / sc->alp[q]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int na = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            sn->bb[q] = sc->bb[q];
+            sn->gam[q] = act[q] ? sums[q] : sc->gam[q]; sn->alp[q] = act[q] ? al[q] : sc->alp[q];
+            sn->iters[q] = sc->iters[q] + (act[q] ? 1 : 0); sn->active[q] = act[q] ? 1 : 0; na += act[q] ? 1 : 0;
+        }
+        sn->nactive = na;
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (!act[q]) continue;
+        const size_t j = (size_t)q * n + i;
+        const double zv = (double)z[j], wv = w[j];
+        const double pn = first ? zv : zv + be[q] * p[j];
+        const double sv = first ? wv : wv + be[q] * s[j];
+        p[j] = pn; s[j] = sv;
+        x[j] += al[q] * pn;
+        r[j] -= al[q] * sv;
+    }
 }
 __global__ void k_pcg_finish(int n, const double* __restrict__ x6, double* __restrict__ X) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -564,12 +587,14 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     }
     const Lvl& F = lv[0];
     const int N = F.n, nb = cdiv(N, 256);
-    DevBuf<double> x6(ctx, (size_t)N * NQ), r(ctx, (size_t)N * NQ), p(ctx, (size_t)N * NQ), Ap(ctx, (size_t)N * NQ), partial(ctx, (size_t)nb * 12);
-    DevBuf<PState> st(ctx, 1);
-    if (!x6.ok() || !r.ok() || !p.ok() || !Ap.ok() || !partial.ok() || !st.ok()) return NCT_ERR_HIP;
+    DevBuf<double> x6(ctx, (size_t)N * NQ), r(ctx, (size_t)N * NQ), p(ctx, (size_t)N * NQ), sv(ctx, (size_t)N * NQ), w(ctx, (size_t)N * NQ), partial(ctx, (size_t)nb * 18), sums(ctx, 18);
+    DevBuf<PState> st2(ctx, 2);
+    if (!x6.ok() || !r.ok() || !p.ok() || !sv.ok() || !w.ok() || !partial.ok() || !sums.ok() || !st2.ok()) return NCT_ERR_HIP;
+    PState* st = (PState*)st2;                         // st[0] / st[1]; `cur` = the state the iteration being enqueued reads
+    const PState* cur = st;
     const double rtol2 = rtol * rtol;
     hipLaunchKernelGGL(k_pcg_start, dim3(nb), dim3(256), 0, s, F, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
-    hipLaunchKernelGGL(k_pcg_start_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
+    hipLaunchKernelGGL(k_pcg_start_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, st, rtol2); LCHK();
 
     // z = Vcycle(r). Levels 0..nl-2 run the tile-fused down/up legs (2 launches per level), the coarsest grid one 6-wave kernel.
     // res[l] = where level l's correction ends up (the up leg cannot write in place: neighbouring tiles still read lv[l].x).
@@ -586,29 +611,28 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     auto down = [&](int l) {
         const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
         if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, (const PState*)st, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
-            else                   hipLaunchKernelGGL((k_mg_down<16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, (const PState*)st, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
         } else {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
-            else                   hipLaunchKernelGGL((k_mg_down<16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
         }
     };
     auto up = [&](int l, const vf* ec) {
         const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
         const int Wc = lv[l + 1].W, nc = lv[l + 1].n;
         if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, (const PState*)st, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            else                   hipLaunchKernelGGL((k_mg_up<16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, (const PState*)st, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
         } else {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            else                   hipLaunchKernelGGL((k_mg_up<16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, (const PState*)st, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
         }
     };
     auto vcycle = [&]() -> int {
         for (int l = 0; l < tail0; ++l) { down(l); LCHK(); }
-        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(TAIL_N), 0, s, (const PState*)st, pack, 60); LCHK();
+        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(TAIL_N), 0, s, cur, pack, 60); LCHK();
         for (int l = tail0 - 1; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
-        hipLaunchKernelGGL(k_pcg_dot, dim3(nb), dim3(256), 0, s, (const PState*)st, N, (const double*)r, (const vf*)lv[0].x2, (double*)partial); LCHK();
         return 0;
     };
     const vf* z = lv[0].x2;
@@ -619,17 +643,18 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     PState* hst = (PState*)ctx->pinned;                   // two slots
     static_assert(2 * sizeof(PState) <= 4096, "pinned read-back area too small");
     auto iteration = [&](int it) -> int {
+        cur = st + (it & 1);
+        PState* nxt = st + ((it + 1) & 1);
         int rc = vcycle(); if (rc) return rc;
-        hipLaunchKernelGGL(k_pcg_rz_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, it == 0 ? 1 : 0); LCHK();
-        hipLaunchKernelGGL(k_pcg_dir, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const PState*)st, z, (double*)p, it == 0 ? 1 : 0); LCHK();
-        hipLaunchKernelGGL(k_pcg_apply, dim3(nb), dim3(256), 0, s, (const PState*)st, F, (const double*)p, (double*)Ap, (double*)partial); LCHK();
-        hipLaunchKernelGGL(k_pcg_alpha_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st); LCHK();
-        hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(256), 0, s, N, (const PState*)st, (const double*)p, (const double*)Ap, (double*)x6, (double*)r, (double*)partial); LCHK();
-        hipLaunchKernelGGL(k_pcg_rr_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, (PState*)st, rtol2); LCHK();
+        hipLaunchKernelGGL(k_cg_apply, dim3(nb), dim3(256), 0, s, cur, F, z, (const double*)r, (double*)w, (double*)partial); LCHK();
+        hipLaunchKernelGGL(k_cg_fin, dim3(3), dim3(256), 0, s, cur, (const double*)partial, nb, (double*)sums); LCHK();
+        hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, s, N, cur, nxt, (const double*)sums, rtol2, it == 0 ? 1 : 0, z, (const double*)w,
+                           (double*)p, (double*)sv, (double*)x6, (double*)r); LCHK();
+        cur = nxt;
         return 0;
     };
     auto snapshot = [&](int slot) -> int {
-        NCT_HIP(hipMemcpyAsync(&hst[slot], (PState*)st, sizeof(PState), hipMemcpyDeviceToHost, s));
+        NCT_HIP(hipMemcpyAsync(&hst[slot], cur, sizeof(PState), hipMemcpyDeviceToHost, s));
         NCT_HIP(hipEventRecord(ctx->ev_poll[slot], s));
         return 0;
     };

@@ -175,10 +175,11 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     lvl_t* F = &lv[0];
     const int n = F->n;
     double* x6 = (double*)malloc(sizeof(double) * (size_t)n * NQ); double* r = (double*)malloc(sizeof(double) * (size_t)n * NQ);
-    double* p = (double*)calloc((size_t)n * NQ, sizeof(double)); double* Ap = (double*)malloc(sizeof(double) * (size_t)n * NQ);
-    double* acc = (double*)malloc(sizeof(double) * (size_t)n * 12);
+    double* p = (double*)calloc((size_t)n * NQ, sizeof(double)); double* sv = (double*)calloc((size_t)n * NQ, sizeof(double));
+    double* w = (double*)malloc(sizeof(double) * (size_t)n * NQ);
+    double* acc = (double*)malloc(sizeof(double) * (size_t)n * 18);
     const double rtol2 = rtol * rtol;
-    double rz[6] = {0}, rr[6], bb[6], al[6] = {0}, be[6] = {0}, s[12];
+    double gam_old[6] = {0}, alp_old[6] = {0}, bb[6], s[18];
     int active[6], iters[6] = {0, 0, 0, 0, 0, 0};
 #define X0(j, q) ((q) < 3 ? a[(size_t)(j) * 3 + (q)] : b[(size_t)(j) * 3 + (q) - 3])
     for (int i = 0; i < n; ++i) {
@@ -193,43 +194,51 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
 #undef X0
     canon_sum(acc, n, 12, s);
     int any = 0;
-    for (int q = 0; q < 6; ++q) { rr[q] = s[q]; bb[q] = s[6 + q]; active[q] = s[q] > rtol2 * s[6 + q]; any |= active[q]; }
+    for (int q = 0; q < 6; ++q) { bb[q] = s[6 + q]; active[q] = s[q] > rtol2 * s[6 + q]; any |= active[q]; }
+    /* single-reduction (Chronopoulos-Gear) PCG, operation for operation as k_cg_apply / k_cg_fin / k_cg_update */
     int it = 0;
     const int maxit = 5000;
     while (any && it < maxit) {
-        vcycle(lv, nl, r);                                             /* z = F->x */
-        for (int i = 0; i < n; ++i) for (int q = 0; q < NQ; ++q) acc[(size_t)i * NQ + q] = r[(size_t)i * NQ + q] * (double)F->x[(size_t)i * NQ + q];
-        canon_sum(acc, n, NQ, s);
-        for (int q = 0; q < 6; ++q) if (active[q]) { be[q] = it == 0 ? 0.0 : s[q] / rz[q]; rz[q] = s[q]; }
-        for (size_t j = 0; j < (size_t)n * NQ; ++j) { const int q = (int)(j % NQ); const double zv = (double)F->x[j]; if (active[q]) p[j] = it == 0 ? zv : zv + be[q] * p[j]; }
-#define PV(j, q) (p[(size_t)(j) * NQ + (q)])
+        const int first = it == 0;
+        vcycle(lv, nl, r);                                             /* u = F->x (fp32), widened exactly below */
+#define UV(j, q) ((double)F->x[(size_t)(j) * NQ + (q)])
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < n; ++i) {
-            double y[NQ]; LVL_OP(F, i, PV, y);
-            for (int q = 0; q < NQ; ++q) { Ap[(size_t)i * NQ + q] = y[q]; acc[(size_t)i * NQ + q] = p[(size_t)i * NQ + q] * y[q]; }
+            double y[NQ]; LVL_OP(F, i, UV, y);
+            for (int q = 0; q < NQ; ++q) {
+                const double u = UV(i, q), rv = r[(size_t)i * NQ + q];
+                w[(size_t)i * NQ + q] = y[q];
+                acc[(size_t)i * 18 + q] = rv * u; acc[(size_t)i * 18 + 6 + q] = y[q] * u; acc[(size_t)i * 18 + 12 + q] = rv * rv;
+            }
         }
-#undef PV
-        canon_sum(acc, n, NQ, s);
-        for (int q = 0; q < 6; ++q) if (active[q]) al[q] = rz[q] / s[q];
+        canon_sum(acc, n, 18, s);                                      /* gamma [0,6), delta [6,12), rho [12,18) */
+        double al[6], be[6]; int act[6];
+        any = 0;
+        for (int q = 0; q < 6; ++q) {
+            const double gam = s[q], del = s[6 + q], rho = s[12 + q];
+            act[q] = active[q] && rho > rtol2 * bb[q];
+            be[q] = first ? 0.0 : gam / gam_old[q];
+            al[q] = first ? gam / del : gam / (del - be[q] * gam / alp_old[q]);
+        }
         for (int i = 0; i < n; ++i)
             for (int q = 0; q < NQ; ++q) {
+                if (!act[q]) continue;
                 const size_t j = (size_t)i * NQ + q;
-                acc[j] = 0.0;
-                if (!active[q]) continue;
-                x6[j] += al[q] * p[j];
-                const double rv = r[j] - al[q] * Ap[j];
-                r[j] = rv; acc[j] = rv * rv;
+                const double zv = UV(i, q), wv = w[j];
+                const double pn = first ? zv : zv + be[q] * p[j];
+                const double sn = first ? wv : wv + be[q] * sv[j];
+                p[j] = pn; sv[j] = sn;
+                x6[j] += al[q] * pn;
+                r[j] -= al[q] * sn;
             }
-        canon_sum(acc, n, NQ, s);
-        any = 0;
-        for (int q = 0; q < 6; ++q) { if (active[q]) { rr[q] = s[q]; iters[q]++; active[q] = s[q] > rtol2 * bb[q]; } any |= active[q]; }
+#undef UV
+        for (int q = 0; q < 6; ++q) { if (act[q]) { gam_old[q] = s[q]; alp_old[q] = al[q]; iters[q]++; } active[q] = act[q]; any |= act[q]; }
         ++it;
     }
-    (void)rr;
     for (int i = 0; i < n; ++i) for (int q = 0; q < NQ; ++q) { if (q < 3) a[(size_t)i * 3 + q] = x6[(size_t)i * NQ + q]; else b[(size_t)i * 3 + q - 3] = x6[(size_t)i * NQ + q]; }
     if (iters_out) memcpy(iters_out, iters, sizeof iters);
     int mx = 0; for (int q = 0; q < 6; ++q) if (iters[q] > mx) mx = iters[q];
     for (int l = 0; l < nl; ++l) { free(lv[l].r); free(lv[l].wx); free(lv[l].wy); free(lv[l].diag); free(lv[l].fdiag); free(lv[l].fdinv); free(lv[l].fwx); free(lv[l].fwy); free(lv[l].b); free(lv[l].x); free(lv[l].x2); }
-    free(x6); free(r); free(p); free(Ap); free(acc);
+    free(x6); free(r); free(p); free(sv); free(w); free(acc);
     return any ? -1 : mx;
 }
