@@ -12,11 +12,12 @@
 //    launches per level (k_mg_down / k_mg_up, iterates exchanged through LDS) and ONE workgroup for all levels <= 512 pixels;
 //  * vectors are planar [6][pixels]: on a regular 5-point stencil the neighbours of consecutive pixels are consecutive, so
 //    every load/store of a wave is one fully coalesced segment per right-hand side;
+//  * the Krylov part is single-reduction (Chronopoulos-Gear) PCG: 3 launches per iteration beside the cycle;
 //  * every dot product is the same two-stage fixed-tree reduction as in k_colorsolve.hip (mirrored by the oracle);
 //  * the host never drains the stream: convergence is polled one batch behind through page-locked memory, kernels enqueued
 //    past convergence return on a device flag.
 // Jacobi-PCG needed 2633/1391/701/359/357 iterations (rtol 1e-10) on the five levels of a 700x700 pair (profiles/r1b); this needs
-// 74/56/42/34/34 (rtol 1e-6) at ~165 us each. Roofline: Infinity-Cache/HBM streaming at 700^2 and 350^2, launch latency below.
+// 74/56/42/34/34 (rtol 1e-6) at ~150 us each. Roofline: Infinity-Cache/HBM streaming at 700^2 and 350^2, launch latency below.
 #include "nct_internal.h"
 #include "nct_device.h"
 #include <vector>
