@@ -483,7 +483,7 @@ __global__ void k_pcg_start_fin(const double* __restrict__ partial, int nb, PSta
 // Single-reduction PCG (Chronopoulos & Gear): per iteration  u = M^-1 r (the V-cycle, fp32) ; w = A u ; gamma = r.u, delta = w.u,
 // rho = r.r in ONE reduction ; beta = gamma/gamma_old, alpha = gamma / (delta - beta*gamma/alpha_old) ; p = u + beta p ; s = w + beta s
 // (= A p by recurrence) ; x += alpha p ; r -= alpha s. Same iterates as textbook PCG in exact arithmetic and the same iteration counts
-// in practice (scripts/mg_convergence_experiments.py), with 3 launches and one reduction per iteration instead of 7 and three.
+// in practice (scripts/cgcg_check.py), with 3 launches and one reduction per iteration instead of 7 and three.
 // w = A u with u = the V-cycle output widened exactly; partial sums of gamma, delta, rho (18 per 256-pixel block)
 __global__ __launch_bounds__(256) void k_cg_apply(const PState* __restrict__ st, Lvl L, const vf* __restrict__ z, const double* __restrict__ r,
                                                   double* __restrict__ w, double* __restrict__ partial) {
