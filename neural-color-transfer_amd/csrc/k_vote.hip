@@ -68,14 +68,19 @@ __device__ __forceinline__ void for_each_source(const uint32_t* __restrict__ val
         pos[t] = in ? start[s] : 0;
         end[t] = in ? start[s + 1] : 0;
     }
+    // 9-way merge with the list heads in registers: only the list that advanced is re-read
+    uint32_t head[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) head[t] = pos[t] < end[t] ? vals[pos[t]] : 0xFFFFFFFFu;
     while (true) {
         uint32_t qbest = 0xFFFFFFFFu; int tsel = -1;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
-            if (pos[t] < end[t]) { uint32_t q = vals[pos[t]]; if (q < qbest) { qbest = q; tsel = t; } }
+            if (head[t] < qbest) { qbest = head[t]; tsel = t; }
         if (tsel < 0) break;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) if (t == tsel) pos[t]++;
+        for (int t = 0; t < 9; ++t)
+            if (t == tsel) { pos[t]++; head[t] = pos[t] < end[t] ? vals[pos[t]] : 0xFFFFFFFFu; }
         const int dx = tsel / 3 - 1, dy = tsel % 3 - 1;
         const int qy = (int)qbest / bw, qx = (int)qbest - qy * bw;
         const int xb = qx + dx, yb = qy + dy;
