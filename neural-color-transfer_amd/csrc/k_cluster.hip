@@ -21,12 +21,6 @@
 #include <algorithm>
 
 // ================================================================= C1: k-means
-__device__ __forceinline__ uint64_t sm64(uint64_t& s) {
-    uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
 __device__ float l2_fd(const float* __restrict__ a, const double* __restrict__ b, int n) {
     float result = 0.f;
     int i = 0;
@@ -53,46 +47,70 @@ constexpr int KM_MAXK = 16;
 constexpr int KM_LDS_PERM = 4096;
 struct KMState { int cidx[KM_MAXK]; int count[KM_MAXK]; unsigned radius[KM_MAXK]; int nc, changed, done; };
 
-// centre selection (chooseCentersRandom with a SplitMix64 Fisher-Yates permutation) — one thread, ~n steps
-__global__ void k_km_init(const float* __restrict__ feat, int n, int C, int K, uint64_t seed, int* __restrict__ perm, KMState* __restrict__ st, int* __restrict__ labels) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) labels[i] = 0;
-    if (threadIdx.x != 0) return;
-    st->nc = 0; st->changed = 0; st->done = 0;
-    for (int i = 0; i < KM_MAXK; ++i) { st->count[i] = 0; st->radius[i] = 0u; }
-    if (n < K) { st->done = 1; return; }
-    // the shuffle is inherently serial (n dependent swaps); in LDS a swap costs ~50 ns instead of two global round trips
-    __shared__ int s_perm[KM_LDS_PERM];
-    int* pm = n <= KM_LDS_PERM ? s_perm : perm;
-    for (int i = 0; i < n; ++i) pm[i] = i;
-    uint64_t sd = seed;
-    for (int i = n - 1; i > 0; --i) {
-        // j = sm64() mod (i+1). The generic 64-bit division is ~1000 cycles in one thread; for divisors < 2^16 the same remainder comes
-        // from four 32-bit ones: z = hi*2^32 + lo  =>  z mod d = ((hi mod d) * (2^32 mod d) + lo mod d) mod d   (products < 2^32)
-        const uint64_t z = sm64(sd);
-        const uint32_t d = (uint32_t)(i + 1);
-        int j;
-        if (d < 65536u) {
+// centre selection (chooseCentersRandom with a SplitMix64 Fisher-Yates permutation). One 256-thread workgroup: SplitMix64 is counter
+// based, so all swap partners are computed in parallel; only the n dependent swaps run in one thread (LDS, ~50 ns each); the
+// duplicate test of a candidate against the centres chosen so far runs one centre per thread (each distance in the reference's
+// sequential float order).
+__device__ __forceinline__ uint64_t sm64_at(uint64_t seed, uint64_t draw /*0-based*/) {
+    uint64_t z = seed + (draw + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_km_init(const float* __restrict__ feat, int n, int C, int K, uint64_t seed, int* __restrict__ perm, KMState* __restrict__ st,
+                                                 int* __restrict__ labels) {
+    __shared__ int s_perm[KM_LDS_PERM], s_j[KM_LDS_PERM];
+    __shared__ int s_cand, s_dup, s_stop;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 256) labels[i] = 0;
+    if (tid == 0) {
+        st->nc = 0; st->changed = 0; st->done = n < K ? 1 : 0;
+        for (int i = 0; i < KM_MAXK; ++i) { st->count[i] = 0; st->radius[i] = 0u; }
+    }
+    if (n < K) return;
+    const bool lds = n <= KM_LDS_PERM;
+    int* pm = lds ? s_perm : perm;
+    for (int i = tid; i < n; i += 256) pm[i] = i;
+    if (lds) {
+        // step i (n-1 down to 1) uses draw n-1-i: j = draw mod (i+1)
+        for (int i = tid + 1; i < n; i += 256) {
+            const uint64_t z = sm64_at(seed, (uint64_t)(n - 1 - i));
+            const uint32_t d = (uint32_t)(i + 1);
+            // z mod d from 32-bit remainders (d < 2^16): z = hi*2^32 + lo  =>  ((hi mod d) * (2^32 mod d) + lo mod d) mod d
             const uint32_t hi = (uint32_t)(z >> 32), lo = (uint32_t)z;
             const uint32_t c = ((0xFFFFFFFFu % d) + 1u) % d;
-            j = (int)(((hi % d) * c + lo % d) % d);
-        } else j = (int)(z % (uint64_t)d);
-        const int t = pm[i]; pm[i] = pm[j]; pm[j] = t;
-    }
-    if (pm != perm) for (int i = 0; i < n; ++i) perm[i] = pm[i];
-    int pos = 0, nc = 0; bool out = false;
-    for (int index = 0; index < K && !out; ++index) {
-        bool dup = true;
-        while (dup) {
-            dup = false;
-            if (pos >= n) { out = true; break; }
-            st->cidx[index] = perm[pos++];
-            for (int j = 0; j < index; ++j)
-                if (l2_ff(feat + (size_t)st->cidx[index] * C, feat + (size_t)st->cidx[j] * C, C) < 1e-16) dup = true;
+            s_j[i] = (int)(((hi % d) * c + lo % d) % d);
         }
-        if (!out) nc = index + 1;
     }
-    st->nc = nc;
-    if (nc < K) st->done = 1;           // root cannot be split: one label
+    __syncthreads();
+    if (tid == 0) {
+        if (lds) {
+            for (int i = n - 1; i > 0; --i) { const int j = s_j[i]; const int t = pm[i]; pm[i] = pm[j]; pm[j] = t; }
+        } else {
+            for (int i = n - 1; i > 0; --i) { const int j = (int)(sm64_at(seed, (uint64_t)(n - 1 - i)) % (uint64_t)(i + 1)); const int t = pm[i]; pm[i] = pm[j]; pm[j] = t; }
+        }
+    }
+    __syncthreads();
+    if (lds) for (int i = tid; i < n; i += 256) perm[i] = pm[i];
+    // first K candidates of the permutation that are not duplicates (squared distance < 1e-16) of an earlier centre
+    int pos = 0, nc = 0;
+    for (int index = 0; index < K; ++index) {
+        bool out = false;
+        while (true) {
+            if (tid == 0) { s_stop = pos >= n ? 1 : 0; s_dup = 0; if (pos < n) { s_cand = pm[pos]; st->cidx[index] = s_cand; } }
+            __syncthreads();
+            if (s_stop) { out = true; break; }
+            ++pos;
+            if (tid < index && l2_ff(feat + (size_t)s_cand * C, feat + (size_t)st->cidx[tid] * C, C) < 1e-16) s_dup = 1;
+            __syncthreads();
+            const bool dup = s_dup != 0;
+            __syncthreads();
+            if (!dup) break;
+        }
+        if (out) break;
+        nc = index + 1;
+    }
+    if (tid == 0) { st->nc = nc; if (nc < K) st->done = 1; }           // root cannot be split: one label
 }
 // first = 1: centres = the chosen points; else: fp64 mean of the members, accumulated in point order (kmeans_index.h:771-785)
 __global__ void k_km_centres(const float* __restrict__ feat, int n, int C, int K, const int* __restrict__ labels, KMState* __restrict__ st, double* __restrict__ dc, int first) {
