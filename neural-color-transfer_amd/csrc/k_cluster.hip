@@ -132,6 +132,40 @@ __global__ void k_km_centres(const float* __restrict__ feat, int n, int C, int K
     for (; p < n; ++p) if (labels[p] == c) s += (double)feat[(size_t)p * C + k];
     dc[i] = s / (double)st->count[c];
 }
+// same sums for C a multiple of 256 (every workgroup then belongs to ONE cluster): wave 0 first compacts the cluster's members into an
+// ascending list in LDS, then every thread adds only the members — 10x fewer loop trips than scanning all points per (cluster, dim)
+__global__ __launch_bounds__(256) void k_km_centres_list(const float* __restrict__ feat, int n, int C, int K, const int* __restrict__ labels, KMState* __restrict__ st,
+                                                         double* __restrict__ dc) {
+    if (st->done) return;
+    __shared__ int s_list[KM_LDS_PERM];
+    __shared__ int s_cnt;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = (blockIdx.x * 256) / C, k = i - c * C;
+    if (threadIdx.x < 64) {
+        int base = 0;
+        for (int p0 = 0; p0 < n; p0 += 64) {
+            const int p = p0 + threadIdx.x;
+            const bool in = p < n && labels[p] == c;
+            const unsigned long long bal = __ballot(in);
+            if (in) s_list[base + __popcll(bal & ((1ull << threadIdx.x) - 1ull))] = p;
+            base += __popcll(bal);
+        }
+        if (threadIdx.x == 0) s_cnt = base;
+    }
+    __syncthreads();
+    const int m = s_cnt;
+    double s = 0.0;
+    int t = 0;
+    for (; t + 8 <= m; t += 8) {
+        float f[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f[u] = feat[(size_t)s_list[t + u] * C + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)f[u];
+    }
+    for (; t < m; ++t) s += (double)feat[(size_t)s_list[t] * C + k];
+    dc[i] = s / (double)st->count[c];
+}
 __global__ void k_km_dist(const float* __restrict__ feat, int n, int C, int K, const double* __restrict__ dc, const KMState* __restrict__ st, float* __restrict__ dist) {
     if (st->done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,7 +216,11 @@ int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat, int n, in
     hipLaunchKernelGGL(k_km_init, dim3(1), dim3(256), 0, s, feat, n, C, K, seed, (int*)perm, (KMState*)st, labels); NCT_LAUNCH_CHECK();
     for (int it = 0; it <= iters; ++it) {          // it == 0: initial assignment to the chosen centres; 1..iters: Lloyd steps
         const int first = it == 0 ? 1 : 0, last = it == iters ? 1 : 0;
-        hipLaunchKernelGGL(k_km_centres, dim3(cdiv(K * C, 256)), dim3(256), 0, s, feat, n, C, K, (const int*)labels, (KMState*)st, (double*)dc, first); NCT_LAUNCH_CHECK();
+        if (!first && C % 256 == 0 && n <= KM_LDS_PERM)
+            hipLaunchKernelGGL(k_km_centres_list, dim3(K * C / 256), dim3(256), 0, s, feat, n, C, K, (const int*)labels, (KMState*)st, (double*)dc);
+        else
+            hipLaunchKernelGGL(k_km_centres, dim3(cdiv(K * C, 256)), dim3(256), 0, s, feat, n, C, K, (const int*)labels, (KMState*)st, (double*)dc, first);
+        NCT_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_km_dist, dim3(cdiv(n * K, 256)), dim3(256), 0, s, feat, n, C, K, (const double*)dc, (const KMState*)st, (float*)dist); NCT_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_km_relabel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, K, (const float*)dist, labels, (KMState*)st, first); NCT_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_km_step_end, dim3(1), dim3(1), 0, s, feat, n, C, K, (const double*)dc, labels, (KMState*)st, first, last); NCT_LAUNCH_CHECK();
@@ -226,8 +264,18 @@ __global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* 
     const unsigned m = mask[cy * lw + cx];
     const unsigned col = (unsigned)lab[(size_t)i * 3] | ((unsigned)lab[(size_t)i * 3 + 1] << 8) | ((unsigned)lab[(size_t)i * 3 + 2] << 16);
     const int nlabels = nlabels_dev ? *nlabels_dev : nlabels_host;   // the pipeline passes the k-means result without a host round trip
-    for (int l = 0; l < nlabels; ++l)
-        if ((m >> l) & 1u) { const int pos = atomicAdd(count, 1); keys[pos] = cell_key(l, col, cs); vals[pos] = (unsigned)i; }
+    // one atomic per wave and label instead of one per entry (the order of the entries is irrelevant: they are sorted afterwards and the
+    // search result does not depend on the order inside a cell)
+    for (int l = 0; l < nlabels; ++l) {
+        const bool in = (m >> l) & 1u;
+        const unsigned long long bal = __ballot(in);
+        if (bal == 0ull) continue;
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(count, __popcll(bal));
+        base = __shfl(base, leader);
+        if (in) { const int pos = base + __popcll(bal & ((1ull << lane) - 1ull)); keys[pos] = cell_key(l, col, cs); vals[pos] = (unsigned)i; }
+    }
 }
 // start[k] = first sorted entry with key >= k, k in [0, nkeys]
 __global__ void k_knn_cell_starts(const unsigned* __restrict__ keys, int m, int* __restrict__ start, int nkeys) {
