@@ -25,9 +25,12 @@
 struct PMGeom { int C, ah, aw, bh, bw, tiles_x, tiles_y; };
 
 // ---- distance of query (ax,ay) to candidate (bx,by): -(sum over valid taps of <a,b>) / n_valid
-template <int NCH>
+// `need`: early-rejection threshold on the tap sum for UNIT-NORM features (every per-pixel vector has norm <= 1, so a tap adds at most 1
+// by Cauchy-Schwarz): a candidate whose partial sum after a patch row cannot reach `need` any more cannot beat the current best and
+// its remaining rows are not fetched (the caller gets FLT_MAX = "not better"). -FLT_MAX disables the test.
+template <int NCH, bool EX>
 __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const PMGeom& g, int ax, int ay, unsigned amask,
-                                         int bx, int by, int v, const float4* __restrict__ a_lds, int lx, int ly) {
+                                         int bx, int by, int v, const float4* __restrict__ a_lds, int lx, int ly, float need) {
     // Fast path: when every tap of the query AND of the candidate lies inside its image — for every query of the wave, so the
     // branch is uniform — the nine B rows are the centre pointer plus wave-uniform offsets, the nine LDS rows are immediates,
     // nothing is masked and n = 9: ~70 VALU instructions per evaluation instead of ~270 (clamps, validity tests, selects and 64-bit
@@ -42,13 +45,27 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
             const float4* pbc = reinterpret_cast<const float4*>(B) + (size_t)(unsigned)(by * g.bw + bx) * C4 + v;
             const float4* pac = a_lds + ((ly + 1) * 6 + (lx + 1)) * C4 + v;
             float facc = 0.f;
-            if constexpr (NCH == 1) {
+            if constexpr (EX) {
+                // one patch row at a time; a hopeless candidate stops after a row
+                // (margins: a tap of unit vectors adds <= 1 + 2e-6, fp32 accumulation error < 1e-4)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const float4* pbr = pbc + dy * g.bw * C4;
+                    const float4* par = pac + dy * 6 * C4;
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) facc = dot4_acc(par[dx * C4 + 16 * k], pbr[dx * C4 + 16 * k], facc);
+                    if (dy < 1 && need > -FLT_MAX) {
+                        const float rem = dy < 0 ? 6.0007f : 3.0004f;
+                        if (row16_sum(facc) + rem < need) return FLT_MAX;
+                    }
+                }
+            } else if constexpr (NCH == 1) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {                      // all nine loads in flight
                     const int dy = t / 3 - 1, dx = t % 3 - 1;
-                    const float4* pb = pbc + (dy * g.bw + dx) * C4;
-                    const float4* pa = pac + (dy * 6 + dx) * C4;
-                    facc = dot4_acc(pa[0], pb[0], facc);
+                    facc = dot4_acc(pac[(dy * 6 + dx) * C4], pbc[(dy * g.bw + dx) * C4], facc);
                 }
             } else {
                 // one patch row (3 taps x NCH chunks) at a time: bounds the loads in flight, and with them the register count
@@ -105,9 +122,9 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 // A launch carries up to two independent jobs (the S->R and the R->S field of one level): workgroups [0, nblk0) belong to
 // job 0, the rest to job 1. Fusing the two directions doubles the number of resident workgroups at the coarse levels
 // (44x44 queries are only 121 workgroups for 256 CUs) and halves the launch count; each job's result is unaffected.
-struct PMJob { const float* A; const float* B; const uint32_t* nnf_in; const float* d_in; uint32_t* nnf_out; float* d_out; PMGeom g; int rs_max; uint32_t seed; };
+struct PMJob { const float* A; const float* B; const uint32_t* nnf_in; const float* d_in; uint32_t* nnf_out; float* d_out; PMGeom g; int rs_max; uint32_t seed; int unit_norm; };
 
-template <int NCH>
+template <int NCH, bool EX>
 __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
                                                  unsigned long long* __restrict__ counter) {
     const bool second = (int)blockIdx.x >= nblk0;
@@ -160,7 +177,7 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
     unsigned nevals = 0;
 
     if (mode == 0) {
-        dbest = pm_dist<NCH>(A, B, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly);
+        dbest = pm_dist<NCH, EX>(A, B, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
         float cut = (float)INT_MAX;                 // dist_single default cutoff
         if (dbest >= cut) dbest = cut;
         nevals = 1;
@@ -194,7 +211,8 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
                 valid = true; rr = FLT_MIN;
             }
             if (valid) {
-                float d = pm_dist<NCH>(A, B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly);
+                // to win, -sum/9 (+rr) < dbest, i.e. sum > -9 dbest: unreachable sums are cut off (unit-norm features only)
+                float d = pm_dist<NCH, EX>(A, B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
                 if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
                 if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; }
                 ++nevals;
@@ -215,12 +233,16 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
 template <int NCH>
 static void launch_step(hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
     const size_t lds = NCH >= 1 ? (size_t)36 * NCH * 16 * sizeof(float4) : 0;      // 6x6 pixels x C/4 float4
-    hipLaunchKernelGGL(k_pm_step<NCH>, dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
+    // unit-norm features (the pipeline): the instantiation with the exact early rejection; it exists for the C with an interior fast path
+    if (j0.unit_norm && NCH >= 1 && NCH <= NCT_PM_FAST_MAX)
+        hipLaunchKernelGGL((k_pm_step<NCH, true>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
+    else
+        hipLaunchKernelGGL((k_pm_step<NCH, false>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
 }
 
 // Runs one PatchMatch (bnn == nullptr) or both directions of a level fused in the same launches (A->B in ann, B->A in bnn).
 static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw, int iters, int rs_max,
-                  uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, unsigned long long* eval_counter) {
+                  uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, unsigned long long* eval_counter, int unit_norm) {
     NCT_REQUIRE(C > 0 && (C & 3) == 0, "patchmatch: C=%d must be a positive multiple of 4", C);
     NCT_REQUIRE(ah >= 1 && aw >= 1 && bh >= 1 && bw >= 1 && ah < 4096 && aw < 4096 && bh < 4096 && bw < 4096,
                 "patchmatch: dims out of range (%dx%d vs %dx%d); NNF coordinates are 12-bit", ah, aw, bh, bw);
@@ -235,8 +257,8 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
     uint32_t* na_buf[2] = {ann, a_tmp}; float* da_buf[2] = {annd, ad_tmp};
     uint32_t* nb_buf[2] = {bnn, b_tmp}; float* db_buf[2] = {bnnd, bd_tmp};
     auto step = [&](int in, int out, int mode, int jump, int iter) {
-        PMJob j0{a_hwc, b_hwc, na_buf[in], da_buf[in], mode ? na_buf[out] : nullptr, da_buf[out], ga, rs_max, seed_ab};
-        PMJob j1{b_hwc, a_hwc, nb_buf[in], db_buf[in], mode ? nb_buf[out] : nullptr, db_buf[out], gb, rs_max, seed_ba};
+        PMJob j0{a_hwc, b_hwc, na_buf[in], da_buf[in], mode ? na_buf[out] : nullptr, da_buf[out], ga, rs_max, seed_ab, unit_norm};
+        PMJob j1{b_hwc, a_hwc, nb_buf[in], db_buf[in], mode ? nb_buf[out] : nullptr, db_buf[out], gb, rs_max, seed_ba, unit_norm};
         switch (C) {
             case 64:  launch_step<1>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
             case 128: launch_step<2>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
@@ -246,8 +268,8 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
         }
     };
     // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device
-    if (C == 512) NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 8 * 16 * (int)sizeof(float4)));
-    if (C == 256) NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 4 * 16 * (int)sizeof(float4)));
+    if (C == 512) NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 8 * 16 * (int)sizeof(float4)));
+    if (C == 256) NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 4 * 16 * (int)sizeof(float4)));
     // the total number of Jacobi steps is even (iters*4), so ping-ponging (nnf,dist) <-> (tmp) ends in (nnf,dist)
     step(0, 0, 0, 0, 0);                           // init: dist(current NNF), NNF untouched
     NCT_LAUNCH_CHECK();
@@ -265,10 +287,10 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
 
 int nctk_patchmatch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
                     int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist, unsigned long long* eval_counter) {
-    return pm_run(ctx, s, a_hwc, b_hwc, C, ah, aw, bh, bw, iters, rs_max, seed, 0u, nnf, dist, nullptr, nullptr, eval_counter);
+    return pm_run(ctx, s, a_hwc, b_hwc, C, ah, aw, bh, bw, iters, rs_max, seed, 0u, nnf, dist, nullptr, nullptr, eval_counter, 0);
 }
 
 int nctk_patchmatch_bidir(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
-                          int iters, int rs_max, uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd) {
-    return pm_run(ctx, s, a_hwc, b_hwc, C, ah, aw, bh, bw, iters, rs_max, seed_ab, seed_ba, ann, annd, bnn, bnnd, nullptr);
+                          int iters, int rs_max, uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, int unit_norm) {
+    return pm_run(ctx, s, a_hwc, b_hwc, C, ah, aw, bh, bw, iters, rs_max, seed_ab, seed_ba, ann, annd, bnn, bnnd, nullptr, unit_norm);
 }

@@ -96,7 +96,8 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
 int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* rough, const double* wx, const double* wy, int H, int W,
                       double rtol, int* iters_out);
 int nctk_patchmatch_bidir(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
-                          int iters, int rs_max, uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd);
+                          int iters, int rs_max, uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd,
+                          int unit_norm /* 1: every feature vector has norm <= 1 (enables the exact early rejection) */);
 // k_vote.hip
 int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, const uint32_t* bnn, const float* pin_hwc, float* pout_hwc, float* pw /*nullable*/,
                            int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp);

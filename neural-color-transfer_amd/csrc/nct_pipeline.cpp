@@ -168,7 +168,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         if (l > 0) { rc = nctk_normalize(ctx, s, sfeat, na, nullptr, C, na_px); if (rc) return rc; }
         rc = nctk_normalize(ctx, s, *rfeat[l], nb, nullptr, C, nb_px); if (rc) return rc;
         const uint32_t seed_ab = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 1)), seed_ba = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 2));
-        rc = nctk_patchmatch_bidir(ctx, s, na, nb, C, ah[l], aw[l], bh[l], bw[l], prm->pm_iters, rs_range[l], seed_ab, seed_ba, ann, annd, bnn, bnnd); if (rc) return rc;
+        rc = nctk_patchmatch_bidir(ctx, s, na, nb, C, ah[l], aw[l], bh[l], bw[l], prm->pm_iters, rs_range[l], seed_ab, seed_ba, ann, annd, bnn, bnnd, 1 /* na, nb are normalised */); if (rc) return rc;
         clk.lap(timing ? &timing->patchmatch_ms : nullptr);
         // BDS votes: guidance image (main.cu:291) and features + matching error (main.cu:303-318)
         rc = nctk_bds_vote_both(ctx, s, rimg[l], *rfeat[l], ann, bnn, C, ah[l], aw[l], bh[l], bw[l], 1.0, prm->bds_weight, guide, voted); if (rc) return rc;
