@@ -187,7 +187,7 @@ def patchmatch_roofline(nct, synth, device, S):
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launch,
             "avg_launch_ms": ms / n_launch, "algorithmic_bytes_per_launch": alg / n_launch, "evals": evals,
             "traffic_GBs": traffic_gbs, "traffic_frac_of_peak": None if traffic_gbs is None else traffic_gbs / HBM_PEAK_GBS,
-            "note": "algorithmic bytes (SURVEY 8d) exceed the memory-side traffic: overlapping candidate tiles are served by L1/L2 "
+            "note": "fixture = random un-normalised features, kernel instantiation without the unit-norm early rejection the pipeline uses; algorithmic bytes (SURVEY 8d) exceed the memory-side traffic: overlapping candidate tiles are served by L1/L2 "
                     "(traffic = FETCH_SIZE x2 (gfx950 correction, calibrated) + WRITE_SIZE per launch, profiles/r1s_pmc_patchmatch.json; traffic_GBs = that traffic over this run's launch time)"}
 
 
