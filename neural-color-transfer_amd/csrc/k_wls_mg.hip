@@ -600,7 +600,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     // z = Vcycle(r). Levels 0..nl-2 run the tile-fused down/up legs (2 launches per level), the coarsest grid one 6-wave kernel.
     // res[l] = where level l's correction ends up (the up leg cannot write in place: neighbouring tiles still read lv[l].x).
     // The deepest levels (<= 512 pixels) run inside one workgroup (k_mg_tail); 44x44 and up keep their own grids — a single CU doing
-    // the 44x44 level as well was slower than the two ~5 us launches it replaced (profiles/r1e).
+    // the 44x44 level as well was slower (157 us per cycle) than the two ~5 us launches it replaced.
     // tail0 = first level of the single-workgroup tail: the deepest run of levels with <= TAIL_N pixels (at most TAIL_LV of them)
     int tail0 = nl - 1;
     while (tail0 > 1 && lv[tail0 - 1].n <= TAIL_N && nl - (tail0 - 1) <= TAIL_LV) --tail0;
