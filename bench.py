@@ -1,26 +1,40 @@
 #!/usr/bin/env python3
 """bench.py — end-to-end throughput of the hot path on N MI355X GPUs (one process per GPU, pairs sharded, no data collective).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-A "step" = one full pass of the hot path (VGG19 features, k-means, L=5->1 PatchMatch both ways, BDS votes, kNN graph,
-nonlocal + WLS colour solves, re-predicts) over one batch of `--inflight` (default 4) synthetic 700x700 source/reference pairs
-per GPU — BASELINE config 2. The pairs of a batch are independent jobs (own context, streams, arena, host thread) that run
-concurrently on the GPU: the launch-latency-bound phases of one overlap the heavy kernels of the others (+17 % pairs/s at 2,
-+24 % at 4 in flight, ~2.6 GB of HBM each; `--inflight 1` gives the single-pair latency, reported as `single_pair_ms` either way).
-`value` = pairs/s summed over ranks, inputs resident in HBM when the timed region starts (nct_pair_run only).
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0. With N > 1 and no
+torch.distributed environment the script re-launches itself under `python -m torch.distributed.run --nproc-per-node N` (one rank per
+GPU over RCCL); launched by torchrun directly it just checks WORLD_SIZE == N.
+
+A "step" = one full pass of the hot path (VGG19 features, k-means, L=5->1 PatchMatch both ways, BDS votes, kNN graphs, nonlocal +
+WLS colour solves, re-predicts) over one batch of `--inflight` (default 4) synthetic 700x700 source/reference pairs per GPU —
+BASELINE config 2 (`--workload pair700`). The pairs of a batch are independent jobs (own context, streams, arena, host thread)
+that run concurrently on the GPU (`--inflight 1` gives the single-pair latency, reported as `single_pair_ms` either way).
+`value` = pairs/s summed over ranks with the inputs resident in HBM when the timed region starts (nct_pair_run); the host-buffer
+in -> host-buffer out rate over the same batch shape (nct_process_pair: + 2.9 MB of PCIe per pair) is `host_to_host_pairs_per_s`.
+Other workloads (parity-test configurations of BASELINE.json, selectable for scaling runs): pair1000 (config 4), pair256l5 (config 1:
+256x256, L=5 only), batch64 (config 3: 64 pairs of 700x700 per step, static i mod N, strong scaling), mixed256 (config 5: 256 pairs
+with sides 256..1000 per step, dynamic tickets from the rendezvous store = work stealing across ranks without a collective).
 
 Extra objects:
-  roofline     — dominant PatchMatch kernel (Jacobi step at the finest level, k_pm_step<1>): algorithmic GB/s from the device
-                 eval counter x SURVEY §8d bytes-per-eval over the kernel time measured with HIP events on the library's
-                 own stream, vs the 8 TB/s HBM peak. `traffic` stays null until the PMC pass is recorded in profiles/.
-  cpu_baseline — the CPU oracle ("port") end-to-end on a bounded sample, on this box's host cores.
-  stages_ms    — per-stage wall time of one extra, instrumented pair (not part of the timed region).
+  roofline     — the dominant kernel AS THE PIPELINE RUNS IT: k_pm_step<1, 1> (C = 64, finest level, both directions per launch, unit-norm
+                 features with the exact row rejection). avg launch time = HIP events recorded on the library's stream around the
+                 level's 41 launches of a real pair; `traffic` = fabric-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE
+                 x2 gfx950 correction + WRITE_SIZE, separate passes) of THIS build — collected live when rocprofv3 is on PATH, else
+                 read from profiles/ only if the recorded build id equals this libnct.so's; `achieved` = traffic / launch time,
+                 `frac` = achieved / 8 TB/s. The SURVEY §8d no-reuse byte model is reported next to it (`algorithmic_GBs`).
+  cpu_baseline — the CPU oracle ("port") end-to-end on a bounded sample of the same workload, on this box's host cores.
+  stages_ms    — per-stage device time of one extra pair (events on the stream; not part of the timed region).
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -30,6 +44,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+WORKLOADS = ("pair700", "pair1000", "pair256l5", "batch64", "mixed256")
 
 
 def pm_bytes(evals, n_queries, n_launches, C):
@@ -37,37 +52,65 @@ def pm_bytes(evals, n_queries, n_launches, C):
     return evals * 9 * C * 4 + n_launches * n_queries * 9 * C * 4 + n_launches * n_queries * 5 * 8
 
 
+def lib_build_id():
+    import nct
+    return hashlib.sha256(open(nct.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=700, help="image side (BASELINE config 2 = 700)")
-    ap.add_argument("--inflight", type=int, default=4, help="independent pairs in flight per GPU per step (batch size)")
+    ap.add_argument("--workload", default="pair700", choices=WORKLOADS)
+    ap.add_argument("--size", type=int, default=0, help="[test hook] image side for the pair* workloads (0 = the workload's own)")
+    ap.add_argument("--inflight", type=int, default=4, help="independent pairs in flight per GPU (contexts + host threads)")
+    ap.add_argument("--batch", type=int, default=0, help="[test hook] pairs per step for batch64 / mixed256 (0 = 64 / 256)")
     ap.add_argument("--dist-backend", default="nccl", help="[test hook] torch.distributed backend (gloo exercises the N>1 path on a 1-GPU box)")
     ap.add_argument("--device-override", type=int, default=-1, help="[test hook] run every rank on this device instead of LOCAL_RANK")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle on the full 700x700 pair (minutes)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 PMC passes (traffic falls back to profiles/)")
+    ap.add_argument("--print-launch", action="store_true", help="[test hook] print the torchrun command --gpus N would re-launch with, and exit")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU: re-launch under torchrun (the driver may also do this itself)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--print-launch"]
+        if args.print_launch:
+            print(json.dumps(cmd)); sys.exit(0)
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
     if args.device_override >= 0:
         local_rank = args.device_override
     import torch
     dist = None
+    rccl_ranks = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
+            rccl_ranks = dist.get_world_size()
         else:
             dist.init_process_group(args.dist_backend)
 
     import nct
     import synth
     from caffemodel_io import synthetic_vgg19, write_caffemodel
+    from nct.shard import shard_pairs, timed_region
 
     K = max(1, args.inflight)
     ctxs = [nct.Context(local_rank) for _ in range(K)]
@@ -80,151 +123,295 @@ def main():
         for c in ctxs:
             c.vgg19_load_caffemodel(path)
 
-    S = args.size
-    # pair i of the job: seeds 1000+2i / 1001+2i
-    def pair(i):
-        return synth.image(1000 + 2 * i, S, S), synth.image(1001 + 2 * i, S, S)
-
     prm = nct.Params.default()
-
-    from nct.shard import shard_pairs, timed_region
-    import threading
-
-    # global pair list of this job: K pairs per GPU per step, pair i -> rank i mod N (weak scaling); slot k of this rank holds
-    # its k-th pair, resident on the device before the timed region starts
-    my_pairs = shard_pairs(world * K, rank, world)
-    for c, pi in zip(ctxs, my_pairs):
-        src, ref = pair(pi)
-        c.pair_upload(src, ref)
-    src, ref = pair(my_pairs[0])
+    wl = args.workload
+    S = args.size or {"pair700": 700, "pair1000": 1000, "pair256l5": 256, "batch64": 700, "mixed256": 0}[wl]
+    if wl == "pair256l5":
+        prm.levels = 1
 
     def sync():
         for c in ctxs:
             c.synchronize()
         torch.cuda.synchronize()
 
-    def step(i):
+    def run_workers(fn):
+        """fn(k) on K host threads (ctypes releases the GIL inside the library calls)."""
         if K == 1:
-            ctx.pair_run(prm)
+            fn(0)
             return
-        ths = [threading.Thread(target=c.pair_run, args=(prm,)) for c in ctxs[1:]]     # ctypes releases the GIL inside the call
+        ths = [threading.Thread(target=fn, args=(k,)) for k in range(1, K)]
         for t in ths:
             t.start()
-        ctx.pair_run(prm)
+        fn(0)
         for t in ths:
             t.join()
 
-    elapsed = timed_region(step, args.steps, args.warmup, dist=dist, sync=sync,
-                           device=torch.device("cuda", local_rank) if (dist is not None and args.dist_backend == "nccl") else None)
+    host_to_host = None
+    if wl.startswith("pair"):
+        # weak scaling: K pairs per GPU per step; pair i of the job: seeds 1000+2i / 1001+2i (SURVEY §8d), pair i -> rank i mod N;
+        # slot k of this rank holds its k-th pair, resident on the device before the timed region starts
+        def pair(i):
+            return synth.image(1000 + 2 * i, S, S), synth.image(1001 + 2 * i, S, S)
+        my_pairs = shard_pairs(world * K, rank, world)
+        host = [pair(pi) for pi in my_pairs]
+        for c, (src, ref) in zip(ctxs, host):
+            c.pair_upload(src, ref)
+        elapsed = timed_region(lambda i: run_workers(lambda k: ctxs[k].pair_run(prm)), args.steps, args.warmup, dist=dist, sync=sync,
+                               device=torch.device("cuda", local_rank) if rccl_ranks else None)
+        pairs_per_step = world * K
+        scaling = "weak"
+        e2 = timed_region(lambda i: run_workers(lambda k: ctxs[k].process_pair(host[k][0], host[k][1], prm)), args.steps, 0, dist=dist, sync=sync,
+                          device=torch.device("cuda", local_rank) if rccl_ranks else None)
+        host_to_host = pairs_per_step * args.steps / e2
+        src, ref = host[0]
+        desc = (f"{K} independent {S}x{S} source/reference pair(s) in flight per GPU per step, " +
+                ("L=5 only (BASELINE config 1)" if wl == "pair256l5" else "full L=5->1 pyramid") + ", bds=2.0, Config.h defaults"
+                + {"pair700": " (BASELINE config 2)", "pair1000": " (BASELINE config 4)"}.get(wl, ""))
+    else:
+        # a step = one whole batch through nct_process_pair (host in -> host out), K workers per GPU
+        nb = args.batch or (64 if wl == "batch64" else 256)
+        if wl == "batch64":
+            sizes = [(S, S, S, S)] * nb
+            mine = shard_pairs(nb, rank, world)                     # static i mod N (config 3)
+        else:
+            sizes = []
+            for i in range(nb):                                     # sides ~U{256..1000}, independently for S and R, seed 5000+i (SURVEY §8d)
+                r = np.random.default_rng(5000 + i).integers(256, 1001, 4)
+                sizes.append(tuple(int(v) for v in r))
+            mine = None                                             # dynamic tickets (config 5)
+        cache = {}
 
-    # single-pair latency (nothing else on the GPU), host-in -> host-out rate for DESIGN.md (never `value`), per-stage times
+        def images(i):
+            if i not in cache:
+                sh, sw, rh, rw = sizes[i]
+                cache[i] = (synth.image(1000 + 2 * i, sh, sw), synth.image(1001 + 2 * i, rh, rw))
+            return cache[i]
+        if mine is not None:
+            for i in mine:
+                images(i)
+        else:
+            for i in range(nb):
+                images(i)                                           # every rank may draw any ticket
+        store = dist.distributed_c10d._get_default_store() if dist is not None else None
+        lock = threading.Lock()
+        local = {"next": 0, "step": -1, "done": 0}
+
+        def ticket(step_id):
+            """next unprocessed pair of this step: a shared counter in the rendezvous store (work stealing across ranks, no collective)"""
+            if store is not None and mine is None:
+                return store.add(f"ticket{step_id}", 1) - 1
+            with lock:
+                t = local["next"]; local["next"] += 1
+                return t
+
+        def batch_step(i):
+            with lock:
+                local["next"] = 0
+            todo = mine if mine is not None else None
+
+            def worker(k):
+                while True:
+                    t = ticket(i)
+                    if todo is not None:
+                        if t >= len(todo):
+                            return
+                        idx = todo[t]
+                    else:
+                        if t >= nb:
+                            return
+                        idx = t
+                    s_, r_ = images(idx)
+                    ctxs[k].process_pair(s_, r_, prm)
+                    with lock:
+                        local["done"] += 1
+            run_workers(worker)
+        elapsed = timed_region(batch_step, args.steps, args.warmup, dist=dist, sync=sync, device=torch.device("cuda", local_rank) if rccl_ranks else None)
+        pairs_per_step = nb
+        scaling = "strong"
+        host_to_host = pairs_per_step * args.steps / elapsed
+        src, ref = images(mine[0] if mine else 0)
+        ctx.pair_upload(src, ref)
+        desc = (f"{nb} pairs per step through nct_process_pair (host in -> host out), {K} workers per GPU; " +
+                ("700x700, static i mod N (BASELINE config 3)" if wl == "batch64" else "sides 256..1000, dynamic tickets (BASELINE config 5)"))
+
+    # single-pair latency (nothing else on the GPU) and per-stage device times of one more pair
+    ctx.pair_run(prm)
     t1 = time.perf_counter()
     ctx.pair_run(prm)
     single_pair_s = time.perf_counter() - t1
-    t1 = time.perf_counter()
-    out = ctx.process_pair(src, ref, prm)
-    pcie_inclusive_s = time.perf_counter() - t1
     stages = ctx.pair_run(prm, want_timing=True)
+    out = ctx.pair_download()
 
     res = {
         "metric": "700x700 pairs/sec end-to-end L=5->1; PatchMatch HBM GB/s vs peak",
-        "value": world * K * args.steps / elapsed,
+        "value": pairs_per_step * args.steps / elapsed,
         "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{K} independent {S}x{S} source/reference pair(s) in flight per GPU per step, full L=5->1 pyramid, bds=2.0, "
-                               "Config.h defaults (BASELINE config 2); synthetic He-init VGG19 loaded from a V1 caffemodel",
-                   "pairs_per_gpu_per_step": K, "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
+        "config": {"workload": desc + "; synthetic He-init VGG19 loaded from a V1 caffemodel", "name": wl,
+                   "pairs_per_gpu_per_step": K if scaling == "weak" else pairs_per_step / world,
+                   "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
+        "rccl_ranks": rccl_ranks,
+        "host_to_host_pairs_per_s": host_to_host,
         "single_pair_ms": 1e3 * single_pair_s,
         "stages_ms": stages,
-        "pcie_inclusive_pairs_per_s": 1.0 / pcie_inclusive_s,
         "output_checksum": int(out.astype(np.uint64).sum()),
+        "build_id": lib_build_id(),
     }
-
-    res["vgg_mfma"] = vgg_mfma(S, stages["vgg_ms"])
-    if rank == 0 and not args.no_roofline:
-        res["roofline"] = patchmatch_roofline(nct, synth, local_rank, S)
+    res["vgg_mfma"] = vgg_mfma(src.shape[0], src.shape[1], ref.shape[0], ref.shape[1], prm.levels, stages["vgg_ms"])
+    if rank == 0 and not args.no_roofline and prm.levels == 5:
+        res["roofline"] = patchmatch_roofline(nct, ctx, prm, src.shape, ref.shape, local_rank, live_pmc=not args.no_pmc and wl == "pair700" and S == 700)
     if rank == 0 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(synth, ws, bs, S)
+        res["cpu_baseline"] = cpu_baseline(synth, ws, bs, src.shape[0], full=args.cpu_baseline_full)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def patchmatch_roofline(nct, synth, device, S):
-    """Finest-level PatchMatch (S x S x 64, both directions, 10 iterations = 82 launches of k_pm_step<1>) on device-resident
-    synthetic features: kernel time from HIP events inside the library, evals from the device counter (separate pass)."""
-    c = nct.Context(device)
+def pmc_traffic(device, live):
+    """FETCH_SIZE / WRITE_SIZE of the finest-level PatchMatch launches of a real 700x700 pair, this build, two separate counter-only
+    passes (MI355X_MICROARCH.md: FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2; FETCH_SIZE reports half the bytes of wide loads on
+    gfx950 -> x2; the k_normalize dispatch of the same pass, a pure 125.44 MB streaming read, is kept as the calibration check).
+    Returns (dict, how) or (None, why)."""
+    exe = shutil.which("rocprofv3")
+    rec = os.path.join(REPO, "profiles", "r3_pmc_patchmatch.json")
+    bid = lib_build_id()
+    why = "live PMC disabled"
+    if live and exe:
+        try:
+            vals = {}
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                    env = dict(os.environ, TMPDIR="/tmp", HIP_VISIBLE_DEVICES=str(device))
+                    subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", td, "-o", "c", "--output-format", "csv", "--",
+                                    sys.executable, os.path.join(REPO, "scripts", "pair_only.py"), "700", "2"],
+                                   cwd=REPO, env=env, check=True, capture_output=True, timeout=300)
+                    vals[ctr] = read_pmc_csv(td, ctr)
+            return finish_pmc(vals, bid, "live rocprofv3 passes inside bench.py"), "live"
+        except Exception as e:      # noqa: BLE001 — fall back to the recorded passes
+            why = f"live PMC failed: {type(e).__name__}: {str(e)[:120]}"
+    elif live:
+        why = "rocprofv3 not on PATH"
+    if os.path.exists(rec):
+        d = json.load(open(rec))
+        if d.get("build_id") == bid:
+            return d, "recorded (profiles/r3_pmc_patchmatch.json, same build id)"
+        why += "; the recorded PMC passes belong to another build"
+    return None, why
+
+
+def read_pmc_csv(td, ctr):
+    import csv, glob
+    f = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+    rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == ctr]
+    v = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"].startswith("void k_pm_step<1, 1>")]
+    norm = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"].startswith("k_normalize(")]
+    return {"dispatches": len(v), "mean": sum(v) / len(v), "normalize_max": max(norm) if norm else None}
+
+
+def finish_pmc(vals, bid, how):
+    fetch = vals["FETCH_SIZE"]["mean"] * 1024 * 2          # KB -> B, x2: gfx950 counts 128-B requests as 64 B (guide, HBM section)
+    write = vals["WRITE_SIZE"]["mean"] * 1024
+    cal = {}
+    if vals["FETCH_SIZE"]["normalize_max"]:
+        cal = {"k_normalize_700x700x64_bytes": 125440000, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"]["normalize_max"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"]["normalize_max"],
+               "fetch_raw_over_actual": vals["FETCH_SIZE"]["normalize_max"] * 1024 / 125440000.0,
+               "write_raw_over_actual": (vals["WRITE_SIZE"]["normalize_max"] or 0) * 1024 / 125440000.0}
+    return {"build_id": bid, "how": how, "kernel": "k_pm_step<1, 1>", "dispatches": vals["FETCH_SIZE"]["dispatches"],
+            "FETCH_SIZE_KB_per_dispatch_raw": vals["FETCH_SIZE"]["mean"], "WRITE_SIZE_KB_per_dispatch_raw": vals["WRITE_SIZE"]["mean"],
+            "calibration": cal, "corrected_bytes_per_launch": {"fetch": fetch, "write": write, "total": fetch + write}}
+
+
+def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
+    """Finest pyramid level of the resident pair: 41 launches of k_pm_step<1, 1> (init + 10 iterations x 4 jumps, S->R and R->S fields in
+    the same launch). Time: HIP events on the library's stream around exactly those launches (nct_pair_timing.pm_level_ms), best of 3
+    pairs; evaluations: device counter in a separate pair (the counting atomics would perturb the timing)."""
+    tms = [ctx.pair_run(prm, want_timing=True) for _ in range(3)]
+    ms = min(t["pm_level_ms"][4] for t in tms)
+    n_launch = tms[0]["pm_level_launches"][4]
+    p2 = nct.Params.default()
+    for k, _ in nct.Params._fields_:
+        setattr(p2, k, getattr(prm, k))
+    p2.flags |= nct.FLAG_COUNT_EVALS
+    evals = ctx.pair_run(p2, want_timing=True)["pm_level_evals"][4]
     C = 64
-    c.pm_bench_setup(synth.features(11, C, S, S), synth.features(12, C, S, S))
-    c.pm_bench_run(iters=10, rs_max=32, seed=1)                      # warm-up
-    ms = 0.0
-    reps = 3
-    for r in range(reps):
-        for d in range(2):
-            m, _, _, _ = c.pm_bench_run(iters=10, rs_max=32, seed=17 + d)
-            ms += m
-    ms /= reps
-    evals = 0
-    for d in range(2):
-        _, ev, _, _ = c.pm_bench_run(iters=10, rs_max=32, seed=17 + d, count_evals=True)
-        evals += ev
-    n_launch = 82
-    alg = pm_bytes(evals, S * S, n_launch, C)
-    achieved = alg / (ms * 1e-3) / 1e9
-    c.close()
-    # HBM/fabric-side bytes per launch come from the recorded, calibrated PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # cannot run inside this process); they apply to the 700x700 workload only.
-    traffic = None
-    pmc = os.path.join(REPO, "profiles", "r1s_pmc_patchmatch.json")
-    if S == 700 and os.path.exists(pmc):
-        traffic = json.load(open(pmc))["corrected_bytes_per_launch"]["total"]
-    traffic_gbs = None if traffic is None else traffic / (ms / n_launch * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": f"k_pm_step<1> (C=64, {S}x{S}, one direction per launch, 10 iters x 2 directions)", "achieved": achieved,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launch,
-            "avg_launch_ms": ms / n_launch, "algorithmic_bytes_per_launch": alg / n_launch, "evals": evals,
-            "traffic_GBs": traffic_gbs, "traffic_frac_of_peak": None if traffic_gbs is None else traffic_gbs / HBM_PEAK_GBS,
-            "note": "fixture = random un-normalised features, kernel instantiation without the unit-norm early rejection the pipeline uses; algorithmic bytes (SURVEY 8d) exceed the memory-side traffic: overlapping candidate tiles are served by L1/L2 "
-                    "(traffic = FETCH_SIZE x2 (gfx950 correction, calibrated) + WRITE_SIZE per launch, profiles/r1s_pmc_patchmatch.json; traffic_GBs = that traffic over this run's launch time)"}
+    nq = sshape[0] * sshape[1] + rshape[0] * rshape[1]
+    alg = pm_bytes(evals, nq, n_launch, C)
+    launch_s = ms * 1e-3 / n_launch
+    alg_gbs = alg / n_launch / launch_s / 1e9
+    traffic, how, pmc = None, "PMC passes exist for the 700x700 pair only", None
+    if tuple(sshape[:2]) == (700, 700) and tuple(rshape[:2]) == (700, 700):
+        pmc, how = pmc_traffic(device, live_pmc)
+        if pmc is not None:
+            traffic = pmc["corrected_bytes_per_launch"]["total"]
+    achieved = (traffic if traffic is not None else alg / n_launch) / launch_s / 1e9
+    return {"bound": "hbm", "kernel": f"k_pm_step<1, 1> (C=64, {sshape[1]}x{sshape[0]} <-> {rshape[1]}x{rshape[0]}, both directions per launch, pipeline features)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "basis": "PMC fabric-side bytes (FETCH_SIZE x2 + WRITE_SIZE) per launch / event-timed launch" if traffic is not None else
+                     "ALGORITHMIC bytes (no PMC pass of this build available) — not an HBM fraction, can exceed 1",
+            "traffic_source": how, "pmc": pmc, "launches": n_launch, "avg_launch_ms": 1e3 * launch_s, "evals": evals,
+            "algorithmic_bytes_per_launch": alg / n_launch, "algorithmic_GBs": alg_gbs,
+            "traffic_over_algorithmic": None if traffic is None else traffic / (alg / n_launch),
+            "note": "the kernel is bound by the L1 (TA/TCP) request path, not by DRAM bytes: overlapping candidate tiles are served by L1/L2, so the "
+                    "no-reuse byte model (algorithmic_GBs) exceeds the HBM peak; see DESIGN.md 3.2 for the experiments"}
 
 
-def vgg_mfma(S, vgg_ms):
-    """VGG19 conv work of one pair (S and R forwards to conv5_1 + re-predicts to conv4_1, 3_1, 2_1, 1_1: SURVEY 8a V2) over the
-    instrumented pair's VGG stage time (which also contains preprocess, pools and layout transposes) vs the f32-MFMA peak."""
+def vgg_mfma(sh, sw, rh, rw, levels, vgg_ms):
+    """VGG19 conv work of one pair (S and R forwards to conv5_1 + one re-predict per further level to conv4_1, 3_1, 2_1, 1_1: SURVEY 8a V2)
+    over the instrumented pair's VGG stage time (which also contains preprocess, pools and layout transposes) vs the f32-MFMA peak."""
     cin = [3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512]
     cout = [64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512]
     pool_after = {1, 3, 7, 11}
     tap_conv = [0, 2, 4, 8, 12]
-    cum, flops, h, w = [], 0, S, S
-    for i in range(13):
-        flops += 2 * 9 * cin[i] * cout[i] * h * w
-        cum.append(flops)
-        if i in pool_after:
-            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    per_pair = 2 * cum[tap_conv[4]] + sum(cum[tap_conv[t]] for t in range(4))
+
+    def cum_flops(h, w):
+        cum, flops = [], 0
+        for i in range(13):
+            flops += 2 * 9 * cin[i] * cout[i] * h * w
+            cum.append(flops)
+            if i in pool_after:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        return cum
+    cs, cr = cum_flops(sh, sw), cum_flops(rh, rw)
+    per_pair = cs[tap_conv[4]] + cr[tap_conv[4]] + sum(cs[tap_conv[t]] for t in range(4 - (levels - 1), 4))
     tf = per_pair / (vgg_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_conv3x3_mfma (v_mfma_f32_32x32x2_f32), all 6 forwards of a pair", "flops_per_pair": per_pair,
+    return {"bound": "mfma", "kernel": "k_conv3x3_mfma (v_mfma_f32_32x32x2_f32), all forwards of a pair", "flops_per_pair": per_pair,
             "stage_ms": vgg_ms, "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
 
 
-def cpu_baseline(synth, ws, bs, S):
-    """Oracle ('port') end-to-end on a bounded sample: one 112x112 pair, scaled to the SxS pair by pixel count."""
+def cpu_baseline(synth, ws, bs, S, full=False):
+    """Oracle ('port') end-to-end, measured on this box's host cores on a bounded sample of the same workload: one 256x256 pair (full
+    L=5->1 loop, same synthetic VGG19) on all cores and one 64x64 pair on a single thread, scaled to the SxS pair by pixel count. The law
+    was checked against full-size runs: the oracle costs 670-830 s per megapixel from 176^2 to 700^2 on 8 cores (profiles/README.md);
+    `--cpu-baseline-full` times the real SxS pair instead (minutes)."""
     import oracle_bind
     orc = oracle_bind.load()
-    threads = min(32, os.cpu_count() or 1)
-    orc.l.orc_set_threads(threads)
-    n = 112
-    src, ref = synth.image(1000, n, n), synth.image(1001, n, n)
-    t0 = time.perf_counter()
-    orc.process_pair(src, ref, ws, bs)
-    dt = time.perf_counter() - t0
+    threads = min(64, os.cpu_count() or 1)
+
+    def run(n, th):
+        orc.l.orc_set_threads(th)
+        src, ref = synth.image(1000, n, n), synth.image(1001, n, n)
+        t0 = time.perf_counter()
+        orc.process_pair(src, ref, ws, bs)
+        return time.perf_counter() - t0
+    n = min(256, S)
+    dt = run(n, threads)
+    n1 = min(64, S)
+    dt1 = run(n1, 1)
     scale = (n * n) / float(S * S)
-    return {"value": scale / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"oracle orc_process_pair on one {n}x{n} pair (full L=5->1 loop, same synthetic VGG19) took {dt:.2f} s on {threads} OpenMP threads; "
-                      f"scaled to a {S}x{S} pair by pixel count ({1 / scale:.1f}x)"}
+    scale1 = (n1 * n1) / float(S * S)
+    res = {"value": scale / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+           "sample": f"oracle orc_process_pair on one {n}x{n} pair (full L=5->1 loop, same synthetic VGG19): {dt:.2f} s on {threads} OpenMP threads, scaled to "
+                     f"{S}x{S} by pixel count ({1 / scale:.2f}x; linear within +-12 % from 176^2 to 700^2, profiles/README.md); one {n1}x{n1} pair on 1 thread: {dt1:.2f} s",
+           "value_1thread": scale1 / dt1, "sample_seconds": dt, "sample_seconds_1thread": dt1}
+    if full:
+        dtf = run(S, threads)
+        res["full_pair_seconds"] = dtf
+        res["value_full_pair"] = 1.0 / dtf
+    return res
 
 
 if __name__ == "__main__":

@@ -104,7 +104,13 @@ typedef struct nct_params {
     double wls_alpha;
     int pm_iters;
     uint32_t seed;
+    int levels;         /* pyramid levels to run, coarse -> fine: 5 = the reference's full L=5..1 loop (main.cu:179); 1 = "L=5 only"
+                           (BASELINE config 1): the result is the full-resolution image after the coarsest level's colour transfer */
+    uint32_t flags;     /* NCT_FLAG_* (extensions; 0 = reference behaviour) */
 } nct_params;
+#define NCT_FLAG_FEAT16      1u   /* opt-in reduced precision: PatchMatch reads fp16 candidate feature tiles (fp32 accumulate). Halves the
+                                     dominant kernel's bytes; the result is NOT bit-identical to the fp32 path (report PSNR against it) */
+#define NCT_FLAG_COUNT_EVALS 2u   /* profiling: count PatchMatch evaluations per level on the device (nct_pair_timing.pm_level_evals …) */
 void nct_params_default(nct_params* p);
 
 /* ---- A1 + third-party (OpenCV 2.4.10) arithmetic used on the path: cvtColor(CV_BGR2Lab / CV_Lab2BGR) on 8U
@@ -147,18 +153,37 @@ int nct_local_color_transfer(nct_ctx* ctx, const float* err, const uint8_t* s_bg
 /* ---- D3: the per-pair hot loop — transfer_color_single_bds (main.cu:47-454): VGG19 features of S and R, k-means of
  * S's conv5_1, then for L = 5..1: NNF init/upsample, normalise, PatchMatch both ways, BDS votes, matching error, kNN
  * graph, local colour transfer, re-predict. Images are 8-bit BGR, tightly packed HWC. out has the size of src.
- * `timing` (nullable) receives per-stage wall milliseconds (stream-synchronised at stage boundaries, so pass NULL when
- * measuring throughput) under the reference's own stage names (main.cu:331,453; ColorTransfer.cpp:1373,1434).
+ * `timing` (nullable) receives per-stage device milliseconds under the reference's own stage names (main.cu:331,453;
+ * ColorTransfer.cpp:1373,1434), taken from events on the stream (no extra host synchronisation).
  * nct_process_pair = nct_pair_upload + nct_pair_run + nct_pair_download; the split form lets a caller keep inputs
  * resident in HBM (bench.py times nct_pair_run only and reports the PCIe-inclusive rate separately). */
 typedef struct nct_pair_timing {
-    double total_ms, vgg_ms, cluster_ms, patchmatch_ms, vote_ms, knn_ms, color_ms, other_ms;
-    int wls_iters[5];     /* PCG iterations of the WLS solve per level */
+    double total_ms;                    /* host wall time of nct_pair_run */
+    /* device time between stage-boundary events on the pair's main stream; read once after the pair has finished, so asking for
+       timing does not add host synchronisation (the kNN graphs run on a side stream: knn_ms is only what the main stream waited) */
+    double vgg_ms, cluster_ms, patchmatch_ms, vote_ms, knn_ms, color_ms, other_ms;
+    double nonlocal_ms, wls_ms;         /* parts of color_ms: S1 = "Nonlocal Solve Time" (ColorTransfer.cpp:1373), S2 = "WLS Solve Time" (:1434) */
+    int wls_iters[5];                   /* PCG iterations of the WLS solve per level */
+    /* PatchMatch per pyramid level (0 = coarsest): kernel time of the level's launches (init + pm_iters*4 steps, both directions per launch) */
+    double pm_level_ms[5];
+    int pm_level_launches[5];
+    double vote_level_ms[5], nonlocal_level_ms[5], wls_level_ms[5];   /* the same split per level, for the reference's per-level log lines */
+    unsigned long long pm_level_evals[5], pm_level_accepted[5];   /* NCT_FLAG_COUNT_EVALS only, else 0: distance evaluations, accepted candidates */
 } nct_pair_timing;
+/* per-level intermediates for level-wise validation (all pointers nullable; level 0 = coarsest … 4 = finest; arrays have the level's
+ * size ah*aw / bh*bw except `result`, the full-resolution intermediate result after that level, H*W*3 like level_out of the oracle) */
+typedef struct nct_pair_levels {
+    uint32_t* ann[5]; uint32_t* bnn[5];
+    float* annd[5]; float* bnnd[5];
+    uint8_t* guide[5];
+    float* err[5];
+    uint8_t* result[5];
+} nct_pair_levels;
 int nct_process_pair(nct_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, const uint8_t* ref_bgr, int rh, int rw, const nct_params* prm,
                      uint8_t* out_bgr, nct_pair_timing* timing);
 int nct_pair_upload(nct_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, const uint8_t* ref_bgr, int rh, int rw);
 int nct_pair_run(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing);
+int nct_pair_run_levels(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing, const nct_pair_levels* levels);   /* + host copies of the intermediates */
 int nct_pair_download(nct_ctx* ctx, uint8_t* out_bgr);
 
 /* ---- measurement hooks (bench.py / rocprof): device-resident PatchMatch on synthetic features ----
@@ -168,6 +193,11 @@ int nct_pair_download(nct_ctx* ctx, uint8_t* out_bgr);
  * number of distance evaluations actually performed (device counter). */
 int nct_pm_bench_setup(nct_ctx* ctx, const float* a_chw, const float* b_chw, int C, int ah, int aw, int bh, int bw);
 int nct_pm_bench_run(nct_ctx* ctx, int iters, int rs_max, uint32_t seed, float* kernel_ms, uint64_t* evals, uint32_t* nnf_out, float* dist_out);
+/* the pipeline's form of the same pass: both directions fused per launch; pm_mode 0 = fp32 tiles, 1 = fp32 tiles + exact row-wise
+ * rejection for unit-norm features (the pipeline's default), 2 = fp16 tiles (NCT_FLAG_FEAT16). counters (nullable, 2 x uint64):
+ * evaluations, accepted candidates. */
+int nct_pm_bench_run_bidir(nct_ctx* ctx, int iters, int rs_max, uint32_t seed, int pm_mode, float* kernel_ms, uint64_t* counters, uint32_t* ann_out, float* annd_out,
+                           uint32_t* bnn_out, float* bnnd_out);
 
 #ifdef __cplusplus
 }

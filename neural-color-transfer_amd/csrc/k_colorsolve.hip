@@ -464,6 +464,7 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
     NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)((unsigned*)mm + 1), 0, 1, s));
     hipLaunchKernelGGL(k_minmax_f, dim3(128), dim3(256), 0, s, err, n, (unsigned*)mm); LCHK();
     hipLaunchKernelGGL(k_err_weight, dim3(nbl), dim3(256), 0, s, err, n, (const unsigned*)mm, (double*)weight); LCHK();
+    { int rcm = ctx->mark(s, nct_stage_tag_color()); if (rcm) return rcm; }
     // ---------------- S1
     const double normFactor = (double)(W * H) / (double)(w * h);
     {
@@ -536,6 +537,7 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
             for (int c = 0; c < 3; ++c) dbg->cg_iters[c] = hst.iters[c];
         }
     }
+    { int rcm = ctx->mark(s, nct_stage_tag_nonlocal()); if (rcm) return rcm; }
     if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_nonlocal, x, (size_t)6 * n); if (rc) return rc; }
     // ---------------- U1: bilinear upsample to full resolution + roughness
     DevBuf<double> X(ctx, (size_t)6 * N), rough(ctx, N);
@@ -558,7 +560,9 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         hipLaunchKernelGGL(k_gradient_weights, dim3(nbL), dim3(256), 0, s, s_lab_full, H, W, lamda, prm.wls_alpha, (double*)gx, (double*)gy); LCHK();
         hipLaunchKernelGGL(k_wls_system, dim3(nbL), dim3(256), 0, s, (const double*)gx, (const double*)gy, (const double*)rough, H, W, (double*)diag, (double*)wx, (double*)wy); LCHK();
         int wit[6] = {0, 0, 0, 0, 0, 0};
+        { int rcm = ctx->mark(s, nct_stage_tag_color()); if (rcm) return rcm; }
         int rc = nctk_wls_solve_mg(ctx, s, X, rough, wx, wy, H, W, 1e-6, wit); if (rc) return rc;
+        { int rcm = ctx->mark(s, nct_stage_tag_wls()); if (rcm) return rcm; }
         if (dbg && dbg->wls_iters) for (int q = 0; q < 6; ++q) dbg->wls_iters[q] = wit[q];
     }
     if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_wls, X, (size_t)6 * N); if (rc) return rc; }

@@ -4,6 +4,7 @@
 // Roofline: HBM streaming (read C*4 B + write C*4 B per pixel). One 16-lane DPP row per pixel, float4 per lane.
 #include "nct_internal.h"
 #include "nct_device.h"
+#include <hip/hip_fp16.h>
 
 // ---------------------------------------------------------------- CHW <-> HWC
 __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
@@ -38,8 +39,10 @@ int nctk_hwc_to_chw(nct_ctx* ctx, hipStream_t s, const float* src, float* dst, i
 // ---------------------------------------------------------------- N1 normalise
 // Summation order (must match oracle/orc_nnf.c): lane v of the 16-lane row owns float4 chunks v, v+16, …;
 // one fmaf chain per lane; 16-lane butterfly.
+// dst_h (nullable): the same values rounded to fp16 (round-to-nearest-even), HWC — the shadow map the PatchMatch prefilter reads
+// (k_patchmatch.hip); |x - fp16(x)| <= 2^-11 |x| for |x| >= 2^-14 and <= 2^-25 below, which is what its rejection bound relies on.
 __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dis_out,
-                                                   int C, int HW) {
+                                                   int C, int HW, uint2* __restrict__ dst_h) {
     int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
     int v = threadIdx.x & 15;
     bool live = pix < HW;
@@ -53,7 +56,13 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ src
     float4* d4 = reinterpret_cast<float4*>(dst + (size_t)p * C);
     for (int j = v; j < nchunk; j += 16) {
         float4 x = s4[j];
-        d4[j] = make_float4(x.x / d, x.y / d, x.z / d, x.w / d);
+        const float4 y = make_float4(x.x / d, x.y / d, x.z / d, x.w / d);
+        d4[j] = y;
+        if (dst_h) {
+            const __half2 lo = __floats2half2_rn(y.x, y.y), hi = __floats2half2_rn(y.z, y.w);
+            uint2 pk; pk.x = *reinterpret_cast<const unsigned*>(&lo); pk.y = *reinterpret_cast<const unsigned*>(&hi);
+            dst_h[(size_t)p * nchunk + j] = pk;
+        }
     }
     if (dis_out && v == 0) dis_out[p] = d;
 }
@@ -79,10 +88,10 @@ __global__ void k_response(const float* __restrict__ dis, float* __restrict__ re
     if (i < n) resp[i] = (dis[i] + (-mn)) * sc;
 }
 
-int nctk_normalize(nct_ctx* ctx, hipStream_t s, const float* src_hwc, float* dst_hwc, float* resp, int C, int HW) {
+int nctk_normalize(nct_ctx* ctx, hipStream_t s, const float* src_hwc, float* dst_hwc, float* resp, int C, int HW, void* dst_h16) {
     NCT_REQUIRE(C > 0 && (C & 3) == 0, "normalize: C=%d must be a positive multiple of 4", C);
     if (!resp) {
-        hipLaunchKernelGGL(k_normalize, dim3(cdiv(HW, 16)), dim3(256), 0, s, src_hwc, dst_hwc, (float*)nullptr, C, HW);
+        hipLaunchKernelGGL(k_normalize, dim3(cdiv(HW, 16)), dim3(256), 0, s, src_hwc, dst_hwc, (float*)nullptr, C, HW, (uint2*)dst_h16);
         NCT_LAUNCH_CHECK();
         return 0;
     }
@@ -91,7 +100,7 @@ int nctk_normalize(nct_ctx* ctx, hipStream_t s, const float* src_hwc, float* dst
     if (!dis.ok() || !mm.ok()) return NCT_ERR_HIP;
     NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)(unsigned int*)mm, (int)0xFFFFFFFFu, 1, s));
     NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)((unsigned int*)mm + 1), 0, 1, s));
-    hipLaunchKernelGGL(k_normalize, dim3(cdiv(HW, 16)), dim3(256), 0, s, src_hwc, dst_hwc, (float*)dis, C, HW);
+    hipLaunchKernelGGL(k_normalize, dim3(cdiv(HW, 16)), dim3(256), 0, s, src_hwc, dst_hwc, (float*)dis, C, HW, (uint2*)dst_h16);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_minmax, dim3(256), dim3(256), 0, s, (const float*)dis, HW, (unsigned int*)mm);
     NCT_LAUNCH_CHECK();

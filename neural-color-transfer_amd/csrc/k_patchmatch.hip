@@ -13,24 +13,39 @@
 //  * the racy single launch of the reference becomes 1 + iters*4 Jacobi steps on a double-buffered NNF
 //    (one launch per (iteration, jump)); random search is fused into the jump==1 step; RNG is counter based.
 //    => results are deterministic and bit-identical to oracle/orc_nnf.c.
-// Roofline: memory (gather of candidate tiles): algorithmic bytes = evals*9*C*4 (+ query tile + NNF r/w).
+// Roofline: memory (gather of candidate tiles): algorithmic bytes = evals*9*C*4 (+ query tile + NNF r/w). What binds it in practice is
+// the L1 (TA/TCP) request path, not DRAM bytes or latency — measured in round 2: perfectly local candidates,
+// half-size fp16 tiles, 10 % fewer evaluations and two tiles in flight per query all leave the launch time unchanged or worse.
 #include "nct_internal.h"
 #include "nct_device.h"
 #include <cfloat>
 #include <climits>
+#include <hip/hip_fp16.h>
 
 #ifndef NCT_PM_FAST_MAX
 #define NCT_PM_FAST_MAX 2
 #endif
 struct PMGeom { int C, ah, aw, bh, bw, tiles_x, tiles_y; };
 
+__device__ __forceinline__ float dot4h_acc(const float4 a, const uint2 bh, float acc) {
+    const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&bh.x));
+    const float2 hi = __half22float2(*reinterpret_cast<const __half2*>(&bh.y));
+    acc = __builtin_fmaf(a.x, lo.x, acc);
+    acc = __builtin_fmaf(a.y, lo.y, acc);
+    acc = __builtin_fmaf(a.z, hi.x, acc);
+    acc = __builtin_fmaf(a.w, hi.y, acc);
+    return acc;
+}
+
 // ---- distance of query (ax,ay) to candidate (bx,by): -(sum over valid taps of <a,b>) / n_valid
 // `need`: early-rejection threshold on the tap sum for UNIT-NORM features (every per-pixel vector has norm <= 1, so a tap adds at most 1
 // by Cauchy-Schwarz): a candidate whose partial sum after a patch row cannot reach `need` any more cannot beat the current best and
-// its remaining rows are not fetched (the caller gets FLT_MAX = "not better"). -FLT_MAX disables the test.
-template <int NCH, bool EX>
-__device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const PMGeom& g, int ax, int ay, unsigned amask,
+// its remaining rows are not fetched (the caller gets FLT_MAX = "not better"). -FLT_MAX disables the test. That is MODE NCT_PM_ROWREJECT;
+// NCT_PM_FP16 (opt-in reduced precision) reads the candidate tile from the fp16 shadow map Bh instead of B (fp32 accumulate).
+template <int NCH, int MODE>
+__device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const uint2* __restrict__ Bh, const PMGeom& g, int ax, int ay, unsigned amask,
                                          int bx, int by, int v, const float4* __restrict__ a_lds, int lx, int ly, float need) {
+    constexpr bool EX = MODE == NCT_PM_ROWREJECT, HALF = MODE == NCT_PM_FP16;
     // Fast path: when every tap of the query AND of the candidate lies inside its image — for every query of the wave, so the
     // branch is uniform — the nine B rows are the centre pointer plus wave-uniform offsets, the nine LDS rows are immediates,
     // nothing is masked and n = 9: ~70 VALU instructions per evaluation instead of ~270 (clamps, validity tests, selects and 64-bit
@@ -38,10 +53,35 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
     // to bound the loads in flight): the kernel is bound by the L2-miss traffic (5.4 TB/s on the fabric side, PMC FETCH_SIZE), not by
     // issue slots; for C >= 256 the fast path measured slower (the LDS-staged 36-73 KB query regions already limit occupancy), so
     // those instantiations keep the general loop.
-    if constexpr (NCH >= 1 && NCH <= NCT_PM_FAST_MAX) {
+    if constexpr (NCH >= 1 && (HALF || NCH <= NCT_PM_FAST_MAX)) {
         const bool inside = amask == 0x1FFu && bx >= 1 && bx < g.bw - 1 && by >= 1 && by < g.bh - 1;
         if (__builtin_amdgcn_ballot_w64(inside) == __builtin_amdgcn_ballot_w64(true)) {
             constexpr int C4 = 16 * NCH;
+            if constexpr (HALF) {
+                // half-size tiles: the interior path pays for every C (one patch row at a time from C = 256 on)
+                const uint2* phc = Bh + (size_t)(unsigned)(by * g.bw + bx) * C4 + v;
+                const float4* pah = a_lds + ((ly + 1) * 6 + (lx + 1)) * C4 + v;
+                float h = 0.f;
+                if constexpr (NCH <= 2) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) h = dot4h_acc(pah[(dy * 6 + dx) * C4 + 16 * k], phc[(dy * g.bw + dx) * C4 + 16 * k], h);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        const uint2* phr = phc + dy * g.bw * C4;
+                        const float4* par = pah + dy * 6 * C4;
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+                            for (int k = 0; k < NCH; ++k) h = dot4h_acc(par[dx * C4 + 16 * k], phr[dx * C4 + 16 * k], h);
+                    }
+                }
+                return (-row16_sum(h)) / 9.0f;
+            }
             const float4* pbc = reinterpret_cast<const float4*>(B) + (size_t)(unsigned)(by * g.bw + bx) * C4 + v;
             const float4* pac = a_lds + ((ly + 1) * 6 + (lx + 1)) * C4 + v;
             float facc = 0.f;
@@ -101,9 +141,15 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 float4 a = pa[v + 16 * k];
-                float4 b = pb[v + 16 * k];
-                if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);     // adding +0 products == skipping the tap
-                acc = dot4_acc(a, b, acc);
+                if constexpr (HALF) {
+                    uint2 b = Bh[((size_t)yc * g.bw + xc) * (size_t)nchunk + v + 16 * k];
+                    if (!valid) b = make_uint2(0u, 0u);
+                    acc = dot4h_acc(a, b, acc);
+                } else {
+                    float4 b = pb[v + 16 * k];
+                    if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);     // adding +0 products == skipping the tap
+                    acc = dot4_acc(a, b, acc);
+                }
             }
         } else {
             for (int j = v; j < nchunk; j += 16) {
@@ -122,14 +168,15 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 // A launch carries up to two independent jobs (the S->R and the R->S field of one level): workgroups [0, nblk0) belong to
 // job 0, the rest to job 1. Fusing the two directions doubles the number of resident workgroups at the coarse levels
 // (44x44 queries are only 121 workgroups for 256 CUs) and halves the launch count; each job's result is unaffected.
-struct PMJob { const float* A; const float* B; const uint32_t* nnf_in; const float* d_in; uint32_t* nnf_out; float* d_out; PMGeom g; int rs_max; uint32_t seed; int unit_norm; };
+struct PMJob { const float* A; const float* B; const uint2* Bh; const uint32_t* nnf_in; const float* d_in; uint32_t* nnf_out; float* d_out; PMGeom g; int rs_max; uint32_t seed; };
 
-template <int NCH, bool EX>
+template <int NCH, int MODE>
 __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
                                                  unsigned long long* __restrict__ counter) {
     const bool second = (int)blockIdx.x >= nblk0;
     const PMJob& J = second ? j1 : j0;
-    const float* __restrict__ A = J.A; const float* __restrict__ B = J.B;
+    const float* __restrict__ A = J.A; const float* __restrict__ B = J.B; const uint2* __restrict__ Bh = J.Bh;
+    constexpr bool EX = MODE == NCT_PM_ROWREJECT;
     const uint32_t* __restrict__ nnf_in = J.nnf_in; const float* __restrict__ d_in = J.d_in;
     uint32_t* __restrict__ nnf_out = J.nnf_out; float* __restrict__ d_out = J.d_out;
     const PMGeom g = J.g; const int rs_max = J.rs_max; const uint32_t seed = J.seed;
@@ -174,10 +221,10 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
     uint32_t vbest = nnf_in[qi];
     int xbest = nnf_x(vbest), ybest = nnf_y(vbest);
     float dbest;
-    unsigned nevals = 0;
+    unsigned nevals = 0, naccept = 0;
 
     if (mode == 0) {
-        dbest = pm_dist<NCH, EX>(A, B, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
+        dbest = pm_dist<NCH, MODE>(A, B, Bh, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
         float cut = (float)INT_MAX;                 // dist_single default cutoff
         if (dbest >= cut) dbest = cut;
         nevals = 1;
@@ -212,42 +259,57 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
             }
             if (valid) {
                 // to win, -sum/9 (+rr) < dbest, i.e. sum > -9 dbest: unreachable sums are cut off (unit-norm features only)
-                float d = pm_dist<NCH, EX>(A, B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                float d = pm_dist<NCH, MODE>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
                 if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
-                if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; }
+                if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; ++naccept; }
                 ++nevals;
             }
         }
     }
     if (live && v == 0) { if (mode != 0) nnf_out[qi] = xy_pack(xbest, ybest); d_out[qi] = dbest; }
     if (counter) {
-        __shared__ unsigned s_cnt;
-        if (threadIdx.x == 0) s_cnt = 0;
+        __shared__ unsigned s_cnt[2];
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        if (live && v == 0) atomicAdd(&s_cnt, nevals);
+        if (live && v == 0) { atomicAdd(&s_cnt[0], nevals); atomicAdd(&s_cnt[1], naccept); }
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(counter, (unsigned long long)s_cnt);
+        if (threadIdx.x < 2) atomicAdd(counter + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]);
     }
 }
 
-template <int NCH>
-static void launch_step(hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
+template <int NCH, int MODE>
+static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
     const size_t lds = NCH >= 1 ? (size_t)36 * NCH * 16 * sizeof(float4) : 0;      // 6x6 pixels x C/4 float4
-    // unit-norm features (the pipeline): the instantiation with the exact early rejection; it exists for the C with an interior fast path
-    if (j0.unit_norm && NCH >= 1 && NCH <= NCT_PM_FAST_MAX)
-        hipLaunchKernelGGL((k_pm_step<NCH, true>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
-    else
-        hipLaunchKernelGGL((k_pm_step<NCH, false>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
+    // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device; set with the init step
+    // of every run (mode 0), i.e. once per PatchMatch and per device the context lives on
+    if (lds > 32768 && mode == 0)
+        NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_pm_step<NCH, MODE>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NCH>
+static int launch_step(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter, int pm_mode) {
+    if (NCH >= 1 && pm_mode == NCT_PM_FP16) return launch_mode<NCH, NCT_PM_FP16>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter);
+    // unit-norm features (the pipeline): the instantiation with the exact early rejection; it exists for the C with an fp32 interior fast path
+    if (NCH >= 1 && NCH <= NCT_PM_FAST_MAX && pm_mode == NCT_PM_ROWREJECT) return launch_mode<NCH, NCT_PM_ROWREJECT>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter);
+    return launch_mode<NCH, NCT_PM_PLAIN>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter);
 }
 
 // Runs one PatchMatch (bnn == nullptr) or both directions of a level fused in the same launches (A->B in ann, B->A in bnn).
-static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw, int iters, int rs_max,
-                  uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, unsigned long long* eval_counter, int unit_norm) {
+static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, const void* a_h16, const void* b_h16, int C, int ah, int aw, int bh, int bw, int iters, int rs_max,
+                  uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, unsigned long long* eval_counter, int pm_mode) {
     NCT_REQUIRE(C > 0 && (C & 3) == 0, "patchmatch: C=%d must be a positive multiple of 4", C);
     NCT_REQUIRE(ah >= 1 && aw >= 1 && bh >= 1 && bw >= 1 && ah < 4096 && aw < 4096 && bh < 4096 && bw < 4096,
                 "patchmatch: dims out of range (%dx%d vs %dx%d); NNF coordinates are 12-bit", ah, aw, bh, bw);
     NCT_REQUIRE(iters >= 0 && rs_max >= 0, "patchmatch: iters/rs_max must be >= 0");
+    NCT_REQUIRE(pm_mode >= NCT_PM_PLAIN && pm_mode <= NCT_PM_FP16, "patchmatch: unknown evaluation mode %d", pm_mode);
     const bool two = bnn != nullptr;
+    if (pm_mode == NCT_PM_FP16) {
+        NCT_REQUIRE(b_h16 && (!two || a_h16), "patchmatch: the fp16 mode needs the fp16 shadow maps");
+        NCT_REQUIRE(C == 64 || C == 128 || C == 256 || C == 512, "patchmatch: the fp16 mode exists for C = 64, 128, 256, 512 (got %d)", C);
+    }
     const int na = ah * aw, nb = bh * bw;
     DevBuf<uint32_t> a_tmp(ctx, na), b_tmp(ctx, two ? nb : 1);
     DevBuf<float> ad_tmp(ctx, na), bd_tmp(ctx, two ? nb : 1);
@@ -256,28 +318,25 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
     const int nblk0 = ga.tiles_x * ga.tiles_y, nblk1 = two ? gb.tiles_x * gb.tiles_y : 0;
     uint32_t* na_buf[2] = {ann, a_tmp}; float* da_buf[2] = {annd, ad_tmp};
     uint32_t* nb_buf[2] = {bnn, b_tmp}; float* db_buf[2] = {bnnd, bd_tmp};
-    auto step = [&](int in, int out, int mode, int jump, int iter) {
-        PMJob j0{a_hwc, b_hwc, na_buf[in], da_buf[in], mode ? na_buf[out] : nullptr, da_buf[out], ga, rs_max, seed_ab, unit_norm};
-        PMJob j1{b_hwc, a_hwc, nb_buf[in], db_buf[in], mode ? nb_buf[out] : nullptr, db_buf[out], gb, rs_max, seed_ba, unit_norm};
+    auto step = [&](int in, int out, int mode, int jump, int iter) -> int {
+        PMJob j0{a_hwc, b_hwc, (const uint2*)b_h16, na_buf[in], da_buf[in], mode ? na_buf[out] : nullptr, da_buf[out], ga, rs_max, seed_ab};
+        PMJob j1{b_hwc, a_hwc, (const uint2*)a_h16, nb_buf[in], db_buf[in], mode ? nb_buf[out] : nullptr, db_buf[out], gb, rs_max, seed_ba};
         switch (C) {
-            case 64:  launch_step<1>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
-            case 128: launch_step<2>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
-            case 256: launch_step<4>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
-            case 512: launch_step<8>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
-            default:  launch_step<0>(s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter); break;
+            case 64:  return launch_step<1>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode);
+            case 128: return launch_step<2>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode);
+            case 256: return launch_step<4>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode);
+            case 512: return launch_step<8>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode);
+            default:  return launch_step<0>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode == NCT_PM_FP16 ? NCT_PM_PLAIN : pm_mode);
         }
     };
-    // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device
-    if (C == 512) NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 8 * 16 * (int)sizeof(float4)));
-    if (C == 256) NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 4 * 16 * (int)sizeof(float4)));
     // the total number of Jacobi steps is even (iters*4), so ping-ponging (nnf,dist) <-> (tmp) ends in (nnf,dist)
-    step(0, 0, 0, 0, 0);                           // init: dist(current NNF), NNF untouched
-    NCT_LAUNCH_CHECK();
+    int rc = step(0, 0, 0, 0, 0);                  // init: dist(current NNF), NNF untouched
+    if (rc) return rc;
     int cur = 0;
     for (int iter = 0; iter < iters; ++iter)
         for (int jump = 8; jump > 0; jump >>= 1) {
-            step(cur, cur ^ 1, 1, jump, iter);
-            NCT_LAUNCH_CHECK();
+            rc = step(cur, cur ^ 1, 1, jump, iter);
+            if (rc) return rc;
             cur ^= 1;
         }
     // cur == 0 here. The tmp buffers return to the arena now; that is safe because arena blocks are recycled in
@@ -287,10 +346,11 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
 
 int nctk_patchmatch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
                     int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist, unsigned long long* eval_counter) {
-    return pm_run(ctx, s, a_hwc, b_hwc, C, ah, aw, bh, bw, iters, rs_max, seed, 0u, nnf, dist, nullptr, nullptr, eval_counter, 0);
+    return pm_run(ctx, s, a_hwc, b_hwc, nullptr, nullptr, C, ah, aw, bh, bw, iters, rs_max, seed, 0u, nnf, dist, nullptr, nullptr, eval_counter, NCT_PM_PLAIN);
 }
 
-int nctk_patchmatch_bidir(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
-                          int iters, int rs_max, uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, int unit_norm) {
-    return pm_run(ctx, s, a_hwc, b_hwc, C, ah, aw, bh, bw, iters, rs_max, seed_ab, seed_ba, ann, annd, bnn, bnnd, nullptr, unit_norm);
+int nctk_patchmatch_bidir(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, const void* a_h16, const void* b_h16, int C, int ah, int aw, int bh, int bw,
+                          int iters, int rs_max, uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, int pm_mode,
+                          unsigned long long* counters) {
+    return pm_run(ctx, s, a_hwc, b_hwc, a_h16, b_h16, C, ah, aw, bh, bw, iters, rs_max, seed_ab, seed_ba, ann, annd, bnn, bnnd, counters, pm_mode);
 }

@@ -640,7 +640,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     // Convergence is polled without draining the stream: after every batch of `batch` iterations the solver state is copied to
     // page-locked host memory and an event is recorded; the host then enqueues the NEXT batch before it waits for that event, so
     // the GPU always has a batch queued. The batch enqueued past convergence costs only empty launches (nactive == 0).
-    const int maxit = 5000, batch = 4;
+    const int maxit = ctx->wls_maxit, batch = 4;
     PState* hst = (PState*)ctx->pinned;                   // two slots
     static_assert(2 * sizeof(PState) <= 4096, "pinned read-back area too small");
     auto iteration = [&](int it) -> int {
@@ -663,12 +663,13 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     { int rc = snapshot(slot); if (rc) return rc; }        // state after the start kernel (x0 may already solve the system)
     PState fin; memset(&fin, 0, sizeof fin);
     while (true) {
-        if (it < maxit) { for (int k = 0; k < batch; ++k, ++it) { int rc = iteration(it); if (rc) return rc; } }
+        const bool enqueued = it < maxit;
+        if (enqueued) { for (int k = 0; k < batch; ++k, ++it) { int rc = iteration(it); if (rc) return rc; } }
         { int rc = snapshot(slot ^ 1); if (rc) return rc; }
         NCT_HIP(hipEventSynchronize(ctx->ev_poll[slot]));  // the snapshot taken BEFORE the batch just enqueued
         fin = hst[slot];
         if (fin.nactive == 0) { done = true; break; }
-        if (it >= maxit + batch) break;
+        if (!enqueued) break;                              // that was the snapshot behind the last batch: the iteration budget is spent
         slot ^= 1;
     }
     // iterations enqueued after `fin` was taken leave the state untouched (nactive == 0), so fin is final

@@ -2,6 +2,7 @@
 // Every function here is a thin marshalling layer: upload, call the device launcher (nctk_*), download.
 #include "nct_internal.h"
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 
 static std::string g_create_err;
@@ -26,6 +27,18 @@ void* nct_ctx::alloc(size_t bytes) {
     for (auto& b : blocks) if (!b.p) { b = {p, bytes, true}; return p; }
     blocks.push_back({p, bytes, true});
     return p;
+}
+int nct_ctx::mark(hipStream_t s, int tag) {
+    if (!tm_on) return 0;
+    const size_t i = tm_tags.size();
+    if (i >= tm_events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return fail(NCT_ERR_HIP, "hipEventCreate failed");
+        tm_events.push_back(e);
+    }
+    if (hipEventRecord(tm_events[i], s) != hipSuccess) return fail(NCT_ERR_HIP, "hipEventRecord failed");
+    tm_tags.push_back(tag);
+    return 0;
 }
 void nct_ctx::release(void* p) {
     if (defer_release) { deferred.push_back(p); return; }
@@ -63,6 +76,7 @@ int nct_create(int device, nct_ctx** out) {
     for (int l = 0; l < 2; ++l)
         if ((e = hipEventCreateWithFlags(&c->ev_poll[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     if ((e = hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault)) != hipSuccess) { g_create_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
+    if (const char* m = getenv("NCT_WLS_MAXIT")) { const int v = atoi(m); if (v > 0) c->wls_maxit = v; }
     *out = c;
     return NCT_OK;
 }
@@ -77,6 +91,9 @@ void nct_destroy(nct_ctx* ctx) {
     for (auto& b : ctx->blocks) if (b.p) (void)hipFree(b.p);
     if (ctx->bench_a) (void)hipFree(ctx->bench_a);
     if (ctx->bench_b) (void)hipFree(ctx->bench_b);
+    if (ctx->bench_ah16) (void)hipFree(ctx->bench_ah16);
+    if (ctx->bench_bh16) (void)hipFree(ctx->bench_bh16);
+    for (hipEvent_t e : ctx->tm_events) (void)hipEventDestroy(e);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -241,16 +258,20 @@ int nct_pm_bench_setup(nct_ctx* ctx, const float* a_chw, const float* b_chw, int
     const size_t na = (size_t)ah * aw, nb = (size_t)bh * bw;
     if (ctx->bench_a) { (void)hipFree(ctx->bench_a); ctx->bench_a = nullptr; }
     if (ctx->bench_b) { (void)hipFree(ctx->bench_b); ctx->bench_b = nullptr; }
+    if (ctx->bench_ah16) { (void)hipFree(ctx->bench_ah16); ctx->bench_ah16 = nullptr; }
+    if (ctx->bench_bh16) { (void)hipFree(ctx->bench_bh16); ctx->bench_bh16 = nullptr; }
     NCT_HIP(hipMalloc(&ctx->bench_a, sizeof(float) * C * na));
     NCT_HIP(hipMalloc(&ctx->bench_b, sizeof(float) * C * nb));
-    if (!ctx->d_counter) NCT_HIP(hipMalloc(&ctx->d_counter, sizeof(unsigned long long)));
+    NCT_HIP(hipMalloc(&ctx->bench_ah16, 2 * (size_t)C * na));
+    NCT_HIP(hipMalloc(&ctx->bench_bh16, 2 * (size_t)C * nb));
+    if (!ctx->d_counter) NCT_HIP(hipMalloc(&ctx->d_counter, 32 * sizeof(unsigned long long)));
     {
         DevBuf<float> t(ctx, (size_t)C * (na > nb ? na : nb)), x(ctx, (size_t)C * (na > nb ? na : nb));
         if (!t.ok() || !x.ok()) return NCT_ERR_HIP;
         RC(upload_hwc(ctx, a_chw, t, x, C, (int)na));
-        RC(nctk_normalize(ctx, ctx->stream, x, ctx->bench_a, nullptr, C, (int)na));
+        RC(nctk_normalize(ctx, ctx->stream, x, ctx->bench_a, nullptr, C, (int)na, ctx->bench_ah16));
         RC(upload_hwc(ctx, b_chw, t, x, C, (int)nb));
-        RC(nctk_normalize(ctx, ctx->stream, x, ctx->bench_b, nullptr, C, (int)nb));
+        RC(nctk_normalize(ctx, ctx->stream, x, ctx->bench_b, nullptr, C, (int)nb, ctx->bench_bh16));
         SYNC();
     }
     ctx->bench_C = C; ctx->bench_ah = ah; ctx->bench_aw = aw; ctx->bench_bh = bh; ctx->bench_bw = bw;
@@ -267,7 +288,7 @@ int nct_pm_bench_run(nct_ctx* ctx, int iters, int rs_max, uint32_t seed, float* 
     if (!n.ok() || !d.ok()) return NCT_ERR_HIP;
     RC(nctk_nnf_init(ctx, ctx->stream, n, ah, aw, bh, bw));
     unsigned long long* counter = evals ? ctx->d_counter : nullptr;
-    if (counter) NCT_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+    if (counter) NCT_HIP(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned long long), ctx->stream));
     NCT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     RC(nctk_patchmatch(ctx, ctx->stream, ctx->bench_a, ctx->bench_b, C, ah, aw, bh, bw, iters, rs_max, seed, n, d, counter));
     NCT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
@@ -278,6 +299,36 @@ int nct_pm_bench_run(nct_ctx* ctx, int iters, int rs_max, uint32_t seed, float* 
     if (evals) { unsigned long long h = 0; NCT_HIP(hipMemcpy(&h, counter, sizeof h, hipMemcpyDeviceToHost)); *evals = (uint64_t)h; }
     if (nnf_out) NCT_HIP(hipMemcpy(nnf_out, n, sizeof(uint32_t) * na, hipMemcpyDeviceToHost));
     if (dist_out) NCT_HIP(hipMemcpy(dist_out, d, sizeof(float) * na, hipMemcpyDeviceToHost));
+    return NCT_OK;
+}
+
+int nct_pm_bench_run_bidir(nct_ctx* ctx, int iters, int rs_max, uint32_t seed, int pm_mode, float* kernel_ms, uint64_t* counters, uint32_t* ann_out, float* annd_out,
+                           uint32_t* bnn_out, float* bnnd_out) {
+    CTX_ENTER();
+    if (!ctx->bench_a) return ctx->fail(NCT_ERR_STATE, "pm_bench_run_bidir: call nct_pm_bench_setup first");
+    NCT_REQUIRE(pm_mode >= NCT_PM_PLAIN && pm_mode <= NCT_PM_FP16, "pm_bench_run_bidir: pm_mode must be 0 (fp32), 1 (fp32 + row rejection) or 2 (fp16)");
+    const int C = ctx->bench_C, ah = ctx->bench_ah, aw = ctx->bench_aw, bh = ctx->bench_bh, bw = ctx->bench_bw;
+    const size_t na = (size_t)ah * aw, nb = (size_t)bh * bw;
+    DevBuf<uint32_t> an(ctx, na), bn(ctx, nb);
+    DevBuf<float> ad(ctx, na), bd(ctx, nb);
+    if (!an.ok() || !bn.ok() || !ad.ok() || !bd.ok()) return NCT_ERR_HIP;
+    RC(nctk_nnf_init(ctx, ctx->stream, an, ah, aw, bh, bw));
+    RC(nctk_nnf_init(ctx, ctx->stream, bn, bh, bw, ah, aw));
+    unsigned long long* counter = counters ? ctx->d_counter : nullptr;
+    if (counter) NCT_HIP(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    NCT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    RC(nctk_patchmatch_bidir(ctx, ctx->stream, ctx->bench_a, ctx->bench_b, ctx->bench_ah16, ctx->bench_bh16, C, ah, aw, bh, bw, iters, rs_max, seed, seed ^ 0x5bd1e995u,
+                             an, ad, bn, bd, pm_mode, counter));
+    NCT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NCT_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    NCT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (kernel_ms) *kernel_ms = ms;
+    if (counters) { unsigned long long h[2] = {0, 0}; NCT_HIP(hipMemcpy(h, counter, sizeof h, hipMemcpyDeviceToHost)); for (int i = 0; i < 2; ++i) counters[i] = (uint64_t)h[i]; }
+    if (ann_out) NCT_HIP(hipMemcpy(ann_out, an, sizeof(uint32_t) * na, hipMemcpyDeviceToHost));
+    if (annd_out) NCT_HIP(hipMemcpy(annd_out, ad, sizeof(float) * na, hipMemcpyDeviceToHost));
+    if (bnn_out) NCT_HIP(hipMemcpy(bnn_out, bn, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost));
+    if (bnnd_out) NCT_HIP(hipMemcpy(bnnd_out, bd, sizeof(float) * nb, hipMemcpyDeviceToHost));
     return NCT_OK;
 }
 

@@ -17,6 +17,7 @@ void nct_params_default(nct_params* p) {
     p->bds_weight = 2.0; p->eps = 0.60; p->nonlocal_weight = 2.0; p->local_weight = 0.125; p->wls_lambda_init = 0.024;
     p->cluster_num = 10; p->k_num = 8; p->patch_size = 3; p->wls_alpha = 1.2;
     p->pm_iters = 10; p->seed = 1;
+    p->levels = 5; p->flags = 0;
 }
 
 int nct_bgr2lab_u8(nct_ctx* ctx, const uint8_t* bgr, size_t npix, uint8_t* lab) {

@@ -22,12 +22,20 @@ struct nct_ctx {
     std::vector<nct_block> blocks;    // cached device allocations, reused across calls and pairs
     size_t bytes_allocated = 0;
     // measurement fixture (nct_pm_bench_*)
-    float *bench_a = nullptr, *bench_b = nullptr; int bench_C = 0, bench_ah = 0, bench_aw = 0, bench_bh = 0, bench_bw = 0;
+    float *bench_a = nullptr, *bench_b = nullptr; void *bench_ah16 = nullptr, *bench_bh16 = nullptr; int bench_C = 0, bench_ah = 0, bench_aw = 0, bench_bh = 0, bench_bw = 0;
     // opaque sub-states owned by other translation units
     void* vgg = nullptr;              // struct vgg_weights* (nct_vgg.cpp)
     void* cvt = nullptr;              // struct cvt_dev* (k_cvt.hip): colour-conversion LUTs on the device
     void* pair = nullptr;             // struct pair_state* (nct_pipeline.cpp): device-resident source/reference/result images
-    unsigned long long* d_counter = nullptr;   // device eval counter (profiling builds of pm kernels)
+    unsigned long long* d_counter = nullptr;   // device counters of the pm kernels (profiling passes): [0] evaluations, [1] exact fp32 re-evaluations
+                                                // behind the fp16 prefilter, [2] accepted candidates; 4 slots per pyramid level in pair runs
+    // stage clock: events recorded on the main stream at stage boundaries, read once after the pair's final synchronise
+    // (no host syncs in between: see nct_pair_timing in nct.h)
+    int wls_maxit = 5000;                       // iteration budget of the WLS solve (test hook: env NCT_WLS_MAXIT)
+    bool tm_on = false;
+    std::vector<hipEvent_t> tm_events;          // pool, reused across pairs
+    std::vector<int> tm_tags;                   // tag of mark i = the stage that ENDS at event i
+    int mark(hipStream_t s, int tag);           // nct_api.cpp; no-op unless tm_on
 
     int fail(int code, const char* fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -64,7 +72,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // k_feat.hip
 int nctk_chw_to_hwc(nct_ctx* ctx, hipStream_t s, const float* src, float* dst, int C, int HW);
 int nctk_hwc_to_chw(nct_ctx* ctx, hipStream_t s, const float* src, float* dst, int C, int HW);
-int nctk_normalize(nct_ctx* ctx, hipStream_t s, const float* src_hwc, float* dst_hwc, float* resp /*nullable*/, int C, int HW);
+int nctk_normalize(nct_ctx* ctx, hipStream_t s, const float* src_hwc, float* dst_hwc, float* resp /*nullable*/, int C, int HW,
+                   void* dst_h16 = nullptr /* nullable: fp16 (round-to-nearest) shadow copy of dst, same HWC layout */);
 int nctk_feature_distance(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, float* err, int C, int HW);
 // k_nnf.hip
 int nctk_nnf_init(nct_ctx* ctx, hipStream_t s, uint32_t* nnf, int ah, int aw, int bh, int bw);
@@ -82,6 +91,7 @@ int nctk_resize_u8c3(nct_ctx* ctx, hipStream_t s, const uint8_t* src, int sh, in
 int nctk_resize_f64c3(nct_ctx* ctx, hipStream_t s, const double* src, int sh, int sw, double* dst, int dh, int dw);
 void nct_cvt_free(nct_ctx* ctx);
 void nct_pair_free(nct_ctx* ctx);   // nct_pipeline.cpp
+int nct_stage_tag_nonlocal(); int nct_stage_tag_wls(); int nct_stage_tag_color();   // event-mark tags of the colour stage (nct_pipeline.cpp)
 // k_cluster.hip
 int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat_hwc_norm, int n, int C, int K, int iters, uint64_t seed, int* labels, int* nlabels_dev);
 int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, int w, const int* labels, int lh, int lw, int nlabels, const int* nlabels_dev /*nullable: overrides nlabels*/, int samples,
@@ -95,9 +105,13 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
 // k_wls_mg.hip
 int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* rough, const double* wx, const double* wy, int H, int W,
                       double rtol, int* iters_out);
-int nctk_patchmatch_bidir(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
+// pm_mode: how candidate distances are evaluated (k_patchmatch.hip)
+enum { NCT_PM_PLAIN = 0,      // fp32 candidate tiles, no rejection (any features)
+       NCT_PM_ROWREJECT = 1,  // unit-norm features: exact row-wise early rejection (same NNF and distances as PLAIN) — the pipeline's default
+       NCT_PM_FP16 = 2 };     // opt-in reduced-precision mode: fp16 candidate tiles (fp32 accumulate); results differ from fp32
+int nctk_patchmatch_bidir(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, const void* a_h16, const void* b_h16, int C, int ah, int aw, int bh, int bw,
                           int iters, int rs_max, uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd,
-                          int unit_norm /* 1: every feature vector has norm <= 1 (enables the exact early rejection) */);
+                          int pm_mode, unsigned long long* counters /*nullable, 4 slots*/);
 // k_vote.hip
 int nctk_bds_vote_features(nct_ctx* ctx, hipStream_t s, const uint32_t* ann, const uint32_t* bnn, const float* pin_hwc, float* pout_hwc, float* pw /*nullable*/,
                            int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp);

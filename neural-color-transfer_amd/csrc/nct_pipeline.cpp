@@ -16,40 +16,66 @@ static pair_state* pair_of(nct_ctx* ctx) {
     if (!ctx->pair) ctx->pair = new pair_state();
     return (pair_state*)ctx->pair;
 }
+// the images live in the context arena like every other device buffer (no hipMalloc/hipFree — device-wide synchronisation points —
+// between the pairs of other contexts in flight on the same GPU)
 void nct_pair_free(nct_ctx* ctx) {
     if (!ctx->pair) return;
     pair_state* p = (pair_state*)ctx->pair;
-    if (p->src) (void)hipFree(p->src);
-    if (p->ref) (void)hipFree(p->ref);
-    if (p->out) (void)hipFree(p->out);
+    if (p->src) ctx->release(p->src);
+    if (p->ref) ctx->release(p->ref);
+    if (p->out) ctx->release(p->out);
     delete p; ctx->pair = nullptr;
 }
 
 static const int kTapC[5] = {64, 128, 256, 512, 512};       // tap 1 (conv1_1) … tap 5 (conv5_1)
 
-struct StageClock {
-    nct_ctx* ctx; hipStream_t s; nct_pair_timing* t; std::chrono::steady_clock::time_point t0;
-    StageClock(nct_ctx* c, hipStream_t st, nct_pair_timing* tm) : ctx(c), s(st), t(tm) { if (t) { (void)hipStreamSynchronize(s); t0 = std::chrono::steady_clock::now(); } }
-    void lap(double* acc) {
-        if (!t) return;
-        (void)hipStreamSynchronize(s);
-        auto t1 = std::chrono::steady_clock::now();
-        *acc += std::chrono::duration<double, std::milli>(t1 - t0).count();
-        t0 = t1;
+// stage tags of the event marks (nct_ctx::mark): tag = stage * 8 + level; a mark closes the stage it names
+enum { ST_OTHER = 0, ST_VGG, ST_CLUSTER, ST_PM, ST_VOTE, ST_KNN, ST_COLOR, ST_NONLOCAL, ST_WLS };
+static thread_local int g_tm_level = 0;          // pyramid level whose colour stage is being enqueued (per host thread = per context)
+int nct_stage_tag_nonlocal() { return ST_NONLOCAL * 8 + g_tm_level; }
+int nct_stage_tag_wls() { return ST_WLS * 8 + g_tm_level; }
+int nct_stage_tag_color() { return ST_COLOR * 8 + g_tm_level; }
+#define MARK(stage, level) do { int rcm_ = ctx->mark(s, (stage) * 8 + (level)); if (rcm_) return rcm_; } while (0)
+
+static int read_marks(nct_ctx* ctx, nct_pair_timing* t) {
+    double* acc[9] = {&t->other_ms, &t->vgg_ms, &t->cluster_ms, &t->patchmatch_ms, &t->vote_ms, &t->knn_ms, &t->color_ms, &t->nonlocal_ms, &t->wls_ms};
+    for (size_t i = 1; i < ctx->tm_tags.size(); ++i) {
+        float ms = 0.f;
+        NCT_HIP(hipEventElapsedTime(&ms, ctx->tm_events[i - 1], ctx->tm_events[i]));
+        const int stage = ctx->tm_tags[i] >> 3, level = ctx->tm_tags[i] & 7;
+        if (stage >= 0 && stage < 9) *acc[stage] += ms;
+        if (level < 5) {
+            if (stage == ST_PM) t->pm_level_ms[level] += ms;
+            else if (stage == ST_VOTE) t->vote_level_ms[level] += ms;
+            else if (stage == ST_NONLOCAL) t->nonlocal_level_ms[level] += ms;
+            else if (stage == ST_WLS) t->wls_level_ms[level] += ms;
+        }
     }
-};
+    t->color_ms += t->nonlocal_ms + t->wls_ms;       // color_ms is the whole stage; the two solves are also reported on their own
+    return 0;
+}
 
 // run the whole L=5->1 loop on device-resident images
-static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing) {
+static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing, const nct_pair_levels* lv) {
     pair_state* P = (pair_state*)ctx->pair;
     if (!P || !P->src || !P->ref) return ctx->fail(NCT_ERR_STATE, "process: no pair uploaded");
     hipStream_t s = ctx->stream;
     const int H = P->sh, W = P->sw, RH = P->rh, RW = P->rw;
     NCT_REQUIRE(prm->patch_size == 3 && prm->k_num == 8, "process: patch_size must be 3 and k_num 8 (Config.h:68-70)");
     NCT_REQUIRE(prm->cluster_num >= 1 && prm->cluster_num <= 16, "process: cluster_num out of range");
+    NCT_REQUIRE(prm->levels >= 1 && prm->levels <= 5, "process: levels must be in [1, 5] (got %d)", prm->levels);
     if (timing) memset(timing, 0, sizeof *timing);
     auto wall0 = std::chrono::steady_clock::now();
-    StageClock clk(ctx, s, timing);
+    ctx->tm_on = timing != nullptr; ctx->tm_tags.clear();
+    struct TmOff { nct_ctx* c; ~TmOff() { c->tm_on = false; } } tm_off{ctx};
+    const int nlevels = prm->levels;
+    const bool feat16 = (prm->flags & NCT_FLAG_FEAT16) != 0;
+    const bool count = timing && (prm->flags & NCT_FLAG_COUNT_EVALS);
+    if (count) {
+        if (!ctx->d_counter) NCT_HIP(hipMalloc(&ctx->d_counter, 32 * sizeof(unsigned long long)));
+        NCT_HIP(hipMemsetAsync(ctx->d_counter, 0, 32 * sizeof(unsigned long long), s));
+    }
+    MARK(ST_OTHER, 0);
 
     // level geometry, coarse -> fine (level 0 = conv5_1)
     int ah[5], aw[5], bh[5], bw[5];
@@ -74,7 +100,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         rc = nctk_resize_u8c3(ctx, s, rimg[l + 1], bh[l + 1], bw[l + 1], *rpyr[l], bh[l], bw[l]); if (rc) return rc;
         simg[l] = *spyr[l]; rimg[l] = *rpyr[l];
     }
-    clk.lap(timing ? &timing->other_ms : nullptr);
+    MARK(ST_OTHER, 0);
 
     // ---- VGG19: R once (all five taps kept, HWC), S to conv5_1 (main.cu:94,102)
     std::vector<DevBuf<float>*> rfeat(5, nullptr);     // R features, un-normalised, HWC, indexed by level
@@ -97,17 +123,19 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         rc = nctk_vgg19_forward(ctx, s, P->src, H, W, W * 3, 5, taps, nullptr); if (rc) return rc;
         rc = nctk_chw_to_hwc(ctx, s, sfeat_chw, sfeat, 512, ah[0] * aw[0]); if (rc) return rc;
     }
-    clk.lap(timing ? &timing->vgg_ms : nullptr);
+    MARK(ST_VGG, 0);
 
     // ---- C1: cluster the coarsest S features (main.cu:139-168)
     DevBuf<int> labels(ctx, (size_t)ah[0] * aw[0]), nlab_dev(ctx, 1);
     DevBuf<float> na(ctx, (size_t)64 * N), nb(ctx, (size_t)64 * (size_t)RH * RW), voted(ctx, (size_t)64 * N), nvoted(ctx, (size_t)64 * N);
-    if (!labels.ok() || !nlab_dev.ok() || !na.ok() || !nb.ok() || !voted.ok() || !nvoted.ok()) return NCT_ERR_HIP;
-    rc = nctk_normalize(ctx, s, sfeat, na, nullptr, 512, ah[0] * aw[0]); if (rc) return rc;
+    // fp16 shadow maps of the normalised features: the candidate tiles of the opt-in reduced-precision mode (NCT_FLAG_FEAT16)
+    DevBuf<uint16_t> na_h(ctx, feat16 ? (size_t)64 * N : 8), nb_h(ctx, feat16 ? (size_t)64 * (size_t)RH * RW : 8);
+    if (!labels.ok() || !nlab_dev.ok() || !na.ok() || !nb.ok() || !voted.ok() || !nvoted.ok() || !na_h.ok() || !nb_h.ok()) return NCT_ERR_HIP;
+    rc = nctk_normalize(ctx, s, sfeat, na, nullptr, 512, ah[0] * aw[0], feat16 ? (uint16_t*)na_h : nullptr); if (rc) return rc;
     rc = nctk_kmeans_labels(ctx, s, na, ah[0] * aw[0], 512, prm->cluster_num, 11, (uint64_t)prm->seed, labels, nlab_dev); if (rc) return rc;
     // the number of labels (1 if k-means degenerated, else K) stays on the device: reading it back would stall the host — and with it
     // the enqueueing of everything below — until the VGG forwards and k-means have finished
-    clk.lap(timing ? &timing->cluster_ms : nullptr);
+    MARK(ST_CLUSTER, 0);
 
     // ---- K1 for all five levels on the side stream: the kNN graph of a level depends only on the level image of S and on the
     // labels (main.cu:351-359), not on the correspondence, so it overlaps with PatchMatch / votes / solvers of the main stream
@@ -126,14 +154,14 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         hipStream_t s2 = ctx->stream2;
         NCT_HIP(hipEventRecord(ctx->ev_fork, s));
         NCT_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-        for (int l = 0; l < 5; ++l) {
+        for (int l = 0; l < nlevels; ++l) {
             const size_t npx = (size_t)ah[l] * aw[l];
             slab[l] = new DevBuf<uint8_t>(ctx, npx * 3); knn_ids[l] = new DevBuf<int>(ctx, npx * 8); knn_ws[l] = new DevBuf<double>(ctx, npx * 8);
             if (!slab[l]->ok() || !knn_ids[l]->ok() || !knn_ws[l]->ok()) return NCT_ERR_HIP;
         }
         int rc2 = 0;
         ctx->defer_release = true;
-        for (int l = 0; l < 5 && rc2 == 0; ++l) {
+        for (int l = 0; l < nlevels && rc2 == 0; ++l) {      // only the levels that run (nct_params.levels)
             rc2 = nctk_bgr2lab(ctx, s2, simg[l], *slab[l], (size_t)ah[l] * aw[l]);
             if (rc2 == 0) rc2 = nctk_knn_graph(ctx, s2, *slab[l], ah[l], aw[l], labels, ah[0], aw[0], 0, nlab_dev, 1 << l, *knn_ids[l], *knn_ws[l]);
             if (rc2 == 0 && hipEventRecord(ctx->ev_level[l], s2) != hipSuccess) rc2 = ctx->fail(NCT_ERR_HIP, "hipEventRecord failed");
@@ -148,10 +176,14 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     DevBuf<uint8_t> guide(ctx, N * 3), g_lab_l(ctx, N * 3), out_lab(ctx, N * 3);
     if (!ann.ok() || !bnn.ok() || !ann_prev.ok() || !bnn_prev.ok() || !annd.ok() || !bnnd.ok() || !err.ok() || !guide.ok() ||
         !g_lab_l.ok() || !out_lab.ok()) return NCT_ERR_HIP;
-    if (!P->out) NCT_HIP(hipMalloc(&P->out, N * 3));
+    if (!P->out) { P->out = (uint8_t*)ctx->alloc(N * 3); if (!P->out) return NCT_ERR_HIP; }
+    auto d2h = [&](void* dst, const void* src, size_t bytes) -> int {
+        if (dst) NCT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+        return 0;
+    };
     nct_color_params cp{prm->eps, prm->nonlocal_weight, prm->local_weight, prm->wls_lambda_init, prm->wls_alpha, (double)prm->k_num};
 
-    for (int l = 0; l < 5; ++l) {
+    for (int l = 0; l < nlevels; ++l) {
         const int C = kTapC[4 - l];
         const int na_px = ah[l] * aw[l], nb_px = bh[l] * bw[l];
         // NNF init / upsample (main.cu:230-251)
@@ -165,43 +197,68 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
             rc = nctk_nnf_upsample(ctx, s, bnn_prev, bnn, bh[l], bw[l], ah[l], aw[l], bh[l - 1], bw[l - 1]); if (rc) return rc;
         }
         // normalise (main.cu:259-275), PatchMatch both directions (main.cu:283-284)
-        if (l > 0) { rc = nctk_normalize(ctx, s, sfeat, na, nullptr, C, na_px); if (rc) return rc; }
-        rc = nctk_normalize(ctx, s, *rfeat[l], nb, nullptr, C, nb_px); if (rc) return rc;
+        if (l > 0) { rc = nctk_normalize(ctx, s, sfeat, na, nullptr, C, na_px, feat16 ? (uint16_t*)na_h : nullptr); if (rc) return rc; }
+        rc = nctk_normalize(ctx, s, *rfeat[l], nb, nullptr, C, nb_px, feat16 ? (uint16_t*)nb_h : nullptr); if (rc) return rc;
+        MARK(ST_OTHER, l);
         const uint32_t seed_ab = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 1)), seed_ba = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 2));
-        rc = nctk_patchmatch_bidir(ctx, s, na, nb, C, ah[l], aw[l], bh[l], bw[l], prm->pm_iters, rs_range[l], seed_ab, seed_ba, ann, annd, bnn, bnnd, 1 /* na, nb are normalised */); if (rc) return rc;
-        clk.lap(timing ? &timing->patchmatch_ms : nullptr);
+        const int pm_mode = feat16 ? NCT_PM_FP16 : NCT_PM_ROWREJECT;        // na, nb are unit vectors: the row-wise rejection is exact
+        rc = nctk_patchmatch_bidir(ctx, s, na, nb, (const uint16_t*)na_h, (const uint16_t*)nb_h, C, ah[l], aw[l], bh[l], bw[l], prm->pm_iters, rs_range[l], seed_ab, seed_ba,
+                                   ann, annd, bnn, bnnd, pm_mode, count ? ctx->d_counter + 4 * l : nullptr); if (rc) return rc;
+        MARK(ST_PM, l);
+        if (timing) timing->pm_level_launches[l] = 1 + 4 * prm->pm_iters;
+        if (lv) {
+            rc = d2h(lv->ann[l], ann, sizeof(uint32_t) * na_px); if (rc) return rc;
+            rc = d2h(lv->bnn[l], bnn, sizeof(uint32_t) * nb_px); if (rc) return rc;
+            rc = d2h(lv->annd[l], annd, sizeof(float) * na_px); if (rc) return rc;
+            rc = d2h(lv->bnnd[l], bnnd, sizeof(float) * nb_px); if (rc) return rc;
+        }
         // BDS votes: guidance image (main.cu:291) and features + matching error (main.cu:303-318)
         rc = nctk_bds_vote_both(ctx, s, rimg[l], *rfeat[l], ann, bnn, C, ah[l], aw[l], bh[l], bw[l], 1.0, prm->bds_weight, guide, voted); if (rc) return rc;
         rc = nctk_normalize(ctx, s, voted, nvoted, nullptr, C, na_px); if (rc) return rc;
         rc = nctk_feature_distance(ctx, s, na, nvoted, err, C, na_px); if (rc) return rc;
-        clk.lap(timing ? &timing->vote_ms : nullptr);
+        MARK(ST_VOTE, l);
+        if (lv) {
+            rc = d2h(lv->guide[l], guide, (size_t)na_px * 3); if (rc) return rc;
+            rc = d2h(lv->err[l], err, sizeof(float) * na_px); if (rc) return rc;
+        }
         // kNN graph in Lab (main.cu:351-359): computed on the side stream; join once before its first use
         rc = nctk_bgr2lab(ctx, s, guide, g_lab_l, na_px); if (rc) return rc;
         if (l == 0) { rc = enqueue_knn(); if (rc) return rc; }
         NCT_HIP(hipStreamWaitEvent(s, ctx->ev_level[l], 0));          // level l's graph only: the fine levels keep overlapping
-        if (l == 4) ctx->flush_deferred();
+        if (l == nlevels - 1) ctx->flush_deferred();
         const uint8_t* s_lab_l = *slab[l]; const int* knn_id = *knn_ids[l]; const double* knn_w = *knn_ws[l];
-        clk.lap(timing ? &timing->knn_ms : nullptr);
+        MARK(ST_KNN, l);
         // local colour transfer (main.cu:368-380)
+        g_tm_level = l;
         nct_color_debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         int wls_it[6] = {0, 0, 0, 0, 0, 0};
         dbg.wls_iters = wls_it;
         rc = nctk_local_color_transfer(ctx, s, err, s_lab_l, g_lab_l, s_lab_full, knn_id, knn_w, l, ah[l], aw[l], H, W, cp, out_lab, timing ? &dbg : nullptr); if (rc) return rc;
         rc = nctk_lab2bgr(ctx, s, out_lab, P->out, N); if (rc) return rc;
         if (timing) { timing->wls_iters[l] = *std::max_element(wls_it, wls_it + 6); }
-        clk.lap(timing ? &timing->color_ms : nullptr);
+        MARK(ST_COLOR, l);
+        if (lv) { rc = d2h(lv->result[l], P->out, N * 3); if (rc) return rc; }
         // re-predict: S features of the next level from the intermediate result (main.cu:424-427)
-        if (l < 4) {
+        if (l < nlevels - 1) {
             const int tap = 4 - l;                         // next level uses tap (5 - (l+1))
             float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
             taps[tap - 1] = sfeat_chw;
             rc = nctk_vgg19_forward(ctx, s, P->out, H, W, W * 3, tap, taps, nullptr); if (rc) return rc;
             rc = nctk_chw_to_hwc(ctx, s, sfeat_chw, sfeat, kTapC[tap - 1], ah[l + 1] * aw[l + 1]); if (rc) return rc;
-            clk.lap(timing ? &timing->vgg_ms : nullptr);
+            MARK(ST_VGG, l);
         }
     }
+    // the side stream holds the kNN graphs of all five levels; levels that did not run still have to finish before their buffers go back
     NCT_HIP(hipStreamSynchronize(s));
-    if (timing) timing->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (timing) {
+        timing->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        rc = read_marks(ctx, timing); if (rc) return rc;
+        if (count) {
+            unsigned long long h[32];
+            NCT_HIP(hipMemcpy(h, ctx->d_counter, sizeof h, hipMemcpyDeviceToHost));
+            for (int l = 0; l < 5; ++l) { timing->pm_level_evals[l] = h[4 * l]; timing->pm_level_accepted[l] = h[4 * l + 1]; }
+        }
+    }
     return NCT_OK;
 }
 
@@ -211,14 +268,16 @@ int nct_pair_upload(nct_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, const 
     if (!ctx) return NCT_ERR_INVALID;
     NCT_HIP(hipSetDevice(ctx->device));
     NCT_REQUIRE(src_bgr && ref_bgr, "pair_upload: null image");
-    NCT_REQUIRE(sh >= 16 && sw >= 16 && rh >= 16 && rw >= 16 && sh <= 4000 && sw <= 4000 && rh <= 4000 && rw <= 4000,
-                "pair_upload: image sides must be in [16, 4000] (got %dx%d and %dx%d)", sw, sh, rw, rh);
+    // the coarsest pyramid level (four ceil-halvings) must be at least 2x2 (init_Ann_kernel scales by (bw-1)/(aw-1)): side >= 17
+    NCT_REQUIRE(sh >= 17 && sw >= 17 && rh >= 17 && rw >= 17 && sh <= 4000 && sw <= 4000 && rh <= 4000 && rw <= 4000,
+                "pair_upload: image sides must be in [17, 4000] (got %dx%d and %dx%d)", sw, sh, rw, rh);
     pair_state* P = pair_of(ctx);
-    if (P->src) { (void)hipFree(P->src); P->src = nullptr; }
-    if (P->ref) { (void)hipFree(P->ref); P->ref = nullptr; }
-    if (P->out) { (void)hipFree(P->out); P->out = nullptr; }
-    NCT_HIP(hipMalloc(&P->src, (size_t)sh * sw * 3));
-    NCT_HIP(hipMalloc(&P->ref, (size_t)rh * rw * 3));
+    if (P->src) { ctx->release(P->src); P->src = nullptr; }
+    if (P->ref) { ctx->release(P->ref); P->ref = nullptr; }
+    if (P->out) { ctx->release(P->out); P->out = nullptr; }
+    P->src = (uint8_t*)ctx->alloc((size_t)sh * sw * 3);
+    P->ref = (uint8_t*)ctx->alloc((size_t)rh * rw * 3);
+    if (!P->src || !P->ref) return NCT_ERR_HIP;
     NCT_HIP(hipMemcpyAsync(P->src, src_bgr, (size_t)sh * sw * 3, hipMemcpyHostToDevice, ctx->stream));
     NCT_HIP(hipMemcpyAsync(P->ref, ref_bgr, (size_t)rh * rw * 3, hipMemcpyHostToDevice, ctx->stream));
     NCT_HIP(hipStreamSynchronize(ctx->stream));
@@ -230,7 +289,14 @@ int nct_pair_run(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing) {
     if (!ctx) return NCT_ERR_INVALID;
     NCT_HIP(hipSetDevice(ctx->device));
     NCT_REQUIRE(prm, "pair_run: null params");
-    return process_resident(ctx, prm, timing);
+    return process_resident(ctx, prm, timing, nullptr);
+}
+
+int nct_pair_run_levels(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing, const nct_pair_levels* levels) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(prm, "pair_run_levels: null params");
+    return process_resident(ctx, prm, timing, levels);
 }
 
 int nct_pair_download(nct_ctx* ctx, uint8_t* out_bgr) {

@@ -1,9 +1,11 @@
 // neural_color_transfer — the reference's console driver re-created on top of libnct (C ABI, include/nct.h).
 // Mirrors: get_input / main (main.cu:29-44, 546-590), transfer_single (main.cu:456-543), Utility::CmdLine
 // (CmdLine.h:58-69,132-147; CmdLine.cpp:21-56,93-109). Same flags, same pairs.txt, same output names, same log lines.
-// Differences: portable path handling ('/' and '\\'), PNG-only I/O (in-repo codec), a missing pairs.txt
-// is an error instead of a NULL dereference (main.cu:463-471), real defaults in the help text (Config.h:58-72 — the strings at
-// main.cu:40-43 quote other numbers), plus `-gpus N` (pairs sharded over N GPUs, one context per worker thread) and `-seed`.
+// Differences: portable path handling ('/' and '\\'), in-repo PNG + baseline-JPEG decoders instead of cv::imread
+// (output is PNG like the reference), a missing pairs.txt is an error instead of a NULL dereference (main.cu:463-471), plus the
+// extensions `-gpus N` (pairs sharded over N GPUs, one context per worker thread), `-inflight K`, `-seed`, `-levels L` (BASELINE
+// config 1: "L=5 only" = -levels 1), `-resume 1` (skip pairs whose output exists; <out>/status.jsonl gets one JSON line per pair)
+// and `-feat16 1` (reduced-precision PatchMatch features; not bit-identical).
 #include <sys/stat.h>
 #include <atomic>
 #include <chrono>
@@ -17,6 +19,7 @@
 #include <vector>
 #include "nct.h"
 #include "png_io.h"
+#include "jpeg_io.h"
 
 namespace {
 constexpr int MAX_SIZE = 1000;                 // Config.h:5
@@ -30,7 +33,13 @@ struct CmdLine {
     static bool is_arg(const char* a) { return a && (a[0] == '-' || a[0] == '/') && a[1] != 0 && !(a[1] >= '0' && a[1] <= '9') && a[1] != '.'; }
     void help(const char* prog) const {
         std::cout << "Running: " << prog << std::endl;
-        for (const auto& p : params) std::cout << "-" << p.flag << ": " << p.comment << std::endl;
+        for (const auto& p : params) {                                          // TParm::Print, CmdLine.h:140-142
+            std::cout << "-" << p.flag << ": " << "(default=";
+            if (p.kind == Param::STR) std::cout << *(const std::string*)p.dst;
+            else if (p.kind == Param::INT) std::cout << *(const int*)p.dst;
+            else std::cout << *(const double*)p.dst;
+            std::cout << ") " << p.comment << std::endl;
+        }
     }
     bool parse(int argc, char** argv) const {
         int i = 1;
@@ -64,7 +73,24 @@ std::string stem(const std::string& path) {          // main.cu:524-531 (find_la
 struct Pair { std::string cnt, stl; float bds; };
 std::mutex g_print;
 
-struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; };
+struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; bool resume = false; };
+std::mutex g_status;
+
+std::string json_escape(const std::string& s) {
+    std::string o;
+    for (char c : s) { if (c == '"' || c == '\\') { o += '\\'; o += c; } else if ((unsigned char)c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; } else o += c; }
+    return o;
+}
+// one JSON line per pair in <output_dir>/status.jsonl (batch bookkeeping for -resume; absent in the reference)
+void write_status(const Config& cfg, size_t index, const char* status, const std::string& cnt, const std::string& stl, double bds, const std::string& out, double sec,
+                  const std::string& msg) {
+    std::lock_guard<std::mutex> g(g_status);
+    FILE* f = fopen((cfg.output_dir + "/status.jsonl").c_str(), "a");
+    if (!f) return;
+    fprintf(f, "{\"pair\": %zu, \"content\": \"%s\", \"style\": \"%s\", \"bds\": %.6g, \"status\": \"%s\", \"output\": \"%s\", \"seconds\": %.4f, \"message\": \"%s\"}\n",
+            index, json_escape(cnt).c_str(), json_escape(stl).c_str(), bds, status, json_escape(out).c_str(), sec, json_escape(msg).c_str());
+    fclose(f);
+}
 
 // shrink so that the longer side is <= MAX_SIZE, int truncation as in main.cu:500-522
 bool shrink(nct_ctx* ctx, ImageBGR& img) {
@@ -77,42 +103,58 @@ bool shrink(nct_ctx* ctx, ImageBGR& img) {
     return true;
 }
 
-void process(nct_ctx* ctx, const Config& cfg, const Pair& p) {
+void process(nct_ctx* ctx, const Config& cfg, const Pair& p, size_t index) {
     char line[1024];
     std::string log;
     auto say = [&](const char* fmt, auto... a) { snprintf(line, sizeof line, fmt, a...); log += line; };
+    const auto t0 = std::chrono::steady_clock::now();
+    auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     log += "-----------------***********************----------------------\n";
     say("Content: %s, style: %s, BDS weight: %f.\n", p.cnt.c_str(), p.stl.c_str(), (double)p.bds);
     const std::string cntStr = cfg.input_dir + "/" + p.cnt, stlStr = cfg.input_dir + "/" + p.stl;
+    char name[1024];
+    snprintf(name, sizeof name, "%s/%s_%s_%2.2f.png", cfg.output_dir.c_str(), stem(cntStr).c_str(), stem(stlStr).c_str(), (double)p.bds);   // main.cu:524-537
     ImageBGR cnt, stl; std::string err;
     auto flush = [&] { std::lock_guard<std::mutex> g(g_print); fputs(log.c_str(), stdout); fflush(stdout); };
-    if (!pngio::read(cntStr, cnt, err)) { say("Error: Fail reading content image: %s\n", cntStr.c_str()); flush(); return; }
+    auto fail = [&](const std::string& msg) { write_status(cfg, index, "error", p.cnt, p.stl, p.bds, name, secs(), msg); flush(); };
+    if (cfg.resume) {
+        struct stat st;
+        if (stat(name, &st) == 0 && st.st_size > 0) {
+            say("Skipping (-resume): %s exists.\n\n", name);
+            write_status(cfg, index, "skipped", p.cnt, p.stl, p.bds, name, 0.0, "output exists");
+            flush(); return;
+        }
+    }
+    if (!imgio::read(cntStr, cnt, err)) { say("Error: Fail reading content image: %s\n", cntStr.c_str()); fail("cannot read content image: " + err); return; }
     say("\n**Read content file: %s, w = %d, h = %d\n", cntStr.c_str(), cnt.w, cnt.h);
-    if (!pngio::read(stlStr, stl, err)) { say("Error: Fail reading style image: %s\n", stlStr.c_str()); flush(); return; }
+    if (!imgio::read(stlStr, stl, err)) { say("Error: Fail reading style image: %s\n", stlStr.c_str()); fail("cannot read style image: " + err); return; }
     say("Read style file: %s, w = %d, h = %d\n", stlStr.c_str(), stl.w, stl.h);
-    if (!shrink(ctx, cnt) || !shrink(ctx, stl)) { say("Error: resize failed: %s\n", nct_last_error(ctx)); flush(); return; }
+    if (!shrink(ctx, cnt) || !shrink(ctx, stl)) { say("Error: resize failed: %s\n", nct_last_error(ctx)); fail(nct_last_error(ctx)); return; }
     nct_params prm = cfg.prm;
     prm.bds_weight = p.bds;                                     // the per-line weight overrides -bds (main.cu:475)
     std::vector<uint8_t> out((size_t)cnt.h * cnt.w * 3);
-    nct_pair_timing tm;
+    nct_pair_timing tm;                                         // stage times come from stream events: asking for them adds no host synchronisation
     const int rc = nct_process_pair(ctx, cnt.px.data(), cnt.h, cnt.w, stl.px.data(), stl.h, stl.w, &prm, out.data(), &tm);
-    if (rc != NCT_OK) { say("Error: %s\n", nct_last_error(ctx)); flush(); return; }
+    if (rc != NCT_OK) { say("Error: %s\n", nct_last_error(ctx)); fail(nct_last_error(ctx)); return; }
+    // the reference's per-level lines (main.cu:331; ColorTransfer.cpp:1373,1434), then its total (main.cu:453)
+    for (int l = 0; l < prm.levels; ++l) {
+        say("Patch Match Time: %lf sec.\n", (tm.pm_level_ms[l] + tm.vote_level_ms[l]) * 1e-3);
+        say("Nonlocal Solve Time: %lf\n", tm.nonlocal_level_ms[l] * 1e-3);
+        say("WLS Solve Time: %lf\n", tm.wls_level_ms[l] * 1e-3);
+    }
     say("VGG19 Time: %lf sec.\n", tm.vgg_ms * 1e-3);
-    say("Patch Match Time: %lf sec.\n", (tm.patchmatch_ms + tm.vote_ms) * 1e-3);
-    say("Color Time (kNN + Nonlocal Solve + WLS Solve): %lf sec.\n", (tm.knn_ms + tm.color_ms + tm.cluster_ms) * 1e-3);
     say("**Finished Time: %lf sec.\n", tm.total_ms * 1e-3);
-    char name[1024];
-    snprintf(name, sizeof name, "%s/%s_%s_%2.2f.png", cfg.output_dir.c_str(), stem(cntStr).c_str(), stem(stlStr).c_str(), (double)p.bds);
-    if (!pngio::write(name, out.data(), cnt.h, cnt.w, err)) { say("Error: cannot write %s: %s\n", name, err.c_str()); flush(); return; }
+    if (!pngio::write(name, out.data(), cnt.h, cnt.w, err)) { say("Error: cannot write %s: %s\n", name, err.c_str()); fail("cannot write output: " + err); return; }
     say("Final output file: %s.\n\n", name);
+    write_status(cfg, index, "done", p.cnt, p.stl, p.bds, name, secs(), "");
     flush();
 }
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc == 4 && !strcmp(argv[1], "--png-roundtrip")) {       // codec self-test hook (no GPU): decode argv[2], re-encode to argv[3]
+    if (argc == 4 && !strcmp(argv[1], "--png-roundtrip")) {       // codec self-test hook (no GPU): decode argv[2] (PNG or JPEG), re-encode to argv[3]
         ImageBGR im; std::string err;
-        if (!pngio::read(argv[2], im, err)) { printf("Error: %s: %s\n", argv[2], err.c_str()); return 1; }
+        if (!imgio::read(argv[2], im, err)) { printf("Error: %s: %s\n", argv[2], err.c_str()); return 1; }
         if (!pngio::write(argv[3], im.px.data(), im.h, im.w, err)) { printf("Error: %s: %s\n", argv[3], err.c_str()); return 1; }
         printf("%d %d\n", im.w, im.h);
         return 0;
@@ -120,21 +162,29 @@ int main(int argc, char** argv) {
     CmdLine cl;
     Config cfg;
     nct_params_default(&cfg.prm);
-    int gpu = 0, ngpus = 1, seed = 1, inflight = 1;
+    int gpu = 0, ngpus = 1, seed = 1, inflight = 1, levels = 5, resume = 0, feat16 = 0;
     cl.add("m", cfg.model_dir, "Directory of network models.");
     cl.add("i", cfg.input_dir, "Input directory of content and style images and pairs.txt.");
     cl.add("o", cfg.output_dir, "Output directory of result images.");
+    // the reference's comment strings (main.cu:32-43); its "(default: ...)" remarks quote other numbers than Config::Config() sets
+    // (Config.h:58-72) — the leading "(default=...)" that CmdLine prints (CmdLine.h:140-142) is the value that really applies
     cl.add("g", gpu, "GPU ID (default: 0).");
     cl.add("bds", cfg.prm.bds_weight, "Weight of reverse color in BDS voting (default: 2.0).");
     cl.add("eps", cfg.prm.eps, "Eps is used to avoid dividing zero (default: 0.6 with range in [0-255]).");
-    cl.add("nl", cfg.prm.nonlocal_weight, "Weight of nonlocal constraint (default: 2.0).");
-    cl.add("l", cfg.prm.local_weight, "Weight of local constraint (default: 0.125).");
-    cl.add("w", cfg.prm.wls_lambda_init, "Initial value of WLS weight (default: 0.024).");
+    cl.add("nl", cfg.prm.nonlocal_weight, "Weight of nonlocal constraint (default: 0.4.");
+    cl.add("l", cfg.prm.local_weight, "Weight of local constraitn (default: 0.001).");
+    cl.add("w", cfg.prm.wls_lambda_init, "Initial value of WLS weight (default: 0.0234375).");
     cl.add("gpus", ngpus, "[extension] number of GPUs to shard pairs.txt over, starting at -g (default: 1).");
     cl.add("inflight", inflight, "[extension] pairs in flight per GPU, one context + host thread each (default: 1; 2-3 raises throughput ~20 %).");
     cl.add("seed", seed, "[extension] seed of the counter-based RNG (default: 1).");
+    cl.add("levels", levels, "[extension] pyramid levels to run, coarse to fine: 5 = the full L=5..1 loop, 1 = L=5 only.");
+    cl.add("resume", resume, "[extension] 1 = skip pairs whose output file exists; every pair appends a JSON line to <output>/status.jsonl.");
+    cl.add("feat16", feat16, "[extension] 1 = fp16 PatchMatch feature tiles (fp32 accumulate); not bit-identical to the default.");
     if (!cl.parse(argc, argv)) return -1;
     cfg.prm.seed = (uint32_t)seed;
+    cfg.prm.levels = levels < 1 ? 1 : (levels > 5 ? 5 : levels);
+    if (feat16) cfg.prm.flags |= NCT_FLAG_FEAT16;
+    cfg.resume = resume != 0;
     if (ngpus < 1) ngpus = 1;
     if (inflight < 1) inflight = 1;
     if (inflight > 8) inflight = 8;
@@ -166,7 +216,7 @@ int main(int argc, char** argv) {
     std::atomic<size_t> next{0};
     std::vector<std::thread> workers;
     for (int j = 0; j < nworkers; ++j)
-        workers.emplace_back([&, j] { for (size_t i; (i = next.fetch_add(1)) < pairs.size();) process(ctxs[j], cfg, pairs[i]); });
+        workers.emplace_back([&, j] { for (size_t i; (i = next.fetch_add(1)) < pairs.size();) process(ctxs[j], cfg, pairs[i], i); });
     for (auto& t : workers) t.join();
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("Processed %zu pair(s) on %d GPU(s), %d in flight each, in %.3f sec (%.3f pairs/sec).\n", pairs.size(), ngpus, inflight, sec, pairs.empty() ? 0.0 : pairs.size() / sec);

@@ -29,18 +29,26 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
     size_t pos = 8;
     int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> idat, plte;
+    bool first = true, have_ihdr = false;
     while (pos + 12 <= d.size()) {
         uint32_t len = be32(&d[pos]);
         if (pos + 12 + (size_t)len > d.size()) { err = "truncated chunk"; return false; }
         const char* type = (const char*)&d[pos + 4];
         const uint8_t* body = &d[pos + 8];
-        if (!memcmp(type, "IHDR", 4)) { w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        // pairs.txt inputs are untrusted files: every chunk's CRC is verified, IHDR must be the first chunk and exactly 13 bytes
+        if ((uint32_t)crc32(0L, &d[pos + 4], (uInt)(4 + len)) != be32(&d[pos + 8 + len])) { err = "chunk CRC mismatch"; return false; }
+        if (first != !memcmp(type, "IHDR", 4)) { err = "IHDR must be the first chunk (and appear once)"; return false; }
+        first = false;
+        if (!memcmp(type, "IHDR", 4)) {
+            if (len != 13) { err = "bad IHDR length"; return false; }
+            w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; have_ihdr = true;
+        }
         else if (!memcmp(type, "PLTE", 4)) plte.assign(body, body + len);
         else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
         else if (!memcmp(type, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
-    if (w <= 0 || h <= 0 || w > 16384 || h > 16384) { err = "bad dimensions"; return false; }
+    if (!have_ihdr || w <= 0 || h <= 0 || w > 16384 || h > 16384 || (size_t)w * h > (64u << 20)) { err = "bad dimensions (limit: 64 megapixels)"; return false; }
     if (interlace) { err = "interlaced PNG not supported"; return false; }
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch || !(depth == 8 || depth == 16 || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4)) || (ctype == 0 && depth < 8))) { err = "unsupported colour type/depth"; return false; }

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))
 REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libnct.so")
+LIB_PATH = os.environ.get("NCT_LIB") or os.path.join(PKG_ROOT, "lib", "libnct.so")      # NCT_LIB: kernel-tuning experiments only
 
 
 class NctError(RuntimeError):
@@ -72,9 +72,11 @@ SIGNATURES = {
     "nct_process_pair": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_void_p, _u8p, C.c_void_p]),
     "nct_pair_upload": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]),
     "nct_pair_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nct_pair_run_levels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nct_pair_download": (C.c_int, [C.c_void_p, _u8p]),
     "nct_pm_bench_setup": (C.c_int, [C.c_void_p, _f32p, _f32p] + [C.c_int] * 5),
     "nct_pm_bench_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
+    "nct_pm_bench_run_bidir": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -93,7 +95,7 @@ class Params(C.Structure):
     """struct nct_params (include/nct.h)."""
     _fields_ = [("bds_weight", C.c_double), ("eps", C.c_double), ("nonlocal_weight", C.c_double), ("local_weight", C.c_double),
                 ("wls_lambda_init", C.c_double), ("cluster_num", C.c_int), ("k_num", C.c_int), ("patch_size", C.c_int),
-                ("wls_alpha", C.c_double), ("pm_iters", C.c_int), ("seed", C.c_uint32)]
+                ("wls_alpha", C.c_double), ("pm_iters", C.c_int), ("seed", C.c_uint32), ("levels", C.c_int), ("flags", C.c_uint32)]
 
     @staticmethod
     def default():
@@ -105,12 +107,27 @@ class Params(C.Structure):
 class PairTiming(C.Structure):
     """struct nct_pair_timing (include/nct.h)."""
     _fields_ = [("total_ms", C.c_double), ("vgg_ms", C.c_double), ("cluster_ms", C.c_double), ("patchmatch_ms", C.c_double),
-                ("vote_ms", C.c_double), ("knn_ms", C.c_double), ("color_ms", C.c_double), ("other_ms", C.c_double), ("wls_iters", C.c_int * 5)]
+                ("vote_ms", C.c_double), ("knn_ms", C.c_double), ("color_ms", C.c_double), ("other_ms", C.c_double),
+                ("nonlocal_ms", C.c_double), ("wls_ms", C.c_double), ("wls_iters", C.c_int * 5),
+                ("pm_level_ms", C.c_double * 5), ("pm_level_launches", C.c_int * 5),
+                ("vote_level_ms", C.c_double * 5), ("nonlocal_level_ms", C.c_double * 5), ("wls_level_ms", C.c_double * 5),
+                ("pm_level_evals", C.c_ulonglong * 5), ("pm_level_accepted", C.c_ulonglong * 5)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "wls_iters"}
-        d["wls_iters"] = list(self.wls_iters)
+        d = {}
+        for k, t in self._fields_:
+            v = getattr(self, k)
+            d[k] = v if isinstance(v, (int, float)) else list(v)
         return d
+
+
+FLAG_FEAT16 = 1
+FLAG_COUNT_EVALS = 2
+
+
+class PairLevels(C.Structure):
+    """struct nct_pair_levels (include/nct.h)."""
+    _fields_ = [(k, C.c_void_p * 5) for k in ("ann", "bnn", "annd", "bnnd", "guide", "err", "result")]
 
 
 class ColorStages(C.Structure):
@@ -355,6 +372,30 @@ class Context:
         self._chk(self._l.nct_pair_run(self._h, C.addressof(prm), C.addressof(tm) if tm is not None else None))
         return tm.as_dict() if want_timing else None
 
+    def pair_run_levels(self, src_shape, ref_shape, params=None):
+        """nct_pair_run_levels on the uploaded pair -> dict of per-level intermediates (lists indexed by level, 0 = coarsest)."""
+        prm = params or Params.default()
+        H, W = src_shape[:2]; RH, RW = ref_shape[:2]
+        dims = []
+        h, w, h2, w2 = H, W, RH, RW
+        for _ in range(5):
+            dims.insert(0, (h, w, h2, w2))
+            h, w, h2, w2 = (h - 1) // 2 + 1, (w - 1) // 2 + 1, (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+        keep = {"ann": [], "bnn": [], "annd": [], "bnnd": [], "guide": [], "err": [], "result": []}
+        for (ah, aw, bh, bw) in dims:
+            keep["ann"].append(np.zeros((ah, aw), np.uint32)); keep["bnn"].append(np.zeros((bh, bw), np.uint32))
+            keep["annd"].append(np.zeros((ah, aw), np.float32)); keep["bnnd"].append(np.zeros((bh, bw), np.float32))
+            keep["guide"].append(np.zeros((ah, aw, 3), np.uint8)); keep["err"].append(np.zeros((ah, aw), np.float32))
+            keep["result"].append(np.zeros((H, W, 3), np.uint8))
+        lv = PairLevels()
+        for k in keep:
+            setattr(lv, k, (C.c_void_p * 5)(*[a.ctypes.data for a in keep[k]]))
+        tm = PairTiming()
+        self._chk(self._l.nct_pair_run_levels(self._h, C.addressof(prm), C.addressof(tm), C.addressof(lv)))
+        keep["timing"] = tm.as_dict()
+        keep["dims"] = dims
+        return keep
+
     def pair_download(self):
         out = np.empty(self._pair_shape, np.uint8)
         self._chk(self._l.nct_pair_download(self._h, out.reshape(-1, 3)))
@@ -367,6 +408,7 @@ class Context:
         Cc, ah, aw = a.shape
         _, bh, bw = b.shape
         self._pm_shape = (ah, aw)
+        self._pm_shape_b = (bh, bw)
         self._chk(self._l.nct_pm_bench_setup(self._h, a, b, Cc, ah, aw, bh, bw))
 
     def pm_bench_run(self, iters=10, rs_max=32, seed=0, count_evals=False, fetch=False):
@@ -378,3 +420,19 @@ class Context:
         self._chk(self._l.nct_pm_bench_run(self._h, iters, rs_max, seed, C.byref(ms), C.byref(ev) if count_evals else None,
                                            _ptr(nnf), _ptr(dist)))
         return ms.value, (ev.value if count_evals else None), nnf, dist
+
+    def pm_bench_run_bidir(self, iters=10, rs_max=32, seed=0, pm_mode=1, count=False, fetch=False, both=False):
+        """The pipeline's form of the pass (both directions per launch; pm_mode 0 fp32 / 1 fp32 + row rejection / 2 fp16).
+        -> (kernel ms, [evals, accepted] or None, ann, annd[, bnn, bnnd])."""
+        ms = C.c_float()
+        cnt = (C.c_uint64 * 2)()
+        ah, aw = self._pm_shape
+        bh, bw = self._pm_shape_b
+        ann = np.empty((ah, aw), np.uint32) if fetch else None
+        annd = np.empty((ah, aw), np.float32) if fetch else None
+        bnn = np.empty((bh, bw), np.uint32) if fetch and both else None
+        bnnd = np.empty((bh, bw), np.float32) if fetch and both else None
+        self._chk(self._l.nct_pm_bench_run_bidir(self._h, iters, rs_max, seed, pm_mode, C.byref(ms), C.addressof(cnt) if count else None,
+                                                 _ptr(ann), _ptr(annd), _ptr(bnn), _ptr(bnnd)))
+        r = (ms.value, (list(cnt) if count else None), ann, annd)
+        return r + (bnn, bnnd) if both else r

@@ -37,13 +37,25 @@ typedef struct {
     double wls_alpha;
     int pm_iters;
     uint32_t seed;
+    int levels;         /* pyramid levels to run, coarse -> fine (5 = full loop; 1 = "L=5 only", BASELINE config 1) */
+    uint32_t flags;     /* ignored by the oracle (the product's reduced-precision / profiling switches) */
 } orc_params;       /* same layout as nct_params (include/nct.h) */
+
+/* per-level intermediates for level-wise validation; same layout as nct_pair_levels (include/nct.h); every pointer nullable */
+typedef struct {
+    uint32_t* ann[5]; uint32_t* bnn[5];
+    float* annd[5]; float* bnnd[5];
+    uint8_t* guide[5];
+    float* err[5];
+    uint8_t* result[5];
+} orc_pair_levels;
 
 static const int kTapC[5] = {64, 128, 256, 512, 512};
 
 /* level_out (nullable): receives the 5 intermediate full-resolution results, [5][H*W*3]. Returns 0 on success. */
-int orc_process_pair(const uint8_t* src, int H, int W, const uint8_t* ref, int RH, int RW, const float* const* weights, const float* const* biases,
-                     const orc_params* prm, uint8_t* out, uint8_t* level_out, int s2_exact) {
+int orc_process_pair_levels(const uint8_t* src, int H, int W, const uint8_t* ref, int RH, int RW, const float* const* weights, const float* const* biases,
+                            const orc_params* prm, uint8_t* out, uint8_t* level_out, int s2_exact, const orc_pair_levels* lv) {
+    const int nlevels = prm->levels >= 1 && prm->levels <= 5 ? prm->levels : 5;
     int ah[5], aw[5], bh[5], bw[5];
     { int h = H, w = W, h2 = RH, w2 = RW;
       for (int t = 0; t < 5; ++t) { ah[4 - t] = h; aw[4 - t] = w; bh[4 - t] = h2; bw[4 - t] = w2; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; h2 = (h2 - 1) / 2 + 1; w2 = (w2 - 1) / 2 + 1; } }
@@ -83,7 +95,7 @@ int orc_process_pair(const uint8_t* src, int H, int W, const uint8_t* ref, int R
     int* knn_id = (int*)malloc(sizeof(int) * N * 8); double* knn_w = (double*)malloc(sizeof(double) * N * 8);
     orc_color_params cp = {prm->eps, prm->nonlocal_weight, prm->local_weight, prm->wls_lambda_init, prm->wls_alpha, (double)prm->k_num};
     int rc = 0;
-    for (int l = 0; l < 5 && rc == 0; ++l) {
+    for (int l = 0; l < nlevels && rc == 0; ++l) {
         const int C = kTapC[4 - l];
         if (l == 0) { orc_nnf_init(ann, ah[0], aw[0], bh[0], bw[0]); orc_nnf_init(bnn, bh[0], bw[0], ah[0], aw[0]); }
         else {
@@ -96,16 +108,27 @@ int orc_process_pair(const uint8_t* src, int H, int W, const uint8_t* ref, int R
         const uint32_t seed_ab = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 1)), seed_ba = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 2));
         orc_patchmatch(na, nb, C, ah[l], aw[l], bh[l], bw[l], 3, prm->pm_iters, rs_range[l], seed_ab, ann, annd);
         orc_patchmatch(nb, na, C, bh[l], bw[l], ah[l], aw[l], 3, prm->pm_iters, rs_range[l], seed_ba, bnn, bnnd);
+        if (lv) {
+            if (lv->ann[l]) memcpy(lv->ann[l], ann, sizeof(uint32_t) * ah[l] * aw[l]);
+            if (lv->bnn[l]) memcpy(lv->bnn[l], bnn, sizeof(uint32_t) * bh[l] * bw[l]);
+            if (lv->annd[l]) memcpy(lv->annd[l], annd, sizeof(float) * ah[l] * aw[l]);
+            if (lv->bnnd[l]) memcpy(lv->bnnd[l], bnnd, sizeof(float) * bh[l] * bw[l]);
+        }
         orc_bds_vote_image(simg[l], ah[l], aw[l], rimg[l], bh[l], bw[l], ann, bnn, 3, 1.0, prm->bds_weight, guide);
         orc_bds_vote_features(ann, bnn, rtap[4 - l], voted, NULL, C, ah[l], aw[l], bh[l], bw[l], 3, 1.f, (float)prm->bds_weight);
         orc_feat_normalize(voted, nvoted, NULL, C, ah[l], aw[l]);
         orc_feature_distance(na, nvoted, err, C, ah[l], aw[l]);
+        if (lv) {
+            if (lv->guide[l]) memcpy(lv->guide[l], guide, (size_t)ah[l] * aw[l] * 3);
+            if (lv->err[l]) memcpy(lv->err[l], err, sizeof(float) * ah[l] * aw[l]);
+        }
         orc_bgr2lab_u8(simg[l], (size_t)ah[l] * aw[l], slab);
         orc_u8_to_f64_scaled(slab, (size_t)ah[l] * aw[l] * 3, labd);
         orc_knn_graph(labd, ah[l], aw[l], labels, ah[0], aw[0], nlabels, 1 << l, 8, knn_id, knn_w);
         rc = orc_local_color_transfer(err, simg[l], guide, src, knn_id, knn_w, l, ah[l], aw[l], H, W, &cp, out, NULL, s2_exact);
         if (level_out) memcpy(level_out + (size_t)l * N * 3, out, N * 3);
-        if (l < 4) {
+        if (lv && lv->result[l]) memcpy(lv->result[l], out, N * 3);
+        if (l < nlevels - 1) {
             const int tap = 4 - l;
             float* taps[5] = {NULL, NULL, NULL, NULL, NULL};
             taps[tap - 1] = sfeat;
@@ -117,4 +140,9 @@ int orc_process_pair(const uint8_t* src, int H, int W, const uint8_t* ref, int R
     free(sfeat); free(na); free(nb); free(voted); free(nvoted); free(labels); free(ann); free(bnn); free(annp); free(bnnp);
     free(annd); free(bnnd); free(err); free(guide); free(slab); free(labd); free(knn_id); free(knn_w);
     return rc;
+}
+
+int orc_process_pair(const uint8_t* src, int H, int W, const uint8_t* ref, int RH, int RW, const float* const* weights, const float* const* biases,
+                     const orc_params* prm, uint8_t* out, uint8_t* level_out, int s2_exact) {
+    return orc_process_pair_levels(src, H, W, ref, RH, RW, weights, biases, prm, out, level_out, s2_exact, NULL);
 }

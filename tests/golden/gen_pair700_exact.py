@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/pair_exact_<name>.npz: the CPU oracle's result with the EXACT S2 solve (s2_exact=1: the reference's
+direct-solve semantics, SparseSolver_CPU.cpp:104-286 — banded Cholesky / converged PCG in oracle/orc_color.c) for the full-size
+pairs of pair700_oracle.json, stored as a sparse delta against the canonical-order oracle result (s2_exact=0, the one whose CRC
+pair700_oracle.json pins and the GPU reproduces byte for byte):
+
+    exact = canonical + delta          (delta: flat indices + int8 values, usually a handful of +-1 LSB)
+
+plus CRC-32 of both images, so the test can (1) check that the GPU output has the canonical CRC, (2) rebuild the exact-solve
+image from it, (3) check the rebuilt image's CRC, (4) report L-inf / PSNR of the product against the exact-solve oracle.
+Also stores the per-level intermediate results' CRCs of both runs (level_out) for the level-wise comparison.
+Runs both oracle variants: ~15 / ~35 / ~5 minutes on 8 cores for 700 / 1000 / mixed."""
+import os, sys, time, zlib
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import numpy as np, oracle_bind, synth
+from caffemodel_io import synthetic_vgg19
+orc = oracle_bind.load()
+orc.l.orc_set_threads(min(32, os.cpu_count() or 1))
+ws, bs = synthetic_vgg19(19)
+CASES = {"700": (700, 700, 700, 700), "1000": (1000, 1000, 1000, 1000), "mixed": (333, 517, 612, 401), "tiny": (64, 56, 48, 64)}
+for name in (sys.argv[1:] or ["700"]):
+    sh, sw, rh, rw = CASES[name]
+    src, ref = synth.image(1000, sh, sw), synth.image(1001, rh, rw)
+    t = time.time(); canon, canon_lv = orc.process_pair(src, ref, ws, bs, want_levels=True, s2_exact=False); t_c = time.time() - t
+    t = time.time(); exact, exact_lv = orc.process_pair(src, ref, ws, bs, want_levels=True, s2_exact=True); t_e = time.time() - t
+    d = exact.astype(np.int16).reshape(-1) - canon.astype(np.int16).reshape(-1)
+    idx = np.flatnonzero(d).astype(np.uint32)
+    lv_linf = [int(np.abs(exact_lv[l].astype(int) - canon_lv[l].astype(int)).max()) for l in range(5)]
+    lv_ndiff = [int((exact_lv[l] != canon_lv[l]).sum()) for l in range(5)]
+    np.savez_compressed(os.path.join(HERE, f"pair_exact_{name}.npz"), shape=np.array([sh, sw, rh, rw]), idx=idx, delta=d[idx].astype(np.int16),
+                        crc_canonical=np.uint32(zlib.crc32(canon.tobytes())), crc_exact=np.uint32(zlib.crc32(exact.tobytes())),
+                        level_crc_canonical=np.array([zlib.crc32(canon_lv[l].tobytes()) for l in range(5)], np.uint32),
+                        level_linf_exact_vs_canonical=np.array(lv_linf), level_ndiff_exact_vs_canonical=np.array(lv_ndiff),
+                        seconds=np.array([t_c, t_e]))
+    mse = float((d.astype(np.float64) ** 2).mean())
+    print(name, "differing bytes:", idx.size, "of", d.size, "L-inf", int(np.abs(d).max()) if idx.size else 0,
+          "PSNR", "inf" if mse == 0 else round(10 * np.log10(255.0 ** 2 / mse), 2), "per-level L-inf", lv_linf, "per-level ndiff", lv_ndiff,
+          "seconds", round(t_c, 1), round(t_e, 1), flush=True)

@@ -177,15 +177,17 @@ class Oracle:
         return (out, keep) if want_stages else out
 
     # ---- whole pair (orc_pipeline.c)
-    def process_pair(self, src, ref, weights, biases, params=None, want_levels=False, s2_exact=False):
+    def process_pair(self, src, ref, weights, biases, params=None, want_levels=False, s2_exact=False, want_nnf=False):
+        """want_levels: also return the 5 intermediate results [5][H][W][3]; want_nnf: also return a dict of per-level
+        ann/bnn/annd/bnnd/guide/err/result lists (level 0 = coarsest), the same intermediates nct_pair_run_levels exposes."""
         import ctypes as Cc
 
         class P(Cc.Structure):
             _fields_ = [("bds_weight", Cc.c_double), ("eps", Cc.c_double), ("nonlocal_weight", Cc.c_double), ("local_weight", Cc.c_double),
                         ("wls_lambda_init", Cc.c_double), ("cluster_num", Cc.c_int), ("k_num", Cc.c_int), ("patch_size", Cc.c_int),
-                        ("wls_alpha", Cc.c_double), ("pm_iters", Cc.c_int), ("seed", Cc.c_uint32)]
+                        ("wls_alpha", Cc.c_double), ("pm_iters", Cc.c_int), ("seed", Cc.c_uint32), ("levels", Cc.c_int), ("flags", Cc.c_uint32)]
         d = dict(bds_weight=2.0, eps=0.60, nonlocal_weight=2.0, local_weight=0.125, wls_lambda_init=0.024, cluster_num=10, k_num=8,
-                 patch_size=3, wls_alpha=1.2, pm_iters=10, seed=1)
+                 patch_size=3, wls_alpha=1.2, pm_iters=10, seed=1, levels=5, flags=0)
         if params:
             d.update(params)
         prm = P(**d)
@@ -195,11 +197,32 @@ class Oracle:
         wp = (C.c_void_p * len(ws))(*[x.ctypes.data for x in ws]); bp = (C.c_void_p * len(bs))(*[x.ctypes.data for x in bs])
         out = np.empty_like(s)
         lv = np.empty((5, H, W, 3), np.uint8) if want_levels else None
-        self.l.orc_process_pair.argtypes = [_u8p, I, I, _u8p, I, I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, _u8p, C.c_void_p, I]
-        self.l.orc_process_pair.restype = I
-        rc = self.l.orc_process_pair(s.reshape(-1, 3), H, W, r.reshape(-1, 3), RH, RW, wp, bp, C.addressof(prm), out.reshape(-1, 3), _ptr(lv), 1 if s2_exact else 0)
+        keep, plv = None, None
+        if want_nnf:
+            dims, h, w, h2, w2 = [], H, W, RH, RW
+            for _ in range(5):
+                dims.insert(0, (h, w, h2, w2))
+                h, w, h2, w2 = (h - 1) // 2 + 1, (w - 1) // 2 + 1, (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+            keep = {k: [] for k in ("ann", "bnn", "annd", "bnnd", "guide", "err", "result")}
+            for (ah, aw, bh, bw) in dims:
+                keep["ann"].append(np.zeros((ah, aw), np.uint32)); keep["bnn"].append(np.zeros((bh, bw), np.uint32))
+                keep["annd"].append(np.zeros((ah, aw), np.float32)); keep["bnnd"].append(np.zeros((bh, bw), np.float32))
+                keep["guide"].append(np.zeros((ah, aw, 3), np.uint8)); keep["err"].append(np.zeros((ah, aw), np.float32))
+                keep["result"].append(np.zeros((H, W, 3), np.uint8))
+
+            class LV(Cc.Structure):
+                _fields_ = [(k, Cc.c_void_p * 5) for k in ("ann", "bnn", "annd", "bnnd", "guide", "err", "result")]
+            plv = LV()
+            for k in keep:
+                setattr(plv, k, (Cc.c_void_p * 5)(*[a.ctypes.data for a in keep[k]]))
+            keep["dims"] = dims
+        self.l.orc_process_pair_levels.argtypes = [_u8p, I, I, _u8p, I, I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, _u8p, C.c_void_p, I, C.c_void_p]
+        self.l.orc_process_pair_levels.restype = I
+        rc = self.l.orc_process_pair_levels(s.reshape(-1, 3), H, W, r.reshape(-1, 3), RH, RW, wp, bp, C.addressof(prm), out.reshape(-1, 3), _ptr(lv), 1 if s2_exact else 0,
+                                            C.addressof(plv) if plv is not None else None)
         assert rc == 0
-        return (out, lv) if want_levels else out
+        res = (out,) + ((lv,) if want_levels else ()) + ((keep,) if want_nnf else ())
+        return res if len(res) > 1 else out
 
     def feat_normalize(self, src, want_resp=False):
         src = np.ascontiguousarray(src, np.float32)

@@ -23,7 +23,11 @@ def test_help_prints_flags_and_returns_minus_one():
         assert r.returncode == 255                               # main.cu:557-560: `return -1`
         for flag in ("-m:", "-i:", "-o:", "-g:", "-bds:", "-eps:", "-nl:", "-l:", "-w:"):
             assert flag in r.stdout
-    assert "default: 0.125" in r.stdout and "default: 0.024" in r.stdout      # real Config.h defaults
+    # CmdLine.h:140-142 prints "-<flag>: (default=<value that applies>) <comment>"; the value is Config::Config()'s (Config.h:58-72),
+    # the comment strings are the reference's own, stale remarks included (main.cu:40-43)
+    assert "-l: (default=0.125) Weight of local constraitn (default: 0.001)." in r.stdout
+    assert "-w: (default=0.024) " in r.stdout and "-bds: (default=2) " in r.stdout and "-g: (default=0) GPU ID" in r.stdout
+    assert "-m: (default=) Directory of network models." in r.stdout
 
 
 def test_unknown_flag():
@@ -73,6 +77,58 @@ def test_png_codec_reads_the_reference_demo_inputs(tmp_path):
         assert np.array_equal(np.asarray(Image.open(dst).convert("RGB")), np.asarray(Image.open(os.path.join(REF_DEMO, name)).convert("RGB")))
 
 
+@pytest.mark.parametrize("sub,q", [(0, 92), (1, 85), (2, 75), ("gray", 90), (2, 40)])
+def test_jpeg_decoder_matches_libjpeg(tmp_path, sub, q):
+    """cv::imread's JPEG path restated (host/jpeg_io.h): islow IDCT, fancy 2x1 / 2x2 chroma upsampling, fixed-point YCbCr->RGB —
+    bit-identical to Pillow's libjpeg(-turbo) decode for 4:4:4 / 4:2:2 / 4:2:0 / grayscale, odd sizes and restart markers."""
+    for (h, w) in ((64, 64), (61, 75), (17, 33), (123, 200)):
+        rgb = synth.image(5 + h, h, w)[..., ::-1].copy()
+        for kw in ({}, {"restart_marker_blocks": 3}):
+            src = str(tmp_path / f"t{h}_{w}_{len(kw)}.jpg")
+            im = Image.fromarray(rgb)
+            try:
+                if sub == "gray":
+                    im.convert("L").save(src, quality=q, **kw)
+                else:
+                    im.save(src, quality=q, subsampling=sub, **kw)
+            except TypeError:
+                continue                                                   # older Pillow without restart_marker_blocks
+            exp = np.asarray(Image.open(src).convert("RGB"))
+            dst = str(tmp_path / "o.png")
+            r = run("--png-roundtrip", src, dst)
+            assert r.returncode == 0, r.stdout
+            assert np.array_equal(np.asarray(Image.open(dst).convert("RGB")), exp), (h, w, sub, q, kw)
+
+
+def test_jpeg_progressive_is_rejected_with_a_message(tmp_path):
+    src = str(tmp_path / "p.jpg")
+    Image.fromarray(synth.image(1, 40, 40)).save(src, progressive=True)
+    r = run("--png-roundtrip", src, str(tmp_path / "o.png"))
+    assert r.returncode == 1 and "progressive JPEG is not supported" in r.stdout
+
+
+def test_png_reader_rejects_malformed_files(tmp_path):
+    """Untrusted inputs: short / misplaced IHDR, corrupted chunk CRC, absurd dimensions — an error message, never a crash."""
+    import struct, zlib
+    good = tmp_path / "g.png"
+    Image.fromarray(synth.image(1, 20, 24)).save(good)
+    raw = good.read_bytes()
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    cases = {
+        "crc": raw[:40] + bytes([raw[40] ^ 0x55]) + raw[41:],                                   # flipped byte inside IDAT
+        "short_ihdr": raw[:8] + chunk(b"IHDR", b"\0" * 5) + raw[33:],
+        "late_ihdr": raw[:8] + chunk(b"tEXt", b"a\0b") + raw[8:],
+        "huge": raw[:8] + chunk(b"IHDR", struct.pack(">IIBBBBB", 16000, 16000, 16, 6, 0, 0, 0)) + raw[33:],
+    }
+    for name, data in cases.items():
+        p = tmp_path / f"{name}.png"
+        p.write_bytes(data)
+        r = run("--png-roundtrip", str(p), str(tmp_path / "o.png"))
+        assert r.returncode == 1 and "Error" in r.stdout, name
+
+
 @pytest.mark.gpu
 def test_cli_batch_matches_library(tmp_path, ctx):
     from caffemodel_io import synthetic_vgg19, write_caffemodel
@@ -89,6 +145,7 @@ def test_cli_batch_matches_library(tmp_path, ctx):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Fail reading content image" in r.stdout                       # unreadable image: message, skip, continue (main.cu:484-496)
     assert "Patch Match Time:" in r.stdout and "**Finished Time:" in r.stdout and "Final output file:" in r.stdout
+    assert r.stdout.count("Nonlocal Solve Time: ") == 10 and r.stdout.count("WLS Solve Time: ") == 10     # per level, like ColorTransfer.cpp:1373,1434
     assert sorted(os.listdir(out)) == ["a_b_2.00.png", "c_a_0.50.png"]     # <srcbase>_<refbase>_<%2.2f bds>.png (main.cu:537)
     ctx.vgg19_load_raw(ws, bs)
     for name, (s, rf, w) in {"a_b_2.00.png": (a, b, 2.0), "c_a_0.50.png": (c, a, 0.5)}.items():
@@ -122,3 +179,43 @@ def test_cli_inflight_workers_give_identical_files(tmp_path):
     assert list(outs[1]) == list(outs[3]) and len(outs[1]) == 5
     for n in outs[1]:
         assert np.array_equal(outs[1][n], outs[3][n]), n
+
+
+@pytest.mark.gpu
+def test_cli_shrink_jpeg_resume_levels(tmp_path, ctx):
+    """transfer_single's shrink-to-1000 path (main.cu:500-522: int truncation of the shorter side) on a JPEG input, `-levels 1`
+    (BASELINE config 1), and `-resume 1` (existing outputs are skipped; status.jsonl gets a line per pair)."""
+    import json
+    from caffemodel_io import synthetic_vgg19, write_caffemodel
+    ws, bs = synthetic_vgg19(19)
+    (tmp_path / "model" / "vgg19").mkdir(parents=True)
+    write_caffemodel(str(tmp_path / "model" / "vgg19" / "VGG_ILSVRC_19_layers.caffemodel"), ws, bs)
+    inp = tmp_path / "in"; inp.mkdir()
+    big = synth.image(4, 1100, 700)                                            # 1100 high: shrinks to 1000 x (int)(1000/1100*700) = 636
+    Image.fromarray(big[..., ::-1].copy()).save(inp / "big.jpg", quality=90, subsampling=2)
+    small = synth.image(5, 120, 160)
+    Image.fromarray(small[..., ::-1].copy()).save(inp / "small.png")
+    (inp / "pairs.txt").write_text("big.jpg small.png 2.0\nsmall.png big.jpg 1.0\n")
+    out = tmp_path / "out"
+    args = ("-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(out), "-levels", "1")
+    r = run(*args)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "w = 700, h = 1100" in r.stdout
+    assert sorted(n for n in os.listdir(out) if n.endswith(".png")) == ["big_small_2.00.png", "small_big_1.00.png"]
+    got = np.asarray(Image.open(out / "big_small_2.00.png").convert("RGB"))[..., ::-1]
+    assert got.shape == (1000, 636, 3)
+    # same pixels as the library fed with the decoded + shrunk images
+    dec = np.asarray(Image.open(inp / "big.jpg").convert("RGB"))[..., ::-1]
+    ctx.vgg19_load_raw(ws, bs)
+    prm = nct.Params.default(); prm.levels = 1
+    exp = ctx.process_pair(ctx.resize_u8c3(dec, 1000, 636), small, prm)
+    assert np.array_equal(got, exp)
+    st = [json.loads(l) for l in (out / "status.jsonl").read_text().splitlines()]
+    assert [s["status"] for s in st] == ["done", "done"] and st[0]["output"].endswith("big_small_2.00.png")
+    mtime = os.path.getmtime(out / "big_small_2.00.png")
+    os.remove(out / "small_big_1.00.png")
+    r = run(*args, "-resume", "1")
+    assert r.returncode == 0 and "Skipping (-resume)" in r.stdout
+    assert os.path.getmtime(out / "big_small_2.00.png") == mtime and os.path.exists(out / "small_big_1.00.png")
+    st = [json.loads(l) for l in (out / "status.jsonl").read_text().splitlines()]
+    assert sorted(s["status"] for s in st[2:]) == ["done", "skipped"]

@@ -7,30 +7,72 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, "bench.py")
 
 
-def test_bench_emits_contract_json():
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--size", "128", "--steps", "2", "--warmup", "1", "--inflight", "2"],
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+def _run(*args, timeout=900, env=None):
+    r = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_gpus_n_relaunches_one_rank_per_gpu():
+    """`python bench.py --gpus 8` (how the driver may call it) must start 8 ranks itself: the re-launch command is torchrun with
+    --nproc-per-node 8 on 127.0.0.1; a WORLD_SIZE that disagrees with --gpus is an error, not a silent 1-rank run."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--print-launch"], capture_output=True, text=True, timeout=60,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "2"]
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, timeout=60, env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_emits_contract_json():
+    d = _run("--size", "128", "--steps", "2", "--warmup", "1", "--inflight", "2")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline"):
+              "roofline", "cpu_baseline", "host_to_host_pairs_per_s", "build_id"):
         assert k in d, k
     assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
-    assert d["config"]["pairs_per_gpu_per_step"] == 2 and "workload" in d["config"]
+    assert d["config"]["pairs_per_gpu_per_step"] == 2 and "workload" in d["config"] and d["config"]["name"] == "pair700"
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    assert 0.5 * d["value"] < d["host_to_host_pairs_per_s"] < 1.5 * d["value"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_GBs"):
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert "k_pm_step<1, 1>" in rf["kernel"] and rf["launches"] == 41 and rf["traffic"] is None       # PMC passes exist for 700x700 only
     cb = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "value_1thread"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
-    assert d["single_pair_ms"] > 0 and d["stages_ms"]["total_ms"] > 0
+    assert d["single_pair_ms"] > 0 and d["stages_ms"]["total_ms"] > 0 and d["stages_ms"]["nonlocal_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_via_self_launch():
+    """--gpus 2 on a 1-GPU box: the script re-launches itself under torchrun; both ranks share GPU 0 (test hook), gloo carries the
+    barrier and the MAX-reduce. The line must say n_gpus 2 and count both ranks' pairs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = _run("--gpus", "2", "--size", "96", "--steps", "2", "--warmup", "1", "--inflight", "1", "--dist-backend", "gloo", "--device-override", "0",
+             "--no-cpu-baseline", "--no-roofline", env=env)
+    assert d["n_gpus"] == 2 and d["config"]["pairs_per_gpu_per_step"] == 1
+    assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wl", ["batch64", "mixed256", "pair256l5"])
+def test_bench_other_workloads(wl):
+    """BASELINE configs 3 / 5 / 1 as bench workloads, at reduced batch sizes: strong-scaling lines with host-in -> host-out steps."""
+    extra = ["--batch", "6"] if wl != "pair256l5" else []
+    if wl == "batch64":
+        extra += ["--size", "96"]
+    d = _run("--workload", wl, "--steps", "1", "--warmup", "0", "--inflight", "2", "--no-cpu-baseline", "--no-roofline", *extra, timeout=1200)
+    assert d["config"]["name"] == wl and d["value"] > 0
+    assert d["scaling"] == ("weak" if wl == "pair256l5" else "strong")

@@ -1,7 +1,6 @@
 """GPU parity for the colour stage (A1/OpenCV restatements, C1, K1, T1, T2, S1, U1, S2) vs the CPU oracle.
-Bars: bit-exact for u8 images, labels, neighbour ids and the local statistics; fp64 solver outputs within the tolerance
-written at each assert (the reduction order of dot products differs between GPU tree reductions and the oracle's
-sequential sums; the truncated CG amplifies that over its 50/100 iterations)."""
+Bars: bit-exact everywhere — u8 images, labels, neighbour ids, local statistics, and the fp64 solver stages too: the operation order
+of both solvers is specified (oracle/orc_color_canon.c, oracle/orc_wls_mg.c), so GPU and oracle perform the same IEEE operations."""
 import numpy as np
 import pytest
 import synth
@@ -91,15 +90,16 @@ def test_local_color_transfer_stages(ctx, oracle, case):
     oo, os_ = oracle.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
     # T1: closed-form statistics — same fp64 expression order => bit exact
     assert np.array_equal(gs["ab_local"].view(np.uint64), os_["ab_local"].view(np.uint64))
-    # S1: same truncated CG recurrence, iteration cap reached on both sides
+    # S1: the truncated CG in the canonical operation order (oracle/orc_color_canon.c mirrors the kernels' operator order and reduction
+    # trees; exp/pow are the shared IEEE-basic-op implementations): iteration cap reached on both sides, iterates bit-identical
     assert gs["cg_iters"].tolist() == os_["cg_iters"].tolist() == [50 if layer == 4 else 100] * 3
-    assert np.allclose(gs["ab_nonlocal"], os_["ab_nonlocal"], rtol=1e-7, atol=1e-9)
-    assert np.allclose(gs["ab_up"], os_["ab_up"], rtol=1e-7, atol=1e-9)
+    assert np.array_equal(gs["ab_nonlocal"].view(np.uint64), os_["ab_nonlocal"].view(np.uint64))
+    assert np.array_equal(gs["ab_up"].view(np.uint64), os_["ab_up"].view(np.uint64))
     assert np.array_equal(gs["roughness"], os_["roughness"])
-    # S2: both converged solvers of the same SPD system (oracle: exact banded Cholesky)
-    assert np.allclose(gs["ab_wls"], os_["ab_wls"], rtol=1e-6, atol=1e-8)
-    # A1: 8-bit output — allow isolated 1-LSB flips from the 1e-7 coefficient differences
-    d = np.abs(go.astype(int) - oo.astype(int))
-    assert d.max() <= 2 and (d > 0).mean() < 0.01
-    mse = (d.astype(float) ** 2).mean()
-    assert mse == 0 or 10 * np.log10(255 ** 2 / mse) > 60
+    # S2: the multigrid-preconditioned single-reduction PCG, mirrored operation for operation by oracle/orc_wls_mg.c: same iteration
+    # counts, bit-identical solution (agreement of that solver with the EXACT solve is a separate test: test_oracle_color.py and
+    # test_gpu_pipeline.py::test_full_size_pair_vs_exact_s2_oracle)
+    assert gs["wls_iters"].tolist() == os_["wls_iters"].tolist()
+    assert np.array_equal(gs["ab_wls"].view(np.uint64), os_["ab_wls"].view(np.uint64))
+    # A1: 8-bit output
+    assert np.array_equal(go, oo)

@@ -141,3 +141,35 @@ def test_bds_vote_image_bit_exact(ctx, oracle, dims):
     bnn = synth.random_nnf(4, bh, bw, ah, aw)
     for wc in (2.0, 0.0, 1.0, 4.0, 8.0):       # the demo's BDS sweep (demo/example/pairs.txt:5-9)
         assert np.array_equal(ctx.bds_vote_image(a, b, ann, bnn, 1.0, wc), oracle.bds_vote_image(a, b, ann, bnn, 1.0, wc))
+
+
+# ---- the pipeline's instantiations: both directions fused per launch, grouped candidate evaluation ------------------------------
+@pytest.mark.parametrize("C,ah,aw,bh,bw,rs", [(64, 37, 41, 33, 45, 8), (128, 30, 26, 28, 31, 16), (256, 21, 24, 23, 20, 8), (512, 14, 13, 12, 15, 4), (64, 9, 70, 80, 7, 32),
+                                              (64, 120, 90, 100, 110, 32), (128, 70, 64, 66, 72, 32), (24, 20, 22, 21, 19, 8)])
+def test_patchmatch_bidir_bit_exact(ctx, oracle, C, ah, aw, bh, bw, rs):
+    """k_pm_step as the pipeline launches it (S->R and R->S fields in the same launches), plain and with the exact row-wise rejection,
+    against the oracle's two single-direction runs with the same seeds: identical NNF and bit-identical distances in BOTH directions."""
+    fa, fb = synth.features(21, C, ah, aw), synth.features(22, C, bh, bw)
+    a, b = oracle.feat_normalize(fa), oracle.feat_normalize(fb)
+    seed = 77
+    o_ann, o_annd = oracle.patchmatch(a, b, oracle.nnf_init(ah, aw, bh, bw), iters=5, rs_max=rs, seed=seed)
+    o_bnn, o_bnnd = oracle.patchmatch(b, a, oracle.nnf_init(bh, bw, ah, aw), iters=5, rs_max=rs, seed=seed ^ 0x5bd1e995)
+    ctx.pm_bench_setup(fa, fb)                         # uploads, normalises, builds the fp16 shadow maps
+    counts = []
+    for mode in (0, 1):
+        ms, cnt, ann, annd, bnn, bnnd = ctx.pm_bench_run_bidir(iters=5, rs_max=rs, seed=seed, pm_mode=mode, count=True, fetch=True, both=True)
+        assert np.array_equal(ann, o_ann) and np.array_equal(bnn, o_bnn), f"mode {mode}: NNF differs from the oracle"
+        assert np.array_equal(annd.view(np.uint32), o_annd.view(np.uint32)) and np.array_equal(bnnd.view(np.uint32), o_bnnd.view(np.uint32)), f"mode {mode}: distances differ"
+        counts.append(cnt)
+    assert counts[0] == counts[1] and counts[0][0] > 0 and counts[0][1] > 0           # same candidates, same acceptances
+
+
+def test_patchmatch_fp16_mode_close(ctx):
+    """Opt-in reduced-precision mode (NCT_FLAG_FEAT16): fp16 candidate tiles, fp32 accumulate. Not bit-identical by definition; the
+    match energies stay within the fp16 rounding bound of the fp32 field's."""
+    for C, ah, aw, bh, bw in ((64, 48, 52, 50, 46), (128, 40, 36, 38, 44), (256, 24, 28, 26, 22), (512, 16, 18, 17, 15)):
+        ctx.pm_bench_setup(synth.features(31, C, ah, aw), synth.features(32, C, bh, bw))
+        _, _, ann, annd = ctx.pm_bench_run_bidir(iters=6, rs_max=16, seed=5, pm_mode=1, fetch=True)
+        _, _, ann16, annd16 = ctx.pm_bench_run_bidir(iters=6, rs_max=16, seed=5, pm_mode=2, fetch=True)
+        assert np.abs(annd16.astype(np.float64).mean() - annd.astype(np.float64).mean()) < 2e-3, C
+        assert (ann16 == ann).mean() > 0.8, C
