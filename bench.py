@@ -383,10 +383,11 @@ def vgg_mfma(sh, sw, rh, rw, levels, vgg_ms):
 
 
 def cpu_baseline(synth, ws, bs, S, full=False):
-    """Oracle ('port') end-to-end, measured on this box's host cores on a bounded sample of the same workload: one 256x256 pair (full
-    L=5->1 loop, same synthetic VGG19) on all cores and one 64x64 pair on a single thread, scaled to the SxS pair by pixel count. The law
-    was checked against full-size runs: the oracle costs 670-830 s per megapixel from 176^2 to 700^2 on 8 cores (profiles/README.md);
-    `--cpu-baseline-full` times the real SxS pair instead (minutes)."""
+    """Oracle ('port') end-to-end, measured on this box's host cores on a bounded sample of the same workload: one 350x350 pair (full
+    L=5->1 loop, same synthetic VGG19; a quarter of the 700x700 pair's pixels) on all cores and one 64x64 pair on a single thread,
+    scaled to the SxS pair by pixel count. The law was checked against full-size runs (profiles/README.md): 670-830 s per megapixel
+    from 176^2 to 700^2 on 8 cores; on the 64-thread GPU box the 700x700 pair itself takes 138 s (0.0072 pairs/s) — small samples
+    parallelise worse there, so the scaled figure UNDERSTATES the CPU a little. `--cpu-baseline-full` times the real SxS pair (minutes)."""
     import oracle_bind
     orc = oracle_bind.load()
     threads = min(64, os.cpu_count() or 1)
@@ -397,7 +398,7 @@ def cpu_baseline(synth, ws, bs, S, full=False):
         t0 = time.perf_counter()
         orc.process_pair(src, ref, ws, bs)
         return time.perf_counter() - t0
-    n = min(256, S)
+    n = min(350, S)
     dt = run(n, threads)
     n1 = min(64, S)
     dt1 = run(n1, 1)
@@ -405,7 +406,7 @@ def cpu_baseline(synth, ws, bs, S, full=False):
     scale1 = (n1 * n1) / float(S * S)
     res = {"value": scale / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
            "sample": f"oracle orc_process_pair on one {n}x{n} pair (full L=5->1 loop, same synthetic VGG19): {dt:.2f} s on {threads} OpenMP threads, scaled to "
-                     f"{S}x{S} by pixel count ({1 / scale:.2f}x; linear within +-12 % from 176^2 to 700^2, profiles/README.md); one {n1}x{n1} pair on 1 thread: {dt1:.2f} s",
+                     f"{S}x{S} by pixel count ({1 / scale:.2f}x; full-size check: profiles/README.md); one {n1}x{n1} pair on 1 thread: {dt1:.2f} s",
            "value_1thread": scale1 / dt1, "sample_seconds": dt, "sample_seconds_1thread": dt1}
     if full:
         dtf = run(S, threads)

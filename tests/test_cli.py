@@ -146,7 +146,7 @@ def test_cli_batch_matches_library(tmp_path, ctx):
     assert "Fail reading content image" in r.stdout                       # unreadable image: message, skip, continue (main.cu:484-496)
     assert "Patch Match Time:" in r.stdout and "**Finished Time:" in r.stdout and "Final output file:" in r.stdout
     assert r.stdout.count("Nonlocal Solve Time: ") == 10 and r.stdout.count("WLS Solve Time: ") == 10     # per level, like ColorTransfer.cpp:1373,1434
-    assert sorted(os.listdir(out)) == ["a_b_2.00.png", "c_a_0.50.png"]     # <srcbase>_<refbase>_<%2.2f bds>.png (main.cu:537)
+    assert sorted(os.listdir(out)) == ["a_b_2.00.png", "c_a_0.50.png", "status.jsonl"]     # <srcbase>_<refbase>_<%2.2f bds>.png (main.cu:537)
     ctx.vgg19_load_raw(ws, bs)
     for name, (s, rf, w) in {"a_b_2.00.png": (a, b, 2.0), "c_a_0.50.png": (c, a, 0.5)}.items():
         prm = nct.Params.default(); prm.bds_weight = w
@@ -175,7 +175,7 @@ def test_cli_inflight_workers_give_identical_files(tmp_path):
         r = run("-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(out), "-g", "0", "-inflight", str(k))
         assert r.returncode == 0, r.stdout + r.stderr
         assert f"{k} in flight each" in r.stdout
-        outs[k] = {n: np.asarray(Image.open(out / n)) for n in sorted(os.listdir(out))}
+        outs[k] = {n: np.asarray(Image.open(out / n)) for n in sorted(os.listdir(out)) if n.endswith(".png")}
     assert list(outs[1]) == list(outs[3]) and len(outs[1]) == 5
     for n in outs[1]:
         assert np.array_equal(outs[1][n], outs[3][n]), n
