@@ -17,7 +17,8 @@
 #include "nct_internal.h"
 #include "nct_device.h"
 #include "nct_detmath.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>   // rocPRIM directly (no CUB-compatibility layer)
 #include <algorithm>
 
 // ================================================================= C1: k-means
@@ -434,10 +435,10 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
                        (int*)count, (unsigned*)keys, (unsigned*)vals);
     NCT_LAUNCH_CHECK();
     size_t tmp_bytes = 0;
-    NCT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 3 * cb + 5, s));
+    NCT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 3 * cb + 5, s));
     DevBuf<char> tmp(ctx, tmp_bytes ? tmp_bytes : 16);
     if (!tmp.ok()) return NCT_ERR_HIP;
-    NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 3 * cb + 5, s));
+    NCT_HIP(rocprim::radix_sort_pairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 3 * cb + 5, s));
     hipLaunchKernelGGL(k_knn_cell_starts, dim3(cdiv(nkeys + 1, 256)), dim3(256), 0, s, (const unsigned*)keys_s, cap, (int*)start, nkeys);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_entry_colours, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, (const int*)count, (const unsigned*)vals_s, (unsigned*)cols);

@@ -20,7 +20,8 @@
 #include "nct_internal.h"
 #include "nct_device.h"
 #include "nct_detmath.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>   // rocPRIM directly (no CUB-compatibility layer)
 
 #define LAB_D(u) ((double)(u) * (1.0 / 255.0))      // Mat::convertTo(CV_64F, 1/255)
 
@@ -488,10 +489,10 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         hipLaunchKernelGGL(k_edge_keys, dim3(cdiv(m, 256)), dim3(256), 0, s, knn_id, m, (unsigned*)ek, (unsigned*)ev); LCHK();
         int end_bit = 1; while ((1u << end_bit) < (unsigned)n && end_bit < 32) ++end_bit;
         size_t tmp_bytes = 0;
-        NCT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned*)ek, (unsigned*)eks, (const unsigned*)ev, (unsigned*)evs, m, 0, end_bit, s));
+        NCT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned*)ek, (unsigned*)eks, (const unsigned*)ev, (unsigned*)evs, m, 0, end_bit, s));
         DevBuf<char> tmp(ctx, tmp_bytes ? tmp_bytes : 16);
         if (!tmp.ok()) return NCT_ERR_HIP;
-        NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)ek, (unsigned*)eks, (const unsigned*)ev, (unsigned*)evs, m, 0, end_bit, s));
+        NCT_HIP(rocprim::radix_sort_pairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)ek, (unsigned*)eks, (const unsigned*)ev, (unsigned*)evs, m, 0, end_bit, s));
         hipLaunchKernelGGL(k_seg_starts, dim3(cdiv(n + 1, 256)), dim3(256), 0, s, (const unsigned*)eks, m, (int*)rstart, n); LCHK();
         hipLaunchKernelGGL(k_rev_edges, dim3(cdiv(m, 256)), dim3(256), 0, s, (const unsigned*)evs, (const double*)iw2, m, (int*)rev_src, (double*)rev_w); LCHK();
         S1Sys S{n, h, w, daa, dab, dbb, gx, gy, knn_id, iw2, rstart, rev_src, rev_w};

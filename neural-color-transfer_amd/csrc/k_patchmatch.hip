@@ -58,26 +58,47 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
         if (__builtin_amdgcn_ballot_w64(inside) == __builtin_amdgcn_ballot_w64(true)) {
             constexpr int C4 = 16 * NCH;
             if constexpr (HALF) {
-                // half-size tiles: the interior path pays for every C (one patch row at a time from C = 256 on)
-                const uint2* phc = Bh + (size_t)(unsigned)(by * g.bw + bx) * C4 + v;
-                const float4* pah = a_lds + ((ly + 1) * 6 + (lx + 1)) * C4 + v;
+                // half-size tiles through FULL-WIDTH (16-byte) loads: the kernel is bound by the number of vector-memory instructions the
+                // L1 address path (TA) has to process, not by bytes, so the fp16 tile is read as 16-byte units (8 channels) — a pixel is
+                // 8 * NCH units; at C = 64 one instruction of the 16-lane row fetches TWO pixels (lanes 0-7 / 8-15): 5 loads per tile
+                // instead of 9, C = 128: 9 instead of 18, …
+                const uint4* ph = reinterpret_cast<const uint4*>(Bh);
                 float h = 0.f;
-                if constexpr (NCH <= 2) {
+                if constexpr (NCH == 1) {
+                    const int vh = v & 7, hi = v >> 3;
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int dy = t / 3 - 1, dx = t % 3 - 1;
-#pragma unroll
-                        for (int k = 0; k < NCH; ++k) h = dot4h_acc(pah[(dy * 6 + dx) * C4 + 16 * k], phc[(dy * g.bw + dx) * C4 + 16 * k], h);
+                    for (int j = 0; j < 5; ++j) {
+                        const int t = 2 * j + hi;
+                        const bool on = t < 9;
+                        const int tt = on ? t : 8;
+                        const int dy = tt / 3 - 1, dx = tt - (dy + 1) * 3 - 1;
+                        uint4 raw = ph[(size_t)(unsigned)((by + dy) * g.bw + bx + dx) * 8 + vh];
+                        const float4* pa = a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * C4 + 2 * vh;
+                        const float4 a0 = pa[0], a1 = pa[1];
+                        if (!on) raw = make_uint4(0u, 0u, 0u, 0u);
+                        h = dot4h_acc(a0, make_uint2(raw.x, raw.y), h);
+                        h = dot4h_acc(a1, make_uint2(raw.z, raw.w), h);
                     }
                 } else {
+                    constexpr int U = 8 * NCH;                     // 16-byte units per pixel (>= 16: every lane of the row reads U/16 units of one pixel)
+                    auto tap = [&](int dy, int dx) {
+                        const uint4* pp = ph + (size_t)(unsigned)((by + dy) * g.bw + bx + dx) * U + v;
+                        const float4* pa = a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * C4 + 2 * v;
+#pragma unroll
+                        for (int m = 0; m < U / 16; ++m) {
+                            const uint4 raw = pp[16 * m];
+                            h = dot4h_acc(pa[32 * m], make_uint2(raw.x, raw.y), h);
+                            h = dot4h_acc(pa[32 * m + 1], make_uint2(raw.z, raw.w), h);
+                        }
+                    };
+                    if constexpr (NCH <= 4) {                      // whole tile in flight (9 / 18 loads)
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) tap(t / 3 - 1, t % 3 - 1);
+                    } else {
 #pragma unroll 1
-                    for (int dy = -1; dy <= 1; ++dy) {
-                        const uint2* phr = phc + dy * g.bw * C4;
-                        const float4* par = pah + dy * 6 * C4;
+                        for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx)
-#pragma unroll
-                            for (int k = 0; k < NCH; ++k) h = dot4h_acc(par[dx * C4 + 16 * k], phr[dx * C4 + 16 * k], h);
+                            for (int dx = -1; dx <= 1; ++dx) tap(dy, dx);
                     }
                 }
                 return (-row16_sum(h)) / 9.0f;
@@ -101,6 +122,11 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
                         if (row16_sum(facc) + rem < need) return FLT_MAX;
                     }
                 }
+                // the complete sum: a candidate 1e-4 short of `need` = -9 dbest loses by > 1e-5 in distance, far outside the rounding of the
+                // product and of the division — rejected without paying for the correctly rounded division (~10 VALU instructions)
+                const float sfull = row16_sum(facc);
+                if (need > -FLT_MAX && sfull + 1e-4f < need) return FLT_MAX;
+                return (-sfull) / 9.0f;
             } else if constexpr (NCH == 1) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {                      // all nine loads in flight
@@ -252,8 +278,12 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
                 const int step = k - 4;
                 const int xmin = max(xbest - mag, 0), xmax = min(xbest + mag + 1, g.bw);
                 const int ymin = max(ybest - mag, 0), ymax = min(ybest + mag + 1, g.bh);
-                xp = xmin + (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)(xmax - xmin)) % (xmax - xmin);
-                yp = ymin + (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)(ymax - ymin)) % (ymax - ymin);
+                // (int)(u * w) % w with u in (0, 1]: the product never exceeds w, so the modulo only folds the value w back to 0 — a
+                // select instead of two integer divisions (~35 VALU instructions each in a kernel that is VALU-issue bound)
+                const int wx = xmax - xmin, wy = ymax - ymin;
+                const int rx = (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)wy);
+                xp = xmin + (rx == wx ? 0 : rx);
+                yp = ymin + (ry == wy ? 0 : ry);
                 mag >>= 1;
                 valid = true; rr = FLT_MIN;
             }

@@ -10,7 +10,8 @@
 // Roofline: HBM/L2 gather, ~18 feature vectors read + 1 written per S pixel.
 #include "nct_internal.h"
 #include "nct_device.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>   // rocPRIM directly (no CUB-compatibility layer)
 
 // ---------------------------------------------------------------- inverse map of the R->S NNF
 __global__ void k_inv_keys(const uint32_t* __restrict__ bnn, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int nb, int aw) {
@@ -42,11 +43,11 @@ static int build_inverse(nct_ctx* ctx, hipStream_t s, const uint32_t* bnn, int b
     NCT_LAUNCH_CHECK();
     int end_bit = 1; while ((1u << end_bit) < (unsigned)na && end_bit < 32) ++end_bit;
     size_t tmp_bytes = 0;
-    NCT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)inv.keys, (uint32_t*)inv.keys_s,
+    NCT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint32_t*)inv.keys, (uint32_t*)inv.keys_s,
                                                (const uint32_t*)inv.vals, (uint32_t*)inv.vals_s, nb, 0, end_bit, s));
     DevBuf<char> tmp(ctx, tmp_bytes ? tmp_bytes : 16);
     if (!tmp.ok()) return NCT_ERR_HIP;
-    NCT_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(char*)tmp, tmp_bytes, (const uint32_t*)inv.keys, (uint32_t*)inv.keys_s,
+    NCT_HIP(rocprim::radix_sort_pairs((void*)(char*)tmp, tmp_bytes, (const uint32_t*)inv.keys, (uint32_t*)inv.keys_s,
                                                (const uint32_t*)inv.vals, (uint32_t*)inv.vals_s, nb, 0, end_bit, s));
     hipLaunchKernelGGL(k_inv_starts, dim3(cdiv(na + 1, 256)), dim3(256), 0, s, (const uint32_t*)inv.keys_s, nb, (int*)inv.start, na);
     NCT_LAUNCH_CHECK();

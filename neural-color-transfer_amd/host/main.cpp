@@ -73,7 +73,70 @@ std::string stem(const std::string& path) {          // main.cu:524-531 (find_la
 struct Pair { std::string cnt, stl; float bds; };
 std::mutex g_print;
 
-struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; bool resume = false; };
+struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; bool resume = false, vis = false; };
+
+// ---- ENABLE_VIS debug outputs (Config.h:8) behind the runtime flag -vis 1: per pyramid level the flow maps of both NNFs (reconstruct_flow,
+// GeneralizedPatchMatch.cu:337-353), the level images tCnt / tStl (main.cu:343-347), the matching-error heat map (getHeat,
+// ColorTransfer.cpp:1127-1178 on the min-max normalised error, :1318-1338) — under the reference's file names <pre>_aFlow_<l>.png … — plus
+// the BDS guidance image and the intermediate result of the level (guide_<l>, result_<l>: not dumped by the reference, but what its
+// refine_* images are for). <pre> = the output file's stem. The coefficient / patch / kNN visualisations are not reproduced.
+void heat(double v, uint8_t* bgr) {
+    v = v < 0 ? 0 : (v > 1 ? 1 : v);
+    double dr, dg, db;
+    if (v < 0.1242) { db = 0.504 + ((1. - 0.504) / 0.1242) * v; dg = dr = 0.; }
+    else if (v < 0.3747) { db = 1.; dr = 0.; dg = (v - 0.1242) * (1. / (0.3747 - 0.1242)); }
+    else if (v < 0.6253) { db = (0.6253 - v) * (1. / (0.6253 - 0.3747)); dg = 1.; dr = (v - 0.3747) * (1. / (0.6253 - 0.3747)); }
+    else if (v < 0.8758) { db = 0.; dr = 1.; dg = (0.8758 - v) * (1. / (0.8758 - 0.6253)); }
+    else { db = 0.; dg = 0.; dr = 1. - (v - 0.8758) * ((1. - 0.504) / (1. - 0.8758)); }
+    auto q = [](double d) { const int i = (int)(255 * d); return (uint8_t)(i > 255 ? 255 : i); };
+    bgr[0] = q(db); bgr[1] = q(dg); bgr[2] = q(dr);
+}
+bool run_with_vis(nct_ctx* ctx, const ImageBGR& cnt, const ImageBGR& stl, const nct_params& prm, const std::string& pre, uint8_t* out, nct_pair_timing* tm, std::string& err) {
+    int ah[5], aw[5], bh[5], bw[5];
+    { int h = cnt.h, w = cnt.w, h2 = stl.h, w2 = stl.w;
+      for (int t = 0; t < 5; ++t) { ah[4 - t] = h; aw[4 - t] = w; bh[4 - t] = h2; bw[4 - t] = w2; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; h2 = (h2 - 1) / 2 + 1; w2 = (w2 - 1) / 2 + 1; } }
+    std::vector<std::vector<uint32_t>> ann(5), bnn(5);
+    std::vector<std::vector<uint8_t>> guide(5), result(5), simg(5), rimg(5);
+    std::vector<std::vector<float>> errm(5);
+    nct_pair_levels lv; memset(&lv, 0, sizeof lv);
+    for (int l = 0; l < prm.levels; ++l) {
+        ann[l].resize((size_t)ah[l] * aw[l]); bnn[l].resize((size_t)bh[l] * bw[l]); guide[l].resize((size_t)ah[l] * aw[l] * 3);
+        errm[l].resize((size_t)ah[l] * aw[l]); result[l].resize((size_t)cnt.h * cnt.w * 3);
+        lv.ann[l] = ann[l].data(); lv.bnn[l] = bnn[l].data(); lv.guide[l] = guide[l].data(); lv.err[l] = errm[l].data(); lv.result[l] = result[l].data();
+    }
+    if (nct_pair_upload(ctx, cnt.px.data(), cnt.h, cnt.w, stl.px.data(), stl.h, stl.w) != NCT_OK || nct_pair_run_levels(ctx, &prm, tm, &lv) != NCT_OK ||
+        nct_pair_download(ctx, out) != NCT_OK) { err = nct_last_error(ctx); return false; }
+    // level images: the progressive bilinear pyramid of main.cu:104-108
+    simg[4] = cnt.px; rimg[4] = stl.px;
+    for (int l = 3; l >= 0; --l) {
+        simg[l].resize((size_t)ah[l] * aw[l] * 3); rimg[l].resize((size_t)bh[l] * bw[l] * 3);
+        if (nct_resize_u8c3(ctx, simg[l + 1].data(), ah[l + 1], aw[l + 1], simg[l].data(), ah[l], aw[l]) != NCT_OK ||
+            nct_resize_u8c3(ctx, rimg[l + 1].data(), bh[l + 1], bw[l + 1], rimg[l].data(), bh[l], bw[l]) != NCT_OK) { err = nct_last_error(ctx); return false; }
+    }
+    auto save = [&](const char* what, int l, const uint8_t* px, int h, int w) {
+        char name[1200]; snprintf(name, sizeof name, "%s_%s_%d.png", pre.c_str(), what, l);
+        std::string e; return pngio::write(name, px, h, w, e);
+    };
+    for (int l = 0; l < prm.levels; ++l) {
+        auto flow = [&](const std::vector<uint32_t>& nn, int h, int w, int oh, int ow) {
+            std::vector<uint8_t> f((size_t)h * w * 3);
+            for (size_t i = 0; i < (size_t)h * w; ++i) {
+                const int xb = (int)(nn[i] & 0xFFFu), yb = (int)((nn[i] >> 12) & 0xFFFu);
+                f[3 * i] = (uint8_t)(255 * ((float)xb / ow)); f[3 * i + 1] = 0; f[3 * i + 2] = (uint8_t)(255 * ((float)yb / oh));
+            }
+            return f;
+        };
+        const auto fa = flow(ann[l], ah[l], aw[l], bh[l], bw[l]), fb = flow(bnn[l], bh[l], bw[l], ah[l], aw[l]);
+        float mn = errm[l][0], mx = errm[l][0];
+        for (float e : errm[l]) { mn = e < mn ? e : mn; mx = e > mx ? e : mx; }
+        std::vector<uint8_t> hm((size_t)ah[l] * aw[l] * 3);
+        for (size_t i = 0; i < errm[l].size(); ++i) heat(((double)errm[l][i] - mn) / ((double)mx - mn), &hm[3 * i]);
+        if (!save("aFlow", l, fa.data(), ah[l], aw[l]) || !save("bFlow", l, fb.data(), bh[l], bw[l]) || !save("tCnt", l, simg[l].data(), ah[l], aw[l]) ||
+            !save("tStl", l, rimg[l].data(), bh[l], bw[l]) || !save("errMap", l, hm.data(), ah[l], aw[l]) || !save("guide", l, guide[l].data(), ah[l], aw[l]) ||
+            !save("result", l, result[l].data(), cnt.h, cnt.w)) { err = "cannot write the -vis images"; return false; }
+    }
+    return true;
+}
 std::mutex g_status;
 
 std::string json_escape(const std::string& s) {
@@ -134,8 +197,13 @@ void process(nct_ctx* ctx, const Config& cfg, const Pair& p, size_t index) {
     prm.bds_weight = p.bds;                                     // the per-line weight overrides -bds (main.cu:475)
     std::vector<uint8_t> out((size_t)cnt.h * cnt.w * 3);
     nct_pair_timing tm;                                         // stage times come from stream events: asking for them adds no host synchronisation
-    const int rc = nct_process_pair(ctx, cnt.px.data(), cnt.h, cnt.w, stl.px.data(), stl.h, stl.w, &prm, out.data(), &tm);
-    if (rc != NCT_OK) { say("Error: %s\n", nct_last_error(ctx)); fail(nct_last_error(ctx)); return; }
+    if (cfg.vis) {
+        std::string pre(name); pre.resize(pre.size() - 4);                  // the output file's stem
+        if (!run_with_vis(ctx, cnt, stl, prm, pre, out.data(), &tm, err)) { say("Error: %s\n", err.c_str()); fail(err); return; }
+    } else {
+        const int rc = nct_process_pair(ctx, cnt.px.data(), cnt.h, cnt.w, stl.px.data(), stl.h, stl.w, &prm, out.data(), &tm);
+        if (rc != NCT_OK) { say("Error: %s\n", nct_last_error(ctx)); fail(nct_last_error(ctx)); return; }
+    }
     // the reference's per-level lines (main.cu:331; ColorTransfer.cpp:1373,1434), then its total (main.cu:453)
     for (int l = 0; l < prm.levels; ++l) {
         say("Patch Match Time: %lf sec.\n", (tm.pm_level_ms[l] + tm.vote_level_ms[l]) * 1e-3);
@@ -162,7 +230,7 @@ int main(int argc, char** argv) {
     CmdLine cl;
     Config cfg;
     nct_params_default(&cfg.prm);
-    int gpu = 0, ngpus = 1, seed = 1, inflight = 1, levels = 5, resume = 0, feat16 = 0;
+    int gpu = 0, ngpus = 1, seed = 1, inflight = 1, levels = 5, resume = 0, feat16 = 0, vis = 0;
     cl.add("m", cfg.model_dir, "Directory of network models.");
     cl.add("i", cfg.input_dir, "Input directory of content and style images and pairs.txt.");
     cl.add("o", cfg.output_dir, "Output directory of result images.");
@@ -179,12 +247,14 @@ int main(int argc, char** argv) {
     cl.add("seed", seed, "[extension] seed of the counter-based RNG (default: 1).");
     cl.add("levels", levels, "[extension] pyramid levels to run, coarse to fine: 5 = the full L=5..1 loop, 1 = L=5 only.");
     cl.add("resume", resume, "[extension] 1 = skip pairs whose output file exists; every pair appends a JSON line to <output>/status.jsonl.");
+    cl.add("vis", vis, "[extension] 1 = the reference's ENABLE_VIS dumps per level (flow maps, level images, error heat map) next to the output.");
     cl.add("feat16", feat16, "[extension] 1 = fp16 PatchMatch feature tiles (fp32 accumulate); not bit-identical to the default.");
     if (!cl.parse(argc, argv)) return -1;
     cfg.prm.seed = (uint32_t)seed;
     cfg.prm.levels = levels < 1 ? 1 : (levels > 5 ? 5 : levels);
     if (feat16) cfg.prm.flags |= NCT_FLAG_FEAT16;
     cfg.resume = resume != 0;
+    cfg.vis = vis != 0;
     if (ngpus < 1) ngpus = 1;
     if (inflight < 1) inflight = 1;
     if (inflight > 8) inflight = 8;

@@ -219,3 +219,39 @@ def test_cli_shrink_jpeg_resume_levels(tmp_path, ctx):
     assert os.path.getmtime(out / "big_small_2.00.png") == mtime and os.path.exists(out / "small_big_1.00.png")
     st = [json.loads(l) for l in (out / "status.jsonl").read_text().splitlines()]
     assert sorted(s["status"] for s in st[2:]) == ["done", "skipped"]
+
+
+@pytest.mark.gpu
+def test_cli_vis_dumps(tmp_path, ctx, oracle):
+    """`-vis 1` (the reference's ENABLE_VIS, Config.h:8): per level <pre>_aFlow/_bFlow/_tCnt/_tStl/_errMap_<l>.png with the reference's
+    arithmetic (reconstruct_flow GeneralizedPatchMatch.cu:337-353; getHeat ColorTransfer.cpp:1127-1178), plus guide_/result_; the
+    final output is unchanged by the flag."""
+    from caffemodel_io import synthetic_vgg19, write_caffemodel
+    ws, bs = synthetic_vgg19(19)
+    (tmp_path / "model" / "vgg19").mkdir(parents=True)
+    write_caffemodel(str(tmp_path / "model" / "vgg19" / "VGG_ILSVRC_19_layers.caffemodel"), ws, bs)
+    inp = tmp_path / "in"; inp.mkdir()
+    a, b = synth.image(1, 80, 64), synth.image(2, 64, 96)
+    Image.fromarray(a[..., ::-1].copy()).save(inp / "a.png"); Image.fromarray(b[..., ::-1].copy()).save(inp / "b.png")
+    (inp / "pairs.txt").write_text("a.png b.png 2.0\n")
+    out = tmp_path / "out"
+    r = run("-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(out), "-vis", "1")
+    assert r.returncode == 0, r.stdout + r.stderr
+    names = set(os.listdir(out))
+    for l in range(5):
+        for what in ("aFlow", "bFlow", "tCnt", "tStl", "errMap", "guide", "result"):
+            assert f"a_b_2.00_{what}_{l}.png" in names, (what, l)
+    ctx.vgg19_load_raw(ws, bs)
+    ctx.pair_upload(a, b)
+    lv = ctx.pair_run_levels(a.shape, b.shape)
+    load = lambda n: np.asarray(Image.open(out / n).convert("RGB"))[..., ::-1]
+    assert np.array_equal(load("a_b_2.00.png"), ctx.pair_download())
+    assert np.array_equal(load("a_b_2.00_result_4.png"), lv["result"][4]) and np.array_equal(load("a_b_2.00_guide_2.png"), lv["guide"][2])
+    assert np.array_equal(load("a_b_2.00_tCnt_4.png"), a) and np.array_equal(load("a_b_2.00_tStl_3.png"), oracle.resize_u8c3(b, 32, 48))
+    ann = lv["ann"][3]; bh, bw = lv["dims"][3][2:]
+    flow = load("a_b_2.00_aFlow_3.png")
+    assert np.array_equal(flow[..., 0], (255 * ((ann & 0xFFF).astype(np.float32) / np.float32(bw))).astype(np.uint8))
+    assert np.array_equal(flow[..., 2], (255 * ((ann >> 12).astype(np.float32) / np.float32(bh))).astype(np.uint8)) and not flow[..., 1].any()
+    hm = load("a_b_2.00_errMap_0.png")
+    e = lv["err"][0].astype(np.float64); i = np.unravel_index(np.argmin(e), e.shape); j = np.unravel_index(np.argmax(e), e.shape)
+    assert hm[i].tolist() == [128, 0, 0] and hm[j].tolist() == [0, 0, 128]          # getHeat(0) = dark blue, getHeat(1) = dark red (BGR)

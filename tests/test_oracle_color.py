@@ -24,6 +24,28 @@ def test_lab_roundtrip_close(oracle):
     assert np.abs(oracle.lab2bgr(oracle.bgr2lab(g)).astype(int) - g).max() <= 1
 
 
+def test_lab2bgr_dark_and_out_of_gamut_pins_the_restated_form(oracle):
+    """CV_Lab2BGR on 8-bit input, restated form: piecewise CIE inverse (linear branch for L* <= 8 and f <= 6/29), linear-RGB clipped to
+    [0, 1], sRGB gamma, round. Independent numpy evaluation of that formula for dark (L_u8 <= 20), grey and out-of-gamut triples, +-1 LSB
+    for the spline-interpolated gamma table. DESIGN.md §4 divergence 8: OpenCV 2.4.10 itself is believed to use the plain cube form
+    without clipping; the two differ only for L_u8 <= 20 and out-of-gamut colours and cannot be arbitrated here (parity unpinned)."""
+    lab = np.array([[0, 128, 128], [5, 128, 128], [12, 130, 120], [20, 128, 128], [21, 128, 128], [10, 160, 90], [60, 128, 128], [137, 128, 128],
+                    [200, 250, 250], [40, 10, 240]], np.uint8)
+    L = lab[:, 0].astype(np.float64) * 100 / 255; a = lab[:, 1].astype(np.float64) - 128; b = lab[:, 2].astype(np.float64) - 128
+    fy = np.where(L <= 0.008856 * 903.3, 7.787 * (L / 903.3) + 16 / 116, (L + 16) / 116)
+    y = np.where(L <= 0.008856 * 903.3, L / 903.3, fy ** 3)
+    fx, fz = a / 500 + fy, fy - b / 200
+    finv = lambda f: np.where(f <= 7.787 * 0.008856 + 16 / 116, (f - 16 / 116) / 7.787, f ** 3)
+    X, Z = finv(fx) * 0.950456, finv(fz) * 1.088754
+    M = np.array([[3.240479, -1.53715, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
+    rgb = np.clip(np.stack([X, y, Z], 1) @ M.T, 0, 1)
+    srgb = np.where(rgb <= 0.0031308, 12.92 * rgb, 1.055 * rgb ** (1 / 2.4) - 0.055)
+    exp_bgr = np.rint(srgb[:, ::-1] * 255)
+    got = oracle.lab2bgr(lab).astype(int)
+    assert np.abs(got - exp_bgr).max() <= 1, (got.tolist(), exp_bgr.tolist())
+    assert got[0].tolist() == [0, 0, 0] and got[7].tolist() == [128, 128, 128]
+
+
 def test_resize_u8_area_and_linear(oracle):
     img = synth.image(3, 8, 12)
     half = oracle.resize_u8c3(img, 4, 6)         # exact 2x -> INTER_AREA: (a+b+c+d+2)>>2
