@@ -277,7 +277,7 @@ def pmc_traffic(device, live):
     gfx950 -> x2; the k_normalize dispatch of the same pass, a pure 125.44 MB streaming read, is kept as the calibration check).
     Returns (dict, how) or (None, why)."""
     exe = shutil.which("rocprofv3")
-    rec = os.path.join(REPO, "profiles", "r3_pmc_patchmatch.json")
+    rec = os.path.join(REPO, "profiles", "round2_pmc_patchmatch.json")
     bid = lib_build_id()
     why = "live PMC disabled"
     if live and exe:
@@ -298,7 +298,7 @@ def pmc_traffic(device, live):
     if os.path.exists(rec):
         d = json.load(open(rec))
         if d.get("build_id") == bid:
-            return d, "recorded (profiles/r3_pmc_patchmatch.json, same build id)"
+            return d, "recorded (profiles/round2_pmc_patchmatch.json, same build id)"
         why += "; the recorded PMC passes belong to another build"
     return None, why
 
