@@ -298,107 +298,70 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
         for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = x2[q] + (bq[q] - y[q]) * c.dinv;
     }
 }
-// Tail of the V-cycle: every level with <= 512 pixels (22x22, 11x11, 6x6 at 700x700) in ONE 512-thread workgroup. Thread t owns
-// pixel t of each tail level; iterates travel through LDS (whole grids, no halos), each thread keeps its rhs / pre-smoothed
-// iterate / coefficients of every tail level in registers for the way back up. Replaces 2 launches per level (~4.8 us each, pure
-// latency) by a few barrier-separated LDS phases. The coarsest grid (n <= 64) is solved by `sweeps` damped-Jacobi sweeps from zero
-// with one wave per right-hand side and one lane per unknown: the iterate stays in a register, the neighbours come through
-// ds_bpermute, no barriers (a 1024-thread LDS version of that solve alone took 82 us per cycle: profiles/r1f_e2e_kernels.md).
-// Same expressions and operation order (+x, -x, +y, -y) as k_mg_down / k_mg_up. lv[0] is the first tail level: its rhs lv[0].b
-// was written by the restriction above it, its correction goes to lv[0].x2.
-constexpr int TAIL_N = 512, TAIL_LV = 4;
-struct TailPack { Lvl lv[TAIL_LV]; int nl; };
-__device__ __forceinline__ void tail_op(const PxCoef& c, const vf* __restrict__ s_v, int p, int pitch, vf (&y)[NQ]) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) y[q] = c.d * s_v[q * TAIL_N + p];
-    if (c.r) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= c.w0 * s_v[q * TAIL_N + p + 1]; }
-    if (c.l) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= c.w1 * s_v[q * TAIL_N + p - 1]; }
-    if (c.dn) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= c.w2 * s_v[q * TAIL_N + p + pitch]; }
-    if (c.up) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= c.w3 * s_v[q * TAIL_N + p - pitch]; }
+// Middle + tail of the V-cycle in ONE launch, one 1024-thread workgroup PER RIGHT-HAND SIDE: the first fused level has <= 4096 pixels
+// (44x44 at 700x700, 63x63 at 1000x1000), the deeper ones <= 1024 (22x22, 11x11, 6x6). The six systems share the operator but not a single
+// value, so no workgroup ever waits for another and the whole sub-cycle needs only __syncthreads(). Everything a level needs for the way
+// back up (right-hand side, pre-smoothed iterate, stencil coefficients of the deeper levels) stays in REGISTERS of the thread that owns
+// the pixel; iterates are exchanged through whole-grid LDS arrays (no halos); coefficients come from global memory once per level (the
+// first fused level re-reads them for the up leg) and all those loads are issued at the start. A first version that re-read
+// coefficients and iterates from global memory in each of its 35 barrier-separated phases was SLOWER than the launches it replaced
+//  — a single workgroup has nothing to hide a global round trip with.
+// Replaces round 1's single-workgroup tail (<= 512 pixels, all six systems in one workgroup: 12.5 us) plus the k_mg_down / k_mg_up
+// launches of the 44x44 level. Same expressions and operation order (+x, -x, +y, -y; children (0,0),(0,1),(1,0),(1,1)) as k_mg_down /
+// k_mg_up, so the cycle is bit-identical. lv[0] is the first fused level: its rhs lv[0].b was written by the restriction above it, its
+// correction goes to lv[0].x2. The coarsest grid (n <= 64) is solved by `sweeps` damped-Jacobi sweeps from zero by one wave (one lane per
+// unknown, the iterate in a register, neighbours through ds_bpermute).
+constexpr int MID_T = 1024, MID_N0 = 4096, MID_N1 = 1024, MID_LV = 6;
+struct MidPack { Lvl lv[MID_LV]; int nl; };
+struct MidCoef { vf d, dinv, w0, w1, w2, w3; unsigned flags; };      // flags: 1 = +x exists, 2 = -x, 4 = +y, 8 = -y
+__device__ __forceinline__ MidCoef mid_coef(const Lvl& L, int i) {
+    const int gy = i / L.W, gx = i - gy * L.W;
+    MidCoef c;
+    const bool r = gx + 1 < L.W, l = gx > 0, dn = gy + 1 < L.H, up = gy > 0;
+    c.flags = (r ? 1u : 0u) | (l ? 2u : 0u) | (dn ? 4u : 0u) | (up ? 8u : 0u);
+    c.d = L.fdiag[i]; c.dinv = L.fdinv[i];
+    c.w0 = r ? L.fwx[i] : 0.f; c.w1 = l ? L.fwx[i - 1] : 0.f; c.w2 = dn ? L.fwy[i] : 0.f; c.w3 = up ? L.fwy[i - L.W] : 0.f;
+    return c;
 }
-__global__ __launch_bounds__(TAIL_N) void k_mg_tail(const PState* __restrict__ st, TailPack P, int sweeps) {
-    if (st->nactive == 0) return;
-    __shared__ vf sA[NQ * TAIL_N], sB[NQ * TAIL_N], sC[NQ * TAIL_N];
-    const int t = threadIdx.x;
-    const int nl = P.nl;
-    vf bs[TAIL_LV][NQ], xs[TAIL_LV][NQ]; PxCoef cs[TAIL_LV];
-    // ---- down
-    {
-        const Lvl& L0 = P.lv[0];
+__device__ __forceinline__ vf mid_op(const MidCoef& c, const vf* __restrict__ s_v, int i, int W) {
+    vf y = c.d * s_v[i];
+    if (c.flags & 1u) y -= c.w0 * s_v[i + 1];
+    if (c.flags & 2u) y -= c.w1 * s_v[i - 1];
+    if (c.flags & 4u) y -= c.w2 * s_v[i + W];
+    if (c.flags & 8u) y -= c.w3 * s_v[i - W];
+    return y;
+}
+// restricted residual of coarse pixel I: children of the fine grid (Wf x Hf) in the order (0,0),(0,1),(1,0),(1,1)
+__device__ __forceinline__ vf mid_restrict(const vf* __restrict__ s_res, int I, int Wc, int Wf, int Hf) {
+    const int Y = I / Wc, X = I - Y * Wc;
+    vf acc = 0.0f;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) bs[0][q] = t < L0.n ? L0.b[(size_t)q * L0.n + t] : 0.f;
+    for (int k = 0; k < 4; ++k) {
+        const int yy = 2 * Y + (k >> 1), xx = 2 * X + (k & 1);
+        if (yy < Hf && xx < Wf) acc += s_res[yy * Wf + xx];
     }
-#pragma unroll
-    for (int l = 0; l < TAIL_LV - 1; ++l) {
-        if (l < nl - 1) {                                                  // the coarsest level (nl - 1) is solved below
-            const Lvl& L = P.lv[l]; const Lvl& C = P.lv[l + 1];
-            const bool live = t < L.n;
-            const int gy = live ? t / L.W : 0, gx = live ? t - gy * L.W : 0;
-            if (live) {
-                cs[l] = px_coef(L, gy, gx);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) sA[q * TAIL_N + t] = bs[l][q] * cs[l].dinv;
-            }
-            __syncthreads();
-            if (live) {
-                vf y[NQ]; tail_op(cs[l], sA, t, L.W, y);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) { const vf x1 = bs[l][q] * cs[l].dinv; xs[l][q] = x1 + (bs[l][q] - y[q]) * cs[l].dinv; sB[q * TAIL_N + t] = xs[l][q]; }
-            }
-            __syncthreads();
-            if (live) {
-                vf yv[NQ]; tail_op(cs[l], sB, t, L.W, yv);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) sA[q * TAIL_N + t] = bs[l][q] - yv[q];
-            }
-            __syncthreads();
-            const bool livec = t < C.n;
-            const int Y = livec ? t / C.W : 0, X = livec ? t - Y * C.W : 0;
-            vf acc[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
-            if (livec) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int yy = 2 * Y + (k >> 1), xx = 2 * X + (k & 1);
-                    if (yy < L.H && xx < L.W) {
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) acc[q] += sA[q * TAIL_N + yy * L.W + xx];
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) bs[l + 1][q] = acc[q];
-            __syncthreads();
-        }
-    }
-    // ---- coarsest grid
-    {
-        const Lvl& L = P.lv[nl - 1];
-        const int n = L.n, W = L.W, H = L.H;
-#pragma unroll
-        for (int l = 0; l < TAIL_LV; ++l)
-            if (l == nl - 1 && t < n) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) sA[q * TAIL_N + t] = bs[l][q];
-            }
+    return acc;
+}
+// Level D of the fused sub-cycle. In: this level's right-hand side b[] in registers (pixel i = t + k * MID_T). Out: this level's correction
+// in s_out (LDS, n values) — or in global L.x2 for D == 0. sA / sB: exchange arrays (>= n); sC: the child's correction (n_child values).
+template <int D>
+__device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __restrict__ sA, vf* __restrict__ sB, vf* __restrict__ sC,
+                                          const vf (&b)[D == 0 ? 4 : 1], int sweeps) {
+    constexpr int PPT = D == 0 ? 4 : 1;
+    const Lvl& L = P.lv[D];
+    const int n = L.n, W = L.W;
+    if (D == P.nl - 1) {
+        // ---- coarsest grid: wave 0, one lane per unknown (same code as the single-workgroup tail of round 1)
+        if (t < n) sA[t] = b[0];
         __syncthreads();
-        if (t < 64 * NQ) {
-            const int q = t >> 6, i = t & 63;
+        if (t < 64) {
+            const int i = t, H = L.H;
             const bool live = i < n;
             const int r = live ? i / W : 0, c = live ? i - r * W : 0;
             vf bq = 0, d = 0, dv = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
             const bool has_r = live && c + 1 < W, has_l = live && c > 0, has_d = live && r + 1 < H, has_u = live && r > 0;
             if (live) {
-                bq = sA[q * TAIL_N + i]; d = L.fdiag[i]; dv = L.fdinv[i];
+                bq = sA[i]; d = L.fdiag[i]; dv = L.fdinv[i];
                 if (has_r) w0 = L.fwx[i];
                 if (has_l) w1 = L.fwx[i - 1];
                 if (has_d) w2 = L.fwy[i];
@@ -414,40 +377,67 @@ __global__ __launch_bounds__(TAIL_N) void k_mg_tail(const PState* __restrict__ s
                 if (has_u) y -= w3 * xu;
                 if (live) x = x + (bq - y) * dv;
             }
-            if (live) { if (nl == 1) L.x2[(size_t)q * n + i] = x; else sC[q * TAIL_N + i] = x; }
+            if (live) { if (D == 0) L.x2[(size_t)q * n + i] = x; else sC[i] = x; }
         }
         __syncthreads();
+        return;
     }
-    // ---- up
+    if constexpr (D + 1 < MID_LV) {
+        const Lvl& C = P.lv[D + 1];
+        MidCoef c[PPT]; vf x[PPT];
+        // ---- down: x1 = b*dinv ; x = x1 + (b - M x1)*dinv ; res = b - M x
 #pragma unroll
-    for (int l = TAIL_LV - 2; l >= 0; --l) {
-        if (l >= nl - 1) continue;
-        const Lvl& L = P.lv[l]; const Lvl& C = P.lv[l + 1];
-        const bool live = t < L.n;
-        const int gy = live ? t / L.W : 0, gx = live ? t - gy * L.W : 0;
-        vf xe[NQ], x2[NQ];
-        if (live) {
-            const int ip = (gy >> 1) * C.W + (gx >> 1);
+        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) { c[k] = mid_coef(L, i); sA[i] = b[k] * c[k].dinv; } }
+        __syncthreads();
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { xe[q] = xs[l][q] + sC[q * TAIL_N + ip]; sA[q * TAIL_N + t] = xe[q]; }
+        for (int k = 0; k < PPT; ++k) {
+            const int i = t + k * MID_T;
+            if (i < n) { const vf x1 = b[k] * c[k].dinv; x[k] = x1 + (b[k] - mid_op(c[k], sA, i, W)) * c[k].dinv; sB[i] = x[k]; }
         }
         __syncthreads();
-        if (live) {
-            vf y[NQ]; tail_op(cs[l], sA, t, L.W, y);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { x2[q] = xe[q] + (bs[l][q] - y[q]) * cs[l].dinv; sB[q * TAIL_N + t] = x2[q]; }
+        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) sA[i] = b[k] - mid_op(c[k], sB, i, W); }
+        __syncthreads();
+        vf bc[1];
+        bc[0] = t < C.n ? mid_restrict(sA, t, C.W, W, L.H) : 0.f;
+        __syncthreads();                                      // the residual array is free again
+        mid_level<D + 1>(P, q, t, sA, sB, sC, bc, sweeps);    // its correction arrives in sC
+        // ---- up: xe = x + e_coarse(parent) ; x2 = xe + (b - M xe)*dinv ; xo = x2 + (b - M x2)*dinv
+        if constexpr (D == 0) {                                // the first fused level does not keep its coefficients across the deeper levels
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) c[k] = mid_coef(L, i); }
+        }
+        vf xe[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = t + k * MID_T;
+            if (i < n) { const int gy = i / W, gx = i - gy * W; xe[k] = x[k] + sC[(gy >> 1) * C.W + (gx >> 1)]; sA[i] = xe[k]; }
         }
         __syncthreads();
-        if (live) {
-            vf y[NQ]; tail_op(cs[l], sB, t, L.W, y);
+        vf x2[PPT];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const vf v = x2[q] + (bs[l][q] - y[q]) * cs[l].dinv;
-                if (l == 0) L.x2[(size_t)q * L.n + t] = v; else sC[q * TAIL_N + t] = v;
+        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) { x2[k] = xe[k] + (b[k] - mid_op(c[k], sA, i, W)) * c[k].dinv; sB[i] = x2[k]; } }
+        __syncthreads();                                      // every thread has also finished reading the child's correction in sC
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = t + k * MID_T;
+            if (i < n) {
+                const vf v = x2[k] + (b[k] - mid_op(c[k], sB, i, W)) * c[k].dinv;
+                if (D == 0) L.x2[(size_t)q * n + i] = v; else sC[i] = v;
             }
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(MID_T) void k_mg_mid(const PState* __restrict__ st, MidPack P, int sweeps) {
+    if (st->nactive == 0) return;
+    __shared__ vf sA[MID_N0], sB[MID_N0], sC[MID_N1];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const Lvl& L0 = P.lv[0];
+    vf b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = t + k * MID_T; b[k] = i < L0.n ? L0.b[(size_t)q * L0.n + i] : 0.f; }
+    mid_level<0>(P, q, t, sA, sB, sC, b, sweeps);
 }
 
 // ---- PCG pieces at the fine level
@@ -599,12 +589,13 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
 
     // z = Vcycle(r). Levels 0..nl-2 run the tile-fused down/up legs (2 launches per level), the coarsest grid one 6-wave kernel.
     // res[l] = where level l's correction ends up (the up leg cannot write in place: neighbouring tiles still read lv[l].x).
-    // The deepest levels (<= 512 pixels) run inside one workgroup (k_mg_tail); 44x44 and up keep their own grids — a single CU doing
-    // the 44x44 level as well was slower (157 us per cycle) than the two ~5 us launches it replaced.
-    // tail0 = first level of the single-workgroup tail: the deepest run of levels with <= TAIL_N pixels (at most TAIL_LV of them)
+    // The deepest levels run in k_mg_mid, one workgroup per right-hand side (round 1's tail — ONE workgroup for all six systems — had to stop
+    // at 512 pixels: with the 44x44 level it took 157 us per cycle).
+    // tail0 = first level of the fused middle + tail (k_mg_mid): the deepest run of levels whose first has <= MID_N0 pixels and the others
+    // <= MID_N1, at most MID_LV of them; never the fine level (its right-hand side is the fp64 PCG residual and its tiles fill the chip)
     int tail0 = nl - 1;
-    while (tail0 > 1 && lv[tail0 - 1].n <= TAIL_N && nl - (tail0 - 1) <= TAIL_LV) --tail0;
-    TailPack pack; memset(&pack, 0, sizeof pack); pack.nl = nl - tail0;
+    while (tail0 > 1 && nl - (tail0 - 1) <= MID_LV && lv[tail0 - 1].n <= MID_N0 && lv[tail0].n <= MID_N1) --tail0;
+    MidPack pack; memset(&pack, 0, sizeof pack); pack.nl = nl - tail0;
     for (int l = tail0; l < nl; ++l) pack.lv[l - tail0] = lv[l];
     // Tile shapes: bandwidth-bound levels use TXB x TYB tiles; below 100k pixels the legs are latency bound, so a 16x8 tile whose
     // haloed footprint (18x10) fits one pass of the 256 threads keeps the dependent load chains short and spreads over more CUs.
@@ -632,7 +623,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     };
     auto vcycle = [&]() -> int {
         for (int l = 0; l < tail0; ++l) { down(l); LCHK(); }
-        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(TAIL_N), 0, s, cur, pack, 60); LCHK();
+        hipLaunchKernelGGL(k_mg_mid, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60); LCHK();
         for (int l = tail0 - 1; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
         return 0;
     };
