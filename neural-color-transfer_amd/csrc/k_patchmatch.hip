@@ -9,7 +9,7 @@
 //    tile so that neighbouring queries — whose candidate tiles overlap when the NNF is coherent — share L1/L2);
 //    lane v owns float4 channel chunks v, v+16, …; the 9*C-term dot product is one fmaf chain per lane followed
 //    by a 4-step DPP rotate-add (no LDS traffic, no bpermute);
-//  * the 6x6xC region of A shared by the 16 queries of a workgroup is staged once per launch in LDS;
+//  * the region of A shared by the queries of a workgroup (8x8 queries at C = 64: 10x10xC) is staged once per launch in LDS;
 //  * the racy single launch of the reference becomes 1 + iters*4 Jacobi steps on a double-buffered NNF
 //    (one launch per (iteration, jump)); random search is fused into the jump==1 step; RNG is counter based.
 //    => results are deterministic and bit-identical to oracle/orc_nnf.c.
@@ -42,7 +42,7 @@ __device__ __forceinline__ float dot4h_acc(const float4 a, const uint2 bh, float
 // by Cauchy-Schwarz): a candidate whose partial sum after a patch row cannot reach `need` any more cannot beat the current best and
 // its remaining rows are not fetched (the caller gets FLT_MAX = "not better"). -FLT_MAX disables the test. That is MODE NCT_PM_ROWREJECT;
 // NCT_PM_FP16 (opt-in reduced precision) reads the candidate tile from the fp16 shadow map Bh instead of B (fp32 accumulate).
-template <int NCH, int MODE>
+template <int NCH, int MODE, int RW>
 __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const uint2* __restrict__ Bh, const PMGeom& g, int ax, int ay, unsigned amask,
                                          int bx, int by, int v, const float4* __restrict__ a_lds, int lx, int ly, float need) {
     constexpr bool EX = MODE == NCT_PM_ROWREJECT, HALF = MODE == NCT_PM_FP16;
@@ -73,7 +73,7 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
                         const int tt = on ? t : 8;
                         const int dy = tt / 3 - 1, dx = tt - (dy + 1) * 3 - 1;
                         uint4 raw = ph[(size_t)(unsigned)((by + dy) * g.bw + bx + dx) * 8 + vh];
-                        const float4* pa = a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * C4 + 2 * vh;
+                        const float4* pa = a_lds + ((ly + 1 + dy) * RW + (lx + 1 + dx)) * C4 + 2 * vh;
                         const float4 a0 = pa[0], a1 = pa[1];
                         if (!on) raw = make_uint4(0u, 0u, 0u, 0u);
                         h = dot4h_acc(a0, make_uint2(raw.x, raw.y), h);
@@ -83,7 +83,7 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
                     constexpr int U = 8 * NCH;                     // 16-byte units per pixel (>= 16: every lane of the row reads U/16 units of one pixel)
                     auto tap = [&](int dy, int dx) {
                         const uint4* pp = ph + (size_t)(unsigned)((by + dy) * g.bw + bx + dx) * U + v;
-                        const float4* pa = a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * C4 + 2 * v;
+                        const float4* pa = a_lds + ((ly + 1 + dy) * RW + (lx + 1 + dx)) * C4 + 2 * v;
 #pragma unroll
                         for (int m = 0; m < U / 16; ++m) {
                             const uint4 raw = pp[16 * m];
@@ -95,16 +95,32 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 #pragma unroll
                         for (int t = 0; t < 9; ++t) tap(t / 3 - 1, t % 3 - 1);
                     } else {
+                        // one patch row at a time, its 3 * U/16 requests issued together before the first use (written as "tap(dy, dx)" calls the
+                        // compiler serialised them load -> wait -> fma at some register budgets: 2.1 vs 0.9 ms at the 44x44 level)
 #pragma unroll 1
-                        for (int dy = -1; dy <= 1; ++dy)
+                        for (int dy = -1; dy <= 1; ++dy) {
+                            uint4 raw[3][U / 16];
 #pragma unroll
-                            for (int dx = -1; dx <= 1; ++dx) tap(dy, dx);
+                            for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+                                for (int m = 0; m < U / 16; ++m) raw[dx + 1][m] = ph[(size_t)(unsigned)((by + dy) * g.bw + bx + dx) * U + v + 16 * m];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                const float4* pa = a_lds + ((ly + 1 + dy) * RW + (lx + 1 + dx)) * C4 + 2 * v;
+#pragma unroll
+                                for (int m = 0; m < U / 16; ++m) {
+                                    h = dot4h_acc(pa[32 * m], make_uint2(raw[dx + 1][m].x, raw[dx + 1][m].y), h);
+                                    h = dot4h_acc(pa[32 * m + 1], make_uint2(raw[dx + 1][m].z, raw[dx + 1][m].w), h);
+                                }
+                            }
+                        }
                     }
                 }
                 return (-row16_sum(h)) / 9.0f;
             }
             const float4* pbc = reinterpret_cast<const float4*>(B) + (size_t)(unsigned)(by * g.bw + bx) * C4 + v;
-            const float4* pac = a_lds + ((ly + 1) * 6 + (lx + 1)) * C4 + v;
+            const float4* pac = a_lds + ((ly + 1) * RW + (lx + 1)) * C4 + v;
             float facc = 0.f;
             if constexpr (EX) {
                 // one patch row at a time; a hopeless candidate stops after a row
@@ -112,7 +128,7 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 #pragma unroll
                 for (int dy = -1; dy <= 1; ++dy) {
                     const float4* pbr = pbc + dy * g.bw * C4;
-                    const float4* par = pac + dy * 6 * C4;
+                    const float4* par = pac + dy * RW * C4;
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
@@ -131,14 +147,14 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {                      // all nine loads in flight
                     const int dy = t / 3 - 1, dx = t % 3 - 1;
-                    facc = dot4_acc(pac[(dy * 6 + dx) * C4], pbc[(dy * g.bw + dx) * C4], facc);
+                    facc = dot4_acc(pac[(dy * RW + dx) * C4], pbc[(dy * g.bw + dx) * C4], facc);
                 }
             } else {
                 // one patch row (3 taps x NCH chunks) at a time: bounds the loads in flight, and with them the register count
 #pragma unroll 1
                 for (int dy = -1; dy <= 1; ++dy) {
                     const float4* pbr = pbc + dy * g.bw * C4;
-                    const float4* par = pac + dy * 6 * C4;
+                    const float4* par = pac + dy * RW * C4;
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
@@ -161,7 +177,7 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
         n += valid ? 1 : 0;
         const int yac = clampi(ay + dy, 0, g.ah - 1), xac = clampi(ax + dx, 0, g.aw - 1);
         // C = 64*NCH: the workgroup's 6x6xC query region sits in LDS (a_lds); generic C reads the query tile through L1
-        const float4* pa = (NCH >= 1) ? a_lds + ((ly + 1 + dy) * 6 + (lx + 1 + dx)) * (g.C >> 2)
+        const float4* pa = (NCH >= 1) ? a_lds + ((ly + 1 + dy) * RW + (lx + 1 + dx)) * (g.C >> 2)
                                       : reinterpret_cast<const float4*>(A + ((size_t)yac * g.aw + xac) * g.C);
         if constexpr (NCH > 0) {
 #pragma unroll
@@ -196,9 +212,17 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 // (44x44 queries are only 121 workgroups for 256 CUs) and halves the launch count; each job's result is unaffected.
 struct PMJob { const float* A; const float* B; const uint2* Bh; const uint32_t* nnf_in; const float* d_in; uint32_t* nnf_out; float* d_out; PMGeom g; int rs_max; uint32_t seed; };
 
-template <int NCH, int MODE>
-__global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
+// TQX x TQY = 4x4 query sub-tiles per workgroup: the workgroup stages the (4 TQX + 2) x (4 TQY + 2) x C region of A once and then walks its
+// sub-tiles one after the other (16 queries at a time, one 16-lane row per query as before). A launch of the round-1 kernel (one sub-tile per
+// workgroup) spent ~165 of its 557 us at 700x700 before the first evaluation: 61 000 workgroups per launch, each paying the serial prologue
+// "stage the region -> barrier -> NNF -> neighbour NNF -> first tile" with only four workgroups resident per CU. Larger tiles pay it once per
+// 64 queries and stage 1.56 instead of 2.25 region pixels per query. Which query a thread serves does not enter any value: results are unchanged.
+// The staged region limits C = 512 to two workgroups per CU (2 waves per SIMD): telling the compiler so (second launch-bounds argument) lets its scheduler
+// keep a patch row's loads in flight together instead of serialising them to save registers for an occupancy the LDS rules out.
+template <int NCH, int MODE, int TQX, int TQY>
+__global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
                                                  unsigned long long* __restrict__ counter) {
+    constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2;
     const bool second = (int)blockIdx.x >= nblk0;
     const PMJob& J = second ? j1 : j0;
     const float* __restrict__ A = J.A; const float* __restrict__ B = J.B; const uint2* __restrict__ Bh = J.Bh;
@@ -216,105 +240,118 @@ __global__ __launch_bounds__(256) void k_pm_step(PMJob j0, PMJob j1, int nblk0, 
     }
     const int ty = bid / g.tiles_x, tx = bid - ty * g.tiles_x;
     const int grp = threadIdx.x >> 4, v = threadIdx.x & 15;
-    const int qx = tx * 4 + (grp & 3), qy = ty * 4 + (grp >> 2);
-    const bool live = qx < g.aw && qy < g.ah;
-    const int ax = live ? qx : g.aw - 1, ay = live ? qy : g.ah - 1;
-    const int qi = ay * g.aw + ax;
-    const int lx = ax - tx * 4, ly = ay - ty * 4;       // position inside the 4x4 query tile (clamped queries stay inside the region)
+    const int ox = tx * 4 * TQX, oy = ty * 4 * TQY;        // origin of the workgroup's query tile
 
-    // stage the 6x6xC region of A that the 16 queries of this workgroup read (their 3x3 tiles overlap) into LDS once per launch:
-    // 9 KB (C=64) ... 72 KB (C=512). Without it every evaluation re-reads its 9*C*4-byte query tile through L1.
+    // stage the region of A that the queries of this workgroup read (their 3x3 tiles overlap) into LDS once per launch. Without it every
+    // evaluation re-reads its 9*C*4-byte query tile through L1.
     extern __shared__ float4 s_a[];
     if constexpr (NCH >= 1) {
         const int c4 = g.C >> 2;
-        for (int e = threadIdx.x; e < 36 * c4; e += 256) {
+        for (int e = threadIdx.x; e < RW * RH * c4; e += 256) {
             const int r = e / c4, j = e - r * c4;
-            const int ry = clampi(ty * 4 - 1 + r / 6, 0, g.ah - 1), rx = clampi(tx * 4 - 1 + r % 6, 0, g.aw - 1);
+            const int ry = clampi(oy - 1 + r / RW, 0, g.ah - 1), rx = clampi(ox - 1 + r % RW, 0, g.aw - 1);
             s_a[e] = reinterpret_cast<const float4*>(A + ((size_t)ry * g.aw + rx) * g.C)[j];
         }
         __syncthreads();
     }
-
-    // validity of the query's own taps
-    unsigned amask = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
-        const int yy = ay + dy, xx = ax + dx;
-        amask |= ((yy >= 0 && yy < g.ah && xx >= 0 && xx < g.aw) ? 1u : 0u) << t;
-    }
-
-    uint32_t vbest = nnf_in[qi];
-    int xbest = nnf_x(vbest), ybest = nnf_y(vbest);
-    float dbest;
+    int rs_start = rs_max;
+    { const int mx = g.bw > g.bh ? g.bw : g.bh; if (rs_start > mx) rs_start = mx; }
+    int nrand = 0;
+    if (jump == 1) for (int mag = rs_start; mag >= 1; mag >>= 1) ++nrand;
     unsigned nevals = 0, naccept = 0;
 
-    if (mode == 0) {
-        dbest = pm_dist<NCH, MODE>(A, B, Bh, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
-        float cut = (float)INT_MAX;                 // dist_single default cutoff
-        if (dbest >= cut) dbest = cut;
-        nevals = 1;
-    } else {
-        dbest = d_in[qi];
-        int rs_start = rs_max;
-        { const int mx = g.bw > g.bh ? g.bw : g.bh; if (rs_start > mx) rs_start = mx; }
-        int nrand = 0;
-        if (jump == 1) for (int mag = rs_start; mag >= 1; mag >>= 1) ++nrand;
-        int mag = rs_start;
-        const int ncand = 4 + nrand;
-        for (int k = 0; k < ncand; ++k) {
-            int xp, yp; bool valid; float rr;
-            if (k < 4) {
-                // 0 left, 1 right, 2 up, 3 down — the neighbour's match shifted back by the jump
-                const int sx = (k == 0) ? -jump : (k == 1 ? jump : 0);
-                const int sy = (k == 2) ? -jump : (k == 3 ? jump : 0);
-                const int nx = ax + sx, ny = ay + sy;
-                valid = nx >= 0 && nx < g.aw && ny >= 0 && ny < g.ah;
-                const uint32_t vp = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
-                xp = nnf_x(vp) - sx; yp = nnf_y(vp) - sy;
-                valid = valid && yp >= 0 && yp < g.bh && xp >= 0 && xp < g.bw;
-                rr = 0.f;
-            } else {
-                const int step = k - 4;
-                const int xmin = max(xbest - mag, 0), xmax = min(xbest + mag + 1, g.bw);
-                const int ymin = max(ybest - mag, 0), ymax = min(ybest + mag + 1, g.bh);
-                // (int)(u * w) % w with u in (0, 1]: the product never exceeds w, so the modulo only folds the value w back to 0 — a
-                // select instead of two integer divisions (~35 VALU instructions each in a kernel that is VALU-issue bound)
-                const int wx = xmax - xmin, wy = ymax - ymin;
-                const int rx = (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)wy);
-                xp = xmin + (rx == wx ? 0 : rx);
-                yp = ymin + (ry == wy ? 0 : ry);
-                mag >>= 1;
-                valid = true; rr = FLT_MIN;
-            }
-            if (valid) {
-                // to win, -sum/9 (+rr) < dbest, i.e. sum > -9 dbest: unreachable sums are cut off (unit-norm features only)
-                float d = pm_dist<NCH, MODE>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
-                if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
-                if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; ++naccept; }
-                ++nevals;
+#pragma unroll 1
+    for (int sub = 0; sub < TQX * TQY; ++sub) {
+        const int sx = sub % TQX, sy = sub / TQX;
+        const int qx = ox + sx * 4 + (grp & 3), qy = oy + sy * 4 + (grp >> 2);
+        if (TQX * TQY > 1 && ox + sx * 4 >= g.aw) continue;                 // sub-tile entirely outside the image (uniform over the workgroup)
+        if (TQX * TQY > 1 && oy + sy * 4 >= g.ah) continue;
+        const bool live = qx < g.aw && qy < g.ah;
+        const int ax = live ? qx : g.aw - 1, ay = live ? qy : g.ah - 1;
+        const int qi = ay * g.aw + ax;
+        // position inside the workgroup's region; a clamped (dead) query may fall outside its sub-tile but stays inside the region only if
+        // the clamp target does — it is kept inside by construction: the image border lies inside or on the edge of a partially filled tile
+        const int lx = ax - ox, ly = ay - oy;
+
+        // validity of the query's own taps
+        unsigned amask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const int yy = ay + dy, xx = ax + dx;
+            amask |= ((yy >= 0 && yy < g.ah && xx >= 0 && xx < g.aw) ? 1u : 0u) << t;
+        }
+
+        uint32_t vbest = nnf_in[qi];
+        int xbest = nnf_x(vbest), ybest = nnf_y(vbest);
+        float dbest;
+
+        if (mode == 0) {
+            dbest = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
+            float cut = (float)INT_MAX;                 // dist_single default cutoff
+            if (dbest >= cut) dbest = cut;
+            if (live && v == 0) nevals += 1;
+        } else {
+            dbest = d_in[qi];
+            int mag = rs_start;
+            const int ncand = 4 + nrand;
+            for (int k = 0; k < ncand; ++k) {
+                int xp, yp; bool valid; float rr;
+                if (k < 4) {
+                    // 0 left, 1 right, 2 up, 3 down — the neighbour's match shifted back by the jump
+                    const int sxx = (k == 0) ? -jump : (k == 1 ? jump : 0);
+                    const int syy = (k == 2) ? -jump : (k == 3 ? jump : 0);
+                    const int nx = ax + sxx, ny = ay + syy;
+                    valid = nx >= 0 && nx < g.aw && ny >= 0 && ny < g.ah;
+                    const uint32_t vp = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
+                    xp = nnf_x(vp) - sxx; yp = nnf_y(vp) - syy;
+                    valid = valid && yp >= 0 && yp < g.bh && xp >= 0 && xp < g.bw;
+                    rr = 0.f;
+                } else {
+                    const int step = k - 4;
+                    const int xmin = max(xbest - mag, 0), xmax = min(xbest + mag + 1, g.bw);
+                    const int ymin = max(ybest - mag, 0), ymax = min(ybest + mag + 1, g.bh);
+                    // (int)(u * w) % w with u in (0, 1]: the product never exceeds w, so the modulo only folds the value w back to 0 — a
+                    // select instead of two integer divisions
+                    const int wx = xmax - xmin, wy = ymax - ymin;
+                    const int rx = (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)wy);
+                    xp = xmin + (rx == wx ? 0 : rx);
+                    yp = ymin + (ry == wy ? 0 : ry);
+                    mag >>= 1;
+                    valid = true; rr = FLT_MIN;
+                }
+                if (valid) {
+                    // to win, -sum/9 (+rr) < dbest, i.e. sum > -9 dbest: unreachable sums are cut off (unit-norm features only)
+                    float d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                    if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
+                    if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; if (live && v == 0) ++naccept; }
+                    if (live && v == 0) ++nevals;
+                }
             }
         }
+        if (live && v == 0) { if (mode != 0) nnf_out[qi] = xy_pack(xbest, ybest); d_out[qi] = dbest; }
     }
-    if (live && v == 0) { if (mode != 0) nnf_out[qi] = xy_pack(xbest, ybest); d_out[qi] = dbest; }
     if (counter) {
         __shared__ unsigned s_cnt[2];
         if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        if (live && v == 0) { atomicAdd(&s_cnt[0], nevals); atomicAdd(&s_cnt[1], naccept); }
+        if (v == 0) { atomicAdd(&s_cnt[0], nevals); atomicAdd(&s_cnt[1], naccept); }
         __syncthreads();
         if (threadIdx.x < 2) atomicAdd(counter + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]);
     }
 }
 
+// query tile of a workgroup per channel count: 8x8 at C = 64 (25 KB of LDS), 8x4 at C = 128 (31 KB), 4x4 above (37 / 74 KB)
+template <int NCH> struct PMTile { static constexpr int TQX = NCH == 1 ? 2 : (NCH == 2 ? 2 : 1), TQY = NCH == 1 ? 2 : 1; };
 template <int NCH, int MODE>
 static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
-    const size_t lds = NCH >= 1 ? (size_t)36 * NCH * 16 * sizeof(float4) : 0;      // 6x6 pixels x C/4 float4
+    constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY;
+    const size_t lds = NCH >= 1 ? (size_t)(4 * TQX + 2) * (4 * TQY + 2) * NCH * 16 * sizeof(float4) : 0;      // region pixels x C/4 float4
     // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device; set with the init step
     // of every run (mode 0), i.e. once per PatchMatch and per device the context lives on
     if (lds > 32768 && mode == 0)
-        NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_pm_step<NCH, MODE>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
+        NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE, TQX, TQY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_pm_step<NCH, MODE, TQX, TQY>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
     NCT_LAUNCH_CHECK();
     return 0;
 }
@@ -344,7 +381,8 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
     DevBuf<uint32_t> a_tmp(ctx, na), b_tmp(ctx, two ? nb : 1);
     DevBuf<float> ad_tmp(ctx, na), bd_tmp(ctx, two ? nb : 1);
     if (!a_tmp.ok() || !b_tmp.ok() || !ad_tmp.ok() || !bd_tmp.ok()) return NCT_ERR_HIP;
-    const PMGeom ga{C, ah, aw, bh, bw, cdiv(aw, 4), cdiv(ah, 4)}, gb{C, bh, bw, ah, aw, cdiv(bw, 4), cdiv(bh, 4)};
+    const int tqx = C == 64 ? PMTile<1>::TQX : (C == 128 ? PMTile<2>::TQX : 1), tqy = C == 64 ? PMTile<1>::TQY : (C == 128 ? PMTile<2>::TQY : 1);
+    const PMGeom ga{C, ah, aw, bh, bw, cdiv(aw, 4 * tqx), cdiv(ah, 4 * tqy)}, gb{C, bh, bw, ah, aw, cdiv(bw, 4 * tqx), cdiv(bh, 4 * tqy)};
     const int nblk0 = ga.tiles_x * ga.tiles_y, nblk1 = two ? gb.tiles_x * gb.tiles_y : 0;
     uint32_t* na_buf[2] = {ann, a_tmp}; float* da_buf[2] = {annd, ad_tmp};
     uint32_t* nb_buf[2] = {bnn, b_tmp}; float* db_buf[2] = {bnnd, bd_tmp};
