@@ -44,20 +44,37 @@ struct Lvl { int H, W, n; double *r, *wx, *wy, *diag;      // fp64 operator: dat
 // few iterations, and every kernel of an iteration enqueued past convergence returns at once when it is 0.
 struct PState { double gam[6], alp[6], bb[6]; int active[6]; int iters[6]; int nactive; };
 
+// Fixed 256-wide tree s[t] += s[t + off], off = 128 … 1 (the order the oracle mirrors), evaluated with two barriers instead of nine: the two
+// cross-wave steps go through LDS, the six steps inside the first wave are lane shifts (a lane t < off adds the value lane t + off held BEFORE
+// the step, exactly as the array form does; what lanes >= off compute is never used).
 template <int NV>
 __device__ __forceinline__ void mg_block_reduce(double (&v)[NV], double* __restrict__ partial) {
-    __shared__ double s_red[256 * NV];
+    __shared__ double s_red[128 * NV];
     const int t = threadIdx.x;
+    if (t >= 128) {
 #pragma unroll
-    for (int q = 0; q < NV; ++q) s_red[q * 256 + t] = v[q];
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (t < off)
-#pragma unroll
-            for (int q = 0; q < NV; ++q) s_red[q * 256 + t] += s_red[q * 256 + t + off];
-        __syncthreads();
+        for (int q = 0; q < NV; ++q) s_red[q * 128 + t - 128] = v[q];
     }
-    if (t < NV) partial[(size_t)blockIdx.x * NV + t] = s_red[t * 256];
+    __syncthreads();
+    if (t < 128) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] += s_red[q * 128 + t];            // off = 128
+    }
+    __syncthreads();
+    if (t >= 64 && t < 128) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) s_red[q * 128 + t - 64] = v[q];
+    }
+    __syncthreads();
+    if (t < 64) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double x = v[q] + s_red[q * 128 + t];                          // off = 64
+            x += __shfl_down(x, 32); x += __shfl_down(x, 16); x += __shfl_down(x, 8);
+            x += __shfl_down(x, 4); x += __shfl_down(x, 2); x += __shfl_down(x, 1);
+            if (t == 0) partial[(size_t)blockIdx.x * NV + q] = x;
+        }
+    }
 }
 template <int NV>
 __device__ __forceinline__ void mg_final_reduce(const double* __restrict__ partial, int nb, double (&out)[NV]) {
