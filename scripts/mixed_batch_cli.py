@@ -24,6 +24,6 @@ r = subprocess.run([exe, "-m", os.path.join(td, "model"), "-i", os.path.join(td,
                    capture_output=True, text=True)
 print(r.stdout.strip().splitlines()[-1])
 assert r.returncode == 0, r.stderr
-outs = os.listdir(os.path.join(td, "out"))
+outs = [n for n in os.listdir(os.path.join(td, "out")) if n.endswith(".png")]          # + status.jsonl
 assert len(outs) == npairs, (len(outs), npairs)
 print("ok:", len(outs), "outputs")
