@@ -1,12 +1,13 @@
-// jpeg_io.h — baseline / extended-sequential JPEG decoder for the CLI (the reference reads its inputs with cv::imread, main.cu:483,491,
+// jpeg_io.h — baseline / extended-sequential / progressive (Huffman) JPEG decoder for the CLI (the reference reads its inputs with cv::imread, main.cu:483,491,
 // which accepts JPEG; OpenCV / libjpeg are not available in this environment and the image is decoded on the host either side of the
 // GPU path). Restates what cv::imread's libjpeg path computes so that the pixels handed to the GPU are the ones the
 // reference would have seen: Huffman sequential DCT (SOF0 / SOF1, 8 bit), the accurate integer inverse DCT (libjpeg "islow",
 // 13-bit constants, two passes), "fancy" triangle-filter chroma upsampling for 2x1 and 2x2 subsampling (pixel replication for other
 // factors), JFIF YCbCr -> RGB with the 16-bit fixed-point tables, output as 8-bit 3-channel BGR (grayscale replicated). EXIF orientation
-// is ignored, as OpenCV 2.4 does. Progressive / arithmetic-coded / 12-bit / CMYK files are rejected with a message.
+// is ignored, as OpenCV 2.4 does. Progressive files (SOF2: spectral selection + successive approximation, jdphuff.c) are decoded into the same
+// coefficient arrays. Arithmetic-coded / lossless / 12-bit / CMYK files are rejected with a message.
 // tests/test_cli.py checks the decoder bit-for-bit against Pillow (libjpeg-turbo, same algorithms) for 4:4:4, 4:2:2, 4:2:0, grayscale,
-// restart intervals and odd sizes.
+// restart intervals, odd sizes and progressive files.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -150,6 +151,7 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
     std::vector<Comp> comps;
     int W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, mcux = 0, mcuy = 0;
     bool adobe = false; int adobe_transform = -1;
+    bool progressive = false;
     size_t pos = 2;
     bool have_frame = false, any_scan = false;
     while (pos + 4 <= d.size()) {
@@ -182,7 +184,8 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
                 memcpy(h.vals, p + i, cnt); i += cnt;
                 huff_build(h);
             }
-        } else if (m == 0xC0 || m == 0xC1) {                // SOF0 / SOF1
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {   // SOF0 / SOF1 (sequential), SOF2 (progressive)
+            progressive = m == 0xC2;
             if (have_frame) { err = "multiple frames"; return false; }
             if (L < 6 || p[0] != 8) { err = "only 8-bit JPEG is supported"; return false; }
             H = (p[1] << 8) | p[2]; W = (p[3] << 8) | p[4];
@@ -204,8 +207,8 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
                 c.coef.assign((size_t)c.bw * c.bh * 64, 0);
             }
             have_frame = true;
-        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            err = m == 0xC2 ? "progressive JPEG is not supported (re-save as baseline)" : "unsupported JPEG coding process";
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            err = "unsupported JPEG coding process (lossless / hierarchical / arithmetic)";
             return false;
         } else if (m == 0xDD) {
             if (L >= 2) restart = (p[0] << 8) | p[1];
@@ -221,11 +224,83 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
                 for (auto& k : comps) if (k.id == p[1 + 2 * i]) c = &k;
                 if (!c) { err = "bad SOS component"; return false; }
                 c->td = p[2 + 2 * i] >> 4; c->ta = p[2 + 2 * i] & 15;
-                if (c->td > 3 || c->ta > 3 || !hdc[c->td].set || !hac[c->ta].set || !qset[c->tq]) { err = "missing Huffman / quantisation table"; return false; }
+                if (c->td > 3 || c->ta > 3 || (!progressive && (!hdc[c->td].set || !hac[c->ta].set))) { err = "missing Huffman table"; return false; }
                 c->pred = 0;
                 sc.push_back(c);
             }
+            const int Ss = p[1 + 2 * ns], Se = p[2 + 2 * ns], Ah = p[3 + 2 * ns] >> 4, Al = p[3 + 2 * ns] & 15;
             BitReader br(d.data(), d.size(), pos + 2 + len);
+            if (progressive) {
+                // jdphuff.c: DC scans (Ss = Se = 0, possibly interleaved) and single-component AC scans over the band Ss..Se, each either a first pass
+                // (Ah = 0: values shifted left by Al) or a refinement pass (Ah > 0: one more bit of every coefficient of the band)
+                if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13) { err = "bad progressive scan parameters"; return false; }
+                for (auto* c : sc) if ((Ss == 0 && Ah == 0 && !hdc[c->td].set) || (Ss > 0 && !hac[c->ta].set)) { err = "missing Huffman table"; return false; }
+                const bool inter = ns > 1;
+                const int nmx = inter ? mcux : (sc[0]->dw + 7) / 8, nmy = inter ? mcuy : (sc[0]->dh + 7) / 8;
+                int rst_left = restart; unsigned eobrun = 0;
+                const int p1 = 1 << Al, m1 = -(1 << Al);
+                for (int my = 0; my < nmy; ++my)
+                    for (int mx = 0; mx < nmx; ++mx) {
+                        if (restart && rst_left == 0) {
+                            br.reset();
+                            size_t q = br.pos;
+                            while (q + 1 < d.size() && !(d[q] == 0xFF && d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7)) ++q;
+                            if (q + 1 < d.size()) q += 2;
+                            br.pos = q; br.reset();
+                            rst_left = restart; eobrun = 0;
+                            for (auto* c : sc) c->pred = 0;
+                        }
+                        for (auto* c : sc) {
+                            const int bxn = inter ? c->h : 1, byn = inter ? c->v : 1;
+                            for (int by = 0; by < byn; ++by)
+                                for (int bx = 0; bx < bxn; ++bx) {
+                                    int16_t* blk = &c->coef[((size_t)(my * byn + by) * c->bw + mx * bxn + bx) * 64];
+                                    if (Ss == 0) {
+                                        if (Ah == 0) { const int s = huff_decode(br, hdc[c->td]); c->pred += extend(br.get(s), s); blk[0] = (int16_t)(c->pred * (1 << Al)); }
+                                        else if (br.get(1)) blk[0] |= (int16_t)p1;
+                                    } else if (Ah == 0) {                  // decode_mcu_AC_first
+                                        if (eobrun > 0) { --eobrun; continue; }
+                                        for (int k = Ss; k <= Se; ++k) {
+                                            const int rs = huff_decode(br, hac[c->ta]), r = rs >> 4, s = rs & 15;
+                                            if (s) { k += r; if (k > 63) break; blk[kZigzag[k]] = (int16_t)(extend(br.get(s), s) * (1 << Al)); }
+                                            else if (r == 15) k += 15;
+                                            else { eobrun = 1u << r; if (r) eobrun += (unsigned)br.get(r); --eobrun; break; }
+                                        }
+                                    } else {                               // decode_mcu_AC_refine
+                                        int k = Ss;
+                                        if (eobrun == 0) {
+                                            for (; k <= Se; ++k) {
+                                                const int rs = huff_decode(br, hac[c->ta]); int r = rs >> 4, s = rs & 15;
+                                                if (s) s = br.get(1) ? p1 : m1;                  // a newly nonzero coefficient: its sign
+                                                else if (r != 15) { eobrun = 1u << r; if (r) eobrun += (unsigned)br.get(r); break; }
+                                                // skip r zero-history coefficients, appending a correction bit to every nonzero one on the way
+                                                do {
+                                                    int16_t& cf = blk[kZigzag[k]];
+                                                    if (cf != 0) { if (br.get(1) && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1)); }
+                                                    else if (--r < 0) break;
+                                                    ++k;
+                                                } while (k <= Se);
+                                                if (s && k <= 63) blk[kZigzag[k]] = (int16_t)s;
+                                            }
+                                        }
+                                        if (eobrun > 0) {                  // the rest of the band: correction bits of the already nonzero coefficients only
+                                            for (; k <= Se; ++k) {
+                                                int16_t& cf = blk[kZigzag[k]];
+                                                if (cf != 0 && br.get(1) && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                                            }
+                                            --eobrun;
+                                        }
+                                    }
+                                }
+                        }
+                        if (restart) --rst_left;
+                    }
+                any_scan = true;
+                size_t q = pos + 2 + len;
+                while (q + 1 < d.size() && !(d[q] == 0xFF && d[q + 1] != 0 && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7) && d[q + 1] != 0xFF)) ++q;
+                pos = q;
+                continue;
+            }
             // interleaved scan: MCUs of hmax x vmax blocks; single-component scan: one block per "MCU", only the blocks covering real samples
             const bool inter = ns > 1;
             const int nmx = inter ? mcux : (sc[0]->dw + 7) / 8, nmy = inter ? mcuy : (sc[0]->dh + 7) / 8;
@@ -273,6 +348,7 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
         pos += 2 + len;
     }
     if (!have_frame || !any_scan) { err = "no image data"; return false; }
+    for (auto& c : comps) if (!qset[c.tq]) { err = "missing quantisation table"; return false; }
     // inverse DCT into component planes (padded to whole blocks)
     for (auto& c : comps) {
         const int pw = c.bw * 8, ph = c.bh * 8;

@@ -1,7 +1,7 @@
 // neural_color_transfer — the reference's console driver re-created on top of libnct (C ABI, include/nct.h).
 // Mirrors: get_input / main (main.cu:29-44, 546-590), transfer_single (main.cu:456-543), Utility::CmdLine
 // (CmdLine.h:58-69,132-147; CmdLine.cpp:21-56,93-109). Same flags, same pairs.txt, same output names, same log lines.
-// Differences: portable path handling ('/' and '\\'), in-repo PNG + baseline-JPEG decoders instead of cv::imread
+// Differences: portable path handling ('/' and '\\'), in-repo PNG + JPEG (baseline, progressive) decoders instead of cv::imread
 // (output is PNG like the reference), a missing pairs.txt is an error instead of a NULL dereference (main.cu:463-471), plus the
 // extensions `-gpus N` (pairs sharded over N GPUs, one context per worker thread), `-inflight K`, `-seed`, `-levels L` (BASELINE
 // config 1: "L=5 only" = -levels 1), `-resume 1` (skip pairs whose output exists; <out>/status.jsonl gets one JSON line per pair)
