@@ -53,8 +53,12 @@ def pm_bytes(evals, n_queries, n_launches, C):
 
 
 def lib_build_id():
-    import nct
-    return hashlib.sha256(open(nct.LIB_PATH, "rb").read()).hexdigest()[:16]
+    """Identity of the kernel build: sha256 over the library's sources (csrc/*, include/nct.h) — reproducible across rebuilds of the same tree, unlike the .so bytes."""
+    import glob
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "neural-color-transfer_amd", "csrc", "*")) + [os.path.join(REPO, "include", "nct.h"), os.path.join(REPO, "neural-color-transfer_amd", "Makefile")]):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def free_port():
@@ -262,8 +266,8 @@ def main():
     }
     res["vgg_mfma"] = vgg_mfma(src.shape[0], src.shape[1], ref.shape[0], ref.shape[1], prm.levels, stages["vgg_ms"])
     if rank == 0 and not args.no_roofline and prm.levels == 5:
-        res["roofline"] = patchmatch_roofline(nct, ctx, prm, src.shape, ref.shape, local_rank, live_pmc=not args.no_pmc and wl == "pair700" and S == 700)
-    if rank == 0 and not args.no_cpu_baseline:
+        res["roofline"] = patchmatch_roofline(nct, ctx, prm, src.shape, ref.shape, local_rank, live_pmc=not args.no_pmc and wl == "pair700" and S == 700 and world == 1)
+    if rank == 0 and not args.no_cpu_baseline and world == 1:               # the CPU port is timed on rank 0 of the 1-GPU run only
         res["cpu_baseline"] = cpu_baseline(synth, ws, bs, src.shape[0], full=args.cpu_baseline_full)
     if rank == 0:
         print(json.dumps(res), flush=True)
