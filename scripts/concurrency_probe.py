@@ -1,26 +1,34 @@
-"""Throughput probe: K pairs in flight on ONE GPU (K contexts, K host threads). Not part of the bench contract."""
-import sys, os, tempfile, threading, time
+"""How much does the per-step join of bench.py cost? K worker threads (own contexts) run `n` resident 700x700 pairs each, (a) joined after every pair (bench.py's
+steps), (b) back to back without joins, (c) back to back with the workers started a quarter of a pair apart. usage: concurrency_probe.py [K] [n]"""
+import sys, time, threading
 sys.path.insert(0, "tests"); sys.path.insert(0, "neural-color-transfer_amd/python")
-import numpy as np, nct, synth
-from caffemodel_io import synthetic_vgg19, write_caffemodel
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+import nct, synth
+from caffemodel_io import synthetic_vgg19
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 ws, bs = synthetic_vgg19(19)
-td = tempfile.mkdtemp(); path = os.path.join(td, "v.caffemodel"); write_caffemodel(path, ws, bs, fmt="v1")
-ctxs = []
-for k in range(K):
-    c = nct.Context(0); c.vgg19_load_caffemodel(path)
+ctxs = [nct.Context(0) for _ in range(K)]
+for k, c in enumerate(ctxs):
+    c.vgg19_load_raw(ws, bs)
     c.pair_upload(synth.image(1000 + 2 * k, 700, 700), synth.image(1001 + 2 * k, 700, 700))
-    ctxs.append(c)
+    c.pair_run()
 prm = nct.Params.default()
-for c in ctxs: c.pair_run(prm)            # warm-up (arena allocation)
-bar = threading.Barrier(K + 1)
-def work(c):
-    bar.wait()
-    for _ in range(steps): c.pair_run(prm)
-    bar.wait()
-ths = [threading.Thread(target=work, args=(c,)) for c in ctxs]
-for t in ths: t.start()
-bar.wait(); t0 = time.perf_counter(); bar.wait(); dt = time.perf_counter() - t0
-for t in ths: t.join()
-print("K=%d pairs in flight: %.2f pairs/s (%.1f ms per pair-slot)" % (K, K * steps / dt, 1e3 * dt / steps))
+
+def run(fn):
+    ths = [threading.Thread(target=fn, args=(k,)) for k in range(K)]
+    t0 = time.perf_counter()
+    for t in ths: t.start()
+    for t in ths: t.join()
+    return time.perf_counter() - t0
+
+t = 0.0
+for i in range(n):
+    t += run(lambda k: ctxs[k].pair_run(prm))
+print(f"(a) joined per pair      : {K * n / t:.2f} pairs/s")
+t = run(lambda k: [ctxs[k].pair_run(prm) for _ in range(n)])
+print(f"(b) back to back         : {K * n / t:.2f} pairs/s")
+def stag(k):
+    time.sleep(0.030 * k)
+    for _ in range(n): ctxs[k].pair_run(prm)
+t = run(stag)
+print(f"(c) staggered by 30 ms   : {K * n / t:.2f} pairs/s (includes the stagger itself)")

@@ -67,6 +67,16 @@ def test_bench_two_ranks_via_self_launch():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_draw_tickets_from_the_store():
+    """mixed256 on 2 ranks (gloo, both on GPU 0): the ranks take pair indices from one counter in the rendezvous store — every pair once, no collective."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = _run("--gpus", "2", "--workload", "mixed256", "--batch", "6", "--steps", "1", "--warmup", "1", "--inflight", "1", "--dist-backend", "gloo",
+             "--device-override", "0", "--no-cpu-baseline", "--no-roofline", env=env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["pairs_per_gpu_per_step"] == 3
+    assert abs(d["value"] - 6 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("wl", ["batch64", "mixed256", "pair256l5"])
 def test_bench_other_workloads(wl):
     """BASELINE configs 3 / 5 / 1 as bench workloads, at reduced batch sizes: strong-scaling lines with host-in -> host-out steps."""
