@@ -178,6 +178,8 @@ typedef struct nct_pair_levels {
     uint8_t* guide[5];
     float* err[5];
     uint8_t* result[5];
+    const nct_color_stages* color[5];   /* the colour stage's coefficient maps of the level (T1 / S1 / U1 / S2), as nct_local_color_transfer returns them */
+    int* labels;                        /* [ah0*aw0] k-means labels of S's deepest features (the kNN graphs' clusters); level 0's size */
 } nct_pair_levels;
 int nct_process_pair(nct_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, const uint8_t* ref_bgr, int rh, int rw, const nct_params* prm,
                      uint8_t* out_bgr, nct_pair_timing* timing);

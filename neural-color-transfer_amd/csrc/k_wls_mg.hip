@@ -328,7 +328,19 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
 // k_mg_up, so the cycle is bit-identical. lv[0] is the first fused level: its rhs lv[0].b was written by the restriction above it, its
 // correction goes to lv[0].x2. The coarsest grid (n <= 64) is solved by `sweeps` damped-Jacobi sweeps from zero by one wave (one lane per
 // unknown, the iterate in a register, neighbours through ds_bpermute).
-constexpr int MID_T = 1024, MID_N0 = 4096, MID_N1 = 1024, MID_LV = 6;
+// Pixels per thread of the first / second fused level. 8 / 2 would take the 88x88 level of a 700x700 pair into the launch as well (two
+// launches fewer per cycle), but 8 pixels x 7 coefficient registers do not fit the 128 VGPRs of a 1024-thread workgroup next to the deeper
+// levels' state: 59 (NCT_MID_LDS0: right-hand side and iterate of depth 0 in LDS) to 92 spilled registers, +14 us per call, 40.5 vs 37.1 ms
+// of WLS per pair.
+#ifndef NCT_MID_P0
+#define NCT_MID_P0 4
+#define NCT_MID_P1 1
+#endif
+#ifndef NCT_MID_LDS0
+#define NCT_MID_LDS0 0      // 1: depth 0 keeps its right-hand side and pre-smoothed iterate in LDS instead of registers
+#endif
+constexpr int MID_T = 1024, MID_P0 = NCT_MID_P0, MID_P1 = NCT_MID_P1, MID_N0 = MID_T * MID_P0, MID_N1 = MID_T * MID_P1, MID_N2 = MID_T, MID_LV = MID_P0 > 4 ? 7 : 6;
+constexpr int mid_ppt(int D) { return D == 0 ? MID_P0 : (D == 1 ? MID_P1 : 1); }      // pixels per thread at depth D of the fused sub-cycle
 struct MidPack { Lvl lv[MID_LV]; int nl; };
 struct MidCoef { vf d, dinv, w0, w1, w2, w3; unsigned flags; };      // flags: 1 = +x exists, 2 = -x, 4 = +y, 8 = -y
 __device__ __forceinline__ MidCoef mid_coef(const Lvl& L, int i) {
@@ -340,8 +352,10 @@ __device__ __forceinline__ MidCoef mid_coef(const Lvl& L, int i) {
     c.w0 = r ? L.fwx[i] : 0.f; c.w1 = l ? L.fwx[i - 1] : 0.f; c.w2 = dn ? L.fwy[i] : 0.f; c.w3 = up ? L.fwy[i - L.W] : 0.f;
     return c;
 }
-__device__ __forceinline__ vf mid_op(const MidCoef& c, const vf* __restrict__ s_v, int i, int W) {
-    vf y = c.d * s_v[i];
+__device__ __forceinline__ vf mid_op(const MidCoef& c, const vf* __restrict__ s_v, int i, int W, vf* centre = nullptr) {
+    const vf v0 = s_v[i];
+    if (centre) *centre = v0;
+    vf y = c.d * v0;
     if (c.flags & 1u) y -= c.w0 * s_v[i + 1];
     if (c.flags & 2u) y -= c.w1 * s_v[i - 1];
     if (c.flags & 4u) y -= c.w2 * s_v[i + W];
@@ -363,13 +377,15 @@ __device__ __forceinline__ vf mid_restrict(const vf* __restrict__ s_res, int I, 
 // in s_out (LDS, n values) — or in global L.x2 for D == 0. sA / sB: exchange arrays (>= n); sC: the child's correction (n_child values).
 template <int D>
 __device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __restrict__ sA, vf* __restrict__ sB, vf* __restrict__ sC,
-                                          const vf (&b)[D == 0 ? 4 : 1], int sweeps) {
-    constexpr int PPT = D == 0 ? 4 : 1;
+                                          vf* __restrict__ sb0, vf* __restrict__ sx0, const vf (&breg)[mid_ppt(D)], int sweeps) {
+    constexpr int PPT = mid_ppt(D);
+    constexpr bool INLDS = D == 0 && NCT_MID_LDS0 != 0;
     const Lvl& L = P.lv[D];
     const int n = L.n, W = L.W;
+    auto bval = [&](int k, int i) -> vf { if constexpr (INLDS) return sb0[i]; else return breg[k]; };
     if (D == P.nl - 1) {
         // ---- coarsest grid: wave 0, one lane per unknown (same code as the single-workgroup tail of round 1)
-        if (t < n) sA[t] = b[0];
+        if (t < n) sA[t] = bval(0, t);
         __syncthreads();
         if (t < 64) {
             const int i = t, H = L.H;
@@ -404,42 +420,56 @@ __device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __
         MidCoef c[PPT]; vf x[PPT];
         // ---- down: x1 = b*dinv ; x = x1 + (b - M x1)*dinv ; res = b - M x
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) { c[k] = mid_coef(L, i); sA[i] = b[k] * c[k].dinv; } }
+        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) { c[k] = mid_coef(L, i); sA[i] = bval(k, i) * c[k].dinv; } }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = t + k * MID_T;
-            if (i < n) { const vf x1 = b[k] * c[k].dinv; x[k] = x1 + (b[k] - mid_op(c[k], sA, i, W)) * c[k].dinv; sB[i] = x[k]; }
+            if (i < n) {
+                const vf bk = bval(k, i), x1 = bk * c[k].dinv, xv = x1 + (bk - mid_op(c[k], sA, i, W)) * c[k].dinv;
+                sB[i] = xv;
+                if constexpr (INLDS) sx0[i] = xv; else x[k] = xv;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) sA[i] = b[k] - mid_op(c[k], sB, i, W); }
+        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) sA[i] = bval(k, i) - mid_op(c[k], sB, i, W); }
         __syncthreads();
-        vf bc[1];
-        bc[0] = t < C.n ? mid_restrict(sA, t, C.W, W, L.H) : 0.f;
+        constexpr int CPT = mid_ppt(D + 1);
+        vf bc[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { const int I = t + k * MID_T; bc[k] = I < C.n ? mid_restrict(sA, I, C.W, W, L.H) : 0.f; }
         __syncthreads();                                      // the residual array is free again
-        mid_level<D + 1>(P, q, t, sA, sB, sC, bc, sweeps);    // its correction arrives in sC
+        mid_level<D + 1>(P, q, t, sA, sB, sC, sb0, sx0, bc, sweeps);    // its correction arrives in sC
         // ---- up: xe = x + e_coarse(parent) ; x2 = xe + (b - M xe)*dinv ; xo = x2 + (b - M x2)*dinv
         if constexpr (D == 0) {                                // the first fused level does not keep its coefficients across the deeper levels
+            asm volatile("" ::: "memory");                     // (a real reload: without the clobber the first loads' registers stay live)
 #pragma unroll
             for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) c[k] = mid_coef(L, i); }
         }
-        vf xe[PPT];
+        // (the iterates xe and x2 of the own pixel are read back from the exchange arrays, where the operator reads them anyway)
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = t + k * MID_T;
-            if (i < n) { const int gy = i / W, gx = i - gy * W; xe[k] = x[k] + sC[(gy >> 1) * C.W + (gx >> 1)]; sA[i] = xe[k]; }
+            if (i < n) {
+                const int gy = i / W, gx = i - gy * W;
+                vf xk; if constexpr (INLDS) xk = sx0[i]; else xk = x[k];
+                sA[i] = xk + sC[(gy >> 1) * C.W + (gx >> 1)];
+            }
         }
         __syncthreads();
-        vf x2[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) { x2[k] = xe[k] + (b[k] - mid_op(c[k], sA, i, W)) * c[k].dinv; sB[i] = x2[k]; } }
+        for (int k = 0; k < PPT; ++k) {
+            const int i = t + k * MID_T;
+            if (i < n) { vf xe; const vf y = mid_op(c[k], sA, i, W, &xe); sB[i] = xe + (bval(k, i) - y) * c[k].dinv; }
+        }
         __syncthreads();                                      // every thread has also finished reading the child's correction in sC
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = t + k * MID_T;
             if (i < n) {
-                const vf v = x2[k] + (b[k] - mid_op(c[k], sB, i, W)) * c[k].dinv;
+                vf x2; const vf y = mid_op(c[k], sB, i, W, &x2);
+                const vf v = x2 + (bval(k, i) - y) * c[k].dinv;
                 if (D == 0) L.x2[(size_t)q * n + i] = v; else sC[i] = v;
             }
         }
@@ -451,10 +481,17 @@ __global__ __launch_bounds__(MID_T) void k_mg_mid(const PState* __restrict__ st,
     __shared__ vf sA[MID_N0], sB[MID_N0], sC[MID_N1];
     const int q = blockIdx.x, t = threadIdx.x;
     const Lvl& L0 = P.lv[0];
-    vf b[4];
+    vf b[MID_P0];
+#if NCT_MID_LDS0
+    __shared__ vf sb0[MID_N0], sx0[MID_N0];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int i = t + k * MID_T; b[k] = i < L0.n ? L0.b[(size_t)q * L0.n + i] : 0.f; }
-    mid_level<0>(P, q, t, sA, sB, sC, b, sweeps);
+    for (int k = 0; k < MID_P0; ++k) { const int i = t + k * MID_T; b[k] = 0.f; if (i < L0.n) sb0[i] = L0.b[(size_t)q * L0.n + i]; }
+    mid_level<0>(P, q, t, sA, sB, sC, sb0, sx0, b, sweeps);         // each thread reads back only what it wrote: no barrier needed
+#else
+#pragma unroll
+    for (int k = 0; k < MID_P0; ++k) { const int i = t + k * MID_T; b[k] = i < L0.n ? L0.b[(size_t)q * L0.n + i] : 0.f; }
+    mid_level<0>(P, q, t, sA, sB, sC, nullptr, nullptr, b, sweeps);
+#endif
 }
 
 // ---- PCG pieces at the fine level
@@ -611,7 +648,12 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     // tail0 = first level of the fused middle + tail (k_mg_mid): the deepest run of levels whose first has <= MID_N0 pixels and the others
     // <= MID_N1, at most MID_LV of them; never the fine level (its right-hand side is the fp64 PCG residual and its tiles fill the chip)
     int tail0 = nl - 1;
-    while (tail0 > 1 && nl - (tail0 - 1) <= MID_LV && lv[tail0 - 1].n <= MID_N0 && lv[tail0].n <= MID_N1) --tail0;
+    auto mid_fits = [&](int first) {                     // levels first .. nl-1 as depths 0 .. of k_mg_mid
+        if (nl - first > MID_LV) return false;
+        for (int l = first; l < nl; ++l) { const int d = l - first; if (lv[l].n > (d == 0 ? MID_N0 : (d == 1 ? MID_N1 : MID_N2))) return false; }
+        return true;
+    };
+    while (tail0 > 1 && mid_fits(tail0 - 1)) --tail0;
     MidPack pack; memset(&pack, 0, sizeof pack); pack.nl = nl - tail0;
     for (int l = tail0; l < nl; ++l) pack.lv[l - tail0] = lv[l];
     // Tile shapes: bandwidth-bound levels use TXB x TYB tiles; below 100k pixels the legs are latency bound, so a 16x8 tile whose

@@ -181,6 +181,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         if (dst) NCT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
         return 0;
     };
+    if (lv) { rc = d2h(lv->labels, labels, sizeof(int) * (size_t)ah[0] * aw[0]); if (rc) return rc; }
     nct_color_params cp{prm->eps, prm->nonlocal_weight, prm->local_weight, prm->wls_lambda_init, prm->wls_alpha, (double)prm->k_num};
 
     for (int l = 0; l < nlevels; ++l) {
@@ -235,7 +236,10 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         nct_color_debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         int wls_it[6] = {0, 0, 0, 0, 0, 0};
         dbg.wls_iters = wls_it;
-        rc = nctk_local_color_transfer(ctx, s, err, s_lab_l, g_lab_l, s_lab_full, knn_id, knn_w, l, ah[l], aw[l], H, W, cp, out_lab, timing ? &dbg : nullptr); if (rc) return rc;
+        const nct_color_stages* cs = lv ? lv->color[l] : nullptr;
+        if (cs) { dbg.ab_local = cs->ab_local; dbg.ab_nonlocal = cs->ab_nonlocal; dbg.ab_up = cs->ab_up; dbg.rough = cs->roughness; dbg.ab_wls = cs->ab_wls; dbg.cg_iters = cs->cg_iters; }
+        rc = nctk_local_color_transfer(ctx, s, err, s_lab_l, g_lab_l, s_lab_full, knn_id, knn_w, l, ah[l], aw[l], H, W, cp, out_lab, (timing || cs) ? &dbg : nullptr); if (rc) return rc;
+        if (cs && cs->wls_iters) for (int q = 0; q < 6; ++q) cs->wls_iters[q] = wls_it[q];
         rc = nctk_lab2bgr(ctx, s, out_lab, P->out, N); if (rc) return rc;
         if (timing) { timing->wls_iters[l] = *std::max_element(wls_it, wls_it + 6); }
         MARK(ST_COLOR, l);

@@ -9,6 +9,8 @@
 #include <sys/stat.h>
 #include <atomic>
 #include <chrono>
+#include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,7 +81,12 @@ struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; bo
 // GeneralizedPatchMatch.cu:337-353), the level images tCnt / tStl (main.cu:343-347), the matching-error heat map (getHeat,
 // ColorTransfer.cpp:1127-1178 on the min-max normalised error, :1318-1338) — under the reference's file names <pre>_aFlow_<l>.png … — plus
 // the BDS guidance image and the intermediate result of the level (guide_<l>, result_<l>: not dumped by the reference, but what its
-// refine_* images are for). <pre> = the output file's stem. The coefficient / patch / kNN visualisations are not reproduced.
+// refine_* images are for); the linear colour coefficients after each stage of the level as aVis / bVis images and the source recoloured by
+// them (aVis_init, bVis_init, refine_init: local statistics sampled with x / samples, ColorTransfer.cpp:1268-1300; aVis_nonlocal, bVis_nonlocal,
+// refine_nonlocal: after the nonlocal solve and the bilinear upsampling, :1384-1413; aVis, bVis: after the WLS solve, :1450-1463); the
+// clusters as <pre>_cluster_small.png and per level as knn_<l>.png (visualizeClusterRandom / findKnns, :222-246, :336-351 — with a hashed
+// palette: the reference's 260-entry RandomColorList is a data table of its Config.h). <pre> = the output file's stem. Not reproduced:
+// patchVis (the 3x3 patches behind the local statistics, tiled).
 void heat(double v, uint8_t* bgr) {
     v = v < 0 ? 0 : (v > 1 ? 1 : v);
     double dr, dg, db;
@@ -98,8 +105,16 @@ bool run_with_vis(nct_ctx* ctx, const ImageBGR& cnt, const ImageBGR& stl, const 
     std::vector<std::vector<uint32_t>> ann(5), bnn(5);
     std::vector<std::vector<uint8_t>> guide(5), result(5), simg(5), rimg(5);
     std::vector<std::vector<float>> errm(5);
+    std::vector<std::vector<double>> ab_local(5), ab_up(5), ab_wls(5);
+    std::vector<int> labels((size_t)ah[0] * aw[0]);
+    nct_color_stages cs[5]; memset(cs, 0, sizeof cs);
+    const size_t N = (size_t)cnt.h * cnt.w;
     nct_pair_levels lv; memset(&lv, 0, sizeof lv);
+    lv.labels = labels.data();
     for (int l = 0; l < prm.levels; ++l) {
+        ab_local[l].resize((size_t)6 * ah[l] * aw[l]); ab_up[l].resize(6 * N); ab_wls[l].resize(6 * N);
+        cs[l].ab_local = ab_local[l].data(); cs[l].ab_up = ab_up[l].data(); cs[l].ab_wls = ab_wls[l].data();
+        lv.color[l] = &cs[l];
         ann[l].resize((size_t)ah[l] * aw[l]); bnn[l].resize((size_t)bh[l] * bw[l]); guide[l].resize((size_t)ah[l] * aw[l] * 3);
         errm[l].resize((size_t)ah[l] * aw[l]); result[l].resize((size_t)cnt.h * cnt.w * 3);
         lv.ann[l] = ann[l].data(); lv.bnn[l] = bnn[l].data(); lv.guide[l] = guide[l].data(); lv.err[l] = errm[l].data(); lv.result[l] = result[l].data();
@@ -117,7 +132,50 @@ bool run_with_vis(nct_ctx* ctx, const ImageBGR& cnt, const ImageBGR& stl, const 
         char name[1200]; snprintf(name, sizeof name, "%s_%s_%d.png", pre.c_str(), what, l);
         std::string e; return pngio::write(name, px, h, w, e);
     };
+    // coefficient images: a -> int(a * 50), b -> int(b * 255 + 127), clamped to a byte (the clamp in double first: the cast of an
+    // out-of-range double is undefined); recoloured source: clamp(lab / 255 * a + b, 0, 1) -> 8 bit (convertTo, round half to even) -> BGR
+    std::vector<uint8_t> lab(N * 3);
+    if (nct_bgr2lab_u8(ctx, cnt.px.data(), N, lab.data()) != NCT_OK) { err = nct_last_error(ctx); return false; }
+    auto coef_images = [&](const char* tag, int l, const double* ab, int h, int w, int samples) {
+        const double* a = ab; const double* b = ab + (size_t)3 * h * w;
+        std::vector<uint8_t> av(N * 3), bv(N * 3), rl(N * 3), rb(N * 3);
+        for (int y = 0; y < cnt.h; ++y)
+            for (int x = 0; x < cnt.w; ++x) {
+                const size_t i = (size_t)y * cnt.w + x, j = (size_t)(y / samples) * w + x / samples;
+                for (int c = 0; c < 3; ++c) {
+                    const double ac = a[3 * j + c], bc = b[3 * j + c];
+                    auto byte = [](double v) { return (uint8_t)(int)(v != v ? 0. : (v < 0. ? 0. : (v > 255. ? 255. : v))); };
+                    av[3 * i + c] = byte(ac * 50); bv[3 * i + c] = byte(bc * 255 + 127);
+                    double v = lab[3 * i + c] / 255.0 * ac + bc;
+                    v = v > 0.0 ? v : 0.0; v = v < 1.0 ? v : 1.0;
+                    rl[3 * i + c] = (uint8_t)nearbyint(v * 255.0);
+                }
+            }
+        char na[40], nb[40], nr[40];
+        snprintf(na, sizeof na, "aVis%s", tag); snprintf(nb, sizeof nb, "bVis%s", tag); snprintf(nr, sizeof nr, "refine%s", tag);
+        if (!save(na, l, av.data(), cnt.h, cnt.w) || !save(nb, l, bv.data(), cnt.h, cnt.w)) return false;
+        if (!tag[0]) return true;                                        // the recoloured source after the WLS solve is result_<l>
+        return nct_lab2bgr_u8(ctx, rl.data(), N, rb.data()) == NCT_OK && save(nr, l, rb.data(), cnt.h, cnt.w);
+    };
+    auto palette = [](int label, uint8_t* bgr) {
+        uint32_t hsh = (uint32_t)(label + 1) * 2654435761u; hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+        bgr[0] = (uint8_t)(64 + (hsh & 0xBF)); bgr[1] = (uint8_t)(64 + ((hsh >> 8) & 0xBF)); bgr[2] = (uint8_t)(64 + ((hsh >> 16) & 0xBF));
+    };
+    auto cluster_image = [&](int h, int w, int samples) {
+        std::vector<uint8_t> im((size_t)h * w * 3);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const int ly = std::min(y / samples, ah[0] - 1), lx = std::min(x / samples, aw[0] - 1);
+                palette(labels[(size_t)ly * aw[0] + lx], &im[((size_t)y * w + x) * 3]);
+            }
+        return im;
+    };
+    { const auto im = cluster_image(ah[0], aw[0], 1);
+      std::string e; if (!pngio::write((pre + "_cluster_small.png").c_str(), im.data(), ah[0], aw[0], e)) { err = "cannot write the -vis images"; return false; } }
     for (int l = 0; l < prm.levels; ++l) {
+        if (!coef_images("_init", l, ab_local[l].data(), ah[l], aw[l], 1 << (4 - l)) || !coef_images("_nonlocal", l, ab_up[l].data(), cnt.h, cnt.w, 1) ||
+            !coef_images("", l, ab_wls[l].data(), cnt.h, cnt.w, 1) || !save("knn", l, cluster_image(ah[l], aw[l], 1 << l).data(), ah[l], aw[l])) {
+            err = "cannot write the -vis images"; return false; }
         auto flow = [&](const std::vector<uint32_t>& nn, int h, int w, int oh, int ow) {
             std::vector<uint8_t> f((size_t)h * w * 3);
             for (size_t i = 0; i < (size_t)h * w; ++i) {
@@ -247,7 +305,7 @@ int main(int argc, char** argv) {
     cl.add("seed", seed, "[extension] seed of the counter-based RNG (default: 1).");
     cl.add("levels", levels, "[extension] pyramid levels to run, coarse to fine: 5 = the full L=5..1 loop, 1 = L=5 only.");
     cl.add("resume", resume, "[extension] 1 = skip pairs whose output file exists; every pair appends a JSON line to <output>/status.jsonl.");
-    cl.add("vis", vis, "[extension] 1 = the reference's ENABLE_VIS dumps per level (flow maps, level images, error heat map) next to the output.");
+    cl.add("vis", vis, "[extension] 1 = the reference's ENABLE_VIS dumps per level (flow maps, level images, error heat map, coefficient and cluster images) next to the output.");
     cl.add("feat16", feat16, "[extension] 1 = fp16 PatchMatch feature tiles (fp32 accumulate); not bit-identical to the default.");
     if (!cl.parse(argc, argv)) return -1;
     cfg.prm.seed = (uint32_t)seed;

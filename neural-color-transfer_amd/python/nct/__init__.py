@@ -127,7 +127,7 @@ FLAG_COUNT_EVALS = 2
 
 class PairLevels(C.Structure):
     """struct nct_pair_levels (include/nct.h)."""
-    _fields_ = [(k, C.c_void_p * 5) for k in ("ann", "bnn", "annd", "bnnd", "guide", "err", "result")]
+    _fields_ = [(k, C.c_void_p * 5) for k in ("ann", "bnn", "annd", "bnnd", "guide", "err", "result", "color")] + [("labels", C.c_void_p)]
 
 
 class ColorStages(C.Structure):
@@ -372,8 +372,9 @@ class Context:
         self._chk(self._l.nct_pair_run(self._h, C.addressof(prm), C.addressof(tm) if tm is not None else None))
         return tm.as_dict() if want_timing else None
 
-    def pair_run_levels(self, src_shape, ref_shape, params=None):
-        """nct_pair_run_levels on the uploaded pair -> dict of per-level intermediates (lists indexed by level, 0 = coarsest)."""
+    def pair_run_levels(self, src_shape, ref_shape, params=None, want_color=False):
+        """nct_pair_run_levels on the uploaded pair -> dict of per-level intermediates (lists indexed by level, 0 = coarsest).
+        want_color adds "color" (per level the dict of coefficient maps local_color_transfer(want_stages=True) returns) and "labels"."""
         prm = params or Params.default()
         H, W = src_shape[:2]; RH, RW = ref_shape[:2]
         dims = []
@@ -390,8 +391,20 @@ class Context:
         lv = PairLevels()
         for k in keep:
             setattr(lv, k, (C.c_void_p * 5)(*[a.ctypes.data for a in keep[k]]))
+        if want_color:
+            color, structs = [], []
+            for (ah, aw, _, _) in dims:
+                d = {"ab_local": np.empty((2, ah * aw, 3)), "ab_nonlocal": np.empty((2, ah * aw, 3)), "ab_up": np.empty((2, H * W, 3)),
+                     "roughness": np.empty(H * W), "ab_wls": np.empty((2, H * W, 3)), "cg_iters": np.zeros(3, np.int32), "wls_iters": np.zeros(6, np.int32)}
+                color.append(d)
+                structs.append(ColorStages(*[d[k].ctypes.data for k in ("ab_local", "ab_nonlocal", "ab_up", "roughness", "ab_wls", "cg_iters", "wls_iters")]))
+            lv.color = (C.c_void_p * 5)(*[C.addressof(st) if i < prm.levels else None for i, st in enumerate(structs)])
+            labels = np.zeros(dims[0][:2], np.int32)
+            lv.labels = labels.ctypes.data
         tm = PairTiming()
         self._chk(self._l.nct_pair_run_levels(self._h, C.addressof(prm), C.addressof(tm), C.addressof(lv)))
+        if want_color:
+            keep["color"] = color; keep["labels"] = labels
         keep["timing"] = tm.as_dict()
         keep["dims"] = dims
         return keep

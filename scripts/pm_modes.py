@@ -1,6 +1,6 @@
-"""PatchMatch evaluation modes (k_patchmatch.hip) inside the real pipeline: per-level kernel time, evaluations, exact fp32
-re-evaluations behind the fp16 prefilter, accepted candidates — on the 700x700 bench pair. NCT_PM_MODE selects the mode of the
-exact path (0 plain, 1 row rejection, 2 fp16 prefilter); FEAT16 is the opt-in reduced-precision mode.
+"""PatchMatch evaluation modes (k_patchmatch.hip) inside the real pipeline: per-level kernel time, candidate evaluations and
+accepted candidates on the 700x700 bench pair, for the exact fp32 path (row rejection) and the opt-in -feat16 mode (FEAT16=1 in
+the child), for the default library and every build under lib/variants/.
 usage: python scripts/pm_modes.py [size]"""
 import os, sys, json, zlib, subprocess
 sys.path.insert(0, "tests"); sys.path.insert(0, "neural-color-transfer_amd/python")

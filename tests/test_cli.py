@@ -264,11 +264,13 @@ def test_cli_vis_dumps(tmp_path, ctx, oracle):
     assert r.returncode == 0, r.stdout + r.stderr
     names = set(os.listdir(out))
     for l in range(5):
-        for what in ("aFlow", "bFlow", "tCnt", "tStl", "errMap", "guide", "result"):
+        for what in ("aFlow", "bFlow", "tCnt", "tStl", "errMap", "guide", "result", "aVis", "bVis", "aVis_init", "bVis_init", "refine_init",
+                     "aVis_nonlocal", "bVis_nonlocal", "refine_nonlocal", "knn"):
             assert f"a_b_2.00_{what}_{l}.png" in names, (what, l)
+    assert "a_b_2.00_cluster_small.png" in names
     ctx.vgg19_load_raw(ws, bs)
     ctx.pair_upload(a, b)
-    lv = ctx.pair_run_levels(a.shape, b.shape)
+    lv = ctx.pair_run_levels(a.shape, b.shape, want_color=True)
     load = lambda n: np.asarray(Image.open(out / n).convert("RGB"))[..., ::-1]
     assert np.array_equal(load("a_b_2.00.png"), ctx.pair_download())
     assert np.array_equal(load("a_b_2.00_result_4.png"), lv["result"][4]) and np.array_equal(load("a_b_2.00_guide_2.png"), lv["guide"][2])
@@ -280,3 +282,32 @@ def test_cli_vis_dumps(tmp_path, ctx, oracle):
     hm = load("a_b_2.00_errMap_0.png")
     e = lv["err"][0].astype(np.float64); i = np.unravel_index(np.argmin(e), e.shape); j = np.unravel_index(np.argmax(e), e.shape)
     assert hm[i].tolist() == [128, 0, 0] and hm[j].tolist() == [0, 0, 128]          # getHeat(0) = dark blue, getHeat(1) = dark red (BGR)
+    # coefficient images (ColorTransfer.cpp:1286-1296, 1400-1410, 1451-1462): int(a*50), int(b*255+127) clamped; recoloured source
+    H, W = a.shape[:2]
+    byte = lambda v: np.clip(v, 0, 255).astype(np.int64).astype(np.uint8)
+    for l in (0, 2, 4):
+        col = lv["color"][l]
+        ab = col["ab_wls"].reshape(2, H, W, 3)
+        assert np.array_equal(load(f"a_b_2.00_aVis_{l}.png"), byte(ab[0] * 50)) and np.array_equal(load(f"a_b_2.00_bVis_{l}.png"), byte(ab[1] * 255 + 127))
+        ah, aw = lv["dims"][l][:2]; smp = 1 << (4 - l)
+        yy, xx = np.meshgrid(np.arange(H) // smp, np.arange(W) // smp, indexing="ij")
+        loc = col["ab_local"].reshape(2, ah, aw, 3)[:, yy, xx]
+        assert np.array_equal(load(f"a_b_2.00_aVis_init_{l}.png"), byte(loc[0] * 50)) and np.array_equal(load(f"a_b_2.00_bVis_init_{l}.png"), byte(loc[1] * 255 + 127))
+        lab = oracle.bgr2lab(a).astype(np.float64) / 255.0
+        up = col["ab_up"].reshape(2, H, W, 3)
+        for tag, cf in (("init", loc), ("nonlocal", up)):
+            rec = np.rint(np.clip(lab * cf[0] + cf[1], 0.0, 1.0) * 255.0).astype(np.uint8)
+            assert np.array_equal(load(f"a_b_2.00_refine_{tag}_{l}.png"), oracle.lab2bgr(rec)), (tag, l)
+    # the S2 coefficients recolour the source into the level's intermediate result
+    ab = lv["color"][4]["ab_wls"].reshape(2, H, W, 3)
+    rec = np.rint(np.clip(oracle.bgr2lab(a).astype(np.float64) / 255.0 * ab[0] + ab[1], 0.0, 1.0) * 255.0).astype(np.uint8)
+    assert np.array_equal(oracle.lab2bgr(rec), lv["result"][4])
+    # cluster images: one colour per k-means label; knn_<l> = the same labels seen from level l (x / 2^l)
+    cl = load("a_b_2.00_cluster_small.png"); lab0 = lv["labels"]
+    assert cl.shape[:2] == lab0.shape
+    for k in np.unique(lab0):
+        assert len(np.unique(cl[lab0 == k].reshape(-1, 3), axis=0)) == 1
+    assert len(np.unique(cl.reshape(-1, 3), axis=0)) == len(np.unique(lab0))
+    kn = load("a_b_2.00_knn_2.png"); ah, aw = lv["dims"][2][:2]
+    yy, xx = np.meshgrid(np.minimum(np.arange(ah) // 4, lab0.shape[0] - 1), np.minimum(np.arange(aw) // 4, lab0.shape[1] - 1), indexing="ij")
+    assert np.array_equal(kn, cl[yy, xx])
