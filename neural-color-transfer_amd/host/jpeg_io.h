@@ -90,7 +90,7 @@ inline void idct_islow(const int16_t* coef, const uint16_t* q, uint8_t* out, int
     for (int c = 0; c < 8; ++c) {
         const int16_t* in = coef + c; const uint16_t* qq = q + c;
         if (!in[8] && !in[16] && !in[24] && !in[32] && !in[40] && !in[48] && !in[56]) {
-            const int dc = (int)((long)in[0] * qq[0]) << P1;
+            const int dc = (int)(((long)in[0] * qq[0]) * (1L << P1));
             for (int r = 0; r < 8; ++r) ws[r * 8 + c] = dc;
             continue;
         }
@@ -98,7 +98,7 @@ inline void idct_islow(const int16_t* coef, const uint16_t* q, uint8_t* out, int
         long z1 = (z2 + z3) * F_0_541;
         long tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
         z2 = (long)in[0] * qq[0]; z3 = (long)in[32] * qq[32];
-        long tmp0 = (z2 + z3) << CB, tmp1 = (z2 - z3) << CB;
+        long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);
         const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = (long)in[56] * qq[56]; tmp1 = (long)in[40] * qq[40]; tmp2 = (long)in[24] * qq[24]; tmp3 = (long)in[8] * qq[8];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3;
@@ -117,7 +117,7 @@ inline void idct_islow(const int16_t* coef, const uint16_t* q, uint8_t* out, int
         long z2 = w[2], z3 = w[6];
         long z1 = (z2 + z3) * F_0_541;
         long tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
-        long tmp0 = ((long)w[0] + w[4]) << CB, tmp1 = ((long)w[0] - w[4]) << CB;
+        long tmp0 = ((long)w[0] + w[4]) * (1L << CB), tmp1 = ((long)w[0] - w[4]) * (1L << CB);
         const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3;
@@ -182,6 +182,8 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
                 i += 16;
                 if (cnt > 256 || i + cnt > L) { err = "bad DHT"; return false; }
                 memcpy(h.vals, p + i, cnt); i += cnt;
+                if (!tc) for (int k = 0; k < cnt; ++k) if (h.vals[k] > 15) { err = "bad DHT (DC category > 15)"; return false; }   // jdhuff.c: JERR_BAD_HUFF_TABLE
+                { int code = 0; for (int l = 1; l <= 16; ++l) { code += h.bits[l]; if (code > (1 << l)) { err = "bad DHT (oversubscribed code lengths)"; return false; } code <<= 1; } }
                 huff_build(h);
             }
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {   // SOF0 / SOF1 (sequential), SOF2 (progressive)

@@ -85,8 +85,9 @@ struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; bo
 // them (aVis_init, bVis_init, refine_init: local statistics sampled with x / samples, ColorTransfer.cpp:1268-1300; aVis_nonlocal, bVis_nonlocal,
 // refine_nonlocal: after the nonlocal solve and the bilinear upsampling, :1384-1413; aVis, bVis: after the WLS solve, :1450-1463); the
 // clusters as <pre>_cluster_small.png and per level as knn_<l>.png (visualizeClusterRandom / findKnns, :222-246, :336-351 — with a hashed
-// palette: the reference's 260-entry RandomColorList is a data table of its Config.h). <pre> = the output file's stem. Not reproduced:
-// patchVis (the 3x3 patches behind the local statistics, tiled).
+// palette: the reference's 260-entry RandomColorList is a data table of its Config.h); patchVis_<l>: per level pixel a 3-wide, 6-high cell
+// with the (border-clipped) 3x3 patch of the guidance image above that of the level image, the windows of the local statistics (:1190-1221).
+// <pre> = the output file's stem.
 void heat(double v, uint8_t* bgr) {
     v = v < 0 ? 0 : (v > 1 ? 1 : v);
     double dr, dg, db;
@@ -172,7 +173,23 @@ bool run_with_vis(nct_ctx* ctx, const ImageBGR& cnt, const ImageBGR& stl, const 
     };
     { const auto im = cluster_image(ah[0], aw[0], 1);
       std::string e; if (!pngio::write((pre + "_cluster_small.png").c_str(), im.data(), ah[0], aw[0], e)) { err = "cannot write the -vis images"; return false; } }
+    auto patch_image = [&](const uint8_t* stl_px, const uint8_t* cnt_px, int h, int w) {
+        const int ps = 3;
+        std::vector<uint8_t> im((size_t)h * ps * 2 * w * ps * 3, 0);
+        const size_t pitch = (size_t)w * ps * 3;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const int sx0 = std::max(x - 1, 0), sy0 = std::max(y - 1, 0), ex = std::min(x + 2, w), ey = std::min(y + 2, h);
+                for (int sy = sy0; sy < ey; ++sy)
+                    for (int sx = sx0; sx < ex; ++sx) {
+                        memcpy(&im[(size_t)(y * ps * 2 + sy - sy0) * pitch + (size_t)(x * ps + sx - sx0) * 3], &stl_px[((size_t)sy * w + sx) * 3], 3);
+                        memcpy(&im[(size_t)(y * ps * 2 + ps + sy - sy0) * pitch + (size_t)(x * ps + sx - sx0) * 3], &cnt_px[((size_t)sy * w + sx) * 3], 3);
+                    }
+            }
+        return im;
+    };
     for (int l = 0; l < prm.levels; ++l) {
+        if (!save("patchVis", l, patch_image(guide[l].data(), simg[l].data(), ah[l], aw[l]).data(), ah[l] * 6, aw[l] * 3)) { err = "cannot write the -vis images"; return false; }
         if (!coef_images("_init", l, ab_local[l].data(), ah[l], aw[l], 1 << (4 - l)) || !coef_images("_nonlocal", l, ab_up[l].data(), cnt.h, cnt.w, 1) ||
             !coef_images("", l, ab_wls[l].data(), cnt.h, cnt.w, 1) || !save("knn", l, cluster_image(ah[l], aw[l], 1 << l).data(), ah[l], aw[l])) {
             err = "cannot write the -vis images"; return false; }

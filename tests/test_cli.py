@@ -154,6 +154,29 @@ def test_png_reader_rejects_malformed_files(tmp_path):
         assert r.returncode == 1 and "Error" in r.stdout, name
 
 
+def test_decoders_survive_mutated_files_under_sanitizers(tmp_path):
+    """tests/fuzz_decoders.cpp: 20 000 mutations (bit flips, 0xFF runs, truncation, splices, header bytes) of PNG / JPEG seed files
+    through host/png_io.h + host/jpeg_io.h built with AddressSanitizer + UBSan: every file decodes or is rejected with a message.
+    (Found and fixed in round 2: DC Huffman categories > 15 and oversubscribed code lengths in DHT, negative left shifts in the IDCT.)"""
+    a = synth.image(5, 48, 40)[..., ::-1].copy()
+    seeds = []
+    def put(name, im, **kw):
+        im.save(tmp_path / name, **kw); seeds.append(str(tmp_path / name))
+    put("a.png", Image.fromarray(a)); put("g.png", Image.fromarray(a).convert("L")); put("p.png", Image.fromarray(a).convert("P"))
+    put("rgba.png", Image.fromarray(a).convert("RGBA")); put("i16.png", Image.fromarray((a[..., 0].astype(np.uint16) * 257)))
+    put("a.jpg", Image.fromarray(a), quality=85); put("pr.jpg", Image.fromarray(a), quality=80, progressive=True)
+    put("s.jpg", Image.fromarray(a), quality=90, subsampling=2); put("g.jpg", Image.fromarray(a).convert("L"), quality=75)
+    exe = str(tmp_path / "fuzz")
+    host = os.path.join(nct.PKG_ROOT, "host")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", host,
+                        os.path.join(os.path.dirname(__file__), "fuzz_decoders.cpp"), "-o", exe, "-lz"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "20000", "7", str(tmp_path / "scratch.bin")] + seeds, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    decoded, rejected = [int(x) for x in r.stdout.split()[1::2]]
+    assert decoded + rejected == 20000 and decoded > 1000 and rejected > 1000
+
+
 @pytest.mark.gpu
 def test_cli_batch_matches_library(tmp_path, ctx):
     from caffemodel_io import synthetic_vgg19, write_caffemodel
@@ -265,7 +288,7 @@ def test_cli_vis_dumps(tmp_path, ctx, oracle):
     names = set(os.listdir(out))
     for l in range(5):
         for what in ("aFlow", "bFlow", "tCnt", "tStl", "errMap", "guide", "result", "aVis", "bVis", "aVis_init", "bVis_init", "refine_init",
-                     "aVis_nonlocal", "bVis_nonlocal", "refine_nonlocal", "knn"):
+                     "aVis_nonlocal", "bVis_nonlocal", "refine_nonlocal", "knn", "patchVis"):
             assert f"a_b_2.00_{what}_{l}.png" in names, (what, l)
     assert "a_b_2.00_cluster_small.png" in names
     ctx.vgg19_load_raw(ws, bs)
@@ -302,6 +325,13 @@ def test_cli_vis_dumps(tmp_path, ctx, oracle):
     ab = lv["color"][4]["ab_wls"].reshape(2, H, W, 3)
     rec = np.rint(np.clip(oracle.bgr2lab(a).astype(np.float64) / 255.0 * ab[0] + ab[1], 0.0, 1.0) * 255.0).astype(np.uint8)
     assert np.array_equal(oracle.lab2bgr(rec), lv["result"][4])
+    # patchVis (ColorTransfer.cpp:1190-1221): per level pixel the clipped 3x3 window of the guidance above that of the level image
+    pv = load("a_b_2.00_patchVis_1.png"); ah, aw = lv["dims"][1][:2]; g = lv["guide"][1]; c1 = load("a_b_2.00_tCnt_1.png")
+    assert pv.shape == (ah * 6, aw * 3, 3)
+    for (y, x) in ((0, 0), (3, 5), (ah - 1, aw - 1), (0, aw - 1)):
+        y0, x0, y1, x1 = max(y - 1, 0), max(x - 1, 0), min(y + 2, ah), min(x + 2, aw)
+        cell = np.zeros((6, 3, 3), np.uint8); cell[:y1 - y0, :x1 - x0] = g[y0:y1, x0:x1]; cell[3:3 + y1 - y0, :x1 - x0] = c1[y0:y1, x0:x1]
+        assert np.array_equal(pv[6 * y:6 * y + 6, 3 * x:3 * x + 3], cell), (y, x)
     # cluster images: one colour per k-means label; knn_<l> = the same labels seen from level l (x / 2^l)
     cl = load("a_b_2.00_cluster_small.png"); lab0 = lv["labels"]
     assert cl.shape[:2] == lab0.shape
