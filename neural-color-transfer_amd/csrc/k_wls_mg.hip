@@ -712,8 +712,26 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     int it = 0, slot = 0; bool done = false;
     { int rc = snapshot(slot); if (rc) return rc; }        // state after the start kernel (x0 may already solve the system)
     PState fin; memset(&fin, 0, sizeof fin);
+    // Experiment hook (NCT_WLS_GRAPH=1): from the second batch on, the 4-iteration batch (its kernels, arguments and the
+    // state double-buffering repeat exactly) is captured once and replayed as a HIP graph instead of being enqueued kernel by kernel.
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    struct GraphCleanup { hipGraph_t& g; hipGraphExec_t& e; ~GraphCleanup() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } gcleanup{graph, gexec};
     while (true) {
         const bool enqueued = it < maxit;
+        if (enqueued && ctx->wls_graph && it >= batch) {
+            if (!gexec) {
+                NCT_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                int rc = 0;
+                for (int k = 0; k < batch && !rc; ++k) rc = iteration(it + k);
+                hipError_t e = hipStreamEndCapture(s, &graph);
+                if (rc) return rc;
+                NCT_HIP(e);
+                NCT_HIP(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+            }
+            NCT_HIP(hipGraphLaunch(gexec, s));
+            it += batch;
+            cur = st + (it & 1);
+        } else
         if (enqueued) { for (int k = 0; k < batch; ++k, ++it) { int rc = iteration(it); if (rc) return rc; } }
         { int rc = snapshot(slot ^ 1); if (rc) return rc; }
         NCT_HIP(hipEventSynchronize(ctx->ev_poll[slot]));  // the snapshot taken BEFORE the batch just enqueued

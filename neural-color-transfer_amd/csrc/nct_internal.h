@@ -31,6 +31,7 @@ struct nct_ctx {
                                                 // behind the fp16 prefilter, [2] accepted candidates; 4 slots per pyramid level in pair runs
     // stage clock: events recorded on the main stream at stage boundaries, read once after the pair's final synchronise
     // (no host syncs in between: see nct_pair_timing in nct.h)
+    int wls_graph = 0;                          // experiment hook (env NCT_WLS_GRAPH=1): replay the PCG iteration batch as a HIP graph
     int wls_maxit = 5000;                       // iteration budget of the WLS solve (test hook: env NCT_WLS_MAXIT)
     bool tm_on = false;
     std::vector<hipEvent_t> tm_events;          // pool, reused across pairs
