@@ -8,14 +8,17 @@
 //  * one 16-lane DPP row per query (4 queries per wave64, 16 per 256-thread workgroup, arranged as a 4x4 pixel
 //    tile so that neighbouring queries — whose candidate tiles overlap when the NNF is coherent — share L1/L2);
 //    lane v owns float4 channel chunks v, v+16, …; the 9*C-term dot product is one fmaf chain per lane followed
-//    by a 4-step DPP rotate-add (no LDS traffic, no bpermute);
+//    by a 4-step DPP rotate-add (no LDS traffic, no bpermute). At C = 64 HALF a row serves a query (8 lanes, two of the
+//    sixteen chains each, the same summation tree — rowq_sum): the per-candidate scalar work of a wave instruction
+//    (candidate generation, RNG, tests, addresses, reductions) then serves eight queries, 20.4 -> 17.6 ms per pair at
+//    the finest level; C = 128 (10.7 vs 8.6 ms) and four lanes per query (22.0 ms) measured slower;
 //  * the region of A shared by the queries of a workgroup (8x8 queries at C = 64: 10x10xC) is staged once per launch in LDS;
 //  * the racy single launch of the reference becomes 1 + iters*4 Jacobi steps on a double-buffered NNF
 //    (one launch per (iteration, jump)); random search is fused into the jump==1 step; RNG is counter based.
 //    => results are deterministic and bit-identical to oracle/orc_nnf.c.
 // Roofline: memory (gather of candidate tiles): algorithmic bytes = evals*9*C*4 (+ query tile + NNF r/w). What binds it in practice is
-// the L1 (TA/TCP) request path, not DRAM bytes or latency — measured in round 2: perfectly local candidates,
-// half-size fp16 tiles, 10 % fewer evaluations and two tiles in flight per query all leave the launch time unchanged or worse.
+// the L1 (TA/TCP) path — 2.3 KB per evaluation at 64 B/clk/CU — together with VALU issue, not DRAM bytes or latency (DESIGN.md §3.2, §9:
+// perfectly local candidates, half-size fp16 tiles and two tiles in flight per query leave the launch time unchanged or worse).
 #include "nct_internal.h"
 #include "nct_device.h"
 #include <cfloat>
@@ -42,10 +45,18 @@ __device__ __forceinline__ float dot4h_acc(const float4 a, const uint2 bh, float
 // by Cauchy-Schwarz): a candidate whose partial sum after a patch row cannot reach `need` any more cannot beat the current best and
 // its remaining rows are not fetched (the caller gets FLT_MAX = "not better"). -FLT_MAX disables the test. That is MODE NCT_PM_ROWREJECT;
 // NCT_PM_FP16 (opt-in reduced precision) reads the candidate tile from the fp16 shadow map Bh instead of B (fp32 accumulate).
-template <int NCH, int MODE, int RW>
+// LPQ = lanes per query: 16 (lane v owns channel chunks v, v+16, ...: one fmaf chain) or 8 (the lane owns the chains of chunks v and v+8 of the
+// 16-lane layout, v = pm_chunk8(lane): the candidate generation, tests, address arithmetic and reductions of a wave instruction then serve
+// eight queries instead of four; same chains and the same summation tree, hence the same bits).
+template <int LPQ> __device__ __forceinline__ float rowq_sum(const float (&f)[16 / LPQ]) {
+    if constexpr (LPQ == 16) return row16_sum(f[0]); else if constexpr (LPQ == 8) return half8_sum(f[0], f[1]); else return quad4_sum(f[0], f[1], f[2], f[3]);
+}
+template <int NCH, int MODE, int RW, int LPQ>
 __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const uint2* __restrict__ Bh, const PMGeom& g, int ax, int ay, unsigned amask,
                                          int bx, int by, int v, const float4* __restrict__ a_lds, int lx, int ly, float need) {
     constexpr bool EX = MODE == NCT_PM_ROWREJECT, HALF = MODE == NCT_PM_FP16;
+    constexpr int NACC = 16 / LPQ;
+    static_assert(LPQ == 16 || ((LPQ == 8 || LPQ == 4) && !HALF && NCH >= 1), "8 / 4 lanes per query: fp32 tiles, C a multiple of 64");
     // Fast path: when every tap of the query AND of the candidate lies inside its image — for every query of the wave, so the
     // branch is uniform — the nine B rows are the centre pointer plus wave-uniform offsets, the nine LDS rows are immediates,
     // nothing is masked and n = 9: ~70 VALU instructions per evaluation instead of ~270 (clamps, validity tests, selects and 64-bit
@@ -121,7 +132,9 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
             }
             const float4* pbc = reinterpret_cast<const float4*>(B) + (size_t)(unsigned)(by * g.bw + bx) * C4 + v;
             const float4* pac = a_lds + ((ly + 1) * RW + (lx + 1)) * C4 + v;
-            float facc = 0.f;
+            float facc[NACC];
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) facc[q] = 0.f;
             if constexpr (EX) {
                 // one patch row at a time; a hopeless candidate stops after a row
                 // (margins: a tap of unit vectors adds <= 1 + 2e-6, fp32 accumulation error < 1e-4)
@@ -132,22 +145,25 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
-                        for (int k = 0; k < NCH; ++k) facc = dot4_acc(par[dx * C4 + 16 * k], pbr[dx * C4 + 16 * k], facc);
+                        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                            for (int q = 0; q < NACC; ++q) facc[q] = dot4_acc(par[dx * C4 + 16 * k + LPQ * q], pbr[dx * C4 + 16 * k + LPQ * q], facc[q]);
                     if (dy < 1 && need > -FLT_MAX) {
                         const float rem = dy < 0 ? 6.0007f : 3.0004f;
-                        if (row16_sum(facc) + rem < need) return FLT_MAX;
+                        if (rowq_sum<LPQ>(facc) + rem < need) return FLT_MAX;
                     }
                 }
                 // the complete sum: a candidate 1e-4 short of `need` = -9 dbest loses by > 1e-5 in distance, far outside the rounding of the
                 // product and of the division — rejected without paying for the correctly rounded division (~10 VALU instructions)
-                const float sfull = row16_sum(facc);
+                const float sfull = rowq_sum<LPQ>(facc);
                 if (need > -FLT_MAX && sfull + 1e-4f < need) return FLT_MAX;
                 return (-sfull) / 9.0f;
             } else if constexpr (NCH == 1) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {                      // all nine loads in flight
                     const int dy = t / 3 - 1, dx = t % 3 - 1;
-                    facc = dot4_acc(pac[(dy * RW + dx) * C4], pbc[(dy * g.bw + dx) * C4], facc);
+#pragma unroll
+                    for (int q = 0; q < NACC; ++q) facc[q] = dot4_acc(pac[(dy * RW + dx) * C4 + LPQ * q], pbc[(dy * g.bw + dx) * C4 + LPQ * q], facc[q]);
                 }
             } else {
                 // one patch row (3 taps x NCH chunks) at a time: bounds the loads in flight, and with them the register count
@@ -158,13 +174,17 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
-                        for (int k = 0; k < NCH; ++k) facc = dot4_acc(par[dx * C4 + 16 * k], pbr[dx * C4 + 16 * k], facc);
+                        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                            for (int q = 0; q < NACC; ++q) facc[q] = dot4_acc(par[dx * C4 + 16 * k + LPQ * q], pbr[dx * C4 + 16 * k + LPQ * q], facc[q]);
                 }
             }
-            return (-row16_sum(facc)) / 9.0f;
+            return (-rowq_sum<LPQ>(facc)) / 9.0f;
         }
     }
-    float acc = 0.f;
+    float acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) acc[q] = 0.f;
     int n = 0;
     const int nchunk = g.C >> 2;
 #pragma unroll
@@ -182,15 +202,19 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
         if constexpr (NCH > 0) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                float4 a = pa[v + 16 * k];
                 if constexpr (HALF) {
+                    float4 a = pa[v + 16 * k];
                     uint2 b = Bh[((size_t)yc * g.bw + xc) * (size_t)nchunk + v + 16 * k];
                     if (!valid) b = make_uint2(0u, 0u);
-                    acc = dot4h_acc(a, b, acc);
+                    acc[0] = dot4h_acc(a, b, acc[0]);
                 } else {
-                    float4 b = pb[v + 16 * k];
-                    if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);     // adding +0 products == skipping the tap
-                    acc = dot4_acc(a, b, acc);
+#pragma unroll
+                    for (int q = 0; q < NACC; ++q) {
+                        float4 a = pa[v + 16 * k + LPQ * q];
+                        float4 b = pb[v + 16 * k + LPQ * q];
+                        if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);     // adding +0 products == skipping the tap
+                        acc[q] = dot4_acc(a, b, acc[q]);
+                    }
                 }
             }
         } else {
@@ -198,11 +222,11 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
                 float4 a = pa[j];
                 float4 b = pb[j];
                 if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);
-                acc = dot4_acc(a, b, acc);
+                acc[0] = dot4_acc(a, b, acc[0]);
             }
         }
     }
-    const float sum = row16_sum(acc);
+    const float sum = rowq_sum<LPQ>(acc);
     return (n == 0) ? 1.0f : (-sum) / (float)n;
 }
 
@@ -219,7 +243,8 @@ struct PMJob { const float* A; const float* B; const uint2* Bh; const uint32_t* 
 // 64 queries and stage 1.56 instead of 2.25 region pixels per query. Which query a thread serves does not enter any value: results are unchanged.
 // The staged region limits C = 512 to two workgroups per CU (2 waves per SIMD): telling the compiler so (second launch-bounds argument) lets its scheduler
 // keep a patch row's loads in flight together instead of serialising them to save registers for an occupancy the LDS rules out.
-template <int NCH, int MODE, int TQX, int TQY>
+// LPQ = 8 (C = 64, 128 with fp32 tiles): 32 queries per pass, an 8x4 sub-tile, two queries per DPP row (see pm_dist).
+template <int NCH, int MODE, int TQX, int TQY, int LPQ>
 __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
                                                  unsigned long long* __restrict__ counter) {
     constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2;
@@ -239,7 +264,10 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int ty = bid / g.tiles_x, tx = bid - ty * g.tiles_x;
-    const int grp = threadIdx.x >> 4, v = threadIdx.x & 15;
+    constexpr int QW = LPQ == 16 ? 4 : 8, QH = 256 / LPQ / QW;      // the sub-tile of one pass: QW x QH queries (4x4, 8x4, 8x8)
+    static_assert((4 * TQX) % QW == 0 && (4 * TQY) % QH == 0, "the workgroup's tile must be a whole number of sub-tiles");
+    const int grp = threadIdx.x / LPQ, lane = threadIdx.x % LPQ;
+    const int v = LPQ == 8 ? pm_chunk8(lane) : lane;       // first channel chunk of the lane (v == 0 <=> lane == 0)
     const int ox = tx * 4 * TQX, oy = ty * 4 * TQY;        // origin of the workgroup's query tile
 
     // stage the region of A that the queries of this workgroup read (their 3x3 tiles overlap) into LDS once per launch. Without it every
@@ -260,12 +288,13 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
     if (jump == 1) for (int mag = rs_start; mag >= 1; mag >>= 1) ++nrand;
     unsigned nevals = 0, naccept = 0;
 
+    constexpr int NSX = 4 * TQX / QW, NSUB = NSX * (4 * TQY / QH);
 #pragma unroll 1
-    for (int sub = 0; sub < TQX * TQY; ++sub) {
-        const int sx = sub % TQX, sy = sub / TQX;
-        const int qx = ox + sx * 4 + (grp & 3), qy = oy + sy * 4 + (grp >> 2);
-        if (TQX * TQY > 1 && ox + sx * 4 >= g.aw) continue;                 // sub-tile entirely outside the image (uniform over the workgroup)
-        if (TQX * TQY > 1 && oy + sy * 4 >= g.ah) continue;
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int sx = sub % NSX, sy = sub / NSX;
+        const int qx = ox + sx * QW + (grp % QW), qy = oy + sy * QH + (grp / QW);
+        if (NSUB > 1 && ox + sx * QW >= g.aw) continue;                 // sub-tile entirely outside the image (uniform over the workgroup)
+        if (NSUB > 1 && oy + sy * QH >= g.ah) continue;
         const bool live = qx < g.aw && qy < g.ah;
         const int ax = live ? qx : g.aw - 1, ay = live ? qy : g.ah - 1;
         const int qi = ay * g.aw + ax;
@@ -287,7 +316,7 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
         float dbest;
 
         if (mode == 0) {
-            dbest = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
+            dbest = pm_dist<NCH, MODE, RW, LPQ>(A, B, Bh, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
             float cut = (float)INT_MAX;                 // dist_single default cutoff
             if (dbest >= cut) dbest = cut;
             if (live && v == 0) nevals += 1;
@@ -306,6 +335,11 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
                     const uint32_t vp = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
                     xp = nnf_x(vp) - sxx; yp = nnf_y(vp) - syy;
                     valid = valid && yp >= 0 && yp < g.bh && xp >= 0 && xp < g.bw;
+#ifndef NCT_PM_EVAL_SAME
+                    // a neighbour that proposes the current match cannot improve it (d == dbest is not < dbest): its lanes sit the evaluation out
+                    // (with the wave near the L1 bandwidth limit the unissued tile requests are what is saved, not instructions)
+                    valid = valid && !(xp == xbest && yp == ybest);
+#endif
                     rr = 0.f;
                 } else {
                     const int step = k - 4;
@@ -322,7 +356,7 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
                 }
                 if (valid) {
                     // to win, -sum/9 (+rr) < dbest, i.e. sum > -9 dbest: unreachable sums are cut off (unit-norm features only)
-                    float d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                    float d = pm_dist<NCH, MODE, RW, LPQ>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
                     if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
                     if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; if (live && v == 0) ++naccept; }
                     if (live && v == 0) ++nevals;
@@ -343,15 +377,23 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
 
 // query tile of a workgroup per channel count: 8x8 at C = 64 (25 KB of LDS), 8x4 at C = 128 (31 KB), 4x4 above (37 / 74 KB)
 template <int NCH> struct PMTile { static constexpr int TQX = NCH == 1 ? 2 : (NCH == 2 ? 2 : 1), TQY = NCH == 1 ? 2 : 1; };
+// lanes per query: 8 where it pays (fp32 tiles at C = 64 / 128: the levels bound by VALU issue and the L1 address path), else 16
+#ifndef NCT_PM_LPQ8_MAX
+#define NCT_PM_LPQ8_MAX 1
+#endif
+#ifndef NCT_PM_LPQ
+#define NCT_PM_LPQ 8
+#endif
+template <int NCH, int MODE> struct PMLanes { static constexpr int LPQ = (MODE != NCT_PM_FP16 && NCH >= 1 && NCH <= NCT_PM_LPQ8_MAX) ? NCT_PM_LPQ : 16; };
 template <int NCH, int MODE>
 static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
-    constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY;
+    constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY, LPQ = PMLanes<NCH, MODE>::LPQ;
     const size_t lds = NCH >= 1 ? (size_t)(4 * TQX + 2) * (4 * TQY + 2) * NCH * 16 * sizeof(float4) : 0;      // region pixels x C/4 float4
     // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device; set with the init step
     // of every run (mode 0), i.e. once per PatchMatch and per device the context lives on
     if (lds > 32768 && mode == 0)
-        NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE, TQX, TQY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_pm_step<NCH, MODE, TQX, TQY>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
+        NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE, TQX, TQY, LPQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_pm_step<NCH, MODE, TQX, TQY, LPQ>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
     NCT_LAUNCH_CHECK();
     return 0;
 }

@@ -34,6 +34,27 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
+// The same sum with EIGHT lanes per group, two of the sixteen partial sums per lane: the lane that holds partials j and j + 8 (j < 8) adds
+// them itself (= the row_ror:8 step: p[j] + p[j+8]); the remaining steps pair j with j^4, then j^2, then j^1, which are lane^1 and lane^2
+// (quad permutes) and "the other quad" (row_half_mirror: lane^7 — all four lanes of a quad hold the same bits by then, IEEE addition
+// being commutative) when lane = pm_lane8(j) below. Same binary tree, same result bit for bit.
+__device__ __forceinline__ float half8_sum(float p_lo, float p_hi) {
+    float x = p_lo + p_hi;
+    x = x + dpp_rot<0xB1>(x);    // quad_perm:[1,0,3,2]
+    x = x + dpp_rot<0x4E>(x);    // quad_perm:[2,3,0,1]
+    x = x + dpp_rot<0x141>(x);   // row_half_mirror
+    return x;
+}
+// partial-sum index j (0..7) served by lane l (0..7) of an 8-lane group: bit 2 of j <-> bit 0 of l, bit 1 <-> bit 1, bit 0 <-> bit 2
+// FOUR lanes per group, partials j, j+4, j+8, j+12 in lane j: the row_ror:8 and row_ror:4 steps are in-lane, j^2 and j^1 are quad permutes
+__device__ __forceinline__ float quad4_sum(float p0, float p4, float p8, float p12) {
+    float x = (p0 + p8) + (p4 + p12);
+    x = x + dpp_rot<0x4E>(x);    // quad_perm:[2,3,0,1]
+    x = x + dpp_rot<0xB1>(x);    // quad_perm:[1,0,3,2]
+    return x;
+}
+__device__ __forceinline__ int pm_chunk8(int l) { return ((l & 1) << 2) | (l & 2) | ((l >> 2) & 1); }
+
 __device__ __forceinline__ float dot4_acc(const float4 a, const float4 b, float acc) {
     acc = __builtin_fmaf(a.x, b.x, acc);
     acc = __builtin_fmaf(a.y, b.y, acc);
