@@ -16,7 +16,7 @@ Other workloads (parity-test configurations of BASELINE.json, selectable for sca
 with sides 256..1000 per step, dynamic tickets from the rendezvous store = work stealing across ranks without a collective).
 
 Extra objects:
-  roofline     — the dominant kernel AS THE PIPELINE RUNS IT: k_pm_step<1, 1, 2, 2> (C = 64, finest level, both directions per launch, unit-norm
+  roofline     — the dominant kernel AS THE PIPELINE RUNS IT: k_pm_step<1, 1, 2, 2, 8> (C = 64, finest level, both directions per launch, unit-norm
                  features with the exact row rejection). avg launch time = HIP events recorded on the library's stream around the
                  level's 41 launches of a real pair; `traffic` = fabric-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE
                  x2 gfx950 correction + WRITE_SIZE, separate passes) of THIS build — collected live when rocprofv3 is on PATH, else
@@ -324,13 +324,13 @@ def finish_pmc(vals, bid, how):
         cal = {"k_normalize_700x700x64_bytes": 125440000, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"]["normalize_max"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"]["normalize_max"],
                "fetch_raw_over_actual": vals["FETCH_SIZE"]["normalize_max"] * 1024 / 125440000.0,
                "write_raw_over_actual": (vals["WRITE_SIZE"]["normalize_max"] or 0) * 1024 / 125440000.0}
-    return {"build_id": bid, "how": how, "kernel": "k_pm_step<1, 1, 2, 2>", "dispatches": vals["FETCH_SIZE"]["dispatches"],
+    return {"build_id": bid, "how": how, "kernel": "k_pm_step<1, 1, 2, 2, 8>", "dispatches": vals["FETCH_SIZE"]["dispatches"],
             "FETCH_SIZE_KB_per_dispatch_raw": vals["FETCH_SIZE"]["mean"], "WRITE_SIZE_KB_per_dispatch_raw": vals["WRITE_SIZE"]["mean"],
             "calibration": cal, "corrected_bytes_per_launch": {"fetch": fetch, "write": write, "total": fetch + write}}
 
 
 def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
-    """Finest pyramid level of the resident pair: 41 launches of k_pm_step<1, 1, 2, 2> (init + 10 iterations x 4 jumps, S->R and R->S fields in
+    """Finest pyramid level of the resident pair: 41 launches of k_pm_step<1, 1, 2, 2, 8> (init + 10 iterations x 4 jumps, S->R and R->S fields in
     the same launch). Time: HIP events on the library's stream around exactly those launches (nct_pair_timing.pm_level_ms), best of 3
     pairs; evaluations: device counter in a separate pair (the counting atomics would perturb the timing)."""
     tms = [ctx.pair_run(prm, want_timing=True) for _ in range(3)]
@@ -352,7 +352,7 @@ def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
         if pmc is not None:
             traffic = pmc["corrected_bytes_per_launch"]["total"]
     achieved = (traffic if traffic is not None else alg / n_launch) / launch_s / 1e9
-    return {"bound": "hbm", "kernel": f"k_pm_step<1, 1, 2, 2> (C=64, 8x8 queries per workgroup, {sshape[1]}x{sshape[0]} <-> {rshape[1]}x{rshape[0]}, both directions per launch, pipeline features)",
+    return {"bound": "hbm", "kernel": f"k_pm_step<1, 1, 2, 2, 8> (C=64, 8x8 queries per workgroup, 8 lanes per query, {sshape[1]}x{sshape[0]} <-> {rshape[1]}x{rshape[0]}, both directions per launch, pipeline features)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "basis": "PMC fabric-side bytes (FETCH_SIZE x2 + WRITE_SIZE) per launch / event-timed launch" if traffic is not None else
                      "ALGORITHMIC bytes (no PMC pass of this build available) — not an HBM fraction, can exceed 1",

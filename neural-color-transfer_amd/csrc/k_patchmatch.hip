@@ -9,22 +9,28 @@
 //    tile so that neighbouring queries — whose candidate tiles overlap when the NNF is coherent — share L1/L2);
 //    lane v owns float4 channel chunks v, v+16, …; the 9*C-term dot product is one fmaf chain per lane followed
 //    by a 4-step DPP rotate-add (no LDS traffic, no bpermute). At C = 64 HALF a row serves a query (8 lanes, two of the
-//    sixteen chains each, the same summation tree — rowq_sum): the per-candidate scalar work of a wave instruction
-//    (candidate generation, RNG, tests, addresses, reductions) then serves eight queries, 20.4 -> 17.6 ms per pair at
-//    the finest level; C = 128 (10.7 vs 8.6 ms) and four lanes per query (22.0 ms) measured slower;
+//    sixteen chains each, advanced together by packed FMAs over a lane-interleaved copy of the maps, the same summation
+//    tree — pm_dist8): a wave then keeps eight instead of four candidate tiles in flight;
 //  * the region of A shared by the queries of a workgroup (8x8 queries at C = 64: 10x10xC) is staged once per launch in LDS;
 //  * the racy single launch of the reference becomes 1 + iters*4 Jacobi steps on a double-buffered NNF
 //    (one launch per (iteration, jump)); random search is fused into the jump==1 step; RNG is counter based.
 //    => results are deterministic and bit-identical to oracle/orc_nnf.c.
-// Roofline: memory (gather of candidate tiles): algorithmic bytes = evals*9*C*4 (+ query tile + NNF r/w). What binds it in practice is
-// the L1 (TA/TCP) path — 2.3 KB per evaluation at 64 B/clk/CU — together with VALU issue, not DRAM bytes or latency (DESIGN.md §3.2, §9:
-// perfectly local candidates, half-size fp16 tiles and two tiles in flight per query leave the launch time unchanged or worse).
+// Roofline: memory (gather of candidate tiles): algorithmic bytes = evals*9*C*4 (+ query tile + NNF r/w). Measured at C = 64:
+// DRAM-side traffic 0.55 of the HBM peak, the L1 data return path (64 B/clk/CU) ~90 % busy, VALU issue 43 %, and a wave's candidates are a
+// dependent chain (neighbour NNF -> tile loads -> dot -> compare -> next), so the remaining lever is latency hiding: 8 candidate tiles per
+// wave in flight and five waves per SIMD. Perfectly local candidates, half-size fp16 tiles at this level, packed FMAs (-38 % VALU) each left
+// the launch time unchanged.
 #include "nct_internal.h"
 #include "nct_device.h"
 #include <cfloat>
 #include <climits>
 #include <hip/hip_fp16.h>
 
+// workgroups per CU (= waves per SIMD) the C = 64 kernels are compiled for: the level is latency bound (a wave walks its candidates one after
+// the other), five waves per SIMD hide more of it than four: 16.0 vs 17.4 ms per pair; six (80 registers, spills) 19.1 ms; C = 128 at five: 10.4 vs 8.5 ms
+#ifndef NCT_PM_OCC8
+#define NCT_PM_OCC8 5
+#endif
 #ifndef NCT_PM_FAST_MAX
 #define NCT_PM_FAST_MAX 2
 #endif
@@ -40,23 +46,94 @@ __device__ __forceinline__ float dot4h_acc(const float4 a, const uint2 bh, float
     return acc;
 }
 
+// ---- C = 64, EIGHT lanes per query, packed fp32 FMAs (k_pm_step<1, MODE, .., 8>)
+// A 16-lane row computes two queries: each lane carries TWO of the sixteen fmaf chains of the layout above — chains j and j + 8, the pair the
+// first step of row16_sum adds — so the per-candidate work of a wave instruction (candidate generation, RNG, validity tests, addresses,
+// reductions) serves eight queries, and the two independent chains advance in ONE v_pk_fma_f32 (each half an IEEE fma of its own chain:
+// the same bits as two fmaf). For the packed operands to sit in aligned register pairs the feature maps are read from a lane-interleaved copy
+// (k_pm_interleave64): float4 l of a pixel = [A.x B.x A.y B.y], float4 l + 8 = [A.z B.z A.w B.w] (each load instruction of a query still
+// reads ONE contiguous 128-byte line; 32-byte lane records touched both lines of the pixel per instruction and cost 4 %) with A = channels
+// 4j..4j+3, B = channels 4(j+8)..4(j+8)+3, j = pm_chunk8(l) — so that the remaining reduction steps (j^4, j^2, j^1) are quad permutes and a half-row
+// mirror (half8_sum). Same chains, same tree: NNF and distances are bit-identical to the 16-lane form (tests/test_gpu_correspondence.py).
+typedef float pm_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pm_f2 pk_dot4_acc(const float4 a0, const float4 a1, const float4 b0, const float4 b1, pm_f2 acc) {
+    acc = __builtin_elementwise_fma(pm_f2{a0.x, a0.y}, pm_f2{b0.x, b0.y}, acc);     // x of both chains
+    acc = __builtin_elementwise_fma(pm_f2{a0.z, a0.w}, pm_f2{b0.z, b0.w}, acc);     // y
+    acc = __builtin_elementwise_fma(pm_f2{a1.x, a1.y}, pm_f2{b1.x, b1.y}, acc);     // z
+    acc = __builtin_elementwise_fma(pm_f2{a1.z, a1.w}, pm_f2{b1.z, b1.w}, acc);     // w
+    return acc;
+}
+__global__ void k_pm_interleave64(const float4* __restrict__ src, float4* __restrict__ dst, int npix) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 8) return;
+    const int px = i >> 3, l = i & 7, j = pm_chunk8(l);
+    const float4 a = src[(size_t)px * 16 + j], b = src[(size_t)px * 16 + j + 8];
+    dst[(size_t)px * 16 + l] = make_float4(a.x, b.x, a.y, b.y);
+    dst[(size_t)px * 16 + l + 8] = make_float4(a.z, b.z, a.w, b.w);
+}
+// B, a_lds: interleaved layout; l = lane of the query's 8-lane group. Same contract as pm_dist below.
+template <int MODE, int RW>
+__device__ __forceinline__ float pm_dist8(const float* __restrict__ B, const PMGeom& g, int ax, int ay, unsigned amask, int bx, int by, int l,
+                                          const float4* __restrict__ a_lds, int lx, int ly, float need) {
+    constexpr bool EX = MODE == NCT_PM_ROWREJECT;
+    constexpr int C4 = 16;
+    const bool inside = amask == 0x1FFu && bx >= 1 && bx < g.bw - 1 && by >= 1 && by < g.bh - 1;
+    if (__builtin_amdgcn_ballot_w64(inside) == __builtin_amdgcn_ballot_w64(true)) {
+        const float4* pbc = reinterpret_cast<const float4*>(B) + (size_t)(unsigned)(by * g.bw + bx) * C4 + l;
+        const float4* pac = a_lds + ((ly + 1) * RW + (lx + 1)) * C4 + l;
+        pm_f2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {                 // one patch row at a time; with EX a hopeless candidate stops after a row
+            const float4* pbr = pbc + dy * g.bw * C4;
+            const float4* par = pac + dy * RW * C4;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) acc = pk_dot4_acc(par[dx * C4], par[dx * C4 + 8], pbr[dx * C4], pbr[dx * C4 + 8], acc);
+            if (EX && dy < 1 && need > -FLT_MAX) {
+                const float rem = dy < 0 ? 6.0007f : 3.0004f;
+                if (half8_sum(acc.x, acc.y) + rem < need) return FLT_MAX;
+            }
+        }
+        const float sfull = half8_sum(acc.x, acc.y);
+        if (EX && need > -FLT_MAX && sfull + 1e-4f < need) return FLT_MAX;
+        return (-sfull) / 9.0f;
+    }
+    // border queries / candidates (a few percent of the waves): a patch row at a time, so that this path does not set the kernel's register count
+    pm_f2 acc = {0.f, 0.f};
+    int n = 0;
+#pragma unroll 1
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = by + dy;
+        const int yc = clampi(yy, 0, g.bh - 1);
+        float4 b0[3], b1[3]; bool valid[3];
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = bx + dx, t = (dy + 1) * 3 + dx + 1;
+            valid[dx + 1] = ((amask >> t) & 1u) && yy >= 0 && yy < g.bh && xx >= 0 && xx < g.bw;
+            const float4* pb = reinterpret_cast<const float4*>(B + ((size_t)yc * g.bw + clampi(xx, 0, g.bw - 1)) * 64) + l;
+            b0[dx + 1] = pb[0]; b1[dx + 1] = pb[8];
+        }
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const float4* pa = a_lds + ((ly + 1 + dy) * RW + (lx + 1 + dx)) * C4 + l;
+            n += valid[dx + 1] ? 1 : 0;
+            float4 c0 = b0[dx + 1], c1 = b1[dx + 1];
+            if (!valid[dx + 1]) { c0 = make_float4(0.f, 0.f, 0.f, 0.f); c1 = c0; }     // adding +0 products == skipping the tap
+            acc = pk_dot4_acc(pa[0], pa[8], c0, c1, acc);
+        }
+    }
+    const float sum = half8_sum(acc.x, acc.y);
+    return (n == 0) ? 1.0f : (-sum) / (float)n;
+}
+
 // ---- distance of query (ax,ay) to candidate (bx,by): -(sum over valid taps of <a,b>) / n_valid
 // `need`: early-rejection threshold on the tap sum for UNIT-NORM features (every per-pixel vector has norm <= 1, so a tap adds at most 1
 // by Cauchy-Schwarz): a candidate whose partial sum after a patch row cannot reach `need` any more cannot beat the current best and
 // its remaining rows are not fetched (the caller gets FLT_MAX = "not better"). -FLT_MAX disables the test. That is MODE NCT_PM_ROWREJECT;
 // NCT_PM_FP16 (opt-in reduced precision) reads the candidate tile from the fp16 shadow map Bh instead of B (fp32 accumulate).
-// LPQ = lanes per query: 16 (lane v owns channel chunks v, v+16, ...: one fmaf chain) or 8 (the lane owns the chains of chunks v and v+8 of the
-// 16-lane layout, v = pm_chunk8(lane): the candidate generation, tests, address arithmetic and reductions of a wave instruction then serve
-// eight queries instead of four; same chains and the same summation tree, hence the same bits).
-template <int LPQ> __device__ __forceinline__ float rowq_sum(const float (&f)[16 / LPQ]) {
-    if constexpr (LPQ == 16) return row16_sum(f[0]); else if constexpr (LPQ == 8) return half8_sum(f[0], f[1]); else return quad4_sum(f[0], f[1], f[2], f[3]);
-}
-template <int NCH, int MODE, int RW, int LPQ>
+template <int NCH, int MODE, int RW>
 __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const float* __restrict__ B, const uint2* __restrict__ Bh, const PMGeom& g, int ax, int ay, unsigned amask,
                                          int bx, int by, int v, const float4* __restrict__ a_lds, int lx, int ly, float need) {
     constexpr bool EX = MODE == NCT_PM_ROWREJECT, HALF = MODE == NCT_PM_FP16;
-    constexpr int NACC = 16 / LPQ;
-    static_assert(LPQ == 16 || ((LPQ == 8 || LPQ == 4) && !HALF && NCH >= 1), "8 / 4 lanes per query: fp32 tiles, C a multiple of 64");
     // Fast path: when every tap of the query AND of the candidate lies inside its image — for every query of the wave, so the
     // branch is uniform — the nine B rows are the centre pointer plus wave-uniform offsets, the nine LDS rows are immediates,
     // nothing is masked and n = 9: ~70 VALU instructions per evaluation instead of ~270 (clamps, validity tests, selects and 64-bit
@@ -64,33 +141,18 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
     // to bound the loads in flight): the kernel is bound by the L2-miss traffic (5.4 TB/s on the fabric side, PMC FETCH_SIZE), not by
     // issue slots; for C >= 256 the fast path measured slower (the LDS-staged 36-73 KB query regions already limit occupancy), so
     // those instantiations keep the general loop.
+    static_assert(NCH != 1, "C = 64 has its own 8-lane forms (pm_dist8, pm_dist8h)");
     if constexpr (NCH >= 1 && (HALF || NCH <= NCT_PM_FAST_MAX)) {
         const bool inside = amask == 0x1FFu && bx >= 1 && bx < g.bw - 1 && by >= 1 && by < g.bh - 1;
         if (__builtin_amdgcn_ballot_w64(inside) == __builtin_amdgcn_ballot_w64(true)) {
             constexpr int C4 = 16 * NCH;
             if constexpr (HALF) {
-                // half-size tiles through FULL-WIDTH (16-byte) loads: the kernel is bound by the number of vector-memory instructions the
-                // L1 address path (TA) has to process, not by bytes, so the fp16 tile is read as 16-byte units (8 channels) — a pixel is
-                // 8 * NCH units; at C = 64 one instruction of the 16-lane row fetches TWO pixels (lanes 0-7 / 8-15): 5 loads per tile
-                // instead of 9, C = 128: 9 instead of 18, …
+                // half-size tiles through FULL-WIDTH (16-byte) loads: what limits these levels is the number of vector-memory instructions and the
+                // bytes the L1 returns, so the fp16 tile is read as 16-byte units (8 channels) — a pixel is 8 * NCH units: C = 128: 9 loads per
+                // tile instead of 18, … (C = 64 has its own 8-lane form, pm_dist8h)
                 const uint4* ph = reinterpret_cast<const uint4*>(Bh);
                 float h = 0.f;
-                if constexpr (NCH == 1) {
-                    const int vh = v & 7, hi = v >> 3;
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        const int t = 2 * j + hi;
-                        const bool on = t < 9;
-                        const int tt = on ? t : 8;
-                        const int dy = tt / 3 - 1, dx = tt - (dy + 1) * 3 - 1;
-                        uint4 raw = ph[(size_t)(unsigned)((by + dy) * g.bw + bx + dx) * 8 + vh];
-                        const float4* pa = a_lds + ((ly + 1 + dy) * RW + (lx + 1 + dx)) * C4 + 2 * vh;
-                        const float4 a0 = pa[0], a1 = pa[1];
-                        if (!on) raw = make_uint4(0u, 0u, 0u, 0u);
-                        h = dot4h_acc(a0, make_uint2(raw.x, raw.y), h);
-                        h = dot4h_acc(a1, make_uint2(raw.z, raw.w), h);
-                    }
-                } else {
+                {
                     constexpr int U = 8 * NCH;                     // 16-byte units per pixel (>= 16: every lane of the row reads U/16 units of one pixel)
                     auto tap = [&](int dy, int dx) {
                         const uint4* pp = ph + (size_t)(unsigned)((by + dy) * g.bw + bx + dx) * U + v;
@@ -132,9 +194,7 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
             }
             const float4* pbc = reinterpret_cast<const float4*>(B) + (size_t)(unsigned)(by * g.bw + bx) * C4 + v;
             const float4* pac = a_lds + ((ly + 1) * RW + (lx + 1)) * C4 + v;
-            float facc[NACC];
-#pragma unroll
-            for (int q = 0; q < NACC; ++q) facc[q] = 0.f;
+            float facc = 0.f;
             if constexpr (EX) {
                 // one patch row at a time; a hopeless candidate stops after a row
                 // (margins: a tap of unit vectors adds <= 1 + 2e-6, fp32 accumulation error < 1e-4)
@@ -145,26 +205,17 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
-                        for (int k = 0; k < NCH; ++k)
-#pragma unroll
-                            for (int q = 0; q < NACC; ++q) facc[q] = dot4_acc(par[dx * C4 + 16 * k + LPQ * q], pbr[dx * C4 + 16 * k + LPQ * q], facc[q]);
+                        for (int k = 0; k < NCH; ++k) facc = dot4_acc(par[dx * C4 + 16 * k], pbr[dx * C4 + 16 * k], facc);
                     if (dy < 1 && need > -FLT_MAX) {
                         const float rem = dy < 0 ? 6.0007f : 3.0004f;
-                        if (rowq_sum<LPQ>(facc) + rem < need) return FLT_MAX;
+                        if (row16_sum(facc) + rem < need) return FLT_MAX;
                     }
                 }
                 // the complete sum: a candidate 1e-4 short of `need` = -9 dbest loses by > 1e-5 in distance, far outside the rounding of the
                 // product and of the division — rejected without paying for the correctly rounded division (~10 VALU instructions)
-                const float sfull = rowq_sum<LPQ>(facc);
+                const float sfull = row16_sum(facc);
                 if (need > -FLT_MAX && sfull + 1e-4f < need) return FLT_MAX;
                 return (-sfull) / 9.0f;
-            } else if constexpr (NCH == 1) {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {                      // all nine loads in flight
-                    const int dy = t / 3 - 1, dx = t % 3 - 1;
-#pragma unroll
-                    for (int q = 0; q < NACC; ++q) facc[q] = dot4_acc(pac[(dy * RW + dx) * C4 + LPQ * q], pbc[(dy * g.bw + dx) * C4 + LPQ * q], facc[q]);
-                }
             } else {
                 // one patch row (3 taps x NCH chunks) at a time: bounds the loads in flight, and with them the register count
 #pragma unroll 1
@@ -174,17 +225,13 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
-                        for (int k = 0; k < NCH; ++k)
-#pragma unroll
-                            for (int q = 0; q < NACC; ++q) facc[q] = dot4_acc(par[dx * C4 + 16 * k + LPQ * q], pbr[dx * C4 + 16 * k + LPQ * q], facc[q]);
+                        for (int k = 0; k < NCH; ++k) facc = dot4_acc(par[dx * C4 + 16 * k], pbr[dx * C4 + 16 * k], facc);
                 }
             }
-            return (-rowq_sum<LPQ>(facc)) / 9.0f;
+            return (-row16_sum(facc)) / 9.0f;
         }
     }
-    float acc[NACC];
-#pragma unroll
-    for (int q = 0; q < NACC; ++q) acc[q] = 0.f;
+    float acc = 0.f;
     int n = 0;
     const int nchunk = g.C >> 2;
 #pragma unroll
@@ -202,19 +249,15 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
         if constexpr (NCH > 0) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
+                float4 a = pa[v + 16 * k];
                 if constexpr (HALF) {
-                    float4 a = pa[v + 16 * k];
                     uint2 b = Bh[((size_t)yc * g.bw + xc) * (size_t)nchunk + v + 16 * k];
                     if (!valid) b = make_uint2(0u, 0u);
-                    acc[0] = dot4h_acc(a, b, acc[0]);
+                    acc = dot4h_acc(a, b, acc);
                 } else {
-#pragma unroll
-                    for (int q = 0; q < NACC; ++q) {
-                        float4 a = pa[v + 16 * k + LPQ * q];
-                        float4 b = pb[v + 16 * k + LPQ * q];
-                        if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);     // adding +0 products == skipping the tap
-                        acc[q] = dot4_acc(a, b, acc[q]);
-                    }
+                    float4 b = pb[v + 16 * k];
+                    if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);     // adding +0 products == skipping the tap
+                    acc = dot4_acc(a, b, acc);
                 }
             }
         } else {
@@ -222,11 +265,11 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
                 float4 a = pa[j];
                 float4 b = pb[j];
                 if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);
-                acc[0] = dot4_acc(a, b, acc[0]);
+                acc = dot4_acc(a, b, acc);
             }
         }
     }
-    const float sum = rowq_sum<LPQ>(acc);
+    const float sum = row16_sum(acc);
     return (n == 0) ? 1.0f : (-sum) / (float)n;
 }
 
@@ -245,7 +288,7 @@ struct PMJob { const float* A; const float* B; const uint2* Bh; const uint32_t* 
 // keep a patch row's loads in flight together instead of serialising them to save registers for an occupancy the LDS rules out.
 // LPQ = 8 (C = 64, 128 with fp32 tiles): 32 queries per pass, an 8x4 sub-tile, two queries per DPP row (see pm_dist).
 template <int NCH, int MODE, int TQX, int TQY, int LPQ>
-__global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
+__global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
                                                  unsigned long long* __restrict__ counter) {
     constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2;
     const bool second = (int)blockIdx.x >= nblk0;
@@ -264,10 +307,10 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int ty = bid / g.tiles_x, tx = bid - ty * g.tiles_x;
-    constexpr int QW = LPQ == 16 ? 4 : 8, QH = 256 / LPQ / QW;      // the sub-tile of one pass: QW x QH queries (4x4, 8x4, 8x8)
-    static_assert((4 * TQX) % QW == 0 && (4 * TQY) % QH == 0, "the workgroup's tile must be a whole number of sub-tiles");
+    constexpr int QW = LPQ == 16 ? 4 : 8, QH = 256 / LPQ / QW;      // the sub-tile of one pass: QW x QH queries (4x4 or 8x4)
+    static_assert((LPQ == 16 || (LPQ == 8 && NCH == 1 && MODE != NCT_PM_FP16)) && (4 * TQX) % QW == 0 && (4 * TQY) % QH == 0, "8 lanes per query: C = 64, fp32 tiles");
     const int grp = threadIdx.x / LPQ, lane = threadIdx.x % LPQ;
-    const int v = LPQ == 8 ? pm_chunk8(lane) : lane;       // first channel chunk of the lane (v == 0 <=> lane == 0)
+    const int v = lane;                                     // LPQ 16: the lane's channel chunk; LPQ 8: its 32-byte record of the interleaved pixel
     const int ox = tx * 4 * TQX, oy = ty * 4 * TQY;        // origin of the workgroup's query tile
 
     // stage the region of A that the queries of this workgroup read (their 3x3 tiles overlap) into LDS once per launch. Without it every
@@ -316,7 +359,8 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
         float dbest;
 
         if (mode == 0) {
-            dbest = pm_dist<NCH, MODE, RW, LPQ>(A, B, Bh, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
+            if constexpr (LPQ == 8) dbest = pm_dist8<MODE, RW>(B, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
+            else dbest = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xbest, ybest, v, s_a, lx, ly, -FLT_MAX);
             float cut = (float)INT_MAX;                 // dist_single default cutoff
             if (dbest >= cut) dbest = cut;
             if (live && v == 0) nevals += 1;
@@ -356,7 +400,9 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
                 }
                 if (valid) {
                     // to win, -sum/9 (+rr) < dbest, i.e. sum > -9 dbest: unreachable sums are cut off (unit-norm features only)
-                    float d = pm_dist<NCH, MODE, RW, LPQ>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                    float d;
+                    if constexpr (LPQ == 8) d = pm_dist8<MODE, RW>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                    else d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
                     if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
                     if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; if (live && v == 0) ++naccept; }
                     if (live && v == 0) ++nevals;
@@ -377,17 +423,12 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : 1) void k_pm_step(PMJob j0, PMJ
 
 // query tile of a workgroup per channel count: 8x8 at C = 64 (25 KB of LDS), 8x4 at C = 128 (31 KB), 4x4 above (37 / 74 KB)
 template <int NCH> struct PMTile { static constexpr int TQX = NCH == 1 ? 2 : (NCH == 2 ? 2 : 1), TQY = NCH == 1 ? 2 : 1; };
-// lanes per query: 8 where it pays (fp32 tiles at C = 64 / 128: the levels bound by VALU issue and the L1 address path), else 16
-#ifndef NCT_PM_LPQ8_MAX
-#define NCT_PM_LPQ8_MAX 1
-#endif
-#ifndef NCT_PM_LPQ
-#define NCT_PM_LPQ 8
-#endif
-template <int NCH, int MODE> struct PMLanes { static constexpr int LPQ = (MODE != NCT_PM_FP16 && NCH >= 1 && NCH <= NCT_PM_LPQ8_MAX) ? NCT_PM_LPQ : 16; };
+// lanes per query: 8 at C = 64 (pm_dist8), else 16. Measured alternatives (two unpacked chains per lane): C = 128 with 8 lanes
+// 10.7 vs 8.6 ms, C = 64 with 4 lanes 22.0 vs 17.6 ms per pair and level.
+template <int NCH> struct PMLanes { static constexpr int LPQ = NCH == 1 ? 8 : 16; };
 template <int NCH, int MODE>
 static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
-    constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY, LPQ = PMLanes<NCH, MODE>::LPQ;
+    constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY, LPQ = PMLanes<NCH>::LPQ;
     const size_t lds = NCH >= 1 ? (size_t)(4 * TQX + 2) * (4 * TQY + 2) * NCH * 16 * sizeof(float4) : 0;      // region pixels x C/4 float4
     // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device; set with the init step
     // of every run (mode 0), i.e. once per PatchMatch and per device the context lives on
@@ -400,7 +441,10 @@ static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob
 
 template <int NCH>
 static int launch_step(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter, int pm_mode) {
-    if (NCH >= 1 && pm_mode == NCT_PM_FP16) return launch_mode<NCH, NCT_PM_FP16>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter);
+    // fp16 tiles from C = 128 on. The C = 64 level is latency bound — a wave walks its candidates one after the other — not byte bound: with
+    // fp16 tiles on the 8-lane kernel (one 16-byte load per lane and tap) it took 15.8 vs 16.0 ms per pair, so it keeps the exact fp32 tiles.
+    if constexpr (NCH >= 2) { if (pm_mode == NCT_PM_FP16) return launch_mode<NCH, NCT_PM_FP16>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter); }
+    if (NCH == 1 && pm_mode == NCT_PM_FP16) pm_mode = NCT_PM_PLAIN;
     // unit-norm features (the pipeline): the instantiation with the exact early rejection; it exists for the C with an fp32 interior fast path
     if (NCH >= 1 && NCH <= NCT_PM_FAST_MAX && pm_mode == NCT_PM_ROWREJECT) return launch_mode<NCH, NCT_PM_ROWREJECT>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter);
     return launch_mode<NCH, NCT_PM_PLAIN>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter);
@@ -416,10 +460,19 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
     NCT_REQUIRE(pm_mode >= NCT_PM_PLAIN && pm_mode <= NCT_PM_FP16, "patchmatch: unknown evaluation mode %d", pm_mode);
     const bool two = bnn != nullptr;
     if (pm_mode == NCT_PM_FP16) {
-        NCT_REQUIRE(b_h16 && (!two || a_h16), "patchmatch: the fp16 mode needs the fp16 shadow maps");
+        NCT_REQUIRE(C == 64 || (b_h16 && (!two || a_h16)), "patchmatch: the fp16 mode needs the fp16 shadow maps");      // C = 64 stays fp32 (launch_step)
         NCT_REQUIRE(C == 64 || C == 128 || C == 256 || C == 512, "patchmatch: the fp16 mode exists for C = 64, 128, 256, 512 (got %d)", C);
     }
     const int na = ah * aw, nb = bh * bw;
+    // C = 64 runs on lane-interleaved copies of both maps (pm_dist8): written once per PatchMatch from the natural maps
+    const bool lanes8 = C == 64;
+    DevBuf<float> a_il(ctx, lanes8 ? (size_t)na * 64 : 1), b_il(ctx, lanes8 ? (size_t)nb * 64 : 1);
+    if (!a_il.ok() || !b_il.ok()) return NCT_ERR_HIP;
+    if (lanes8) {
+        hipLaunchKernelGGL(k_pm_interleave64, dim3(cdiv(na * 8, 256)), dim3(256), 0, s, (const float4*)a_hwc, (float4*)(float*)a_il, na); NCT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pm_interleave64, dim3(cdiv(nb * 8, 256)), dim3(256), 0, s, (const float4*)b_hwc, (float4*)(float*)b_il, nb); NCT_LAUNCH_CHECK();
+        a_hwc = a_il; b_hwc = b_il;
+    }
     DevBuf<uint32_t> a_tmp(ctx, na), b_tmp(ctx, two ? nb : 1);
     DevBuf<float> ad_tmp(ctx, na), bd_tmp(ctx, two ? nb : 1);
     if (!a_tmp.ok() || !b_tmp.ok() || !ad_tmp.ok() || !bd_tmp.ok()) return NCT_ERR_HIP;

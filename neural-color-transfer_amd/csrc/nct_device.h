@@ -46,13 +46,6 @@ __device__ __forceinline__ float half8_sum(float p_lo, float p_hi) {
     return x;
 }
 // partial-sum index j (0..7) served by lane l (0..7) of an 8-lane group: bit 2 of j <-> bit 0 of l, bit 1 <-> bit 1, bit 0 <-> bit 2
-// FOUR lanes per group, partials j, j+4, j+8, j+12 in lane j: the row_ror:8 and row_ror:4 steps are in-lane, j^2 and j^1 are quad permutes
-__device__ __forceinline__ float quad4_sum(float p0, float p4, float p8, float p12) {
-    float x = (p0 + p8) + (p4 + p12);
-    x = x + dpp_rot<0x4E>(x);    // quad_perm:[2,3,0,1]
-    x = x + dpp_rot<0xB1>(x);    // quad_perm:[1,0,3,2]
-    return x;
-}
 __device__ __forceinline__ int pm_chunk8(int l) { return ((l & 1) << 2) | (l & 2) | ((l >> 2) & 1); }
 
 __device__ __forceinline__ float dot4_acc(const float4 a, const float4 b, float acc) {
