@@ -366,6 +366,14 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
             if (live && v == 0) nevals += 1;
         } else {
             dbest = d_in[qi];
+            // the four neighbours' matches are independent of the evaluations: all four loads are issued together, in front of the candidate walk
+            // (inside the loop each would be one more dependent round trip per candidate)
+            uint32_t vnb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int nx = ax + ((k == 0) ? -jump : (k == 1 ? jump : 0)), ny = ay + ((k == 2) ? -jump : (k == 3 ? jump : 0));
+                vnb[k] = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
+            }
             int mag = rs_start;
             const int ncand = 4 + nrand;
             for (int k = 0; k < ncand; ++k) {
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
                     const int syy = (k == 2) ? -jump : (k == 3 ? jump : 0);
                     const int nx = ax + sxx, ny = ay + syy;
                     valid = nx >= 0 && nx < g.aw && ny >= 0 && ny < g.ah;
-                    const uint32_t vp = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
+                    const uint32_t vp = k == 0 ? vnb[0] : (k == 1 ? vnb[1] : (k == 2 ? vnb[2] : vnb[3]));
                     xp = nnf_x(vp) - sxx; yp = nnf_y(vp) - syy;
                     valid = valid && yp >= 0 && yp < g.bh && xp >= 0 && xp < g.bw;
 #ifndef NCT_PM_EVAL_SAME
