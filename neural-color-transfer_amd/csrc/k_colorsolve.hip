@@ -314,14 +314,19 @@ __global__ void k_cg_beta(const double* __restrict__ partial, int nb, CGState* _
         if (st->active[c]) { st->r0[c] = st->r1[c]; st->r1[c] = s[c]; st->vb[c] = s[c] / st->r0[c]; st->iters[c]++; st->active[c] = s[c] > tol2 ? 1 : 0; }
     }
 }
-__global__ void k_s1_dir(int n, const CGState* __restrict__ st, const double* __restrict__ r, double* __restrict__ p, int first) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over 2*n*3 scalars
-    if (i >= 2 * n * 3) return;
-    const int c = i % 3;
-    if (!st->active[c]) return;
-    const int part = i / (n * 3), px = (i - part * n * 3) / 3;
-    const size_t j = (size_t)px * 6 + part * 3 + c;            // p is interleaved [pixel][6]; r stays [part][pixel][3]
-    p[j] = first ? r[i] : st->vb[c] * p[j] + r[i];
+// thread per pixel (both parts): p (interleaved [pixel][6]) is one contiguous 48-byte record per thread, r ([part][pixel][3]) two dense streams
+__global__ __launch_bounds__(256) void k_s1_dir(int n, const CGState* __restrict__ st, const double* __restrict__ r, double* __restrict__ p, int first) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (!st->active[c]) continue;
+            const size_t j = (size_t)i * 6 + part * 3 + c;
+            const double rv = r[((size_t)part * n + i) * 3 + c];
+            p[j] = first ? rv : st->vb[c] * p[j] + rv;
+        }
 }
 // ---- fused variants for levels with few partial sums (nb <= S1_FUSE_NB): the two single-workgroup kernels of an iteration
 // (k_cg_alpha, k_cg_beta: ~5 us each, pure latency) disappear — EVERY workgroup of the following vector kernel repeats the
@@ -545,7 +550,7 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         } else {
             hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2, 3); LCHK();
             for (int k = 1; k <= maxit; ++k) {
-                hipLaunchKernelGGL(k_s1_dir, dim3(cdiv(6 * n, 256)), dim3(256), 0, s, n, (const CGState*)st, (const double*)r, (double*)p, k == 1 ? 1 : 0); LCHK();
+                hipLaunchKernelGGL(k_s1_dir, dim3(nbl), dim3(256), 0, s, n, (const CGState*)st, (const double*)r, (double*)p, k == 1 ? 1 : 0); LCHK();
                 if (coop) hipLaunchKernelGGL(k_s1_apply<true>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial);
                 else      hipLaunchKernelGGL(k_s1_apply<false>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial);
                 LCHK();
