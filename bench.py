@@ -287,13 +287,14 @@ def pmc_traffic(device, live):
     if live and exe:
         try:
             vals = {}
-            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            for ctrs in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE")):
                 with tempfile.TemporaryDirectory(dir="/tmp") as td:
                     env = dict(os.environ, TMPDIR="/tmp", HIP_VISIBLE_DEVICES=str(device))
-                    subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", td, "-o", "c", "--output-format", "csv", "--",
+                    subprocess.run([exe, "--pmc", *ctrs, "--kernel-trace", "-d", td, "-o", "c", "--output-format", "csv", "--",
                                     sys.executable, os.path.join(REPO, "scripts", "pair_only.py"), "700", "2"],
                                    cwd=REPO, env=env, check=True, capture_output=True, timeout=300)
-                    vals[ctr] = read_pmc_csv(td, ctr)
+                    for ctr in ctrs:
+                        vals[ctr] = read_pmc_csv(td, ctr)
             return finish_pmc(vals, bid, "live rocprofv3 passes inside bench.py"), "live"
         except Exception as e:      # noqa: BLE001 — fall back to the recorded passes
             why = f"live PMC failed: {type(e).__name__}: {str(e)[:120]}"
@@ -324,9 +325,16 @@ def finish_pmc(vals, bid, how):
         cal = {"k_normalize_700x700x64_bytes": 125440000, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"]["normalize_max"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"]["normalize_max"],
                "fetch_raw_over_actual": vals["FETCH_SIZE"]["normalize_max"] * 1024 / 125440000.0,
                "write_raw_over_actual": (vals["WRITE_SIZE"]["normalize_max"] or 0) * 1024 / 125440000.0}
+    # L1 side: vector-memory read instructions x 64 lanes x 16 bytes (the candidate-tile loads; the ~6 % of 4-byte NNF loads make this an upper
+    # bound) against what 256 L1s return in the launch's own cycles (GRBM_GUI_ACTIVE counts per XCD: / 8) at 64 bytes per clock and CU
+    l1 = None
+    if "SQ_INSTS_VMEM_RD" in vals:
+        cyc = vals["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+        l1 = {"vmem_read_instructions_per_launch": vals["SQ_INSTS_VMEM_RD"]["mean"], "bytes_per_launch_upper_bound": vals["SQ_INSTS_VMEM_RD"]["mean"] * 1024.0,
+              "launch_cycles": cyc, "frac_of_l1_return_bandwidth": vals["SQ_INSTS_VMEM_RD"]["mean"] * 1024.0 / (cyc * 256 * 64)}
     return {"build_id": bid, "how": how, "kernel": "k_pm_step<1, 1, 2, 2, 8>", "dispatches": vals["FETCH_SIZE"]["dispatches"],
             "FETCH_SIZE_KB_per_dispatch_raw": vals["FETCH_SIZE"]["mean"], "WRITE_SIZE_KB_per_dispatch_raw": vals["WRITE_SIZE"]["mean"],
-            "calibration": cal, "corrected_bytes_per_launch": {"fetch": fetch, "write": write, "total": fetch + write}}
+            "calibration": cal, "corrected_bytes_per_launch": {"fetch": fetch, "write": write, "total": fetch + write}, "l1": l1}
 
 
 def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
@@ -359,8 +367,9 @@ def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
             "traffic_source": how, "pmc": pmc, "launches": n_launch, "avg_launch_ms": 1e3 * launch_s, "evals": evals,
             "algorithmic_bytes_per_launch": alg / n_launch, "algorithmic_GBs": alg_gbs,
             "traffic_over_algorithmic": None if traffic is None else traffic / (alg / n_launch),
-            "note": "the kernel is bound by the L1 (TA/TCP) request path, not by DRAM bytes: overlapping candidate tiles are served by L1/L2, so the "
-                    "no-reuse byte model (algorithmic_GBs) exceeds the HBM peak; see DESIGN.md 3.2 for the experiments"}
+            "l1_frac": None if not (pmc and pmc.get("l1")) else pmc["l1"]["frac_of_l1_return_bandwidth"],
+            "note": "frac is the DRAM-side demand; the kernel itself is latency bound close to what the 256 L1s can return (l1_frac, 64 B/clk/CU): "
+                    "overlapping candidate tiles are served by L1/L2, so the no-reuse byte model (algorithmic_GBs) exceeds the HBM peak; DESIGN.md 3.2"}
 
 
 def vgg_mfma(sh, sw, rh, rw, levels, vgg_ms):
