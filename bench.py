@@ -243,6 +243,16 @@ def main():
     t1 = time.perf_counter()
     ctx.pair_run(prm)
     single_pair_s = time.perf_counter() - t1
+    # the same pair with NCT_FLAG_LATENCY (a-/b-halves of the WLS solves on two streams: more launches, same bytes, same result)
+    plat = nct.Params.default()
+    for k, _ in nct.Params._fields_:
+        setattr(plat, k, getattr(prm, k))
+    plat.flags |= nct.FLAG_LATENCY
+    ctx.pair_run(plat)
+    t1 = time.perf_counter()
+    ctx.pair_run(plat)
+    single_pair_latency_s = time.perf_counter() - t1
+    latency_checksum = int(np.asarray(ctx.pair_download(), dtype=np.uint64).sum())
     stages = ctx.pair_run(prm, want_timing=True)
     out = ctx.pair_download()
 
@@ -260,8 +270,10 @@ def main():
         "rccl_ranks": rccl_ranks,
         "host_to_host_pairs_per_s": host_to_host,
         "single_pair_ms": 1e3 * single_pair_s,
+        "single_pair_latency_flag_ms": 1e3 * single_pair_latency_s,
         "stages_ms": stages,
         "output_checksum": int(out.astype(np.uint64).sum()),
+        "latency_flag_output_identical": latency_checksum == int(out.astype(np.uint64).sum()),
         "build_id": lib_build_id(),
     }
     res["vgg_mfma"] = vgg_mfma(src.shape[0], src.shape[1], ref.shape[0], ref.shape[1], prm.levels, stages["vgg_ms"])

@@ -111,6 +111,8 @@ typedef struct nct_params {
 #define NCT_FLAG_FEAT16      1u   /* opt-in reduced precision: PatchMatch reads fp16 candidate feature tiles (fp32 accumulate). Halves the
                                      dominant kernel's bytes; the result is NOT bit-identical to the fp32 path (report PSNR against it) */
 #define NCT_FLAG_COUNT_EVALS 2u   /* profiling: count PatchMatch evaluations per level on the device (nct_pair_timing.pm_level_evals …) */
+#define NCT_FLAG_LATENCY     4u   /* one pair in flight on this GPU: spend extra launches on its latency — the a- and b-halves of each WLS solve
+                                     run concurrently on two streams. Same result bit for bit; with several pairs in flight it only adds launches */
 void nct_params_default(nct_params* p);
 
 /* ---- A1 + third-party (OpenCV 2.4.10) arithmetic used on the path: cvtColor(CV_BGR2Lab / CV_Lab2BGR) on 8U

@@ -22,10 +22,13 @@
 #include "nct_device.h"
 #include <vector>
 #include <cstring>
+#include <string>
+#include <thread>
+#include <cstdarg>
 
 namespace {
 constexpr double OMEGA = 0.8;
-constexpr int NQ = 6;
+constexpr int NQMAX = 6;      // right-hand sides of a solve: 6 (a and b of the 3 Lab channels) or 3 + 3 on two streams (template parameter NQ)
 #ifndef NCT_MG_TXB
 #define NCT_MG_TXB 48
 #define NCT_MG_TYB 8
@@ -126,7 +129,7 @@ __device__ __forceinline__ void mg_final_reduce_strided(const double* __restrict
 }
 
 // y = M v at pixel i of a level (diag*v - sum_w w*v_nbr, neighbour order +x, -x, +y, -y)
-template <typename F>
+template <int NQ, typename F>
 __device__ __forceinline__ void lvl_op(const Lvl& L, int i, F&& val /* val(j, q) */, double (&y)[NQ]) {
     const int W = L.W, H = L.H;
     const int r = i / W, c = i - r * W;
@@ -204,7 +207,7 @@ __device__ __forceinline__ PxCoef px_coef(const Lvl& L, int gy, int gx) {
     return c;
 }
 // y = M v at the pixel stored at LDS position p of a grid with row pitch LW (same operation order as lvl_op: +x, -x, +y, -y)
-template <int LW, int LN>
+template <int NQ, int LW, int LN>
 __device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s_v, int p, vf (&y)[NQ]) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) y[q] = c.d * s_v[q * LN + p];
@@ -223,7 +226,7 @@ __device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s
 }
 constexpr int mg_threads(int TX, int TY) { return ((TX + 4) * (TY + 4) + 63) / 64 * 64; }
 // TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below.
-template <int TX, int TY, typename TB>
+template <int NQ, int TX, int TY, typename TB>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc) {
     if (st->nactive == 0) return;
     constexpr int LW = TX + 4, LH = TY + 4, LN = LW * LH;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
     }
     __syncthreads();
     if (ring1) {
-        vf y[NQ]; lds_op<LW, LN>(c, s_a, p, y);
+        vf y[NQ]; lds_op<NQ, LW, LN>(c, s_a, p, y);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const vf v = x1[q] + (bq[q] - y[q]) * c.dinv;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
     }
     __syncthreads();
     if (interior) {
-        vf yv[NQ]; lds_op<LW, LN>(c, s_b, p, yv);
+        vf yv[NQ]; lds_op<NQ, LW, LN>(c, s_b, p, yv);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) s_a[q * LN + p] = bq[q] - yv[q];
     }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
     }
 }
 // xo must not alias x (neighbouring tiles still read x for their halo)
-template <int TX, int TY, typename TB>
+template <int NQ, int TX, int TY, typename TB>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __restrict__ st, Lvl L, const TB* __restrict__ b, const vf* __restrict__ x, int Wc, int nc,
                                                               const vf* __restrict__ ec, vf* __restrict__ xo) {
     if (st->nactive == 0) return;
@@ -304,13 +307,13 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
     __syncthreads();
     vf x2[NQ];
     if (ring1) {
-        vf y[NQ]; lds_op<LW, LN>(c, s_a, p, y);
+        vf y[NQ]; lds_op<NQ, LW, LN>(c, s_a, p, y);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { x2[q] = xe[q] + (bq[q] - y[q]) * c.dinv; s_b[q * LN + p] = x2[q]; }
     }
     __syncthreads();
     if (interior) {
-        vf y[NQ]; lds_op<LW, LN>(c, s_b, p, y);
+        vf y[NQ]; lds_op<NQ, LW, LN>(c, s_b, p, y);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = x2[q] + (bq[q] - y[q]) * c.dinv;
     }
@@ -497,14 +500,15 @@ __global__ __launch_bounds__(MID_T) void k_mg_mid(const PState* __restrict__ st,
 // ---- PCG pieces at the fine level
 
 // x6 = interleave(X); r = rough*x0 - M x0 ; partial: rr, bb (12)
+template <int NQ>
 __global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restrict__ X /*[2][n][3]*/, double* __restrict__ x6, double* __restrict__ r, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    double acc[12];
+    double acc[2 * NQ];
 #pragma unroll
-    for (int q = 0; q < 12; ++q) acc[q] = 0.0;
+    for (int q = 0; q < 2 * NQ; ++q) acc[q] = 0.0;
     if (i < L.n) {
         auto xv = [&](int j, int q) { return X[((size_t)(q / 3) * L.n + j) * 3 + (q % 3)]; };
-        double y[NQ]; lvl_op(L, i, xv, y);
+        double y[NQ]; lvl_op<NQ>(L, i, xv, y);
         const double rg = L.r[i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -512,49 +516,53 @@ __global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restri
             const double bq = rg * x0;
             const double rv = bq - y[q];
             x6[(size_t)q * L.n + i] = x0; r[(size_t)q * L.n + i] = rv;
-            acc[q] = rv * rv; acc[6 + q] = bq * bq;
+            acc[q] = rv * rv; acc[NQ + q] = bq * bq;
         }
     }
-    mg_block_reduce<12>(acc, partial);
+    mg_block_reduce<2 * NQ>(acc, partial);
 }
+template <int NQ>
 __global__ void k_pcg_start_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, double rtol2) {
-    double s[12]; mg_final_reduce<12>(partial, nb, s);
-    if (threadIdx.x < 6) { const int q = threadIdx.x; st->bb[q] = s[6 + q]; st->gam[q] = 0; st->alp[q] = 0; st->iters[q] = 0;
-                           st->active[q] = (s[q] > rtol2 * s[6 + q]) ? 1 : 0; }
+    double s[2 * NQ]; mg_final_reduce<2 * NQ>(partial, nb, s);
+    if (threadIdx.x < NQ) { const int q = threadIdx.x; st->bb[q] = s[NQ + q]; st->gam[q] = 0; st->alp[q] = 0; st->iters[q] = 0;
+                            st->active[q] = (s[q] > rtol2 * s[NQ + q]) ? 1 : 0; }
     __syncthreads();
-    if (threadIdx.x == 0) { int na = 0; for (int q = 0; q < 6; ++q) na += st->active[q]; st->nactive = na; }
+    if (threadIdx.x == 0) { int na = 0; for (int q = 0; q < NQ; ++q) na += st->active[q]; st->nactive = na; }
 }
 // Single-reduction PCG (Chronopoulos & Gear): per iteration  u = M^-1 r (the V-cycle, fp32) ; w = A u ; gamma = r.u, delta = w.u,
 // rho = r.r in ONE reduction ; beta = gamma/gamma_old, alpha = gamma / (delta - beta*gamma/alpha_old) ; p = u + beta p ; s = w + beta s
 // (= A p by recurrence) ; x += alpha p ; r -= alpha s. Same iterates as textbook PCG in exact arithmetic and the same iteration counts
 // in practice (scripts/cgcg_check.py), with 3 launches and one reduction per iteration instead of 7 and three.
 // w = A u with u = the V-cycle output widened exactly; partial sums of gamma, delta, rho (18 per 256-pixel block)
+template <int NQ>
 __global__ __launch_bounds__(256) void k_cg_apply(const PState* __restrict__ st, Lvl L, const vf* __restrict__ z, const double* __restrict__ r,
                                                   double* __restrict__ w, double* __restrict__ partial) {
     if (st->nactive == 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    double acc[18];
+    double acc[3 * NQ];
 #pragma unroll
-    for (int q = 0; q < 18; ++q) acc[q] = 0.0;
+    for (int q = 0; q < 3 * NQ; ++q) acc[q] = 0.0;
     if (i < L.n) {
         auto uv = [&](int j, int q) { return (double)z[(size_t)q * L.n + j]; };
-        double y[NQ]; lvl_op(L, i, uv, y);
+        double y[NQ]; lvl_op<NQ>(L, i, uv, y);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const double u = uv(i, q), rv = r[(size_t)q * L.n + i];
             w[(size_t)q * L.n + i] = y[q];
-            acc[q] = rv * u; acc[6 + q] = y[q] * u; acc[12 + q] = rv * rv;
+            acc[q] = rv * u; acc[NQ + q] = y[q] * u; acc[2 * NQ + q] = rv * rv;
         }
     }
-    mg_block_reduce<18>(acc, partial);
+    mg_block_reduce<3 * NQ>(acc, partial);
 }
 // three workgroups: workgroup j reduces gamma (0), delta (1), rho (2) of all 6 systems in the fixed order
+template <int NQ>
 __global__ void k_cg_fin(const PState* __restrict__ st, const double* __restrict__ partial, int nb, double* __restrict__ sums) {
     if (st->nactive == 0) return;
-    double s[6]; mg_final_reduce_strided<6>(partial + blockIdx.x * 6, nb, 18, s);
-    if (threadIdx.x < 6) sums[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x];
+    double s[NQ]; mg_final_reduce_strided<NQ>(partial + blockIdx.x * NQ, nb, 3 * NQ, s);
+    if (threadIdx.x < NQ) sums[blockIdx.x * NQ + threadIdx.x] = s[threadIdx.x];
 }
 // scalars + all four vector recurrences; every workgroup derives the scalars itself, workgroup 0 publishes the next state
+template <int NQ>
 __global__ __launch_bounds__(256) void k_cg_update(int n, const PState* __restrict__ sc, PState* __restrict__ sn, const double* __restrict__ sums, double rtol2, int first,
                                                    const vf* __restrict__ z, const double* __restrict__ w, double* __restrict__ p, double* __restrict__ s,
                                                    double* __restrict__ x, double* __restrict__ r) {
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(256) void k_cg_update(int n, const PState* __restri
     double al[NQ], be[NQ]; bool act[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const double gam = sums[q], del = sums[6 + q], rho = sums[12 + q];
+        const double gam = sums[q], del = sums[NQ + q], rho = sums[2 * NQ + q];
         act[q] = sc->active[q] != 0 && rho > rtol2 * sc->bb[q];
         be[q] = first ? 0.0 : gam / sc->gam[q];
         al[q] = first ? gam / del : gam / (del - be[q] * gam / sc->alp[q]);
@@ -591,6 +599,7 @@ __global__ __launch_bounds__(256) void k_cg_update(int n, const PState* __restri
         r[j] -= al[q] * sv;
     }
 }
+template <int NQ>
 __global__ void k_pcg_finish(int n, const double* __restrict__ x6, double* __restrict__ X) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * NQ) return;
@@ -601,45 +610,32 @@ __global__ void k_pcg_finish(int n, const double* __restrict__ x6, double* __res
 
 #define LCHK() NCT_LAUNCH_CHECK()
 
-// X: [2][N][3] in (x0) / out. rough, wx, wy: fine-level data term and edge weights (wx[i] = edge (i,i+1), wy[i] = edge (i,i+W)).
-int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* rough, const double* wx, const double* wy, int H, int W,
-                      double rtol, int* iters_out /*host[6], nullable*/) {
-    // ---- hierarchy
-    std::vector<Lvl> lv;
-    std::vector<void*> owned;
-    struct Cleanup { nct_ctx* c; std::vector<void*>& v; ~Cleanup() { for (void* q : v) c->release(q); } } cleanup{ctx, owned};
-    auto newd = [&](size_t n) -> double* { void* q = ctx->alloc(n * sizeof(double)); if (q) owned.push_back(q); return (double*)q; };
-    auto newf = [&](size_t n) -> vf* { void* q = ctx->alloc(n * sizeof(vf)); if (q) owned.push_back(q); return (vf*)q; };
-    {
-        int h = H, w = W;
-        for (int l = 0;; ++l) {
-            Lvl L; memset(&L, 0, sizeof L); L.H = h; L.W = w; L.n = h * w;
-            if (l == 0) { L.r = (double*)rough; L.wx = (double*)wx; L.wy = (double*)wy; }
-            else { L.r = newd(L.n); L.wx = newd(L.n); L.wy = newd(L.n); }
-            L.diag = newd(L.n); L.fdiag = newf(L.n); L.fdinv = newf(L.n); L.fwx = newf(L.n); L.fwy = newf(L.n);
-            L.b = l == 0 ? nullptr : newf((size_t)L.n * NQ); L.x = newf((size_t)L.n * NQ); L.x2 = newf((size_t)L.n * NQ);
-            if (!L.r || !L.wx || !L.wy || !L.diag || !L.fdiag || !L.fdinv || !L.fwx || !L.fwy || (l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
-            lv.push_back(L);
-            if (L.n <= 64 || (h <= 8 && w <= 8) || lv.size() >= 16) break;
-            h = (h + 1) / 2; w = (w + 1) / 2;
-        }
-        if (lv.back().n > 64 || lv.size() < 2) return ctx->fail(NCT_ERR_INVALID, "wls: unsupported grid %dx%d (coarsest level %d)", W, H, lv.back().n);
-    }
+namespace {
+// One PCG solve over NQ right-hand sides on its own stream. Everything it needs was allocated by the caller (the arena is not thread safe);
+// `ctx` here is only an error sink, so that the second half of a split solve can run on a helper thread.
+struct ErrSink {
+    std::string err;
+    int fail(int code, const char* fmt, ...) { char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); err = buf; return code; }
+};
+struct PartBufs {
+    double *x6, *r, *p, *sv, *w, *partial, *sums; PState* st;      // Krylov vectors [NQ][N], reduction scratch, double-buffered state
+    std::vector<Lvl> lv;                                            // the shared operator hierarchy with THIS part's V-cycle vectors (b, x, x2)
+    PState* hst; hipEvent_t ev[2];                                  // two page-locked read-back slots and their events
+    int maxit, graph;
+    int iters[NQMAX];
+};
+template <int NQ>
+int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(s) */, PartBufs& B, double rtol) {
+    const std::vector<Lvl>& lv = B.lv;
     const int nl = (int)lv.size();
-    for (int l = 0; l < nl; ++l) {
-        if (l > 0) { hipLaunchKernelGGL(k_mg_coarsen, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l - 1], lv[l]); LCHK(); }
-        hipLaunchKernelGGL(k_mg_diag, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l]); LCHK();
-    }
     const Lvl& F = lv[0];
     const int N = F.n, nb = cdiv(N, 256);
-    DevBuf<double> x6(ctx, (size_t)N * NQ), r(ctx, (size_t)N * NQ), p(ctx, (size_t)N * NQ), sv(ctx, (size_t)N * NQ), w(ctx, (size_t)N * NQ), partial(ctx, (size_t)nb * 18), sums(ctx, 18);
-    DevBuf<PState> st2(ctx, 2);
-    if (!x6.ok() || !r.ok() || !p.ok() || !sv.ok() || !w.ok() || !partial.ok() || !sums.ok() || !st2.ok()) return NCT_ERR_HIP;
-    PState* st = (PState*)st2;                         // st[0] / st[1]; `cur` = the state the iteration being enqueued reads
+    double *x6 = B.x6, *r = B.r, *p = B.p, *sv = B.sv, *w = B.w, *partial = B.partial, *sums = B.sums;
+    PState* st = B.st;                                 // st[0] / st[1]; `cur` = the state the iteration being enqueued reads
     const PState* cur = st;
     const double rtol2 = rtol * rtol;
-    hipLaunchKernelGGL(k_pcg_start, dim3(nb), dim3(256), 0, s, F, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
-    hipLaunchKernelGGL(k_pcg_start_fin, dim3(1), dim3(256), 0, s, (const double*)partial, nb, st, rtol2); LCHK();
+    hipLaunchKernelGGL(k_pcg_start<NQ>, dim3(nb), dim3(256), 0, s, F, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
+    hipLaunchKernelGGL(k_pcg_start_fin<NQ>, dim3(1), dim3(256), 0, s, (const double*)partial, nb, st, rtol2); LCHK();
 
     // z = Vcycle(r). Levels 0..nl-2 run the tile-fused down/up legs (2 launches per level), the coarsest grid one 6-wave kernel.
     // res[l] = where level l's correction ends up (the up leg cannot write in place: neighbouring tiles still read lv[l].x).
@@ -662,22 +658,22 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     auto down = [&](int l) {
         const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
         if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
-            else                   hipLaunchKernelGGL((k_mg_down<16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
         } else {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
-            else                   hipLaunchKernelGGL((k_mg_down<16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
         }
     };
     auto up = [&](int l, const vf* ec) {
         const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
         const int Wc = lv[l + 1].W, nc = lv[l + 1].n;
         if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            else                   hipLaunchKernelGGL((k_mg_up<16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
         } else {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            else                   hipLaunchKernelGGL((k_mg_up<16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
         }
     };
     auto vcycle = [&]() -> int {
@@ -690,23 +686,22 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     // Convergence is polled without draining the stream: after every batch of `batch` iterations the solver state is copied to
     // page-locked host memory and an event is recorded; the host then enqueues the NEXT batch before it waits for that event, so
     // the GPU always has a batch queued. The batch enqueued past convergence costs only empty launches (nactive == 0).
-    const int maxit = ctx->wls_maxit, batch = 4;
-    PState* hst = (PState*)ctx->pinned;                   // two slots
-    static_assert(2 * sizeof(PState) <= 4096, "pinned read-back area too small");
+    const int maxit = B.maxit, batch = 4;
+    PState* hst = B.hst;                                  // two slots of page-locked memory
     auto iteration = [&](int it) -> int {
         cur = st + (it & 1);
         PState* nxt = st + ((it + 1) & 1);
         int rc = vcycle(); if (rc) return rc;
-        hipLaunchKernelGGL(k_cg_apply, dim3(nb), dim3(256), 0, s, cur, F, z, (const double*)r, (double*)w, (double*)partial); LCHK();
-        hipLaunchKernelGGL(k_cg_fin, dim3(3), dim3(256), 0, s, cur, (const double*)partial, nb, (double*)sums); LCHK();
-        hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, s, N, cur, nxt, (const double*)sums, rtol2, it == 0 ? 1 : 0, z, (const double*)w,
+        hipLaunchKernelGGL(k_cg_apply<NQ>, dim3(nb), dim3(256), 0, s, cur, F, z, (const double*)r, (double*)w, (double*)partial); LCHK();
+        hipLaunchKernelGGL(k_cg_fin<NQ>, dim3(3), dim3(256), 0, s, cur, (const double*)partial, nb, (double*)sums); LCHK();
+        hipLaunchKernelGGL(k_cg_update<NQ>, dim3(nb), dim3(256), 0, s, N, cur, nxt, (const double*)sums, rtol2, it == 0 ? 1 : 0, z, (const double*)w,
                            (double*)p, (double*)sv, (double*)x6, (double*)r); LCHK();
         cur = nxt;
         return 0;
     };
     auto snapshot = [&](int slot) -> int {
         NCT_HIP(hipMemcpyAsync(&hst[slot], cur, sizeof(PState), hipMemcpyDeviceToHost, s));
-        NCT_HIP(hipEventRecord(ctx->ev_poll[slot], s));
+        NCT_HIP(hipEventRecord(B.ev[slot], s));
         return 0;
     };
     int it = 0, slot = 0; bool done = false;
@@ -718,7 +713,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     struct GraphCleanup { hipGraph_t& g; hipGraphExec_t& e; ~GraphCleanup() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } gcleanup{graph, gexec};
     while (true) {
         const bool enqueued = it < maxit;
-        if (enqueued && ctx->wls_graph && it >= batch) {
+        if (enqueued && B.graph && it >= batch) {
             if (!gexec) {
                 NCT_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 int rc = 0;
@@ -734,7 +729,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
         } else
         if (enqueued) { for (int k = 0; k < batch; ++k, ++it) { int rc = iteration(it); if (rc) return rc; } }
         { int rc = snapshot(slot ^ 1); if (rc) return rc; }
-        NCT_HIP(hipEventSynchronize(ctx->ev_poll[slot]));  // the snapshot taken BEFORE the batch just enqueued
+        NCT_HIP(hipEventSynchronize(B.ev[slot]));  // the snapshot taken BEFORE the batch just enqueued
         fin = hst[slot];
         if (fin.nactive == 0) { done = true; break; }
         if (!enqueued) break;                              // that was the snapshot behind the last batch: the iteration budget is spent
@@ -742,7 +737,92 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     }
     // iterations enqueued after `fin` was taken leave the state untouched (nactive == 0), so fin is final
     if (!done) return ctx->fail(NCT_ERR_HIP, "WLS MG-PCG did not converge in %d iterations", maxit);
-    hipLaunchKernelGGL(k_pcg_finish, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const double*)x6, X); LCHK();
-    if (iters_out) for (int q = 0; q < 6; ++q) iters_out[q] = fin.iters[q];
+    hipLaunchKernelGGL(k_pcg_finish<NQ>, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const double*)x6, X); LCHK();
+    for (int q = 0; q < NQ; ++q) B.iters[q] = fin.iters[q];
+    return 0;
+}
+}  // namespace
+
+// X: [2][N][3] in (x0) / out. rough, wx, wy: fine-level data term and edge weights (wx[i] = edge (i,i+1), wy[i] = edge (i,i+W)).
+// ctx->wls_split (NCT_FLAG_LATENCY): the a-half and the b-half (3 right-hand sides each, same operator, no shared value) are solved
+// concurrently — the second on ctx->stream2 from a helper thread — so that one half's latency-bound coarse legs hide behind the other's
+// bandwidth-bound 700x700 kernels. Every right-hand side sees exactly the same arithmetic as in the 6-wide solve (per-system reductions,
+// scalars and convergence tests): the result is bit-identical. It doubles the launches, so it is for ONE pair in flight.
+int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* rough, const double* wx, const double* wy, int H, int W,
+                      double rtol, int* iters_out /*host[6], nullable*/) {
+    const bool split = ctx->wls_split != 0;
+    const int nq0 = split ? 3 : 6;
+    // ---- hierarchy
+    std::vector<Lvl> lv;
+    std::vector<void*> owned;
+    struct Cleanup { nct_ctx* c; std::vector<void*>& v; ~Cleanup() { for (void* q : v) c->release(q); } } cleanup{ctx, owned};
+    auto newd = [&](size_t n) -> double* { void* q = ctx->alloc(n * sizeof(double)); if (q) owned.push_back(q); return (double*)q; };
+    auto newf = [&](size_t n) -> vf* { void* q = ctx->alloc(n * sizeof(vf)); if (q) owned.push_back(q); return (vf*)q; };
+    {
+        int h = H, w = W;
+        for (int l = 0;; ++l) {
+            Lvl L; memset(&L, 0, sizeof L); L.H = h; L.W = w; L.n = h * w;
+            if (l == 0) { L.r = (double*)rough; L.wx = (double*)wx; L.wy = (double*)wy; }
+            else { L.r = newd(L.n); L.wx = newd(L.n); L.wy = newd(L.n); }
+            L.diag = newd(L.n); L.fdiag = newf(L.n); L.fdinv = newf(L.n); L.fwx = newf(L.n); L.fwy = newf(L.n);
+            L.b = l == 0 ? nullptr : newf((size_t)L.n * nq0); L.x = newf((size_t)L.n * nq0); L.x2 = newf((size_t)L.n * nq0);
+            if (!L.r || !L.wx || !L.wy || !L.diag || !L.fdiag || !L.fdinv || !L.fwx || !L.fwy || (l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
+            lv.push_back(L);
+            if (L.n <= 64 || (h <= 8 && w <= 8) || lv.size() >= 16) break;
+            h = (h + 1) / 2; w = (w + 1) / 2;
+        }
+        if (lv.back().n > 64 || lv.size() < 2) return ctx->fail(NCT_ERR_INVALID, "wls: unsupported grid %dx%d (coarsest level %d)", W, H, lv.back().n);
+    }
+    const int nl = (int)lv.size();
+    for (int l = 0; l < nl; ++l) {
+        if (l > 0) { hipLaunchKernelGGL(k_mg_coarsen, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l - 1], lv[l]); LCHK(); }
+        hipLaunchKernelGGL(k_mg_diag, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l]); LCHK();
+    }
+    const int N = lv[0].n, nb = cdiv(N, 256);
+    static_assert(4 * sizeof(PState) <= 4096, "pinned read-back area too small");
+    // ---- per-part buffers (both parts' before anything runs: the helper thread must not touch the arena)
+    PartBufs part[2];
+    const int nparts = split ? 2 : 1;
+    for (int h = 0; h < nparts; ++h) {
+        PartBufs& B = part[h];
+        const size_t v = (size_t)N * nq0;
+        B.x6 = newd(v); B.r = newd(v); B.p = newd(v); B.sv = newd(v); B.w = newd(v); B.partial = newd((size_t)nb * 3 * nq0); B.sums = newd(3 * nq0);
+        B.st = (PState*)ctx->alloc(2 * sizeof(PState)); if (B.st) owned.push_back(B.st);
+        if (!B.x6 || !B.r || !B.p || !B.sv || !B.w || !B.partial || !B.sums || !B.st) return NCT_ERR_HIP;
+        B.lv = lv;
+        if (h == 1) for (int l = 0; l < nl; ++l) {             // the second part's own V-cycle vectors
+            Lvl& L = B.lv[l];
+            L.b = l == 0 ? nullptr : newf((size_t)L.n * nq0); L.x = newf((size_t)L.n * nq0); L.x2 = newf((size_t)L.n * nq0);
+            if ((l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
+        }
+        B.hst = (PState*)ctx->pinned + 2 * h; B.ev[0] = ctx->ev_poll[2 * h]; B.ev[1] = ctx->ev_poll[2 * h + 1];
+        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph;
+        memset(B.iters, 0, sizeof B.iters);
+    }
+    if (!split) {
+        ErrSink sink;
+        const int rc = pcg_part<6>(&sink, s, X, part[0], rtol);
+        if (rc) return ctx->fail(rc, "%s", sink.err.c_str());
+        if (iters_out) for (int q = 0; q < 6; ++q) iters_out[q] = part[0].iters[q];
+        return 0;
+    }
+    // fork: the helper stream starts when the hierarchy (and everything before it on s) is complete; join: s waits for the helper's last kernel
+    hipStream_t s2 = ctx->stream_wls;
+    NCT_HIP(hipEventRecord(ctx->ev_wls_fork, s));
+    NCT_HIP(hipStreamWaitEvent(s2, ctx->ev_wls_fork, 0));
+    ErrSink sink_a, sink_b;
+    int rc_b = 0;
+    const int dev = ctx->device;
+    std::thread helper([&] {
+        if (hipSetDevice(dev) != hipSuccess) { rc_b = sink_b.fail(NCT_ERR_HIP, "hipSetDevice failed on the WLS helper thread"); return; }
+        rc_b = pcg_part<3>(&sink_b, s2, X + (size_t)3 * N, part[1], rtol);
+    });
+    const int rc_a = pcg_part<3>(&sink_a, s, X, part[0], rtol);
+    helper.join();
+    hipError_t e1 = hipEventRecord(ctx->ev_wls_join, s2), e2 = hipStreamWaitEvent(s, ctx->ev_wls_join, 0);     // also on errors: the arena blocks return in s's order
+    if (rc_a) return ctx->fail(rc_a, "%s", sink_a.err.c_str());
+    if (rc_b) return ctx->fail(rc_b, "%s", sink_b.err.c_str());
+    NCT_HIP(e1); NCT_HIP(e2);
+    if (iters_out) for (int q = 0; q < 3; ++q) { iters_out[q] = part[0].iters[q]; iters_out[3 + q] = part[1].iters[q]; }
     return 0;
 }

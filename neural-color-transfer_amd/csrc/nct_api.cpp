@@ -65,6 +65,9 @@ int nct_create(int device, nct_ctx** out) {
     c->device = device;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->stream_wls, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_wls_fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_wls_join, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) {
@@ -73,7 +76,7 @@ int nct_create(int device, nct_ctx** out) {
     }
     for (int l = 0; l < 5; ++l)
         if ((e = hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < 4; ++l)
         if ((e = hipEventCreateWithFlags(&c->ev_poll[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     if ((e = hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault)) != hipSuccess) { g_create_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     if (const char* g = getenv("NCT_WLS_GRAPH")) c->wls_graph = atoi(g);
@@ -103,7 +106,10 @@ void nct_destroy(nct_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (int l = 0; l < 5; ++l) if (ctx->ev_level[l]) (void)hipEventDestroy(ctx->ev_level[l]);
-    for (int l = 0; l < 2; ++l) if (ctx->ev_poll[l]) (void)hipEventDestroy(ctx->ev_poll[l]);
+    for (int l = 0; l < 4; ++l) if (ctx->ev_poll[l]) (void)hipEventDestroy(ctx->ev_poll[l]);
+    if (ctx->stream_wls) (void)hipStreamDestroy(ctx->stream_wls);
+    if (ctx->ev_wls_fork) (void)hipEventDestroy(ctx->ev_wls_fork);
+    if (ctx->ev_wls_join) (void)hipEventDestroy(ctx->ev_wls_join);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
 }

@@ -16,7 +16,9 @@ struct nct_ctx {
     hipStream_t stream2 = nullptr;    // second stream (R->S direction runs concurrently)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_level[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // side-stream completion of level l's kNN graph
-    hipEvent_t ev_poll[2] = {nullptr, nullptr};   // completion of the two in-flight solver-state read-backs (k_wls_mg.hip)
+    hipEvent_t ev_poll[4] = {nullptr, nullptr, nullptr, nullptr};   // completion of the in-flight solver-state read-backs (k_wls_mg.hip: two per half-solve)
+    hipStream_t stream_wls = nullptr;  // helper stream of the split WLS solve (NCT_FLAG_LATENCY)
+    hipEvent_t ev_wls_fork = nullptr, ev_wls_join = nullptr;
     void* pinned = nullptr;                        // 4 KB of page-locked host memory for those read-backs
     std::string err;
     std::vector<nct_block> blocks;    // cached device allocations, reused across calls and pairs
@@ -31,6 +33,7 @@ struct nct_ctx {
                                                 // behind the fp16 prefilter, [2] accepted candidates; 4 slots per pyramid level in pair runs
     // stage clock: events recorded on the main stream at stage boundaries, read once after the pair's final synchronise
     // (no host syncs in between: see nct_pair_timing in nct.h)
+    int wls_split = 0;                          // NCT_FLAG_LATENCY of the running pair: a- and b-half of the WLS solve on two streams
     int wls_graph = 0;                          // experiment hook (env NCT_WLS_GRAPH=1): replay the PCG iteration batch as a HIP graph
     int wls_maxit = 5000;                       // iteration budget of the WLS solve (test hook: env NCT_WLS_MAXIT)
     bool tm_on = false;

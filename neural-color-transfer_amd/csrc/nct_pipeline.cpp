@@ -70,6 +70,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     struct TmOff { nct_ctx* c; ~TmOff() { c->tm_on = false; } } tm_off{ctx};
     const int nlevels = prm->levels;
     const bool feat16 = (prm->flags & NCT_FLAG_FEAT16) != 0;
+    ctx->wls_split = (prm->flags & NCT_FLAG_LATENCY) ? 1 : 0;
     const bool count = timing && (prm->flags & NCT_FLAG_COUNT_EVALS);
     if (count) {
         if (!ctx->d_counter) NCT_HIP(hipMalloc(&ctx->d_counter, 32 * sizeof(unsigned long long)));

@@ -328,6 +328,7 @@ int main(int argc, char** argv) {
     cfg.prm.seed = (uint32_t)seed;
     cfg.prm.levels = levels < 1 ? 1 : (levels > 5 ? 5 : levels);
     if (feat16) cfg.prm.flags |= NCT_FLAG_FEAT16;
+    if (inflight <= 1) cfg.prm.flags |= NCT_FLAG_LATENCY;          // one pair at a time per GPU: split WLS solves (same result, -3 ms per 700x700 pair)
     cfg.resume = resume != 0;
     cfg.vis = vis != 0;
     if (ngpus < 1) ngpus = 1;

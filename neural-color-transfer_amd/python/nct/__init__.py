@@ -123,6 +123,7 @@ class PairTiming(C.Structure):
 
 FLAG_FEAT16 = 1
 FLAG_COUNT_EVALS = 2
+FLAG_LATENCY = 4
 
 
 class PairLevels(C.Structure):

@@ -18,6 +18,8 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     prm = nct.Params.default()
     if os.environ.get("FEAT16"):
         prm.flags |= nct.FLAG_FEAT16
+    if os.environ.get("LATENCY"):
+        prm.flags |= nct.FLAG_LATENCY
     c.pair_run(prm)
     tms = [c.pair_run(prm, want_timing=True) for _ in range(3)]
     tm = min(tms, key=lambda t: t["total_ms"])
