@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle on the full 700x700 pair (minutes)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 PMC passes (traffic falls back to profiles/)")
+    ap.add_argument("--no-latency-flag", action="store_true", help="skip the two extra single-pair runs with NCT_FLAG_LATENCY (kernel-trace runs: keeps the launch count per pair comparable)")
     ap.add_argument("--print-launch", action="store_true", help="[test hook] print the torchrun command --gpus N would re-launch with, and exit")
     args = ap.parse_args()
 
@@ -248,11 +249,13 @@ def main():
     for k, _ in nct.Params._fields_:
         setattr(plat, k, getattr(prm, k))
     plat.flags |= nct.FLAG_LATENCY
-    ctx.pair_run(plat)
-    t1 = time.perf_counter()
-    ctx.pair_run(plat)
-    single_pair_latency_s = time.perf_counter() - t1
-    latency_checksum = int(np.asarray(ctx.pair_download(), dtype=np.uint64).sum())
+    single_pair_latency_s, latency_checksum = None, None
+    if not args.no_latency_flag:
+        ctx.pair_run(plat)
+        t1 = time.perf_counter()
+        ctx.pair_run(plat)
+        single_pair_latency_s = time.perf_counter() - t1
+        latency_checksum = int(np.asarray(ctx.pair_download(), dtype=np.uint64).sum())
     stages = ctx.pair_run(prm, want_timing=True)
     out = ctx.pair_download()
 
@@ -270,10 +273,10 @@ def main():
         "rccl_ranks": rccl_ranks,
         "host_to_host_pairs_per_s": host_to_host,
         "single_pair_ms": 1e3 * single_pair_s,
-        "single_pair_latency_flag_ms": 1e3 * single_pair_latency_s,
+        "single_pair_latency_flag_ms": None if single_pair_latency_s is None else 1e3 * single_pair_latency_s,
         "stages_ms": stages,
         "output_checksum": int(out.astype(np.uint64).sum()),
-        "latency_flag_output_identical": latency_checksum == int(out.astype(np.uint64).sum()),
+        "latency_flag_output_identical": None if latency_checksum is None else latency_checksum == int(out.astype(np.uint64).sum()),
         "build_id": lib_build_id(),
     }
     res["vgg_mfma"] = vgg_mfma(src.shape[0], src.shape[1], ref.shape[0], ref.shape[1], prm.levels, stages["vgg_ms"])

@@ -34,7 +34,7 @@ pairs = 3 * 4          # context warm-up + (1 warm-up + 2 timed) steps + host-to
 calls = sum(int(r["Calls"]) for r in rows)
 total = sum(int(r["TotalDurationNs"]) for r in rows)
 pm = [r for r in rows if r["Name"].startswith("void k_pm_step<1, 1,")][0]
-L = [f"# round 2 — `rocprofv3 --kernel-trace --stats` of `python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc` (one pair in flight), MI355X", "",
+L = [f"# round 2 — `rocprofv3 --kernel-trace --stats` of `python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-latency-flag` (one pair in flight), MI355X", "",
      f"Build id {prof['build_id']} (the build of profiles/round2_bench.json: {bench['build_id']}). The run processes {pairs} pairs (context warm-up, 1 warm-up + 2 timed steps, the host-to-host",
      f"region, the latency / stage / roofline pairs): divide calls and totals by {pairs} for one 700x700 pair. Bench line of this profiled run: {prof['value']:.2f} pairs/s, single pair {prof['single_pair_ms']:.1f} ms (tracing on);",
      f"its event-timed average launch of `{prof['roofline']['kernel'].split(' (')[0]}` is {prof['roofline']['avg_launch_ms'] * 1e3:.1f} us, the trace's own average below {float(pm['AverageNs']) / 1e3:.1f} us (the un-traced bench: {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us).",

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 timeout 1700 python -m pytest tests -q -m gpu > $out/pytest_gpu.txt 2>&1; tail -3 $out/pytest_gpu.txt
 timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; cut -c1-300 $out/bench.json
 cp profiles/round2_pmc_patchmatch.json $out/pmc_fallback_before.json 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o b -- python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc > $out/prof_bench.json 2> $out/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o b -- python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-latency-flag > $out/prof_bench.json 2> $out/prof.err
 find $out/prof -name "*kernel_trace*" -delete; find $out/prof -name "*.db" -delete
 timeout 300 python scripts/pm_modes.py 700 > $out/pm_modes.log 2>&1
 timeout 300 python bench.py --workload pair1000 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc > $out/bench_1000.json 2>/dev/null
