@@ -8,7 +8,7 @@
 //  * the hierarchy needs no Galerkin triple products: with 2x2 aggregates and piecewise-constant interpolation, P^T A P of a
 //    weighted 5-point graph Laplacian + diagonal is again one (coarse data term = sum of the 4 fine ones, coarse edge = sum of
 //    the fine edges crossing between the two aggregates);
-//  * smoother = damped Jacobi (omega 0.8) — order independent, so the result is reproducible; one cycle is two tile-fused
+//  * smoother = two Chebyshev-weighted Jacobi sweeps (0.58, 2.64) — order independent, so the result is reproducible; one cycle is two tile-fused
 //    launches per level (k_mg_down / k_mg_up, iterates exchanged through LDS) and ONE workgroup for all levels <= 512 pixels;
 //  * vectors are planar [6][pixels]: on a regular 5-point stencil the neighbours of consecutive pixels are consecutive, so
 //    every load/store of a wave is one fully coalesced segment per right-hand side;
@@ -17,7 +17,7 @@
 //  * the host never drains the stream: convergence is polled one batch behind through page-locked memory, kernels enqueued
 //    past convergence return on a device flag.
 // Jacobi-PCG needed 2633/1391/701/359/357 iterations (rtol 1e-10) on the five levels of a 700x700 pair (profiles/r1b); this needs
-// 74/56/42/34/34 (rtol 1e-6) at ~150 us each. Roofline: Infinity-Cache/HBM streaming at 700^2 and 350^2, launch latency below.
+// 63/47/34/27/27 (rtol 1e-6) at ~150 us each. Roofline: Infinity-Cache/HBM streaming at 700^2 and 350^2, launch latency below.
 #include "nct_internal.h"
 #include "nct_device.h"
 #include <vector>
@@ -27,7 +27,18 @@
 #include <cstdarg>
 
 namespace {
-constexpr double OMEGA = 0.8;
+// Smoother: two damped-Jacobi sweeps per leg with the weights of the degree-2 Chebyshev polynomial on [lambda_max / 20, lambda_max] of D^-1 M,
+// lambda_max <= 2 for these diagonally dominant M-matrices: omega = 1 / (1.05 -+ 0.95 cos(pi/4)) = 0.5808, 2.6437 (first sweep, second sweep).
+// Order independent like plain Jacobi, and the pre- and post-smoother stay adjoint (polynomials in the same operator commute), so the cycle
+// is still a symmetric preconditioner. Against omega = 0.8 twice (round 1): 63/47/34/27/27 instead of 74/56/42/34/34 PCG iterations on the
+// five solves of a 700x700 pair (-17 %) at the same cost per cycle; [lambda_max/4, lambda_max] (0.562, 1.39) gave -8 %, wider intervals
+// than /20 nothing more (scripts: NCT_MG_W1 / NCT_MG_W2 builds). The coarsest grid keeps 60 sweeps at 0.8.
+#ifndef NCT_MG_W1
+#define NCT_MG_W1 0.5808
+#define NCT_MG_W2 2.6437
+#endif
+constexpr double OMEGA = NCT_MG_W1;
+constexpr float MG_R2 = (float)(NCT_MG_W2 / NCT_MG_W1), MG_R0 = (float)(0.8 / NCT_MG_W1);   // second-sweep and coarsest-grid weights relative to the first (fdinv = omega_1 / diag)
 constexpr int NQMAX = 6;      // right-hand sides of a solve: 6 (a and b of the 3 Lab channels) or 3 + 3 on two streams (template parameter NQ)
 #ifndef NCT_MG_TXB
 #define NCT_MG_TXB 48
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
         vf y[NQ]; lds_op<NQ, LW, LN>(c, s_a, p, y);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const vf v = x1[q] + (bq[q] - y[q]) * c.dinv;
+            const vf v = x1[q] + (bq[q] - y[q]) * (c.dinv * MG_R2);
             s_b[q * LN + p] = v;
             if (interior) x[(size_t)q * F.n + i] = v;
         }
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
     if (interior) {
         vf y[NQ]; lds_op<NQ, LW, LN>(c, s_b, p, y);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = x2[q] + (bq[q] - y[q]) * c.dinv;
+        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = x2[q] + (bq[q] - y[q]) * (c.dinv * MG_R2);
     }
 }
 // Middle + tail of the V-cycle in ONE launch, one 1024-thread workgroup PER RIGHT-HAND SIDE: the first fused level has <= 4096 pixels
@@ -411,7 +422,7 @@ __device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __
                 if (has_l) y -= w1 * xl;
                 if (has_d) y -= w2 * xd;
                 if (has_u) y -= w3 * xu;
-                if (live) x = x + (bq - y) * dv;
+                if (live) x = x + (bq - y) * (dv * MG_R0);
             }
             if (live) { if (D == 0) L.x2[(size_t)q * n + i] = x; else sC[i] = x; }
         }
@@ -429,7 +440,7 @@ __device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __
         for (int k = 0; k < PPT; ++k) {
             const int i = t + k * MID_T;
             if (i < n) {
-                const vf bk = bval(k, i), x1 = bk * c[k].dinv, xv = x1 + (bk - mid_op(c[k], sA, i, W)) * c[k].dinv;
+                const vf bk = bval(k, i), x1 = bk * c[k].dinv, xv = x1 + (bk - mid_op(c[k], sA, i, W)) * (c[k].dinv * MG_R2);
                 sB[i] = xv;
                 if constexpr (INLDS) sx0[i] = xv; else x[k] = xv;
             }
@@ -472,7 +483,7 @@ __device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __
             const int i = t + k * MID_T;
             if (i < n) {
                 vf x2; const vf y = mid_op(c[k], sB, i, W, &x2);
-                const vf v = x2 + (bval(k, i) - y) * c[k].dinv;
+                const vf v = x2 + (bval(k, i) - y) * (c[k].dinv * MG_R2);
                 if (D == 0) L.x2[(size_t)q * n + i] = v; else sC[i] = v;
             }
         }

@@ -6,7 +6,7 @@
  * fixture) in tests/test_oracle_color.py. It exists in this exact arithmetic order so that the 8-bit result of the GPU
  * path can be compared bit-for-bit (see orc_color_canon.c for why that matters: S1 downstream is chaotic).
  * Hierarchy: 2x2 aggregation (coarse data term = sum of the 4 fine ones, coarse edge = sum of the crossing fine edges), built in
- * fp64; V(2,2) cycle, damped Jacobi (omega 0.8), 60 Jacobi sweeps on the coarsest grid — the cycle runs in fp32 on rounded copies
+ * fp64; V(2,2) cycle, Chebyshev-weighted Jacobi (omega 0.5808 then 2.6437), 60 Jacobi sweeps (0.8) on the coarsest grid — the cycle runs in fp32 on rounded copies
  * of the level operators (it is only the preconditioner; the CG recurrences, the operator and every dot product stay fp64);
  * two-stage 256-wide tree reductions. */
 #include "orc_common.h"
@@ -15,7 +15,11 @@
 void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double* diag, double* wx, double* wy);
 
 #define NQ 6
-static const double OMEGA = 0.8;
+/* two Chebyshev-weighted Jacobi sweeps per leg (k_wls_mg.hip: NCT_MG_W1 / NCT_MG_W2); fdinv = (float)(W1 / diag), the second sweep and the
+ * coarsest grid scale it in fp32 exactly as the kernels do */
+static const double OMEGA = 0.5808, OMEGA2 = 2.6437;
+#define MG_R2 ((float)(OMEGA2 / OMEGA))
+#define MG_R0 ((float)(0.8 / OMEGA))
 typedef struct { int H, W, n; double *r, *wx, *wy, *diag; float *fdiag, *fdinv, *fwx, *fwy, *b, *x, *x2; } lvl_t;   /* fdinv = (float)(omega / diag) */
 
 static void tree256(double* s) { for (int off = 128; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) s[t] += s[t + off]; }
@@ -64,7 +68,7 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < L->n; ++i) {
             float y[NQ]; LVL_OPF(L, i, X1, y);
-            const float d = L->fdinv[i];
+            const float d = L->fdinv[i] * MG_R2;
             for (int q = 0; q < NQ; ++q) { const float x1 = X1(i, q); const float t = BV(i, q) - y[q]; const float u = t * d; L->x[(size_t)i * NQ + q] = x1 + u; }
         }
 #undef X1
@@ -94,7 +98,7 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
 #define CV(j, q) (cur[(size_t)(j) * NQ + (q)])
             for (int i = 0; i < L->n; ++i) {
                 float y[NQ]; LVL_OPF(L, i, CV, y);
-                const float d = L->fdinv[i];
+                const float d = L->fdinv[i] * MG_R0;
                 for (int q = 0; q < NQ; ++q) { const float t = L->b[(size_t)i * NQ + q] - y[q]; const float u = t * d; nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + u; }
             }
 #undef CV
@@ -118,7 +122,7 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < L->n; ++i) {
             float y[NQ]; LVL_OPF(L, i, X2, y);
-            const float d = L->fdinv[i];
+            const float d = L->fdinv[i] * MG_R2;
             for (int q = 0; q < NQ; ++q) { const float t = BV(i, q) - y[q]; const float u = t * d; L->x[(size_t)i * NQ + q] = L->x2[(size_t)i * NQ + q] + u; }
         }
 #undef X2

@@ -27,7 +27,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     tc = c.pair_run(prm, want_timing=True)
     out = c.pair_download()
     print(json.dumps({"total_ms": tm["total_ms"], "pm_ms": tm["patchmatch_ms"], "pm_level_ms": tm["pm_level_ms"], "evals": tc["pm_level_evals"],
-                      "accepted": tc["pm_level_accepted"], "crc": zlib.crc32(out.tobytes()),
+                      "accepted": tc["pm_level_accepted"], "crc": zlib.crc32(out.tobytes()), "wls_iters": tm["wls_iters"],
                       "stages": {k: tm[k] for k in ("vgg_ms", "cluster_ms", "patchmatch_ms", "vote_ms", "knn_ms", "color_ms", "nonlocal_ms", "wls_ms", "other_ms")}}))
     sys.exit(0)
 
@@ -44,5 +44,5 @@ for lname, lpath in libs:
             print(lname, name, "FAILED", r.stderr[-800:]); continue
         d = json.loads(line[0])
         print(f"{lname:8s} {name:7s} total {d['total_ms']:7.2f} ms  PM {d['pm_ms']:6.2f} ms  per level {[round(x, 2) for x in d['pm_level_ms']]}  crc {d['crc']}")
-        print(f"{'':16s} evals {d['evals']}  accepted {d['accepted']}")
+        print(f"{'':16s} evals {d['evals']}  accepted {d['accepted']}  wls_iters {d['wls_iters']}")
         print(f"{'':16s} stages {json.dumps({k: round(v, 2) for k, v in d['stages'].items()})}", flush=True)
