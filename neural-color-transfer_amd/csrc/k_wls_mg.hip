@@ -620,6 +620,9 @@ __global__ void k_pcg_finish(int n, const double* __restrict__ x6, double* __res
 }  // namespace
 
 #define LCHK() NCT_LAUNCH_CHECK()
+#ifndef NCT_WLS_BATCH
+#define NCT_WLS_BATCH 2      // iterations enqueued between two convergence polls (even: the state double buffer); 4: +1.0 ms of empty launches past convergence per pair, 6: +1.3
+#endif
 
 namespace {
 // One PCG solve over NQ right-hand sides on its own stream. Everything it needs was allocated by the caller (the arena is not thread safe);
@@ -697,7 +700,7 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     // Convergence is polled without draining the stream: after every batch of `batch` iterations the solver state is copied to
     // page-locked host memory and an event is recorded; the host then enqueues the NEXT batch before it waits for that event, so
     // the GPU always has a batch queued. The batch enqueued past convergence costs only empty launches (nactive == 0).
-    const int maxit = B.maxit, batch = 4;
+    const int maxit = B.maxit, batch = NCT_WLS_BATCH;
     PState* hst = B.hst;                                  // two slots of page-locked memory
     auto iteration = [&](int it) -> int {
         cur = st + (it & 1);
@@ -718,7 +721,7 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     int it = 0, slot = 0; bool done = false;
     { int rc = snapshot(slot); if (rc) return rc; }        // state after the start kernel (x0 may already solve the system)
     PState fin; memset(&fin, 0, sizeof fin);
-    // Experiment hook (NCT_WLS_GRAPH=1): from the second batch on, the 4-iteration batch (its kernels, arguments and the
+    // Experiment hook (NCT_WLS_GRAPH=1): from the second batch on, the iteration batch (its kernels, arguments and the
     // state double-buffering repeat exactly) is captured once and replayed as a HIP graph instead of being enqueued kernel by kernel.
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     struct GraphCleanup { hipGraph_t& g; hipGraphExec_t& e; ~GraphCleanup() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } gcleanup{graph, gexec};
