@@ -70,20 +70,23 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
 
     // per-lane tap tables for the 9 k-steps of a channel pair (k = 2s + half within 18)
     // out-of-image taps read the (in-bounds) own pixel instead and are zeroed by a select: no divergent branches in the K loop
-    int off0[9], off1[9]; unsigned vm0 = 0, vm1 = 0;
+    // (one offset table for both pixel tiles: an out-of-image tap is redirected to the lane's own pixel of that channel by a select on the
+    //  ADDRESS, nine registers fewer than a table per tile — the difference between two and three waves per SIMD)
+    int boff[9]; unsigned vm0 = 0, vm1 = 0;
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         const int k = 2 * s + half;
         const int ci = k / 9, tap = k - 9 * ci, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int boff = ci * HW + dy * g.W + dx;
+        boff[s] = ci * HW + dy * g.W + dx;
         const bool v0 = live0 && (x0 + dx) >= 0 && (x0 + dx) < g.W && (y0 + dy) >= 0 && (y0 + dy) < g.H;
         const bool v1 = live1 && (x1 + dx) >= 0 && (x1 + dx) < g.W && (y1 + dy) >= 0 && (y1 + dy) < g.H;
         vm0 |= (unsigned)v0 << s; vm1 |= (unsigned)v1 << s;
-        off0[s] = v0 ? boff : ci * HW; off1[s] = v1 ? boff : ci * HW;
     }
+    auto own = [&](int s) { return s < 4 ? 0 : (s > 4 ? HW : half * HW); };      // ci * HW of k-step s (k = 2 s + half, ci = k / 9)
     const float* b0p = in + pc0;
     const float* b1p = in + pc1;
-    const float* ap = wp + (size_t)half * g.Cout + m0 + l31;
+    const float4* ap4 = reinterpret_cast<const float4*>(wp) + (size_t)half * g.Cout + m0 + l31;       // s 0..3 of the pair; + 2 Cout float4: s 4..7
+    const float* ap1 = wp + (size_t)16 * g.Cout + (size_t)half * g.Cout + m0 + l31;                  // s 8
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};   // [cout tile][pixel tile]
     // Software pipeline in registers: the 36 operands of channel pair c2+2 are requested before the 36 MFMAs of pair c2 issue
@@ -93,50 +96,61 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
     // applied right before each MFMA group, so the only s_waitcnt in front of an MFMA block is for loads issued a whole block
     // earlier. (Selects or register copies directly behind the loads put the full L2 latency in front of every block: the conv
     // layers ran at 55-60 % MFMA utilisation that way.)
-    float a0x[9], a1x[9], b0x[9], b1x[9], a0y[9], a1y[9], b0y[9], b1y[9];
-    auto load_pair = [&](float (&a0)[9], float (&a1)[9], float (&b0)[9], float (&b1)[9]) {
+    struct ASet { float4 q0, q1; float s8; };               // the nine A values of a pair: s 0..3, s 4..7, s 8
+    ASet a0x, a1x, a0y, a1y; float b0x[9], b1x[9], b0y[9], b1y[9];
+    auto load_pair = [&](ASet& a0, ASet& a1, float (&b0)[9], float (&b1)[9]) {
+        a0.q0 = ap4[0]; a1.q0 = ap4[32];
+        a0.q1 = ap4[(size_t)2 * g.Cout]; a1.q1 = ap4[(size_t)2 * g.Cout + 32];
+        a0.s8 = ap1[0]; a1.s8 = ap1[32];
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            a0[s] = ap[(size_t)(2 * s) * g.Cout];
-            a1[s] = ap[(size_t)(2 * s) * g.Cout + 32];
-            b0[s] = b0p[off0[s]];
-            if constexpr (PT == 2) b1[s] = b1p[off1[s]];
+            b0[s] = b0p[((vm0 >> s) & 1u) ? boff[s] : own(s)];
+            if constexpr (PT == 2) b1[s] = b1p[((vm1 >> s) & 1u) ? boff[s] : own(s)];
         }
-        ap += (size_t)18 * g.Cout;
+        ap4 += (size_t)18 * g.Cout / 4;
+        ap1 += (size_t)18 * g.Cout;
         b0p += (size_t)2 * HW;
         b1p += (size_t)2 * HW;
     };
-    auto mma_pair = [&](const float (&a0)[9], const float (&a1)[9], const float (&b0)[9], const float (&b1)[9]) {
+    auto aval = [](const ASet& a, int s) -> float {
+        switch (s) { case 0: return a.q0.x; case 1: return a.q0.y; case 2: return a.q0.z; case 3: return a.q0.w;
+                     case 4: return a.q1.x; case 5: return a.q1.y; case 6: return a.q1.z; case 7: return a.q1.w; default: return a.s8; }
+    };
+    auto mma_pair = [&](const ASet& a0, const ASet& a1, const float (&b0)[9], const float (&b1)[9]) {
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             const float x0 = ((vm0 >> s) & 1u) ? b0[s] : 0.f;
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], x0, acc00, 0, 0, 0);
+            const float av0 = aval(a0, s), av1 = aval(a1, s);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, x0, acc00, 0, 0, 0);
             if constexpr (PT == 2) {
                 const float x1 = ((vm1 >> s) & 1u) ? b1[s] : 0.f;
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], x1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x1, acc11, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, x1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, x0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, x1, acc11, 0, 0, 0);
             } else {
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x0, acc10, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, x0, acc10, 0, 0, 0);
             }
         }
     };
     // schedule of one half iteration: MFMA, load, MFMA, load, ... — the 36 loads ride in the shadow of the 36 MFMAs instead of
     // draining the matrix pipe while they issue in one burst
     auto interleave = [] {
-        if constexpr (PT == 2) {
+        if constexpr (PT == 2) {                                       // 36 MFMAs, 24 loads (6 A + 18 B)
 #pragma unroll
-            for (int i = 0; i < 36; ++i) {
+            for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
-        } else {                                                       // 18 MFMAs, 27 loads
+        } else {                                                       // 18 MFMAs, 15 loads (6 A + 9 B)
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
     };
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ 
         __builtin_amdgcn_sched_barrier(0);
         // channels c2+4, c2+5 — unconditionally: a branch around these loads makes the waitcnt pass assume they were NOT issued and
         // drain everything inside the next MFMA block. Past the last pair the pointers are rewound and the (unused) loads re-read it.
-        if (c2 + 4 >= g.Cin) { ap -= (size_t)18 * g.Cout; b0p -= (size_t)2 * HW; b1p -= (size_t)2 * HW; }
+        if (c2 + 4 >= g.Cin) { ap4 -= (size_t)18 * g.Cout / 4; ap1 -= (size_t)18 * g.Cout; b0p -= (size_t)2 * HW; b1p -= (size_t)2 * HW; }
         load_pair(a0x, a1x, b0x, b1x);
         mma_pair(a0y, a1y, b0y, b1y);
         interleave();
@@ -216,12 +230,22 @@ int nctk_vgg_preprocess(nct_ctx* ctx, hipStream_t s, const uint8_t* bgr, int str
 }
 
 // ---------------------------------------------------------------- weight packing: Caffe [Cout][Cin][3][3] -> [Cin_pad*9][Cout]
+// Layout per channel pair P (18 k values, k18 = 2 s + h: s = k-step of the pair, h = lane half of the MFMA A operand; ci = 2 P + k18 / 9,
+// tap = k18 % 9), 18 * Cout floats: [s 0..3: [h][cout][4]] [s 4..7: [h][cout][4]] [s 8: [h][cout]] — a lane fetches its nine A values of a
+// pair with two 16-byte loads and one 4-byte load (coalesced over the 32 couts of its half) instead of nine 4-byte loads: the operand
+// stream of the implicit GEMM is bound by vector-memory INSTRUCTIONS on the L1 address path (~12 cycles per 4-byte-per-lane load, 16 per
+// 16-byte one), not by bytes.
 __global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int Cin_pad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)Cin_pad * 9 * Cout) return;
     const int co = (int)(i % Cout); const int k = (int)(i / Cout);
     const int ci = k / 9, tap = k - ci * 9;
-    wp[i] = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+    const float v = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+    const int P = ci >> 1, k18 = (ci & 1) * 9 + tap, s_ = k18 >> 1, h = k18 & 1;
+    const size_t base = (size_t)P * 18 * Cout;
+    const size_t dst = s_ < 8 ? base + (size_t)(s_ >> 2) * 8 * Cout + ((size_t)h * Cout + co) * 4 + (s_ & 3)
+                              : base + (size_t)16 * Cout + (size_t)h * Cout + co;
+    wp[dst] = v;
 }
 
 int nctk_pack_weights(nct_ctx* ctx, hipStream_t s, const float* w, float* wp, int Cout, int Cin, int Cin_pad) {
