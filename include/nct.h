@@ -113,13 +113,24 @@ typedef struct nct_params {
 #define NCT_FLAG_COUNT_EVALS 2u   /* profiling: count PatchMatch evaluations per level on the device (nct_pair_timing.pm_level_evals …) */
 #define NCT_FLAG_LATENCY     4u   /* one pair in flight on this GPU: spend extra launches on its latency — the a- and b-halves of each WLS solve
                                      run concurrently on two streams. Same result bit for bit; with several pairs in flight it only adds launches */
+#define NCT_FLAG_LAB2BGR_CUBE 8u  /* CV_Lab2BGR in the older plain-cube form of OpenCV's Lab2RGB_f (no linear branch, no clipping) instead of the default piecewise
+                                     form — see nct_lab2bgr_u8_form for which one the reference's own result images show */
 void nct_params_default(nct_params* p);
 
 /* ---- A1 + third-party (OpenCV 2.4.10) arithmetic used on the path: cvtColor(CV_BGR2Lab / CV_Lab2BGR) on 8U
  * (main.cu:352,371; ColorTransfer.h:58; ColorTransfer.cpp:1469) and cv::resize(INTER_LINEAR) on 8UC3 / 64FC3
  * (main.cu:106-107; ColorTransfer.cpp:462-463; includes cv::resize's silent INTER_AREA switch for an exact 2x shrink). */
 int nct_bgr2lab_u8(nct_ctx* ctx, const uint8_t* bgr, size_t npix, uint8_t* lab);
-int nct_lab2bgr_u8(nct_ctx* ctx, const uint8_t* lab, size_t npix, uint8_t* bgr);
+int nct_lab2bgr_u8(nct_ctx* ctx, const uint8_t* lab, size_t npix, uint8_t* bgr);      /* = form NCT_LAB2BGR_PIECEWISE */
+/* The two forms of Lab2RGB_f in OpenCV's history (the sources of the pinned 2.4.10 cannot be inspected here — SURVEY App. A):
+ * NCT_LAB2BGR_PIECEWISE (default): CIE's linear branch below L* = 8 / f = 6/29 and linear RGB clipped to [0, 1]; NCT_LAB2BGR_CUBE: fY = (L+16)/116,
+ * fX = fY + a/500, fZ = fY - b/200, all cubed, linear RGB NOT clipped (the inverse-gamma spline extrapolates, the final cast saturates).
+ * The default is decided by the reference's own artefacts: the cube form cannot produce a pixel darker than (9, 9, 9) on the grey axis nor (0, 0, 0) at
+ * all (Y >= (16/116)^3 > 0), yet demo/example/res/in0_tar0_2.00.png holds 415 pixels with all channels < 5 incl. (0, 0, 0) and every result image with
+ * dark regions has pixels like (0, 2, 0) = the linear branch at L_u8 = 1..2 (tests/golden/demo_res_dark_stats.json). */
+#define NCT_LAB2BGR_PIECEWISE 0
+#define NCT_LAB2BGR_CUBE 1
+int nct_lab2bgr_u8_form(nct_ctx* ctx, const uint8_t* lab, size_t npix, uint8_t* bgr, int form);
 int nct_resize_u8c3(nct_ctx* ctx, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
 int nct_resize_f64c3(nct_ctx* ctx, const double* src, int sh, int sw, double* dst, int dh, int dw);
 

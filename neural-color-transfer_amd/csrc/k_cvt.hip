@@ -104,24 +104,43 @@ __device__ __forceinline__ float spline_eval(float x, const float* __restrict__ 
     return ((tab[3] * x + tab[2]) * x + tab[1]) * x + tab[0];
 }
 
+// CV_Lab2BGR on 8U = Lab2RGB_b: L * 100/255, a - 128, b - 128 -> float Lab2RGB_f -> * 255 -> saturate_cast<uchar> (cvRound). Two forms of Lab2RGB_f exist in
+// OpenCV's history; the sources of the reference's pinned release cannot be inspected here, its result images can:
+//   FORM 0 (default, NCT_LAB2BGR_PIECEWISE): CIE's linear branch for L* <= 8 and f <= 6/29, linear RGB clipped to [0, 1] before the inverse-gamma table. The
+//           reference's own demo results contain (0, 0, 0) and (0, 2, 0)-like pixels, which only this form can produce (include/nct.h).
+//   FORM 1 (NCT_FLAG_LAB2BGR_CUBE): the older form — fY = (L + 16) * (1/116), fX = fY + a * 0.002f, fZ = fY - b * 0.005f, every one cubed, NO clipping of the
+//           linear RGB: the spline is evaluated at the clamped table index with the unclamped offset (it extrapolates its first / last cubic), only the
+//           final cast saturates. Black comes out as (9, 9, 9).
+// They agree wherever L* > 8, fX and fZ > 6/29 and the colour is inside the sRGB gamut. Both are pinned by independent evaluations (tests/test_oracle_color.py).
+template <int FORM>
 __global__ void k_lab2bgr(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n, const CvtTables* __restrict__ t) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float lThresh = 0.008856f * 903.3f;
-    const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
     const float li = (float)src[i * 3] * (100.f / 255.f), ai = (float)((int)src[i * 3 + 1] - 128), bi = (float)((int)src[i * 3 + 2] - 128);
-    float y, fy;
-    if (li <= lThresh) { y = li / 903.3f; fy = 7.787f * y + 16.0f / 116.0f; }
-    else { fy = (li + 16.0f) / 116.0f; y = fy * fy * fy; }
-    float fx = ai / 500.0f + fy, fz = fy - bi / 200.0f;
-    fx = fx <= fThresh ? (fx - 16.0f / 116.0f) / 7.787f : fx * fx * fx;
-    fz = fz <= fThresh ? (fz - 16.0f / 116.0f) / 7.787f : fz * fz * fz;
+    float fx, y, fz;
+    if constexpr (FORM == 1) {
+        const float fy = (li + 16.f) * (1.f / 116.f);
+        fx = fy + ai * 0.002f; fz = fy - bi * 0.005f;
+        y = fy * fy * fy; fx = fx * fx * fx; fz = fz * fz * fz;
+    } else {
+        const float lThresh = 0.008856f * 903.3f;
+        const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
+        float fy;
+        if (li <= lThresh) { y = li / 903.3f; fy = 7.787f * y + 16.0f / 116.0f; }
+        else { fy = (li + 16.0f) / 116.0f; y = fy * fy * fy; }
+        fx = ai / 500.0f + fy; fz = fy - bi / 200.0f;
+        fx = fx <= fThresh ? (fx - 16.0f / 116.0f) / 7.787f : fx * fx * fx;
+        fz = fz <= fThresh ? (fz - 16.0f / 116.0f) / 7.787f : fz * fz * fz;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float v = t->l2r[k * 3] * fx + t->l2r[k * 3 + 1] * y + t->l2r[k * 3 + 2] * fz;
-        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+        if constexpr (FORM == 0) v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
         v = spline_eval(v * (float)GAMMA_TAB, t->inv_gamma);
-        dst[i * 3 + k] = sat8((int)rintf(v * 255.f));
+        v = v * 255.f;
+        // saturate_cast<uchar>(float) = saturate(cvRound(v)); the clamp in float first keeps the conversion defined for extrapolated values
+        v = v < -1.f ? -1.f : (v > 256.f ? 256.f : v);
+        dst[i * 3 + k] = sat8((int)rintf(v));
     }
 }
 
@@ -131,9 +150,10 @@ int nctk_bgr2lab(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, 
     NCT_LAUNCH_CHECK();
     return 0;
 }
-int nctk_lab2bgr(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix) {
+int nctk_lab2bgr(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix, int form) {
     const CvtTables* t; int rc = get_tables(ctx, &t); if (rc) return rc;
-    hipLaunchKernelGGL(k_lab2bgr, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, src, dst, npix, t);
+    if (form == 1) hipLaunchKernelGGL(k_lab2bgr<1>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, src, dst, npix, t);
+    else hipLaunchKernelGGL(k_lab2bgr<0>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, src, dst, npix, t);
     NCT_LAUNCH_CHECK();
     return 0;
 }

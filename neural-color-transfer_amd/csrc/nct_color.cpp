@@ -30,13 +30,15 @@ int nct_bgr2lab_u8(nct_ctx* ctx, const uint8_t* bgr, size_t npix, uint8_t* lab) 
     D2H(lab, b, npix * 3); SYNC();
     return NCT_OK;
 }
-int nct_lab2bgr_u8(nct_ctx* ctx, const uint8_t* lab, size_t npix, uint8_t* bgr) {
+int nct_lab2bgr_u8(nct_ctx* ctx, const uint8_t* lab, size_t npix, uint8_t* bgr) { return nct_lab2bgr_u8_form(ctx, lab, npix, bgr, NCT_LAB2BGR_PIECEWISE); }
+int nct_lab2bgr_u8_form(nct_ctx* ctx, const uint8_t* lab, size_t npix, uint8_t* bgr, int form) {
     CTX_ENTER();
     NCT_REQUIRE(bgr && lab && npix > 0, "lab2bgr: bad arguments");
+    NCT_REQUIRE(form == NCT_LAB2BGR_CUBE || form == NCT_LAB2BGR_PIECEWISE, "lab2bgr: unknown form %d", form);
     DevBuf<uint8_t> a(ctx, npix * 3), b(ctx, npix * 3);
     if (!a.ok() || !b.ok()) return NCT_ERR_HIP;
     H2D(a, lab, npix * 3);
-    RC(nctk_lab2bgr(ctx, ctx->stream, a, b, npix));
+    RC(nctk_lab2bgr(ctx, ctx->stream, a, b, npix, form));
     D2H(bgr, b, npix * 3); SYNC();
     return NCT_OK;
 }
@@ -114,7 +116,7 @@ int nct_local_color_transfer(nct_ctx* ctx, const float* err, const uint8_t* s_bg
     if (stages) { dbg.ab_local = stages->ab_local; dbg.ab_nonlocal = stages->ab_nonlocal; dbg.ab_up = stages->ab_up; dbg.rough = stages->roughness;
                   dbg.ab_wls = stages->ab_wls; dbg.cg_iters = stages->cg_iters; dbg.wls_iters = stages->wls_iters; }
     RC(nctk_local_color_transfer(ctx, ctx->stream, derr, slab, glab, sflab, id, kw, layer, h, w, H, W, cp, olab, stages ? &dbg : nullptr));
-    RC(nctk_lab2bgr(ctx, ctx->stream, olab, obgr, N));        // ColorTransfer.cpp:1469
+    RC(nctk_lab2bgr(ctx, ctx->stream, olab, obgr, N, (prm->flags & NCT_FLAG_LAB2BGR_CUBE) ? 1 : 0));        // ColorTransfer.cpp:1469
     D2H(out_bgr_full, obgr, N * 3); SYNC();
     return NCT_OK;
 }

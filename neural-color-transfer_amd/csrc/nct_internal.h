@@ -90,7 +90,7 @@ int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H,
 void nct_vgg_free(nct_ctx* ctx);
 // k_cvt.hip
 int nctk_bgr2lab(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix);
-int nctk_lab2bgr(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix);
+int nctk_lab2bgr(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix, int form = 0 /* 0 = piecewise form (default), 1 = plain-cube form: k_cvt.hip */);
 int nctk_resize_u8c3(nct_ctx* ctx, hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
 int nctk_resize_f64c3(nct_ctx* ctx, hipStream_t s, const double* src, int sh, int sw, double* dst, int dh, int dw);
 void nct_cvt_free(nct_ctx* ctx);

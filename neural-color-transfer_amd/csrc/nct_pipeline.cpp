@@ -244,7 +244,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         if (cs) { dbg.ab_local = cs->ab_local; dbg.ab_nonlocal = cs->ab_nonlocal; dbg.ab_up = cs->ab_up; dbg.rough = cs->roughness; dbg.ab_wls = cs->ab_wls; dbg.cg_iters = cs->cg_iters; }
         rc = nctk_local_color_transfer(ctx, s, err, s_lab_l, g_lab_l, s_lab_full, knn_id, knn_w, l, ah[l], aw[l], H, W, cp, out_lab, (timing || cs) ? &dbg : nullptr); if (rc) return rc;
         if (cs && cs->wls_iters) for (int q = 0; q < 6; ++q) cs->wls_iters[q] = wls_it[q];
-        rc = nctk_lab2bgr(ctx, s, out_lab, P->out, N); if (rc) return rc;
+        rc = nctk_lab2bgr(ctx, s, out_lab, P->out, N, (prm->flags & NCT_FLAG_LAB2BGR_CUBE) ? 1 : 0); if (rc) return rc;
         if (timing) { timing->wls_iters[l] = *std::max_element(wls_it, wls_it + 6); }
         MARK(ST_COLOR, l);
         if (lv) { rc = d2h(lv->result[l], P->out, N * 3); if (rc) return rc; }

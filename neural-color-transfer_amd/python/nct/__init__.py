@@ -64,6 +64,7 @@ SIGNATURES = {
     "nct_params_default": (None, [C.c_void_p]),
     "nct_bgr2lab_u8": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p]),
     "nct_lab2bgr_u8": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p]),
+    "nct_lab2bgr_u8_form": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_int]),
     "nct_resize_u8c3": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]),
     "nct_resize_f64c3": (C.c_int, [C.c_void_p, _f64p, C.c_int, C.c_int, _f64p, C.c_int, C.c_int]),
     "nct_cluster_features": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _i32p, C.POINTER(C.c_int)]),
@@ -124,6 +125,8 @@ class PairTiming(C.Structure):
 FLAG_FEAT16 = 1
 FLAG_COUNT_EVALS = 2
 FLAG_LATENCY = 4
+FLAG_LAB2BGR_CUBE = 8
+LAB2BGR_PIECEWISE, LAB2BGR_CUBE = 0, 1
 
 
 class PairLevels(C.Structure):
@@ -297,10 +300,13 @@ class Context:
         self._chk(self._l.nct_bgr2lab_u8(self._h, a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3)))
         return out
 
-    def lab2bgr(self, lab):
+    def lab2bgr(self, lab, form=None):
         a = np.ascontiguousarray(lab, np.uint8)
         out = np.empty_like(a)
-        self._chk(self._l.nct_lab2bgr_u8(self._h, a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3)))
+        if form is None:
+            self._chk(self._l.nct_lab2bgr_u8(self._h, a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3)))
+        else:
+            self._chk(self._l.nct_lab2bgr_u8_form(self._h, a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3), form))
         return out
 
     def resize_u8c3(self, img, dh, dw):

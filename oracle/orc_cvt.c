@@ -112,31 +112,48 @@ void orc_bgr2lab_u8(const uint8_t* src, size_t npix, uint8_t* dst) {
     }
 }
 
-void orc_lab2bgr_u8(const uint8_t* src, size_t npix, uint8_t* dst) {
+/* CV_Lab2BGR on 8U (ColorTransfer.cpp:1469) = Lab2RGB_b around the float Lab2RGB_f. Two forms of Lab2RGB_f exist in OpenCV's history; the sources of the
+ * reference's pinned 2.4.10 cannot be read here (parity unpinned), but its artefacts can (tests/golden/demo_res_dark_stats.json):
+ *   form 0 (DEFAULT): piecewise — CIE linear branch for L* <= 8 and f <= 6/29, linear RGB clipped to [0, 1]. The reference's demo results contain (0,0,0)
+ *           and (0,2,0)-like pixels that only this form produces;
+ *   form 1: plain cubes — fY = (L+16)*(1/116), fX = fY + a*0.002f, fZ = fY - b*0.005f, each cubed; linear RGB is NOT clipped: splineInterpolate clamps only
+ *           the table index, so out-of-gamut values run along the first / last cubic, and saturate_cast<uchar>(v*255) does the clamping.
+ * They coincide for in-gamut colours with L* > 8, fX > 6/29, fZ > 6/29. */
+static int g_lab2bgr_form = 0;
+void orc_set_lab2bgr_form(int form) { g_lab2bgr_form = form ? 1 : 0; }
+int orc_get_lab2bgr_form(void) { return g_lab2bgr_form; }
+void orc_lab2bgr_u8_form(const uint8_t* src, size_t npix, uint8_t* dst, int form) {
     init_tabs();
     const float lThresh = 0.008856f * 903.3f;
     const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
     const float* C = lab2rgb_coeffs;
     for (size_t i = 0; i < npix; ++i) {
         float li = src[i * 3] * (100.f / 255.f), ai = (float)(src[i * 3 + 1] - 128), bi = (float)(src[i * 3 + 2] - 128);
-        float y, fy;
-        if (li <= lThresh) { y = li / 903.3f; fy = 7.787f * y + 16.0f / 116.0f; }
-        else { fy = (li + 16.0f) / 116.0f; y = fy * fy * fy; }
-        float fxz[2] = {ai / 500.0f + fy, fy - bi / 200.0f};
-        for (int j = 0; j < 2; j++)
-            if (fxz[j] <= fThresh) fxz[j] = (fxz[j] - 16.0f / 116.0f) / 7.787f;
-            else fxz[j] = fxz[j] * fxz[j] * fxz[j];
-        float x = fxz[0], z = fxz[1];
-        float o[3];
+        float x, y, z;
+        if (form == 1) {
+            float fy = (li + 16.f) * (1.f / 116.f);
+            x = fy + ai * 0.002f; z = fy - bi * 0.005f;
+            y = fy * fy * fy; x = x * x * x; z = z * z * z;
+        } else {
+            float fy;
+            if (li <= lThresh) { y = li / 903.3f; fy = 7.787f * y + 16.0f / 116.0f; }
+            else { fy = (li + 16.0f) / 116.0f; y = fy * fy * fy; }
+            float fxz[2] = {ai / 500.0f + fy, fy - bi / 200.0f};
+            for (int j = 0; j < 2; j++)
+                if (fxz[j] <= fThresh) fxz[j] = (fxz[j] - 16.0f / 116.0f) / 7.787f;
+                else fxz[j] = fxz[j] * fxz[j] * fxz[j];
+            x = fxz[0]; z = fxz[1];
+        }
         for (int k = 0; k < 3; ++k) {
             float v = C[k * 3] * x + C[k * 3 + 1] * y + C[k * 3 + 2] * z;
-            v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
-            v = spline_interp(v * (float)GAMMA_TAB_SIZE, sRGBInvGammaTab, GAMMA_TAB_SIZE);
-            o[k] = v;
+            if (form == 0) v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+            v = spline_interp(v * (float)GAMMA_TAB_SIZE, sRGBInvGammaTab, GAMMA_TAB_SIZE) * 255.f;
+            v = v < -1.f ? -1.f : (v > 256.f ? 256.f : v);          /* keeps the int conversion defined; saturate_cast clamps anyway */
+            dst[i * 3 + k] = sat_u8(cv_round(v));
         }
-        for (int k = 0; k < 3; ++k) dst[i * 3 + k] = sat_u8(cv_round(o[k] * 255.f));
     }
 }
+void orc_lab2bgr_u8(const uint8_t* src, size_t npix, uint8_t* dst) { orc_lab2bgr_u8_form(src, npix, dst, g_lab2bgr_form); }
 
 /* ---------------------------------------------------------------- resize (INTER_LINEAR semantics of cv::resize) */
 static void linear_coeffs(int ssize, int dsize, int* ofs, float* alpha, int* xmax_out) {

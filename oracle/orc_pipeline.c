@@ -18,11 +18,14 @@ void orc_feat_normalize(const float* src_chw, float* dst_chw, float* resp, int C
 void orc_nnf_init(uint32_t* nnf, int ah, int aw, int bh, int bw);
 void orc_nnf_upsample(const uint32_t* nnf_half, uint32_t* nnf, int ah, int aw, int bh, int bw, int ah_half, int aw_half);
 void orc_patchmatch(const float* a_chw, const float* b_chw, int C, int ah, int aw, int bh, int bw, int patch, int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist);
+int orc_patchmatch_inplace(const float* a_chw, const float* b_chw, int C, int ah, int aw, int bh, int bw, int patch, int iters, int rs_max, uint32_t seed, int schedule, uint32_t* nnf, float* dist);
+int orc_get_pm_schedule(void);      /* orc_nnf_inplace.c: 0 = the product's Jacobi schedule (default), 1 / 2 = the reference's in-place schedule under two legal interleavings */
 void orc_feature_distance(const float* a_chw, const float* b_chw, float* err, int C, int H, int W);
 void orc_bds_vote_features(const uint32_t* ann, const uint32_t* bnn, const float* pin, float* pout, float* pw_out, int C, int ah, int aw, int bh, int bw, int patch, float wCohen, float wComplete);
 void orc_bds_vote_image(const uint8_t* a, int ah, int aw, const uint8_t* b, int bh, int bw, const uint32_t* ann, const uint32_t* bnn, int patch, double wCohen, double wComplete, uint8_t* out);
 void orc_resize_u8c3(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
 void orc_bgr2lab_u8(const uint8_t* src, size_t npix, uint8_t* dst);
+void orc_set_lab2bgr_form(int form); int orc_get_lab2bgr_form(void);
 void orc_u8_to_f64_scaled(const uint8_t* src, size_t n, double* dst);
 int orc_kmeans_labels(const float* feat, int n, int C, int K, int iters, uint64_t seed, int* labels);
 void orc_knn_graph(const double* lab, int h, int w, const int* labels, int lh, int lw, int nlabels, int samples, int k, int* knn_id, double* knn_w);
@@ -38,7 +41,7 @@ typedef struct {
     int pm_iters;
     uint32_t seed;
     int levels;         /* pyramid levels to run, coarse -> fine (5 = full loop; 1 = "L=5 only", BASELINE config 1) */
-    uint32_t flags;     /* ignored by the oracle (the product's reduced-precision / profiling switches) */
+    uint32_t flags;     /* only bit 8 (NCT_FLAG_LAB2BGR_CUBE) is honoured; the product's reduced-precision / profiling switches are ignored */
 } orc_params;       /* same layout as nct_params (include/nct.h) */
 
 /* per-level intermediates for level-wise validation; same layout as nct_pair_levels (include/nct.h); every pointer nullable */
@@ -56,6 +59,8 @@ static const int kTapC[5] = {64, 128, 256, 512, 512};
 int orc_process_pair_levels(const uint8_t* src, int H, int W, const uint8_t* ref, int RH, int RW, const float* const* weights, const float* const* biases,
                             const orc_params* prm, uint8_t* out, uint8_t* level_out, int s2_exact, const orc_pair_levels* lv) {
     const int nlevels = prm->levels >= 1 && prm->levels <= 5 ? prm->levels : 5;
+    const int form_before = orc_get_lab2bgr_form();
+    if (prm->flags & 8u) orc_set_lab2bgr_form(1);
     int ah[5], aw[5], bh[5], bw[5];
     { int h = H, w = W, h2 = RH, w2 = RW;
       for (int t = 0; t < 5; ++t) { ah[4 - t] = h; aw[4 - t] = w; bh[4 - t] = h2; bw[4 - t] = w2; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; h2 = (h2 - 1) / 2 + 1; w2 = (w2 - 1) / 2 + 1; } }
@@ -106,8 +111,13 @@ int orc_process_pair_levels(const uint8_t* src, int H, int W, const uint8_t* ref
         if (l > 0) orc_feat_normalize(sfeat, na, NULL, C, ah[l], aw[l]);
         orc_feat_normalize(rtap[4 - l], nb, NULL, C, bh[l], bw[l]);
         const uint32_t seed_ab = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 1)), seed_ba = prm->seed ^ (0x9E3779B9u * (uint32_t)(2 * l + 2));
-        orc_patchmatch(na, nb, C, ah[l], aw[l], bh[l], bw[l], 3, prm->pm_iters, rs_range[l], seed_ab, ann, annd);
-        orc_patchmatch(nb, na, C, bh[l], bw[l], ah[l], aw[l], 3, prm->pm_iters, rs_range[l], seed_ba, bnn, bnnd);
+        if (orc_get_pm_schedule() == 0) {
+            orc_patchmatch(na, nb, C, ah[l], aw[l], bh[l], bw[l], 3, prm->pm_iters, rs_range[l], seed_ab, ann, annd);
+            orc_patchmatch(nb, na, C, bh[l], bw[l], ah[l], aw[l], 3, prm->pm_iters, rs_range[l], seed_ba, bnn, bnnd);
+        } else {      /* schedule experiment (tests/golden/gen_pm_inplace_band.py): the reference's own in-place, thread-ordered schedule */
+            orc_patchmatch_inplace(na, nb, C, ah[l], aw[l], bh[l], bw[l], 3, prm->pm_iters, rs_range[l], seed_ab, orc_get_pm_schedule(), ann, annd);
+            orc_patchmatch_inplace(nb, na, C, bh[l], bw[l], ah[l], aw[l], 3, prm->pm_iters, rs_range[l], seed_ba, orc_get_pm_schedule(), bnn, bnnd);
+        }
         if (lv) {
             if (lv->ann[l]) memcpy(lv->ann[l], ann, sizeof(uint32_t) * ah[l] * aw[l]);
             if (lv->bnn[l]) memcpy(lv->bnn[l], bnn, sizeof(uint32_t) * bh[l] * bw[l]);
@@ -139,6 +149,7 @@ int orc_process_pair_levels(const uint8_t* src, int H, int W, const uint8_t* ref
     for (int t = 0; t < 5; ++t) free(rtap[t]);
     free(sfeat); free(na); free(nb); free(voted); free(nvoted); free(labels); free(ann); free(bnn); free(annp); free(bnnp);
     free(annd); free(bnnd); free(err); free(guide); free(slab); free(labd); free(knn_id); free(knn_w);
+    orc_set_lab2bgr_form(form_before);
     return rc;
 }
 

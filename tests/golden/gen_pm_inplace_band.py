@@ -1,0 +1,84 @@
+"""Generates tests/golden/pm_inplace_band.json — SURVEY §8c G4: energy statistics of the REFERENCE'S OWN PatchMatch schedule
+(oracle/orc_nnf_inplace.c: in-place NNF, thread order of the 24x24-block launch, sequential channel sum, column-shared random
+streams; GeneralizedPatchMatch.cu:677-831) under two legal interleavings, next to the product's schedule (orc_patchmatch = what the
+GPU reproduces bit for bit), on three seeded feature pairs of the pipeline's level shapes — and the end-to-end distance between
+the schedules on one whole pair.
+
+    python tests/golden/gen_pm_inplace_band.py          (about 3 minutes on 8 cores; CPU only, needs nothing from /root/reference)
+
+The fixture holds only statistics (mean / percentiles of annd, evaluation counts, PSNR): the racy reference has no single NNF to
+store. tests/test_oracle_nnf.py re-derives the small case from scratch; tests/test_gpu_correspondence.py asserts that the
+PRODUCT's energy on the same inputs lies inside the band stated here."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_bind  # noqa: E402
+import synth  # noqa: E402
+from caffemodel_io import synthetic_vgg19  # noqa: E402
+
+# (name, C, ah, aw, bh, bw, rs_max, seeds): the 700x700 pyramid's level shapes at conv5_1 / conv3_1 and the 256x256 pair's conv1_1
+CASES = [("44x44x512", 512, 44, 44, 44, 44, 43, (11, 12)),
+         ("175x175x256", 256, 175, 175, 175, 175, 10, (13, 14)),
+         ("256x256x64", 64, 256, 256, 256, 256, 32, (15, 16))]
+SCHED = {"product_jacobi": 0, "reference_sequential": 1, "reference_lockstep": 2}
+
+
+def psnr(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    per = [10 * np.log10(255.0 ** 2 / max(np.mean(d[..., c] ** 2), 1e-12)) for c in range(3)]
+    return min(per), int(np.abs(d).max())
+
+
+def main():
+    orc = oracle_bind.load()
+    out = {"generator": "tests/golden/gen_pm_inplace_band.py", "stats": "mean, p5, p25, p50, p75, p95 of annd (negative mean cosine of the best match)", "cases": {}}
+    for name, C, ah, aw, bh, bw, rs, (sa, sb) in CASES:
+        a = orc.feat_normalize(synth.features(sa, C, ah, aw)); b = orc.feat_normalize(synth.features(sb, C, bh, bw))
+        n0 = orc.nnf_init(ah, aw, bh, bw)
+        case = {"C": C, "ah": ah, "aw": aw, "bh": bh, "bw": bw, "iters": 10, "rs_max": rs, "feature_seeds": [sa, sb], "pm_seed": 7}
+        _, d0 = orc.patchmatch(a, b, n0, iters=0, rs_max=rs, seed=7)
+        case["init"] = [float(v) for v in orc.field_stats(d0)]
+        for sname, s in SCHED.items():
+            t = time.time()
+            if s == 0:
+                nn, d = orc.patchmatch(a, b, n0, iters=10, rs_max=rs, seed=7); ev = orc.last_evals()
+            else:
+                nn, d = orc.patchmatch_inplace(a, b, n0, iters=10, rs_max=rs, seed=7, schedule=s); ev = int(orc.l.orc_patchmatch_inplace_last_evals())
+            st = orc.field_stats(d)
+            case[sname] = {"stats": [float(v) for v in st], "evals": ev, "improved_frac": float(np.mean(d < d0)), "seconds": round(time.time() - t, 1)}
+            print(name, sname, ["%.5f" % v for v in st], ev, "%.1fs" % (time.time() - t), flush=True)
+        out["cases"][name] = case
+    # end to end: the whole pair under each schedule (all five levels, both directions), result vs the product schedule's result
+    ws, bs = synthetic_vgg19(19)
+    S = 256
+    src, ref = synth.image(1000, S, S), synth.image(1001, S, S)
+    res = {}
+    for sname, s in SCHED.items():
+        orc.set_pm_schedule(s)
+        t = time.time()
+        img, keep = orc.process_pair(src, ref, ws, bs, want_nnf=True)
+        res[sname] = (img, [float(np.mean(x)) for x in keep["annd"]], [float(np.mean(x)) for x in keep["err"]])
+        print("pair", sname, "%.1fs" % (time.time() - t), res[sname][1], flush=True)
+    orc.set_pm_schedule(0)
+    e2e = {"pair": "synth.image(1000/1001, 256, 256), synthetic VGG19 seed 19, defaults", "level_mean_annd": {k: v[1] for k, v in res.items()},
+           "level_mean_matching_error": {k: v[2] for k, v in res.items()}}
+    for sname in ("reference_sequential", "reference_lockstep"):
+        p, linf = psnr(res[sname][0], res["product_jacobi"][0])
+        e2e["psnr_min_channel_vs_product_schedule_" + sname] = p
+        e2e["linf_vs_product_schedule_" + sname] = linf
+    p, linf = psnr(res["reference_sequential"][0], res["reference_lockstep"][0])
+    e2e["psnr_min_channel_sequential_vs_lockstep"] = p
+    e2e["linf_sequential_vs_lockstep"] = linf
+    out["end_to_end_256"] = e2e
+    json.dump(out, open(os.path.join(HERE, "pm_inplace_band.json"), "w"), indent=1)
+    print(json.dumps(e2e, indent=1))
+
+
+if __name__ == "__main__":
+    main()

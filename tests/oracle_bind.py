@@ -119,10 +119,15 @@ class Oracle:
         self.l.orc_bgr2lab_u8(a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3))
         return out
 
-    def lab2bgr(self, lab):
+    def lab2bgr(self, lab, form=None):
+        """form None = the oracle's current default (0 = piecewise form unless orc_set_lab2bgr_form changed it; 1 = plain-cube form); 0 / 1 explicit"""
         self._decl_color()
         a = np.ascontiguousarray(lab, np.uint8); out = np.empty_like(a)
-        self.l.orc_lab2bgr_u8(a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3))
+        if form is None:
+            self.l.orc_lab2bgr_u8(a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3))
+        else:
+            self.l.orc_lab2bgr_u8_form.argtypes = [_u8p, C.c_size_t, _u8p, I]
+            self.l.orc_lab2bgr_u8_form(a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3), form)
         return out
 
     def resize_u8c3(self, img, dh, dw):
@@ -255,6 +260,31 @@ class Oracle:
 
     def last_evals(self):
         return int(self.l.orc_patchmatch_last_evals())
+
+    def patchmatch_inplace(self, a, b, nnf, iters=10, rs_max=32, seed=0, patch=3, schedule=1):
+        """the reference's own in-place schedule (orc_nnf_inplace.c): schedule 1 = thread-sequential, 2 = lock step."""
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        Cc, ah, aw = a.shape
+        _, bh, bw = b.shape
+        nnf = np.array(nnf, np.uint32, order="C", copy=True).reshape(ah, aw)
+        dist = np.empty((ah, aw), np.float32)
+        self.l.orc_patchmatch_inplace.argtypes = [_f32p, _f32p, I, I, I, I, I, I, I, I, C.c_uint32, I, _u32p, _f32p]
+        rc = self.l.orc_patchmatch_inplace(a, b, Cc, ah, aw, bh, bw, patch, iters, rs_max, seed, schedule, nnf, dist)
+        assert rc == 0
+        return nnf, dist
+
+    def field_stats(self, d):
+        """mean, p5, p25, p50, p75, p95 of a distance field"""
+        d = np.ascontiguousarray(d, np.float32)
+        out = np.empty(6, np.float64)
+        self.l.orc_field_stats.argtypes = [_f32p, I, _f64p]
+        self.l.orc_field_stats(d.reshape(-1), d.size, out)
+        return out
+
+    def set_pm_schedule(self, s):
+        """which PatchMatch schedule process_pair runs: 0 = the product's (default), 1 / 2 = the reference's in-place schedule"""
+        self.l.orc_set_pm_schedule(int(s))
 
     def feature_distance(self, a, b):
         a = np.ascontiguousarray(a, np.float32)

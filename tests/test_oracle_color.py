@@ -1,3 +1,4 @@
+import os
 """CPU tests of the colour-stage oracle: known answers for the OpenCV restatements, brute-force/independent checks of
 k-means, kNN, the CG recurrence and the WLS solve (vs scipy sparse direct solve; MKL PARDISO fixture where available)."""
 import numpy as np
@@ -24,26 +25,66 @@ def test_lab_roundtrip_close(oracle):
     assert np.abs(oracle.lab2bgr(oracle.bgr2lab(g)).astype(int) - g).max() <= 1
 
 
-def test_lab2bgr_dark_and_out_of_gamut_pins_the_restated_form(oracle):
-    """CV_Lab2BGR on 8-bit input, restated form: piecewise CIE inverse (linear branch for L* <= 8 and f <= 6/29), linear-RGB clipped to
-    [0, 1], sRGB gamma, round. Independent numpy evaluation of that formula for dark (L_u8 <= 20), grey and out-of-gamut triples, +-1 LSB
-    for the spline-interpolated gamma table. DESIGN.md §4 divergence 8: OpenCV 2.4.10 itself is believed to use the plain cube form
-    without clipping; the two differ only for L_u8 <= 20 and out-of-gamut colours and cannot be arbitrated here (parity unpinned)."""
-    lab = np.array([[0, 128, 128], [5, 128, 128], [12, 130, 120], [20, 128, 128], [21, 128, 128], [10, 160, 90], [60, 128, 128], [137, 128, 128],
-                    [200, 250, 250], [40, 10, 240]], np.uint8)
+LAB_PIN = np.array([[0, 128, 128], [5, 128, 128], [12, 130, 120], [20, 128, 128], [21, 128, 128], [10, 160, 90], [60, 128, 128], [137, 128, 128],
+                    [200, 250, 250], [40, 10, 240], [128, 128, 250], [128, 20, 128]], np.uint8)
+
+
+def _lab2bgr_numpy(lab, form):
+    """float64 evaluation of the two Lab2RGB_f forms, no tables (exact sRGB gamma): the independent pin of both restatements."""
     L = lab[:, 0].astype(np.float64) * 100 / 255; a = lab[:, 1].astype(np.float64) - 128; b = lab[:, 2].astype(np.float64) - 128
-    fy = np.where(L <= 0.008856 * 903.3, 7.787 * (L / 903.3) + 16 / 116, (L + 16) / 116)
-    y = np.where(L <= 0.008856 * 903.3, L / 903.3, fy ** 3)
-    fx, fz = a / 500 + fy, fy - b / 200
-    finv = lambda f: np.where(f <= 7.787 * 0.008856 + 16 / 116, (f - 16 / 116) / 7.787, f ** 3)
-    X, Z = finv(fx) * 0.950456, finv(fz) * 1.088754
+    if form == 1:        # plain cubes, no clipping before the gamma table
+        fy = (L + 16) / 116
+        y, X, Z = fy ** 3, (fy + a / 500) ** 3 * 0.950456, (fy - b / 200) ** 3 * 1.088754
+    else:                # piecewise: CIE's linear branch below L* = 8 / f = 6/29, clip to [0, 1]
+        fy = np.where(L <= 0.008856 * 903.3, 7.787 * (L / 903.3) + 16 / 116, (L + 16) / 116)
+        y = np.where(L <= 0.008856 * 903.3, L / 903.3, fy ** 3)
+        finv = lambda f: np.where(f <= 7.787 * 0.008856 + 16 / 116, (f - 16 / 116) / 7.787, f ** 3)
+        X, Z = finv(a / 500 + fy) * 0.950456, finv(fy - b / 200) * 1.088754
     M = np.array([[3.240479, -1.53715, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
-    rgb = np.clip(np.stack([X, y, Z], 1) @ M.T, 0, 1)
-    srgb = np.where(rgb <= 0.0031308, 12.92 * rgb, 1.055 * rgb ** (1 / 2.4) - 0.055)
-    exp_bgr = np.rint(srgb[:, ::-1] * 255)
-    got = oracle.lab2bgr(lab).astype(int)
-    assert np.abs(got - exp_bgr).max() <= 1, (got.tolist(), exp_bgr.tolist())
-    assert got[0].tolist() == [0, 0, 0] and got[7].tolist() == [128, 128, 128]
+    rgb = np.stack([X, y, Z], 1) @ M.T
+    far_out = rgb[:, ::-1] < -0.02      # cube form only: far below the gamut the table's first cubic is extrapolated hundreds of steps and its tiny cubic
+    #                                     term takes over (-> a saturated byte, 0 or 255, decided by the spline coefficients): not modelled here
+    if form == 0:
+        rgb = np.clip(rgb, 0, 1)
+    srgb = np.where(rgb <= 0.0031308, 12.92 * rgb, 1.055 * np.maximum(rgb, 0) ** (1 / 2.4) - 0.055)
+    return np.clip(np.rint(srgb[:, ::-1] * 255), 0, 255), (far_out if form == 1 else np.zeros_like(far_out))
+
+
+def test_lab2bgr_both_forms_pinned(oracle):
+    """CV_Lab2BGR on 8-bit input (ColorTransfer.cpp:1469), both forms of OpenCV's Lab2RGB_f: the 2.4.x cube form (default: the reference
+    links OpenCV 2.4.10) and the 3.x piecewise form. Independent float64 evaluation for dark (L_u8 <= 20), grey, saturated and out-of-gamut triples, +-1 LSB for
+    the spline-interpolated gamma table, plus hand-computed values where the two forms must differ."""
+    for form in (0, 1):
+        got = oracle.lab2bgr(LAB_PIN, form=form).astype(int)
+        exp, far_out = _lab2bgr_numpy(LAB_PIN, form)
+        assert np.abs(got - exp)[~far_out].max() <= 1, (form, got.tolist(), exp.tolist())
+        assert np.isin(got[far_out], (0, 255)).all()
+        assert got[7].tolist() == [128, 128, 128]
+    pw, cube = oracle.lab2bgr(LAB_PIN, form=0).astype(int), oracle.lab2bgr(LAB_PIN, form=1).astype(int)
+    # hand-computed. L_u8 = 0 (L* = 0): piecewise Y = 0 -> (0, 0, 0); cube fY = 16/116, Y = (16/116)^3 = 0.0026241 = R = G = B on the grey axis, below the sRGB
+    # toe: 12.92 * 0.0026241 * 255 = 8.65 -> 9. L_u8 = 5 (L* = 1.961): piecewise Y = 1.961/903.3 = 0.0021708 -> 12.92 * Y * 255 = 7.15 -> 7; cube
+    # ((1.961+16)/116)^3 = 0.0037120 -> 12.23 -> 12. L_u8 = 21 (L* = 8.235 > 8): both ((8.235+16)/116)^3 = 0.0091190 -> 1.055 Y^(1/2.4) - 0.055 = 0.0940 -> 24.
+    assert pw[0].tolist() == [0, 0, 0] and cube[0].tolist() == [9, 9, 9]
+    assert pw[1].tolist() == [7, 7, 7] and cube[1].tolist() == [12, 12, 12]
+    assert pw[4].tolist() == [24, 24, 24] and cube[4].tolist() == [24, 24, 24]
+    assert pw[6].tolist() == cube[6].tolist() and pw[7].tolist() == cube[7].tolist()          # in-gamut greys above L* = 8: identical
+    assert oracle.lab2bgr(LAB_PIN).tolist() == pw.tolist()                                       # the default is the piecewise form
+
+
+def test_lab2bgr_default_form_is_the_one_the_reference_results_show(oracle):
+    """Which Lab2RGB_f the reference's OpenCV ran is decided by its own artefacts: over ALL 2^24 8-bit Lab inputs the plain-cube form never outputs a pixel
+    whose brightest channel is below 9 (Y >= (16/116)^3), the piecewise form does (Y = L/903.3 -> 0) — and the original binary's demo results
+    (tests/golden/demo_res_dark_stats.json, statistics of demo/example/res/*.png) hold hundreds of such pixels, pure black included."""
+    import json
+    g = np.arange(256, dtype=np.uint8)
+    lab = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    cube_floor = int(oracle.lab2bgr(lab, form=1).max(1).min())
+    pw_floor = int(oracle.lab2bgr(lab, form=0).max(1).min())
+    assert cube_floor == 9 and pw_floor == 0
+    stats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_res_dark_stats.json")))["images"]
+    below = {k: v["pixels_brightest_channel_below_9"] for k, v in stats.items()}
+    assert below["in0_tar0_2.00.png"] > 1000 and stats["in0_tar0_2.00.png"]["pixels_pure_black"] > 0
+    assert sum(1 for v in below.values() if v > 0) >= 7          # nearly every result image rules the cube form out
 
 
 def test_resize_u8_area_and_linear(oracle):

@@ -217,3 +217,40 @@ def test_bds_vote_image_known_answers(oracle):
                             bcol += b[by + dy, bx + dx]; bn += 1
         exp = ((acol * wa + bcol * wb) / (an * wa + bn * wb)).astype(np.uint8)
         assert np.array_equal(g2[ay, ax], exp)
+
+
+def test_inplace_reference_schedule_fixture_reproduces(oracle):
+    """oracle/orc_nnf_inplace.c — patchmatch_single under the reference's own in-place schedule (GeneralizedPatchMatch.cu:677-831, two legal
+    interleavings) — reproduces the committed statistics of tests/golden/pm_inplace_band.json on the conv5_1-shaped case, improves on the
+    initial field, and the product's schedule (orc_patchmatch) is not worse than either."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pm_inplace_band.json")))["cases"]["44x44x512"]
+    a = oracle.feat_normalize(synth.features(fx["feature_seeds"][0], 512, 44, 44)); b = oracle.feat_normalize(synth.features(fx["feature_seeds"][1], 512, 44, 44))
+    n0 = oracle.nnf_init(44, 44, 44, 44)
+    means = {}
+    for name, sched in (("reference_sequential", 1), ("reference_lockstep", 2)):
+        nn, d = oracle.patchmatch_inplace(a, b, n0, iters=10, rs_max=fx["rs_max"], seed=fx["pm_seed"], schedule=sched)
+        st = oracle.field_stats(d)
+        assert np.allclose(st, fx[name]["stats"], rtol=0, atol=1e-7), (name, st, fx[name]["stats"])
+        assert st[0] < fx["init"][0] - 0.01                                     # a real improvement over the scaled-identity field
+        assert (nn & 0xFFF).max() < 44 and (nn >> 12).max() < 44
+        means[name] = st[0]
+    _, dj = oracle.patchmatch(a, b, n0, iters=10, rs_max=fx["rs_max"], seed=fx["pm_seed"])
+    mj = oracle.field_stats(dj)[0]
+    assert abs(mj - fx["product_jacobi"]["stats"][0]) < 1e-7
+    assert mj <= min(means.values()) + 1e-4 and mj >= min(means.values()) * 1.01      # energies are negative: within 1 % below the better interleaving
+
+
+def test_inplace_schedule_sequential_channel_sum_matches_definition(oracle):
+    """dist_compute_single as written (:355-405): sequential `pixel_sum1 -= a*b` over channels, CHW, divided by the number of valid taps — checked against a
+    float64 evaluation on a border query (4 valid taps) through a zero-iteration run."""
+    a = oracle.feat_normalize(synth.features(3, 16, 5, 6)); b = oracle.feat_normalize(synth.features(4, 16, 7, 5))
+    n0 = oracle.nnf_init(5, 6, 7, 5)
+    _, d = oracle.patchmatch_inplace(a, b, n0, iters=0, rs_max=4, seed=1, schedule=1)
+    bx, by = int(n0[0, 0] & 0xFFF), int(n0[0, 0] >> 12)
+    s, cnt = 0.0, 0
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            if 0 <= dy < 5 and 0 <= dx < 6 and 0 <= by + dy < 7 and 0 <= bx + dx < 5:
+                s -= float(np.dot(a[:, dy, dx].astype(np.float64), b[:, by + dy, bx + dx].astype(np.float64))); cnt += 1
+    assert cnt == 4 and abs(d[0, 0] - s / cnt) < 1e-6
