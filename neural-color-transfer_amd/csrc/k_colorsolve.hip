@@ -590,7 +590,7 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         hipLaunchKernelGGL(k_wls_system, dim3(nbL), dim3(256), 0, s, (const double*)gx, (const double*)gy, (const double*)rough, H, W, (double*)diag, (double*)wx, (double*)wy); LCHK();
         int wit[6] = {0, 0, 0, 0, 0, 0};
         { int rcm = ctx->mark(s, nct_stage_tag_color()); if (rcm) return rcm; }
-        int rc = nctk_wls_solve_mg(ctx, s, X, rough, wx, wy, H, W, 1e-6, wit); if (rc) return rc;
+        int rc = nctk_wls_solve_mg(ctx, s, X, rough, wx, wy, H, W, ctx->wls_rtol, wit); if (rc) return rc;
         { int rcm = ctx->mark(s, nct_stage_tag_wls()); if (rcm) return rcm; }
         if (dbg && dbg->wls_iters) for (int q = 0; q < 6; ++q) dbg->wls_iters[q] = wit[q];
     }

@@ -515,6 +515,10 @@ void orc_nonlocal_solve(double* a, double* b, const double* src, const double* r
 int orc_wls_solve_canon(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, int* iters_out);
 int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double rtol, int* iters_out);
 
+/* relative residual of the S2 solve (the product's default; orc_set_wls_rtol is the oracle side of the NCT_WLS_RTOL experiment hook) */
+static double g_wls_rtol = 1e-6;
+void orc_set_wls_rtol(double r) { if (r > 0 && r < 1) g_wls_rtol = r; }
+
 /* Same contract as nct_local_color_transfer (include/nct.h). S1 = canonical-order truncated CG (orc_color_canon.c).
  * s2_exact == 0: S2 by the canonical-order PCG; != 0: S2 by the exact solve (banded Cholesky / converged PCG). */
 int orc_local_color_transfer(const float* err, const uint8_t* s_bgr_level, const uint8_t* g_bgr_level, const uint8_t* s_bgr_full,
@@ -545,7 +549,7 @@ int orc_local_color_transfer(const float* err, const uint8_t* s_bgr_level, const
     if (h == H && w == W) lamda *= 4;
     int wit[6] = {0, 0, 0, 0, 0, 0};
     int it = s2_exact ? orc_wls_solve(A, B, full, H, W, lamda, prm->wls_alpha, rough, 0)
-                      : orc_wls_solve_mg(A, B, full, H, W, lamda, prm->wls_alpha, rough, 1e-6, wit);
+                      : orc_wls_solve_mg(A, B, full, H, W, lamda, prm->wls_alpha, rough, g_wls_rtol, wit);
     if (st && st->wls_iters) memcpy(st->wls_iters, wit, sizeof wit);
     if (st && st->ab_wls) { memcpy(st->ab_wls, A, sizeof(double) * 3 * N); memcpy(st->ab_wls + (size_t)3 * N, B, sizeof(double) * 3 * N); }
     uint8_t* olab = (uint8_t*)malloc((size_t)N * 3);
