@@ -1,0 +1,48 @@
+"""S2 (WLS) stopping tolerance sweep — VERDICT r2 item 1c: what does rtol 1e-7 / 1e-8 buy in dB against the EXACT S2 solve, and what does it cost?
+For rtol in (1e-6, 1e-7, 1e-8, 1e-10): the 700x700 bench pair and the mixed-size pair through nct_process_pair with NCT_WLS_RTOL set; PSNR (min channel) / L-inf of
+the result against the exact-solve oracle image (tests/golden/pair_exact_<name>.npz: canonical + delta, rebuilt from the default-rtol run whose CRC the
+fixture pins), per-level WLS iterations, WLS and pair milliseconds (best of 3, one pair in flight).
+usage (GPU box): python scripts/wls_rtol_sweep.py > gpurun_out/<tag>/wls_rtol_sweep.json"""
+import json, os, sys, zlib
+sys.path.insert(0, "tests"); sys.path.insert(0, "neural-color-transfer_amd/python")
+import numpy as np
+import nct, synth
+from caffemodel_io import synthetic_vgg19
+
+ws, bs = synthetic_vgg19(19)
+
+
+def psnr(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    return min(10 * np.log10(255.0 ** 2 / max(np.mean(d[..., c] ** 2), 1e-12)) for c in range(3))
+
+
+exact, pairs = {}, {}
+for name in ("700", "mixed", "1000"):
+    p = os.path.join("tests", "golden", f"pair_exact_{name}.npz")
+    if os.path.exists(p):
+        g = np.load(p)
+        sh, sw, rh, rw = (int(v) for v in g["shape"])
+        pairs[name] = (synth.image(1000, sh, sw), synth.image(1001, rh, rw), g)
+out = {"rtol": {}}
+for rtol in ("1e-6", "1e-7", "1e-8", "1e-10"):
+    os.environ["NCT_WLS_RTOL"] = rtol
+    with nct.Context(0) as c:
+        c.vgg19_load_raw(ws, bs)
+        row = {}
+        for name, (src, ref, g) in pairs.items():
+            got = c.process_pair(src, ref)
+            if rtol == "1e-6":
+                assert zlib.crc32(got.tobytes()) == int(g["crc_canonical"]), "default-rtol result is not the canonical image"
+                e = got.astype(np.int16).reshape(-1); e[g["idx"]] += g["delta"]; exact[name] = e.astype(np.uint8).reshape(got.shape)
+                assert zlib.crc32(exact[name].tobytes()) == int(g["crc_exact"])
+            c.pair_upload(src, ref)
+            prm = nct.Params.default()
+            tms = [c.pair_run(prm, want_timing=True) for _ in range(3)]
+            best = min(tms, key=lambda t: t["total_ms"])
+            row[name] = {"psnr_min_channel_vs_exact_s2": round(psnr(got, exact[name]), 2), "linf_vs_exact_s2": int(np.abs(got.astype(int) - exact[name].astype(int)).max()),
+                         "bytes_differing": int((got != exact[name]).sum()), "wls_iters_per_level": best["wls_iters"], "wls_ms": round(best["wls_ms"], 2),
+                         "pair_ms": round(best["total_ms"], 2)}
+        out["rtol"][rtol] = row
+        print(rtol, json.dumps(row), file=sys.stderr, flush=True)
+print(json.dumps(out, indent=1))
