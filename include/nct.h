@@ -44,6 +44,10 @@ void nct_destroy(nct_ctx* ctx);
 const char* nct_last_error(const nct_ctx* ctx);     /* ctx may be NULL: returns the last create() failure */
 int nct_version(void);
 int nct_device_name(nct_ctx* ctx, char* buf, int buflen);
+/* no context needed: number of visible HIP devices, and a device's PCI address "dddd:bb:dd.f" — the key of /sys/bus/pci/devices/<addr>/numa_node and
+ * local_cpulist, which the CLI pins a GPU's worker threads to ("worker thread pinned to the GPU's NUMA node") */
+int nct_device_count(int* count);
+int nct_device_pci_bus_id(int device, char* buf, int buflen);
 int nct_synchronize(nct_ctx* ctx);
 
 /* ---- N1: feature L2 normalisation — `norm` (GeneralizedPatchMatch.cu:237-283), called main.cu:265,274,313.
@@ -81,6 +85,23 @@ int nct_bds_vote_image(nct_ctx* ctx, const uint8_t* a_bgr, int ah, int aw, const
  * (13 layers) are required/uploaded. _load_raw takes Caffe-layout arrays [Cout][Cin][3][3] + [Cout] in net order. */
 int nct_vgg19_load_caffemodel(nct_ctx* ctx, const char* path);
 int nct_vgg19_load_raw(nct_ctx* ctx, const float* const* weights, const float* const* biases, int nlayers);
+/* A driver with several contexts (the CLI's -gpus N -inflight K; main.cu:581-582 builds two Nets from the file): parse the 575 MB file ONCE per process into a
+ * host-side model (80 MB: the 13 needed layers), upload it ONCE per GPU (nct_vgg19_load_model), and let the other contexts of that GPU use the same read-only
+ * device copy (nct_vgg19_share_weights; both contexts must live on the same device; the copy is freed with its last user). nct_model_* need no context;
+ * nct_model_last_error() returns the message of the last failed parse on the calling thread. nct_vgg19_weights_info: identity (device address of conv1_1's
+ * packed weights), size in bytes and number of contexts sharing this context's copy. */
+typedef struct nct_model nct_model;
+int nct_model_parse_caffemodel(const char* path, nct_model** out);
+void nct_model_free(nct_model* m);
+const char* nct_model_last_error(void);
+int nct_vgg19_load_model(nct_ctx* ctx, const nct_model* m);
+int nct_vgg19_share_weights(nct_ctx* ctx, nct_ctx* from);
+int nct_vgg19_weights_info(nct_ctx* ctx, uint64_t* id, size_t* bytes, int* sharers);
+/* Classifier::Classifier builds its Net from <model_dir>/vgg19/VGG_ILSVRC_19_layers_deploy.prototxt (Classifier.cpp:16; main.cu:575-577). This library's
+ * topology is built in, so the file is only checked (protobuf text format, `layer` or V1 `layers` messages): conv1_1..conv5_1 in order with the built-in
+ * channel counts, 3x3 / pad 1 / stride 1, each followed by an in-place ReLU, 2x2 / stride-2 MAX pools after conv1_2, 2_2, 3_4, 4_4. Anything else ->
+ * NCT_ERR_IO with a message (ctx nullable: then through nct_model_last_error). Layers behind relu5_1 are not looked at. */
+int nct_vgg19_check_prototxt(nct_ctx* ctx, const char* path);
 
 /* ---- V2/R1: VGG19 features — Classifier::Predict (Classifier.cpp:59-143), called main.cu:94,102,426.
  * bgr: u8 BGR HWC image (row stride in bytes). Runs preprocess (mean subtraction, Classifier.cpp:211-275) and the net

@@ -14,7 +14,10 @@
 //  * the region of A shared by the queries of a workgroup (8x8 queries at C = 64: 10x10xC) is staged once per launch in LDS;
 //  * the racy single launch of the reference becomes 1 + iters*4 Jacobi steps on a double-buffered NNF
 //    (one launch per (iteration, jump)); random search is fused into the jump==1 step; RNG is counter based.
-//    => results are deterministic and bit-identical to oracle/orc_nnf.c.
+//    => results are deterministic and bit-identical to oracle/orc_nnf.c;
+//  * a propagation candidate that cannot win is not evaluated: the neighbour proposes the query's current match, or the neighbour's match has not changed since
+//    the same jump of the previous iteration (that candidate lost then, and the query's best only decreases). The step a match last changed in travels in the
+//    spare top byte of the double-buffered NNF word. -47 % evaluations at the finest level of a 700x700 pair, -40 ... -60 % below, same NNF and distances.
 // Roofline: memory (gather of candidate tiles): algorithmic bytes = evals*9*C*4 (+ query tile + NNF r/w). Measured at C = 64:
 // DRAM-side traffic 0.55 of the HBM peak, the L1 data return path (64 B/clk/CU) ~90 % busy, VALU issue 43 %, and a wave's candidates are a
 // dependent chain (neighbour NNF -> tile loads -> dot -> compare -> next), so the remaining lever is latency hiding: 8 candidate tiles per
@@ -289,7 +292,7 @@ struct PMJob { const float* A; const float* B; const uint2* Bh; const uint32_t* 
 // LPQ = 8 (C = 64, 128 with fp32 tiles): 32 queries per pass, an 8x4 sub-tile, two queries per DPP row (see pm_dist).
 template <int NCH, int MODE, int TQX, int TQY, int LPQ>
 __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
-                                                 unsigned long long* __restrict__ counter) {
+                                                 int tstep, int strip, unsigned long long* __restrict__ counter) {
     constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2;
     const bool second = (int)blockIdx.x >= nblk0;
     const PMJob& J = second ? j1 : j0;
@@ -339,10 +342,12 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
         if (NSUB > 1 && ox + sx * QW >= g.aw) continue;                 // sub-tile entirely outside the image (uniform over the workgroup)
         if (NSUB > 1 && oy + sy * QH >= g.ah) continue;
         const bool live = qx < g.aw && qy < g.ah;
-        const int ax = live ? qx : g.aw - 1, ay = live ? qy : g.ah - 1;
+        // a dead query (beyond the image in a partially filled tile) is clamped PER AXIS, so it stays inside its tile's staged region and has the tap mask of
+        // a live border query
+        const int ax = qx < g.aw ? qx : g.aw - 1, ay = qy < g.ah ? qy : g.ah - 1;
+        // (it walks the candidates of that border query and writes nothing; masking dead queries out of every evaluation instead measured slower: the random
+        // search's validity became a per-lane value)
         const int qi = ay * g.aw + ax;
-        // position inside the workgroup's region; a clamped (dead) query may fall outside its sub-tile but stays inside the region only if
-        // the clamp target does — it is kept inside by construction: the image border lies inside or on the edge of a partially filled tile
         const int lx = ax - ox, ly = ay - oy;
 
         // validity of the query's own taps
@@ -354,8 +359,9 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
             amask |= ((yy >= 0 && yy < g.ah && xx >= 0 && xx < g.aw) ? 1u : 0u) << t;
         }
 
-        uint32_t vbest = nnf_in[qi];
+        const uint32_t vbest = nnf_in[qi];
         int xbest = nnf_x(vbest), ybest = nnf_y(vbest);
+        const int x0 = xbest, y0 = ybest;
         float dbest;
 
         if (mode == 0) {
@@ -374,19 +380,43 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
                 const int nx = ax + ((k == 0) ? -jump : (k == 1 ? jump : 0)), ny = ay + ((k == 2) ? -jump : (k == 3 ? jump : 0));
                 vnb[k] = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
             }
+            // ---- propagation candidates: 0 left, 1 right, 2 up, 3 down — the neighbour's match shifted back by the jump. Each query first packs the
+            // candidates that can still win into a short list (in that order), then the wave walks the lists round by round: with most candidates
+            // dropping out (below) a wave needs max-over-its-queries rounds instead of four, and no round is spent on a slot whose queries all sit out.
+            uint32_t cl0 = 0, cl1 = 0, cl2 = 0, cl3 = 0; int ncl = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sxx = (k == 0) ? -jump : (k == 1 ? jump : 0);
+                const int syy = (k == 2) ? -jump : (k == 3 ? jump : 0);
+                const int nx = ax + sxx, ny = ay + syy;
+                const uint32_t vp = vnb[k];
+                const int xp = nnf_x(vp) - sxx, yp = nnf_y(vp) - syy;
+                bool valid = nx >= 0 && nx < g.aw && ny >= 0 && ny < g.ah && yp >= 0 && yp < g.bh && xp >= 0 && xp < g.bw;
+#ifndef NCT_PM_EVAL_STALE
+                // A neighbour whose match has not changed since the step of the PREVIOUS iteration with this jump (four steps ago) proposes the candidate that
+                // was evaluated then and lost (or won and has been the best, or been beaten, since): the query's best only ever decreases, so d >= dbest
+                // again — it cannot win and is not fetched. Exact: same NNF, same distances (the oracle evaluates everything). The step a match last
+                // changed in travels in the top byte of its (double-buffered) NNF word, so the test costs no load. As the field converges — 70-95 % of the
+                // matches are unchanged from iteration 3 on — most propagation candidates drop out; the random search is always fresh.
+                valid = valid && !(tstep > 4 && (int)(vp >> 24) < tstep - 4);
+#endif
+                if (valid) {
+                    const uint32_t c = xy_pack(xp, yp);
+                    cl0 = ncl == 0 ? c : cl0; cl1 = ncl == 1 ? c : cl1; cl2 = ncl == 2 ? c : cl2; cl3 = ncl == 3 ? c : cl3;
+                    ++ncl;
+                }
+            }
+            int nprop = 0;                                    // wave-uniform: the longest list among the wave's queries
+#pragma unroll
+            for (int i = 1; i <= 4; ++i) nprop += __builtin_amdgcn_ballot_w64(ncl >= i) != 0 ? 1 : 0;
             int mag = rs_start;
-            const int ncand = 4 + nrand;
+            const int ncand = nprop + nrand;
             for (int k = 0; k < ncand; ++k) {
                 int xp, yp; bool valid; float rr;
-                if (k < 4) {
-                    // 0 left, 1 right, 2 up, 3 down — the neighbour's match shifted back by the jump
-                    const int sxx = (k == 0) ? -jump : (k == 1 ? jump : 0);
-                    const int syy = (k == 2) ? -jump : (k == 3 ? jump : 0);
-                    const int nx = ax + sxx, ny = ay + syy;
-                    valid = nx >= 0 && nx < g.aw && ny >= 0 && ny < g.ah;
-                    const uint32_t vp = k == 0 ? vnb[0] : (k == 1 ? vnb[1] : (k == 2 ? vnb[2] : vnb[3]));
-                    xp = nnf_x(vp) - sxx; yp = nnf_y(vp) - syy;
-                    valid = valid && yp >= 0 && yp < g.bh && xp >= 0 && xp < g.bw;
+                if (k < nprop) {
+                    const uint32_t c = k == 0 ? cl0 : (k == 1 ? cl1 : (k == 2 ? cl2 : cl3));
+                    xp = nnf_x(c); yp = nnf_y(c);
+                    valid = k < ncl;
 #ifndef NCT_PM_EVAL_SAME
                     // a neighbour that proposes the current match cannot improve it (d == dbest is not < dbest): its lanes sit the evaluation out
                     // (with the wave near the L1 bandwidth limit the unissued tile requests are what is saved, not instructions)
@@ -394,7 +424,7 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
 #endif
                     rr = 0.f;
                 } else {
-                    const int step = k - 4;
+                    const int step = k - nprop;
                     const int xmin = max(xbest - mag, 0), xmax = min(xbest + mag + 1, g.bw);
                     const int ymin = max(ybest - mag, 0), ymax = min(ybest + mag + 1, g.bh);
                     // (int)(u * w) % w with u in (0, 1]: the product never exceeds w, so the modulo only folds the value w back to 0 — a
@@ -417,7 +447,14 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
                 }
             }
         }
-        if (live && v == 0) { if (mode != 0) nnf_out[qi] = xy_pack(xbest, ybest); d_out[qi] = dbest; }
+        if (live && v == 0) {
+            if (mode != 0) {
+                // top byte: the step this match last changed in (0 = still the initial one); the last step of a run writes the plain (y << 12) | x word
+                const uint32_t stamp = (xbest != x0 || ybest != y0) ? (uint32_t)tstep : (vbest >> 24);
+                nnf_out[qi] = xy_pack(xbest, ybest) | (strip ? 0u : stamp << 24);
+            }
+            d_out[qi] = dbest;
+        }
     }
     if (counter) {
         __shared__ unsigned s_cnt[2];
@@ -435,27 +472,27 @@ template <int NCH> struct PMTile { static constexpr int TQX = NCH == 1 ? 2 : (NC
 // 10.7 vs 8.6 ms, C = 64 with 4 lanes 22.0 vs 17.6 ms per pair and level.
 template <int NCH> struct PMLanes { static constexpr int LPQ = NCH == 1 ? 8 : 16; };
 template <int NCH, int MODE>
-static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter) {
+static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, int tstep, int strip, unsigned long long* counter) {
     constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY, LPQ = PMLanes<NCH>::LPQ;
     const size_t lds = NCH >= 1 ? (size_t)(4 * TQX + 2) * (4 * TQY + 2) * NCH * 16 * sizeof(float4) : 0;      // region pixels x C/4 float4
     // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device; set with the init step
     // of every run (mode 0), i.e. once per PatchMatch and per device the context lives on
     if (lds > 32768 && mode == 0)
         NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE, TQX, TQY, LPQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_pm_step<NCH, MODE, TQX, TQY, LPQ>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, counter);
+    hipLaunchKernelGGL((k_pm_step<NCH, MODE, TQX, TQY, LPQ>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, tstep, strip, counter);
     NCT_LAUNCH_CHECK();
     return 0;
 }
 
 template <int NCH>
-static int launch_step(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, unsigned long long* counter, int pm_mode) {
+static int launch_step(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, int tstep, int strip, unsigned long long* counter, int pm_mode) {
     // fp16 tiles from C = 128 on. The C = 64 level is latency bound — a wave walks its candidates one after the other — not byte bound: with
     // fp16 tiles on the 8-lane kernel (one 16-byte load per lane and tap) it took 15.8 vs 16.0 ms per pair, so it keeps the exact fp32 tiles.
-    if constexpr (NCH >= 2) { if (pm_mode == NCT_PM_FP16) return launch_mode<NCH, NCT_PM_FP16>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter); }
+    if constexpr (NCH >= 2) { if (pm_mode == NCT_PM_FP16) return launch_mode<NCH, NCT_PM_FP16>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, counter); }
     if (NCH == 1 && pm_mode == NCT_PM_FP16) pm_mode = NCT_PM_PLAIN;
     // unit-norm features (the pipeline): the instantiation with the exact early rejection; it exists for the C with an fp32 interior fast path
-    if (NCH >= 1 && NCH <= NCT_PM_FAST_MAX && pm_mode == NCT_PM_ROWREJECT) return launch_mode<NCH, NCT_PM_ROWREJECT>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter);
-    return launch_mode<NCH, NCT_PM_PLAIN>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, counter);
+    if (NCH >= 1 && NCH <= NCT_PM_FAST_MAX && pm_mode == NCT_PM_ROWREJECT) return launch_mode<NCH, NCT_PM_ROWREJECT>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, counter);
+    return launch_mode<NCH, NCT_PM_PLAIN>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, counter);
 }
 
 // Runs one PatchMatch (bnn == nullptr) or both directions of a level fused in the same launches (A->B in ann, B->A in bnn).
@@ -489,24 +526,28 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
     const int nblk0 = ga.tiles_x * ga.tiles_y, nblk1 = two ? gb.tiles_x * gb.tiles_y : 0;
     uint32_t* na_buf[2] = {ann, a_tmp}; float* da_buf[2] = {annd, ad_tmp};
     uint32_t* nb_buf[2] = {bnn, b_tmp}; float* db_buf[2] = {bnnd, bd_tmp};
-    auto step = [&](int in, int out, int mode, int jump, int iter) -> int {
+    // tstep: 1-based index of the propagation step (0 = init; 0 throughout when the step count does not fit the NNF word's spare byte: no stale-candidate
+    // test then); strip: the run's last step writes NNF words without the step stamp
+    const bool stamps = 4 * iters <= 250;
+    auto step = [&](int in, int out, int mode, int jump, int iter, int tstep, int strip) -> int {
         PMJob j0{a_hwc, b_hwc, (const uint2*)b_h16, na_buf[in], da_buf[in], mode ? na_buf[out] : nullptr, da_buf[out], ga, rs_max, seed_ab};
         PMJob j1{b_hwc, a_hwc, (const uint2*)a_h16, nb_buf[in], db_buf[in], mode ? nb_buf[out] : nullptr, db_buf[out], gb, rs_max, seed_ba};
         switch (C) {
-            case 64:  return launch_step<1>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode);
-            case 128: return launch_step<2>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode);
-            case 256: return launch_step<4>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode);
-            case 512: return launch_step<8>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode);
-            default:  return launch_step<0>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, eval_counter, pm_mode == NCT_PM_FP16 ? NCT_PM_PLAIN : pm_mode);
+            case 64:  return launch_step<1>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, eval_counter, pm_mode);
+            case 128: return launch_step<2>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, eval_counter, pm_mode);
+            case 256: return launch_step<4>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, eval_counter, pm_mode);
+            case 512: return launch_step<8>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, eval_counter, pm_mode);
+            default:  return launch_step<0>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, eval_counter, pm_mode == NCT_PM_FP16 ? NCT_PM_PLAIN : pm_mode);
         }
     };
     // the total number of Jacobi steps is even (iters*4), so ping-ponging (nnf,dist) <-> (tmp) ends in (nnf,dist)
-    int rc = step(0, 0, 0, 0, 0);                  // init: dist(current NNF), NNF untouched
+    int rc = step(0, 0, 0, 0, 0, 0, 0);            // init: dist(current NNF), NNF untouched
     if (rc) return rc;
-    int cur = 0;
+    int cur = 0, t = 0;
     for (int iter = 0; iter < iters; ++iter)
         for (int jump = 8; jump > 0; jump >>= 1) {
-            rc = step(cur, cur ^ 1, 1, jump, iter);
+            ++t;
+            rc = step(cur, cur ^ 1, 1, jump, iter, stamps ? t : 0, (!stamps || t == 4 * iters) ? 1 : 0);
             if (rc) return rc;
             cur ^= 1;
         }

@@ -86,6 +86,21 @@ int nct_create(int device, nct_ctx** out) {
     return NCT_OK;
 }
 
+int nct_device_count(int* count) {
+    if (!count) return NCT_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { *count = 0; g_create_err = "nct_device_count: no HIP device (no CPU fallback)"; return NCT_ERR_NO_DEVICE; }
+    *count = n;
+    return NCT_OK;
+}
+int nct_device_pci_bus_id(int device, char* buf, int buflen) {
+    if (!buf || buflen < 13) return NCT_ERR_INVALID;
+    hipError_t e = hipDeviceGetPCIBusId(buf, buflen, device);
+    if (e != hipSuccess) { g_create_err = std::string("hipDeviceGetPCIBusId: ") + hipGetErrorString(e); return NCT_ERR_HIP; }
+    for (char* p = buf; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');      // sysfs spells the address in lower case
+    return NCT_OK;
+}
+
 void nct_destroy(nct_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

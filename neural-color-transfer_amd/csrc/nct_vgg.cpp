@@ -7,6 +7,9 @@
 #include "nct_internal.h"
 #include <cstring>
 #include <cstdlib>
+#include <memory>
+#include <cctype>
+#include <map>
 #include <cerrno>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -27,23 +30,38 @@ static const bool kPoolAfter[NCONV] = {false, true, false, true, false, false, f
 static const int kTapConv[5] = {0, 2, 4, 8, 12};     // conv1_1, conv2_1, conv3_1, conv4_1, conv5_1
 static const int kNeeded = 13;                       // conv5_2..conv5_4 are never needed
 
+// Device copy of the packed weights. Read-only after loading, so every context on the same GPU can use ONE copy (nct_vgg19_share_weights: the CLI
+// with -inflight K keeps one 80 MB copy per GPU instead of K; the reference keeps two Nets per process, main.cu:581-582). Freed with its last user.
 struct vgg_weights {
+    int device = 0;
     float* wp[NCONV] = {nullptr};     // packed [Cin_pad*9][Cout]
     float* bias[NCONV] = {nullptr};
+    size_t bytes = 0;
     bool loaded = false;
+    ~vgg_weights() {
+        int cur = 0; (void)hipGetDevice(&cur); (void)hipSetDevice(device);
+        for (int i = 0; i < NCONV; ++i) { if (wp[i]) (void)hipFree(wp[i]); if (bias[i]) (void)hipFree(bias[i]); }
+        (void)hipSetDevice(cur);
+    }
 };
+struct vgg_holder { std::shared_ptr<vgg_weights> w; };
 
 static vgg_weights* vgg_of(nct_ctx* ctx) {
-    if (!ctx->vgg) ctx->vgg = new vgg_weights();
-    return (vgg_weights*)ctx->vgg;
+    if (!ctx->vgg) { auto* h = new vgg_holder(); h->w = std::make_shared<vgg_weights>(); h->w->device = ctx->device; ctx->vgg = h; }
+    return ((vgg_holder*)ctx->vgg)->w.get();
+}
+// a context about to (re)load weights must not write into a copy other contexts read: detach to a fresh one
+static vgg_weights* vgg_own(nct_ctx* ctx) {
+    if (ctx->vgg && ((vgg_holder*)ctx->vgg)->w.use_count() > 1) { delete (vgg_holder*)ctx->vgg; ctx->vgg = nullptr; }
+    return vgg_of(ctx);
 }
 
 static int upload_layer(nct_ctx* ctx, int i, const float* w, const float* b) {
     vgg_weights* v = vgg_of(ctx);
     const int cin_pad = (kCin[i] + 1) & ~1;
     const size_t nw = (size_t)kCout[i] * kCin[i] * 9;
-    if (!v->wp[i]) NCT_HIP(hipMalloc(&v->wp[i], sizeof(float) * (size_t)cin_pad * 9 * kCout[i]));
-    if (!v->bias[i]) NCT_HIP(hipMalloc(&v->bias[i], sizeof(float) * kCout[i]));
+    if (!v->wp[i]) { NCT_HIP(hipMalloc(&v->wp[i], sizeof(float) * (size_t)cin_pad * 9 * kCout[i])); v->bytes += sizeof(float) * (size_t)cin_pad * 9 * kCout[i]; }
+    if (!v->bias[i]) { NCT_HIP(hipMalloc(&v->bias[i], sizeof(float) * kCout[i])); v->bytes += sizeof(float) * kCout[i]; }
     DevBuf<float> tmp(ctx, nw);
     if (!tmp.ok()) return NCT_ERR_HIP;
     NCT_HIP(hipMemcpyAsync(tmp, w, sizeof(float) * nw, hipMemcpyHostToDevice, ctx->stream));
@@ -91,32 +109,24 @@ static bool parse_blob(PB b, BlobView& out) {
 
 static int64_t blob_count(const BlobView& b) { int64_t n = 1; for (int i = 0; i < b.ndim; ++i) n *= b.dims[i]; return b.ndim ? n : 0; }
 
-extern "C" {
+// Host copy of the 13 needed conv layers (80 MB): what a process parses ONCE from the 575 MB caffemodel and then uploads to every GPU it drives.
+struct nct_model {
+    std::vector<float> w[NCONV], b[NCONV];
+    std::string err;
+};
+static thread_local std::string g_model_err;
 
-int nct_vgg19_load_raw(nct_ctx* ctx, const float* const* weights, const float* const* biases, int nlayers) {
-    if (!ctx) return NCT_ERR_INVALID;
-    NCT_HIP(hipSetDevice(ctx->device));
-    NCT_REQUIRE(weights && biases && nlayers >= kNeeded && nlayers <= NCONV, "vgg19_load_raw: need >= %d conv layers (conv1_1..conv5_1)", kNeeded);
-    for (int i = 0; i < kNeeded; ++i) {
-        NCT_REQUIRE(weights[i] && biases[i], "vgg19_load_raw: layer %s missing", kConvName[i]);
-        int rc = upload_layer(ctx, i, weights[i], biases[i]);
-        if (rc) return rc;
-    }
-    vgg_of(ctx)->loaded = true;
-    return NCT_OK;
-}
-
-int nct_vgg19_load_caffemodel(nct_ctx* ctx, const char* path) {
-    if (!ctx) return NCT_ERR_INVALID;
-    NCT_HIP(hipSetDevice(ctx->device));
-    NCT_REQUIRE(path, "vgg19_load_caffemodel: null path");
+// parses `path` into m; returns NCT_OK or an error code with the message in `err`
+static int parse_caffemodel(const char* path, nct_model& m, std::string& err) {
+    char buf[512];
+    auto fail = [&](int code, const char* fmt, auto... a) { snprintf(buf, sizeof buf, fmt, a...); err = buf; return code; };
     int fd = open(path, O_RDONLY);
-    if (fd < 0) return ctx->fail(NCT_ERR_IO, "cannot open caffemodel '%s': %s", path, strerror(errno));
+    if (fd < 0) return fail(NCT_ERR_IO, "cannot open caffemodel '%s': %s", path, strerror(errno));
     struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); return ctx->fail(NCT_ERR_IO, "cannot stat caffemodel '%s'", path); }
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); return fail(NCT_ERR_IO, "cannot stat caffemodel '%s'", path); }
     void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
-    if (map == MAP_FAILED) return ctx->fail(NCT_ERR_IO, "mmap of '%s' failed: %s", path, strerror(errno));
+    if (map == MAP_FAILED) return fail(NCT_ERR_IO, "mmap of '%s' failed: %s", path, strerror(errno));
     bool found[NCONV] = {false};
     int rc = NCT_OK;
     PB net{(const uint8_t*)map, (const uint8_t*)map + st.st_size};
@@ -133,47 +143,213 @@ int nct_vgg19_load_caffemodel(nct_ctx* ctx, const char* path) {
             else if (lf == blobs_field && lw == 2) blobs.push_back(layer.sub());
             else layer.skip(lw);
         }
-        if (!layer.ok) { rc = ctx->fail(NCT_ERR_IO, "malformed layer message in '%s'", path); break; }
+        if (!layer.ok) { rc = fail(NCT_ERR_IO, "malformed layer message in '%s'", path); break; }
         int idx = -1;
         for (int i = 0; i < NCONV; ++i) if (name == kConvName[i]) idx = i;
         if (idx < 0 || blobs.empty()) continue;          // unknown source layer: ignored (net.cpp:770-773)
         if (idx >= kNeeded) { found[idx] = true; continue; }
-        if (blobs.size() < 2) { rc = ctx->fail(NCT_ERR_IO, "layer %s has %zu blobs, expected weights + bias", name.c_str(), blobs.size()); break; }
+        if (blobs.size() < 2) { rc = fail(NCT_ERR_IO, "layer %s has %zu blobs, expected weights + bias", name.c_str(), blobs.size()); break; }
         BlobView w, b;
-        if (!parse_blob(blobs[0], w) || !parse_blob(blobs[1], b)) { rc = ctx->fail(NCT_ERR_IO, "malformed blob in layer %s", name.c_str()); break; }
+        if (!parse_blob(blobs[0], w) || !parse_blob(blobs[1], b)) { rc = fail(NCT_ERR_IO, "malformed blob in layer %s", name.c_str()); break; }
         const int64_t nw = (int64_t)kCout[idx] * kCin[idx] * 9;
         const bool wshape = w.ndim == 4 && w.dims[0] == kCout[idx] && w.dims[1] == kCin[idx] && w.dims[2] == 3 && w.dims[3] == 3;
         if (!wshape || (int64_t)w.data.size() != nw)      // shape mismatch is fatal (net.cpp:780-791)
-            { rc = ctx->fail(NCT_ERR_IO, "layer %s: weight shape mismatch (got %lldx%lldx%lldx%lld, %zu values; expected %dx%dx3x3)", name.c_str(),
-                             (long long)w.dims[0], (long long)w.dims[1], (long long)w.dims[2], (long long)w.dims[3], w.data.size(), kCout[idx], kCin[idx]); break; }
+            { rc = fail(NCT_ERR_IO, "layer %s: weight shape mismatch (got %lldx%lldx%lldx%lld, %zu values; expected %dx%dx3x3)", name.c_str(),
+                        (long long)w.dims[0], (long long)w.dims[1], (long long)w.dims[2], (long long)w.dims[3], w.data.size(), kCout[idx], kCin[idx]); break; }
         if (blob_count(b) != kCout[idx] || (int64_t)b.data.size() != kCout[idx])
-            { rc = ctx->fail(NCT_ERR_IO, "layer %s: bias shape mismatch (%zu values, expected %d)", name.c_str(), b.data.size(), kCout[idx]); break; }
-        rc = upload_layer(ctx, idx, w.data.data(), b.data.data());
+            { rc = fail(NCT_ERR_IO, "layer %s: bias shape mismatch (%zu values, expected %d)", name.c_str(), b.data.size(), kCout[idx]); break; }
+        m.w[idx] = std::move(w.data); m.b[idx] = std::move(b.data);
         found[idx] = true;
     }
-    if (rc == NCT_OK && !net.ok) rc = ctx->fail(NCT_ERR_IO, "malformed NetParameter in '%s'", path);
+    if (rc == NCT_OK && !net.ok) rc = fail(NCT_ERR_IO, "malformed NetParameter in '%s'", path);
     munmap(map, (size_t)st.st_size);
     if (rc != NCT_OK) return rc;
     for (int i = 0; i < kNeeded; ++i)
-        if (!found[i]) return ctx->fail(NCT_ERR_IO, "caffemodel '%s' has no weights for layer %s", path, kConvName[i]);
+        if (!found[i]) return fail(NCT_ERR_IO, "caffemodel '%s' has no weights for layer %s", path, kConvName[i]);
+    return NCT_OK;
+}
+
+// ---------------------------------------------------------------- deploy prototxt (protobuf text format) -> topology check
+// Classifier::Classifier builds the Net from <model_dir>/vgg19/VGG_ILSVRC_19_layers_deploy.prototxt (Classifier.cpp:16, main.cu:575-577). The topology
+// is built into k_vgg.hip, so the file is only CHECKED: a model directory whose prototxt describes another network must not be accepted silently.
+namespace {
+struct TxtLayer { std::string name, type, pool; std::vector<std::string> bottom, top; long num_output = -1, kernel = -1, pad = 0, stride = 1; };
+struct TxtTok { const char* p; const char* end; bool ok = true;
+    void ws() { while (p < end) { if (*p == '#') { while (p < end && *p != '\n') ++p; } else if (isspace((unsigned char)*p)) ++p; else break; } }
+    bool ident(std::string& out) { ws(); const char* s = p; while (p < end && (isalnum((unsigned char)*p) || *p == '_' || *p == '.' || *p == '-' || *p == '+')) ++p; out.assign(s, p); return p > s; }
+    bool lit(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
+    bool value(std::string& out) {      // "string" | identifier/number
+        ws();
+        if (p < end && (*p == '"' || *p == '\'')) { const char q = *p++; const char* s = p; while (p < end && *p != q) ++p; if (p >= end) return false; out.assign(s, p); ++p; return true; }
+        return ident(out);
+    }
+};
+// parses `field: value` / `field { ... }` pairs of one message body until '}' (or the end of the file at depth 0)
+bool parse_msg(TxtTok& t, int depth, TxtLayer* L, std::vector<TxtLayer>* layers, const std::string& path_in_layer) {
+    for (;;) {
+        t.ws();
+        if (t.p >= t.end) return depth == 0;
+        if (*t.p == '}') { if (depth == 0) return false; ++t.p; return true; }
+        std::string key;
+        if (!t.ident(key)) return false;
+        const bool colon = t.lit(':');
+        t.ws();
+        if (t.p < t.end && (*t.p == '{' || *t.p == '<')) {
+            ++t.p;
+            if (depth == 0 && (key == "layer" || key == "layers")) {
+                TxtLayer nl;
+                if (!parse_msg(t, 1, &nl, nullptr, "")) return false;
+                layers->push_back(nl);
+            } else if (!parse_msg(t, depth + 1, L, nullptr, path_in_layer.empty() ? key : path_in_layer + "." + key)) return false;
+            continue;
+        }
+        if (!colon) return false;
+        std::string v;
+        if (!t.value(v)) return false;
+        if (L && depth >= 1) {
+            const std::string full = path_in_layer.empty() ? key : path_in_layer + "." + key;
+            if (full == "name") L->name = v; else if (full == "type") L->type = v;
+            else if (full == "bottom") L->bottom.push_back(v); else if (full == "top") L->top.push_back(v);
+            else if (full == "convolution_param.num_output") L->num_output = atol(v.c_str());
+            else if (full == "convolution_param.kernel_size" || full == "pooling_param.kernel_size") L->kernel = atol(v.c_str());
+            else if (full == "convolution_param.pad") L->pad = atol(v.c_str());
+            else if (full == "convolution_param.stride" || full == "pooling_param.stride") L->stride = atol(v.c_str());
+            else if (full == "pooling_param.pool") L->pool = v;
+        }
+    }
+}
+std::string lower(std::string s) { for (auto& c : s) c = (char)tolower((unsigned char)c); return s; }
+}  // namespace
+
+static int check_prototxt(const char* path, std::string& err) {
+    char buf[512];
+    auto fail = [&](const char* fmt, auto... a) { snprintf(buf, sizeof buf, fmt, a...); err = buf; return (int)NCT_ERR_IO; };
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail("cannot open prototxt '%s': %s", path, strerror(errno));
+    std::string txt; char chunk[65536]; size_t n;
+    while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) { txt.append(chunk, n); if (txt.size() > (64u << 20)) break; }
+    fclose(f);
+    TxtTok t{txt.data(), txt.data() + txt.size()};
+    std::vector<TxtLayer> layers;
+    if (!parse_msg(t, 0, nullptr, &layers, "")) return fail("prototxt '%s': not protobuf text format (near byte %zu)", path, (size_t)(t.p - txt.data()));
+    // walk the data path: every conv of the built-in topology up to conv5_1 must be there, in order, 3x3 / pad 1 / stride 1 with the built-in
+    // channel count, followed by an in-place ReLU; a 2x2 / stride-2 MAX pool exactly after conv1_2, conv2_2, conv3_4, conv4_4
+    int ci = 0; std::string cur = "data"; bool expect_relu = false, expect_pool = false;
+    for (const TxtLayer& L : layers) {
+        if (ci >= kNeeded && !expect_relu) break;
+        const std::string ty = lower(L.type);
+        if (ty == "convolution" || ty == "4") {
+            if (expect_relu) return fail("prototxt '%s': %s is not followed by a ReLU", path, kConvName[ci - 1]);
+            if (expect_pool) return fail("prototxt '%s': no 2x2 max pool after %s", path, kConvName[ci - 1]);
+            if (L.name != kConvName[ci]) return fail("prototxt '%s': conv layer %d is '%s', expected '%s'", path, ci + 1, L.name.c_str(), kConvName[ci]);
+            if (L.num_output != kCout[ci] || L.kernel != 3 || L.pad != 1 || L.stride != 1)
+                return fail("prototxt '%s': %s is num_output %ld kernel %ld pad %ld stride %ld, expected %d / 3 / 1 / 1", path, L.name.c_str(), L.num_output, L.kernel, L.pad, L.stride, kCout[ci]);
+            if (L.bottom.size() != 1 || L.bottom[0] != cur || L.top.size() != 1) return fail("prototxt '%s': %s does not consume '%s'", path, L.name.c_str(), cur.c_str());
+            cur = L.top[0]; expect_relu = true; expect_pool = kPoolAfter[ci]; ++ci;
+        } else if (ty == "relu" || ty == "18") {
+            if (!expect_relu || L.bottom.size() != 1 || L.bottom[0] != cur || L.top.size() != 1 || L.top[0] != cur)
+                return fail("prototxt '%s': unexpected ReLU '%s'", path, L.name.c_str());
+            expect_relu = false;
+        } else if (ty == "pooling" || ty == "17") {
+            if (!expect_pool || expect_relu) return fail("prototxt '%s': unexpected pooling layer '%s'", path, L.name.c_str());
+            if ((lower(L.pool) != "max" && L.pool != "0" && !L.pool.empty()) || L.kernel != 2 || L.stride != 2 || L.bottom.size() != 1 || L.bottom[0] != cur || L.top.size() != 1)
+                return fail("prototxt '%s': %s is not a 2x2 / stride-2 MAX pool of '%s'", path, L.name.c_str(), cur.c_str());
+            cur = L.top[0]; expect_pool = false;
+        } else return fail("prototxt '%s': layer '%s' of type '%s' in front of conv5_1 — not the VGG19 this library implements", path, L.name.c_str(), L.type.c_str());
+    }
+    if (ci < kNeeded || expect_relu) return fail("prototxt '%s': the network ends before relu5_1 (%d of %d conv layers)", path, ci, kNeeded);
+    return NCT_OK;
+}
+
+extern "C" {
+
+int nct_vgg19_load_raw(nct_ctx* ctx, const float* const* weights, const float* const* biases, int nlayers) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(weights && biases && nlayers >= kNeeded && nlayers <= NCONV, "vgg19_load_raw: need >= %d conv layers (conv1_1..conv5_1)", kNeeded);
+    vgg_own(ctx)->loaded = false;
+    for (int i = 0; i < kNeeded; ++i) {
+        NCT_REQUIRE(weights[i] && biases[i], "vgg19_load_raw: layer %s missing", kConvName[i]);
+        int rc = upload_layer(ctx, i, weights[i], biases[i]);
+        if (rc) return rc;
+    }
     vgg_of(ctx)->loaded = true;
     return NCT_OK;
+}
+
+int nct_model_parse_caffemodel(const char* path, nct_model** out) {
+    if (!path || !out) { g_model_err = "nct_model_parse_caffemodel: null argument"; return NCT_ERR_INVALID; }
+    nct_model* m = new nct_model();
+    const int rc = parse_caffemodel(path, *m, g_model_err);
+    if (rc != NCT_OK) { delete m; *out = nullptr; return rc; }
+    *out = m;
+    return NCT_OK;
+}
+void nct_model_free(nct_model* m) { delete m; }
+const char* nct_model_last_error(void) { return g_model_err.c_str(); }
+
+int nct_vgg19_load_model(nct_ctx* ctx, const nct_model* m) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(m, "vgg19_load_model: null model");
+    vgg_own(ctx)->loaded = false;
+    for (int i = 0; i < kNeeded; ++i) { int rc = upload_layer(ctx, i, m->w[i].data(), m->b[i].data()); if (rc) return rc; }
+    vgg_of(ctx)->loaded = true;
+    return NCT_OK;
+}
+
+int nct_vgg19_load_caffemodel(nct_ctx* ctx, const char* path) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_HIP(hipSetDevice(ctx->device));
+    NCT_REQUIRE(path, "vgg19_load_caffemodel: null path");
+    nct_model m; std::string err;
+    const int rc = parse_caffemodel(path, m, err);
+    if (rc != NCT_OK) return ctx->fail(rc, "%s", err.c_str());
+    return nct_vgg19_load_model(ctx, &m);
+}
+
+int nct_vgg19_share_weights(nct_ctx* ctx, nct_ctx* from) {
+    if (!ctx) return NCT_ERR_INVALID;
+    NCT_REQUIRE(from && from != ctx, "vgg19_share_weights: need another context");
+    NCT_REQUIRE(from->device == ctx->device, "vgg19_share_weights: contexts live on different GPUs (%d vs %d): load the weights once per GPU", ctx->device, from->device);
+    vgg_holder* src = (vgg_holder*)from->vgg;
+    if (!src || !src->w || !src->w->loaded) return ctx->fail(NCT_ERR_STATE, "vgg19_share_weights: the source context has no weights loaded");
+    if (!ctx->vgg) ctx->vgg = new vgg_holder();
+    ((vgg_holder*)ctx->vgg)->w = src->w;           // read-only after loading: no synchronisation needed between the sharers
+    return NCT_OK;
+}
+
+int nct_vgg19_weights_info(nct_ctx* ctx, uint64_t* id, size_t* bytes, int* sharers) {
+    if (!ctx) return NCT_ERR_INVALID;
+    vgg_holder* h = (vgg_holder*)ctx->vgg;
+    if (!h || !h->w || !h->w->loaded) return ctx->fail(NCT_ERR_STATE, "vgg19_weights_info: no weights loaded");
+    if (id) *id = (uint64_t)(uintptr_t)h->w->wp[0];
+    if (bytes) *bytes = h->w->bytes;
+    if (sharers) *sharers = (int)h->w.use_count();
+    return NCT_OK;
+}
+
+int nct_vgg19_check_prototxt(nct_ctx* ctx, const char* path) {
+    std::string err;
+    if (!path) { if (ctx) ctx->fail(NCT_ERR_INVALID, "vgg19_check_prototxt: null path"); else g_model_err = "vgg19_check_prototxt: null path"; return NCT_ERR_INVALID; }
+    const int rc = check_prototxt(path, err);
+    if (rc != NCT_OK) { if (ctx) ctx->fail(rc, "%s", err.c_str()); else g_model_err = err; }
+    return rc;
 }
 
 }  // extern "C"
 
 void nct_vgg_free(nct_ctx* ctx) {
     if (!ctx || !ctx->vgg) return;
-    vgg_weights* v = (vgg_weights*)ctx->vgg;
-    for (int i = 0; i < NCONV; ++i) { if (v->wp[i]) (void)hipFree(v->wp[i]); if (v->bias[i]) (void)hipFree(v->bias[i]); }
-    delete v; ctx->vgg = nullptr;
+    delete (vgg_holder*)ctx->vgg;          // the device copy goes with its last holder
+    ctx->vgg = nullptr;
 }
 
 // ---------------------------------------------------------------- forward (device): taps in CHW
 // d_bgr: device u8 BGR HWC. d_taps[t] (nullable, caller-owned device buffers of C*h*w floats) receive tap t+1.
 // dims[t] = {C,h,w} is filled for every tap <= deepest_tap.
 int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps, int* dims) {
-    vgg_weights* v = (vgg_weights*)ctx->vgg;
+    vgg_weights* v = ctx->vgg ? ((vgg_holder*)ctx->vgg)->w.get() : nullptr;
     if (!v || !v->loaded) return ctx->fail(NCT_ERR_STATE, "vgg19: weights not loaded (nct_vgg19_load_caffemodel / _load_raw)");
     NCT_REQUIRE(deepest_tap >= 1 && deepest_tap <= 5, "vgg19: deepest_tap must be 1..5");
     NCT_REQUIRE(H >= 2 && W >= 2 && H < 4096 && W < 4096, "vgg19: image size %dx%d out of range", W, H);

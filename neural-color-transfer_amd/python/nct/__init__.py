@@ -57,6 +57,15 @@ SIGNATURES = {
     "nct_feature_distance": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),
     "nct_bds_vote_image": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, _u32p, _u32p, C.c_int, C.c_double, C.c_double, _u8p]),
     "nct_vgg19_load_caffemodel": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "nct_model_parse_caffemodel": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "nct_model_free": (None, [C.c_void_p]),
+    "nct_model_last_error": (C.c_char_p, []),
+    "nct_vgg19_load_model": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nct_vgg19_share_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nct_vgg19_weights_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "nct_vgg19_check_prototxt": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "nct_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "nct_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "nct_vgg19_load_raw": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]),
     "nct_vgg19_features": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
     "nct_conv3x3_relu": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, _f32p, C.c_int]),
@@ -127,6 +136,31 @@ FLAG_COUNT_EVALS = 2
 FLAG_LATENCY = 4
 FLAG_LAB2BGR_CUBE = 8
 LAB2BGR_PIECEWISE, LAB2BGR_CUBE = 0, 1
+
+
+class Model:
+    """host-side parsed caffemodel (nct_model): parse the file once per process, upload it once per GPU (Context.vgg19_load_model)."""
+
+    def __init__(self, path):
+        m = C.c_void_p()
+        rc = lib().nct_model_parse_caffemodel(os.fsencode(path), C.byref(m))
+        if rc != 0:
+            raise NctError(rc, (lib().nct_model_last_error() or b"").decode())
+        self._m = m
+
+    def close(self):
+        if self._m:
+            lib().nct_model_free(self._m); self._m = None
+
+    def __del__(self):
+        self.close()
+
+
+def check_prototxt(path):
+    """nct_vgg19_check_prototxt without a context (no GPU needed): raises NctError with the reason when the file is not this library's VGG19"""
+    rc = lib().nct_vgg19_check_prototxt(None, os.fsencode(path))
+    if rc != 0:
+        raise NctError(rc, (lib().nct_model_last_error() or b"").decode())
 
 
 class PairLevels(C.Structure):
@@ -252,6 +286,22 @@ class Context:
 
     def vgg19_load_caffemodel(self, path):
         self._chk(self._l.nct_vgg19_load_caffemodel(self._h, os.fsencode(path)))
+
+    def vgg19_load_model(self, model):
+        """model: a Model (nct_model_parse_caffemodel) — upload the host copy to this context's GPU"""
+        self._chk(self._l.nct_vgg19_load_model(self._h, model._m))
+
+    def vgg19_share_weights(self, other):
+        """use `other`'s device copy of the weights (same GPU): no parse, no upload, no second copy"""
+        self._chk(self._l.nct_vgg19_share_weights(self._h, other._h))
+
+    def vgg19_weights_info(self):
+        i, b, n = C.c_uint64(), C.c_size_t(), C.c_int()
+        self._chk(self._l.nct_vgg19_weights_info(self._h, C.byref(i), C.byref(b), C.byref(n)))
+        return {"id": i.value, "bytes": b.value, "sharers": n.value}
+
+    def vgg19_check_prototxt(self, path):
+        self._chk(self._l.nct_vgg19_check_prototxt(self._h, os.fsencode(path)))
 
     def vgg19_load_raw(self, weights, biases):
         ws = [np.ascontiguousarray(w, np.float32) for w in weights]

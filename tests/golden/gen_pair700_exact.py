@@ -9,8 +9,9 @@ pair700_oracle.json pins and the GPU reproduces byte for byte):
 plus CRC-32 of both images, so the test can (1) check that the GPU output has the canonical CRC, (2) rebuild the exact-solve
 image from it, (3) check the rebuilt image's CRC, (4) report L-inf / PSNR of the product against the exact-solve oracle.
 Also stores the per-level intermediate results' CRCs of both runs (level_out) for the level-wise comparison.
+Also refreshes the pair's entry of pair700_oracle.json (CRC-32 and byte sum of the canonical-order result, the fixture the GPU path is pinned to at full size).
 Runs both oracle variants: ~15 / ~35 / ~5 minutes on 8 cores for 700 / 1000 / mixed."""
-import os, sys, time, zlib
+import json, os, sys, time, zlib
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import numpy as np, oracle_bind, synth
@@ -33,6 +34,11 @@ for name in (sys.argv[1:] or ["700"]):
                         level_crc_canonical=np.array([zlib.crc32(canon_lv[l].tobytes()) for l in range(5)], np.uint32),
                         level_linf_exact_vs_canonical=np.array(lv_linf), level_ndiff_exact_vs_canonical=np.array(lv_ndiff),
                         seconds=np.array([t_c, t_e]))
+    jpath = os.path.join(HERE, "pair700_oracle.json")
+    if name in ("700", "1000", "mixed"):
+        js = json.load(open(jpath)) if os.path.exists(jpath) else {}
+        js[name] = {"src_seed": 1000, "ref_seed": 1001, "shape": [sh, sw, rh, rw], "crc32": zlib.crc32(canon.tobytes()), "sum": int(canon.astype(np.uint64).sum()), "oracle_seconds": round(t_c, 1)}
+        json.dump(js, open(jpath, "w"), indent=1)
     mse = float((d.astype(np.float64) ** 2).mean())
     print(name, "differing bytes:", idx.size, "of", d.size, "L-inf", int(np.abs(d).max()) if idx.size else 0,
           "PSNR", "inf" if mse == 0 else round(10 * np.log10(255.0 ** 2 / mse), 2), "per-level L-inf", lv_linf, "per-level ndiff", lv_ndiff,

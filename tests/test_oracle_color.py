@@ -287,7 +287,7 @@ def test_canonical_cg_matches_explicit_for_few_iterations(oracle):
 
 
 def test_canonical_wls_matches_exact_solve(oracle):
-    """S2: the canonical-order MG-PCG (mirror of the product, stopped at 1e-6 relative residual) agrees with the exact
+    """S2: the canonical-order MG-PCG (mirror of the product, stopped at 1e-7 relative residual) agrees with the exact
     banded-Cholesky solve to ~1e-5 in the coefficients, i.e. far below one 8-bit quantisation step of the output."""
     err, s, g, ids, ws = _s1_inputs(oracle)
     full = synth.image(3, 48, 48)
