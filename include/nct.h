@@ -86,7 +86,7 @@ int nct_bds_vote_image(nct_ctx* ctx, const uint8_t* a_bgr, int ah, int aw, const
 int nct_vgg19_load_caffemodel(nct_ctx* ctx, const char* path);
 int nct_vgg19_load_raw(nct_ctx* ctx, const float* const* weights, const float* const* biases, int nlayers);
 /* A driver with several contexts (the CLI's -gpus N -inflight K; main.cu:581-582 builds two Nets from the file): parse the 575 MB file ONCE per process into a
- * host-side model (80 MB: the 13 needed layers), upload it ONCE per GPU (nct_vgg19_load_model), and let the other contexts of that GPU use the same read-only
+ * host-side model (52 MB: the 13 needed layers), upload it ONCE per GPU (nct_vgg19_load_model), and let the other contexts of that GPU use the same read-only
  * device copy (nct_vgg19_share_weights; both contexts must live on the same device; the copy is freed with its last user). nct_model_* need no context;
  * nct_model_last_error() returns the message of the last failed parse on the calling thread. nct_vgg19_weights_info: identity (device address of conv1_1's
  * packed weights), size in bytes and number of contexts sharing this context's copy. */

@@ -31,7 +31,7 @@ static const int kTapConv[5] = {0, 2, 4, 8, 12};     // conv1_1, conv2_1, conv3_
 static const int kNeeded = 13;                       // conv5_2..conv5_4 are never needed
 
 // Device copy of the packed weights. Read-only after loading, so every context on the same GPU can use ONE copy (nct_vgg19_share_weights: the CLI
-// with -inflight K keeps one 80 MB copy per GPU instead of K; the reference keeps two Nets per process, main.cu:581-582). Freed with its last user.
+// with -inflight K keeps one 52 MB copy per GPU instead of K; the reference keeps two Nets per process, main.cu:581-582). Freed with its last user.
 struct vgg_weights {
     int device = 0;
     float* wp[NCONV] = {nullptr};     // packed [Cin_pad*9][Cout]
@@ -109,7 +109,7 @@ static bool parse_blob(PB b, BlobView& out) {
 
 static int64_t blob_count(const BlobView& b) { int64_t n = 1; for (int i = 0; i < b.ndim; ++i) n *= b.dims[i]; return b.ndim ? n : 0; }
 
-// Host copy of the 13 needed conv layers (80 MB): what a process parses ONCE from the 575 MB caffemodel and then uploads to every GPU it drives.
+// Host copy of the 13 needed conv layers (52 MB): what a process parses ONCE from the 575 MB caffemodel and then uploads to every GPU it drives.
 struct nct_model {
     std::vector<float> w[NCONV], b[NCONV];
     std::string err;

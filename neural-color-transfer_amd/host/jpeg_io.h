@@ -154,6 +154,7 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
     bool progressive = false;
     size_t pos = 2;
     bool have_frame = false, any_scan = false;
+    int nscans = 0;
     while (pos + 4 <= d.size()) {
         if (d[pos] != 0xFF) { ++pos; continue; }
         const int m = d[pos + 1];
@@ -218,6 +219,9 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
             if (L >= 12 && !memcmp(p, "Adobe", 5)) { adobe = true; adobe_transform = p[11]; }
         } else if (m == 0xDA) {                             // SOS + entropy-coded data
             if (!have_frame) { err = "SOS before SOF"; return false; }
+            // every scan walks all MCUs of the frame (up to 64 MP): a crafted file with thousands of tiny SOS segments would cost O(scans x blocks).
+            // libjpeg-turbo's max_scans guard; real progressive files have ~10 scans
+            if (++nscans > 256) { err = "too many scans (limit: 256)"; return false; }
             const int ns = p[0];
             if (ns < 1 || ns > (int)comps.size() || L < 1 + 2 * (size_t)ns + 3) { err = "bad SOS"; return false; }
             std::vector<Comp*> sc;
@@ -225,6 +229,7 @@ inline bool read(const std::string& path, ImageBGR& img, std::string& err) {
                 Comp* c = nullptr;
                 for (auto& k : comps) if (k.id == p[1 + 2 * i]) c = &k;
                 if (!c) { err = "bad SOS component"; return false; }
+                for (Comp* prev : sc) if (prev == c) { err = "duplicate component in SOS"; return false; }
                 c->td = p[2 + 2 * i] >> 4; c->ta = p[2 + 2 * i] & 15;
                 if (c->td > 3 || c->ta > 3 || (!progressive && (!hdc[c->td].set || !hac[c->ta].set))) { err = "missing Huffman table"; return false; }
                 c->pred = 0;

@@ -3,12 +3,16 @@
 // (CmdLine.h:58-69,132-147; CmdLine.cpp:21-56,93-109). Same flags, same pairs.txt, same output names, same log lines.
 // Differences: portable path handling ('/' and '\\'), in-repo PNG + JPEG (baseline, progressive) decoders instead of cv::imread
 // (output is PNG like the reference), a missing pairs.txt is an error instead of a NULL dereference (main.cu:463-471), plus the
-// extensions `-gpus N` (pairs sharded over N GPUs, one context per worker thread), `-inflight K`, `-seed`, `-levels L` (BASELINE
+// extensions `-gpus N` (pairs sharded over N GPUs, one context per worker thread), `-inflight K`, `-io T` (shared decode/encode pool: the GPU workers never
+// touch zlib), `-pin` (threads on the GPU's NUMA node), weights parsed once per process and held once per GPU, `-seed`, `-levels L` (BASELINE
 // config 1: "L=5 only" = -levels 1), `-resume 1` (skip pairs whose output exists; <out>/status.jsonl gets one JSON line per pair)
 // and `-feat16 1` (reduced-precision PatchMatch features; not bit-identical).
 #include <sys/stat.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <cmath>
 #include <algorithm>
 #include <cstdio>
@@ -22,6 +26,7 @@
 #include "nct.h"
 #include "png_io.h"
 #include "jpeg_io.h"
+#include "affinity.h"
 
 namespace {
 constexpr int MAX_SIZE = 1000;                 // Config.h:5
@@ -89,7 +94,7 @@ struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; bo
 // with the (border-clipped) 3x3 patch of the guidance image above that of the level image, the windows of the local statistics (:1190-1221).
 // <pre> = the output file's stem.
 void heat(double v, uint8_t* bgr) {
-    v = v < 0 ? 0 : (v > 1 ? 1 : v);
+    v = !(v >= 0) ? 0 : (v > 1 ? 1 : v);          // NaN -> 0 as well
     double dr, dg, db;
     if (v < 0.1242) { db = 0.504 + ((1. - 0.504) / 0.1242) * v; dg = dr = 0.; }
     else if (v < 0.3747) { db = 1.; dr = 0.; dg = (v - 0.1242) * (1. / (0.3747 - 0.1242)); }
@@ -205,7 +210,8 @@ bool run_with_vis(nct_ctx* ctx, const ImageBGR& cnt, const ImageBGR& stl, const 
         float mn = errm[l][0], mx = errm[l][0];
         for (float e : errm[l]) { mn = e < mn ? e : mn; mx = e > mx ? e : mx; }
         std::vector<uint8_t> hm((size_t)ah[l] * aw[l] * 3);
-        for (size_t i = 0; i < errm[l].size(); ++i) heat(((double)errm[l][i] - mn) / ((double)mx - mn), &hm[3 * i]);
+        // a constant error map normalises to 0 (cv::normalize's min-max of a flat image), not 0/0
+        for (size_t i = 0; i < errm[l].size(); ++i) heat(mx > mn ? ((double)errm[l][i] - mn) / ((double)mx - mn) : 0.0, &hm[3 * i]);
         if (!save("aFlow", l, fa.data(), ah[l], aw[l]) || !save("bFlow", l, fb.data(), bh[l], bw[l]) || !save("tCnt", l, simg[l].data(), ah[l], aw[l]) ||
             !save("tStl", l, rimg[l].data(), bh[l], bw[l]) || !save("errMap", l, hm.data(), ah[l], aw[l]) || !save("guide", l, guide[l].data(), ah[l], aw[l]) ||
             !save("result", l, result[l].data(), cnt.h, cnt.w)) { err = "cannot write the -vis images"; return false; }
@@ -241,56 +247,134 @@ bool shrink(nct_ctx* ctx, ImageBGR& img) {
     return true;
 }
 
-void process(nct_ctx* ctx, const Config& cfg, const Pair& p, size_t index) {
-    char line[1024];
-    std::string log;
-    auto say = [&](const char* fmt, auto... a) { snprintf(line, sizeof line, fmt, a...); log += line; };
-    const auto t0 = std::chrono::steady_clock::now();
-    auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    log += "-----------------***********************----------------------\n";
-    say("Content: %s, style: %s, BDS weight: %f.\n", p.cnt.c_str(), p.stl.c_str(), (double)p.bds);
-    const std::string cntStr = cfg.input_dir + "/" + p.cnt, stlStr = cfg.input_dir + "/" + p.stl;
+// ---- one pair = three stages, so that the GPU workers never wait on zlib (the CLI lost up to 30 % to PNG work):
+//   load  (I/O pool)   : resume check, decode both images (PNG / JPEG)
+//   run   (GPU worker) : shrink to MAX_SIZE on the GPU, nct_process_pair, the reference's log lines
+//   store (I/O pool)   : PNG-encode the result (zlib level 3), status line
+// With `-io 0` a GPU worker runs all three itself (the round-2 behaviour).
+struct Job {
+    size_t index = 0; Pair p; std::string name, log, err;
+    ImageBGR cnt, stl; std::vector<uint8_t> out;
+    std::chrono::steady_clock::time_point t0;
+    enum { LOADED, SKIPPED, FAILED, DONE } state = LOADED;
+    template <typename... A> void say(const char* fmt, A... a) { char line[1200]; snprintf(line, sizeof line, fmt, a...); log += line; }
+    double secs() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+void finish(const Config& cfg, Job& j) {           // status line + the pair's log block, printed in one piece
+    const char* st = j.state == Job::DONE ? "done" : (j.state == Job::SKIPPED ? "skipped" : "error");
+    write_status(cfg, j.index, st, j.p.cnt, j.p.stl, j.p.bds, j.name, j.state == Job::SKIPPED ? 0.0 : j.secs(), j.state == Job::SKIPPED ? "output exists" : j.err);
+    std::lock_guard<std::mutex> g(g_print); fputs(j.log.c_str(), stdout); fflush(stdout);
+}
+
+void load_pair(const Config& cfg, Job& j) {
+    j.t0 = std::chrono::steady_clock::now();
+    j.log += "-----------------***********************----------------------\n";
+    j.say("Content: %s, style: %s, BDS weight: %f.\n", j.p.cnt.c_str(), j.p.stl.c_str(), (double)j.p.bds);
+    const std::string cntStr = cfg.input_dir + "/" + j.p.cnt, stlStr = cfg.input_dir + "/" + j.p.stl;
     char name[1024];
-    snprintf(name, sizeof name, "%s/%s_%s_%2.2f.png", cfg.output_dir.c_str(), stem(cntStr).c_str(), stem(stlStr).c_str(), (double)p.bds);   // main.cu:524-537
-    ImageBGR cnt, stl; std::string err;
-    auto flush = [&] { std::lock_guard<std::mutex> g(g_print); fputs(log.c_str(), stdout); fflush(stdout); };
-    auto fail = [&](const std::string& msg) { write_status(cfg, index, "error", p.cnt, p.stl, p.bds, name, secs(), msg); flush(); };
-    if (cfg.resume) {
-        struct stat st;
-        if (stat(name, &st) == 0 && st.st_size > 0) {
-            say("Skipping (-resume): %s exists.\n\n", name);
-            write_status(cfg, index, "skipped", p.cnt, p.stl, p.bds, name, 0.0, "output exists");
-            flush(); return;
-        }
+    snprintf(name, sizeof name, "%s/%s_%s_%2.2f.png", cfg.output_dir.c_str(), stem(cntStr).c_str(), stem(stlStr).c_str(), (double)j.p.bds);   // main.cu:524-537
+    j.name = name;
+    if (cfg.resume && pngio::looks_complete(j.name)) {           // a truncated file (killed run, full disk) is redone, not skipped
+        j.say("Skipping (-resume): %s exists.\n\n", name);
+        j.state = Job::SKIPPED; return;
     }
-    if (!imgio::read(cntStr, cnt, err)) { say("Error: Fail reading content image: %s\n", cntStr.c_str()); fail("cannot read content image: " + err); return; }
-    say("\n**Read content file: %s, w = %d, h = %d\n", cntStr.c_str(), cnt.w, cnt.h);
-    if (!imgio::read(stlStr, stl, err)) { say("Error: Fail reading style image: %s\n", stlStr.c_str()); fail("cannot read style image: " + err); return; }
-    say("Read style file: %s, w = %d, h = %d\n", stlStr.c_str(), stl.w, stl.h);
-    if (!shrink(ctx, cnt) || !shrink(ctx, stl)) { say("Error: resize failed: %s\n", nct_last_error(ctx)); fail(nct_last_error(ctx)); return; }
+    std::string err;
+    if (!imgio::read(cntStr, j.cnt, err)) { j.say("Error: Fail reading content image: %s\n", cntStr.c_str()); j.err = "cannot read content image: " + err; j.state = Job::FAILED; return; }
+    j.say("\n**Read content file: %s, w = %d, h = %d\n", cntStr.c_str(), j.cnt.w, j.cnt.h);
+    if (!imgio::read(stlStr, j.stl, err)) { j.say("Error: Fail reading style image: %s\n", stlStr.c_str()); j.err = "cannot read style image: " + err; j.state = Job::FAILED; return; }
+    j.say("Read style file: %s, w = %d, h = %d\n", stlStr.c_str(), j.stl.w, j.stl.h);
+}
+
+void run_pair(nct_ctx* ctx, const Config& cfg, Job& j) {
+    if (!shrink(ctx, j.cnt) || !shrink(ctx, j.stl)) { j.say("Error: resize failed: %s\n", nct_last_error(ctx)); j.err = nct_last_error(ctx); j.state = Job::FAILED; return; }
     nct_params prm = cfg.prm;
-    prm.bds_weight = p.bds;                                     // the per-line weight overrides -bds (main.cu:475)
-    std::vector<uint8_t> out((size_t)cnt.h * cnt.w * 3);
+    prm.bds_weight = j.p.bds;                                   // the per-line weight overrides -bds (main.cu:475)
+    j.out.resize((size_t)j.cnt.h * j.cnt.w * 3);
     nct_pair_timing tm;                                         // stage times come from stream events: asking for them adds no host synchronisation
     if (cfg.vis) {
-        std::string pre(name); pre.resize(pre.size() - 4);                  // the output file's stem
-        if (!run_with_vis(ctx, cnt, stl, prm, pre, out.data(), &tm, err)) { say("Error: %s\n", err.c_str()); fail(err); return; }
+        std::string pre(j.name); pre.resize(pre.size() - 4);    // the output file's stem
+        std::string err;
+        if (!run_with_vis(ctx, j.cnt, j.stl, prm, pre, j.out.data(), &tm, err)) { j.say("Error: %s\n", err.c_str()); j.err = err; j.state = Job::FAILED; return; }
     } else {
-        const int rc = nct_process_pair(ctx, cnt.px.data(), cnt.h, cnt.w, stl.px.data(), stl.h, stl.w, &prm, out.data(), &tm);
-        if (rc != NCT_OK) { say("Error: %s\n", nct_last_error(ctx)); fail(nct_last_error(ctx)); return; }
+        const int rc = nct_process_pair(ctx, j.cnt.px.data(), j.cnt.h, j.cnt.w, j.stl.px.data(), j.stl.h, j.stl.w, &prm, j.out.data(), &tm);
+        if (rc != NCT_OK) { j.say("Error: %s\n", nct_last_error(ctx)); j.err = nct_last_error(ctx); j.state = Job::FAILED; return; }
     }
     // the reference's per-level lines (main.cu:331; ColorTransfer.cpp:1373,1434), then its total (main.cu:453)
     for (int l = 0; l < prm.levels; ++l) {
-        say("Patch Match Time: %lf sec.\n", (tm.pm_level_ms[l] + tm.vote_level_ms[l]) * 1e-3);
-        say("Nonlocal Solve Time: %lf\n", tm.nonlocal_level_ms[l] * 1e-3);
-        say("WLS Solve Time: %lf\n", tm.wls_level_ms[l] * 1e-3);
+        j.say("Patch Match Time: %lf sec.\n", (tm.pm_level_ms[l] + tm.vote_level_ms[l]) * 1e-3);
+        j.say("Nonlocal Solve Time: %lf\n", tm.nonlocal_level_ms[l] * 1e-3);
+        j.say("WLS Solve Time: %lf\n", tm.wls_level_ms[l] * 1e-3);
     }
-    say("VGG19 Time: %lf sec.\n", tm.vgg_ms * 1e-3);
-    say("**Finished Time: %lf sec.\n", tm.total_ms * 1e-3);
-    if (!pngio::write(name, out.data(), cnt.h, cnt.w, err)) { say("Error: cannot write %s: %s\n", name, err.c_str()); fail("cannot write output: " + err); return; }
-    say("Final output file: %s.\n\n", name);
-    write_status(cfg, index, "done", p.cnt, p.stl, p.bds, name, secs(), "");
-    flush();
+    j.say("VGG19 Time: %lf sec.\n", tm.vgg_ms * 1e-3);
+    j.say("**Finished Time: %lf sec.\n", tm.total_ms * 1e-3);
+    j.stl.px.clear(); j.stl.px.shrink_to_fit();
+}
+
+void store_pair(Job& j) {
+    std::string err;
+    if (!pngio::write(j.name, j.out.data(), j.cnt.h, j.cnt.w, err)) { j.say("Error: cannot write %s: %s\n", j.name.c_str(), err.c_str()); j.err = "cannot write output: " + err; j.state = Job::FAILED; return; }
+    j.say("Final output file: %s.\n\n", j.name.c_str());
+    j.state = Job::DONE;
+}
+
+// Bounded hand-over between the I/O pool and the GPU workers. `ready` holds decoded pairs (at most `cap`: the decoders stay a little ahead of the GPUs, not a
+// whole batch), `results` finished ones waiting for the PNG encoder (the same bound: a worker blocks rather than pile up results if zlib falls behind).
+struct Pipeline {
+    std::mutex m; std::condition_variable cv;
+    std::deque<std::unique_ptr<Job>> ready, results;
+    size_t cap = 4, total = 0, next_load = 0, loading = 0, finished = 0;
+    bool loads_done() const { return next_load >= total && loading == 0; }
+};
+
+void io_thread(Pipeline& P, const Config& cfg, const std::vector<Pair>& pairs) {
+    for (;;) {
+        std::unique_ptr<Job> j; bool store = false; size_t idx = 0;
+        {
+            std::unique_lock<std::mutex> lk(P.m);
+            P.cv.wait(lk, [&] { return !P.results.empty() || (P.next_load < P.total && P.ready.size() + P.loading < P.cap) || P.finished == P.total; });
+            if (!P.results.empty()) { j = std::move(P.results.front()); P.results.pop_front(); store = true; }       // encoding first: it frees memory and unblocks workers
+            else if (P.next_load < P.total && P.ready.size() + P.loading < P.cap) { idx = P.next_load++; ++P.loading; }
+            else return;                                                                                                 // finished == total
+        }
+        P.cv.notify_all();
+        if (store) {
+            store_pair(*j); finish(cfg, *j);
+            { std::lock_guard<std::mutex> lk(P.m); ++P.finished; }
+        } else {
+            j.reset(new Job()); j->index = idx; j->p = pairs[idx];
+            load_pair(cfg, *j);
+            const bool go = j->state == Job::LOADED;
+            if (!go) finish(cfg, *j);
+            std::lock_guard<std::mutex> lk(P.m);
+            --P.loading;
+            if (go) P.ready.push_back(std::move(j)); else ++P.finished;
+        }
+        P.cv.notify_all();
+    }
+}
+
+void gpu_worker(Pipeline& P, nct_ctx* ctx, const Config& cfg) {
+    for (;;) {
+        std::unique_ptr<Job> j;
+        {
+            std::unique_lock<std::mutex> lk(P.m);
+            P.cv.wait(lk, [&] { return !P.ready.empty() || P.loads_done(); });
+            if (P.ready.empty()) return;
+            j = std::move(P.ready.front()); P.ready.pop_front();
+        }
+        P.cv.notify_all();
+        run_pair(ctx, cfg, *j);
+        if (j->state == Job::FAILED) {
+            finish(cfg, *j);
+            { std::lock_guard<std::mutex> lk(P.m); ++P.finished; }
+        } else {
+            std::unique_lock<std::mutex> lk(P.m);
+            P.cv.wait(lk, [&] { return P.results.size() < P.cap; });
+            P.results.push_back(std::move(j));
+        }
+        P.cv.notify_all();
+    }
 }
 }  // namespace
 
@@ -302,10 +386,20 @@ int main(int argc, char** argv) {
         printf("%d %d\n", im.w, im.h);
         return 0;
     }
+    if (argc == 3 && !strcmp(argv[1], "--gpu-locality")) {        // affinity self-test hook (no GPU): NUMA node and CPU list of the PCI device argv[2]
+        const affinity::GpuLocality g = affinity::gpu_locality(argv[2]);
+        printf("%d %s\n", g.numa_node, affinity::cpus_to_string(g.cpus).c_str());
+        return 0;
+    }
+    if (argc == 3 && !strcmp(argv[1], "--check-prototxt")) {      // deploy-prototxt self-test hook (no GPU)
+        if (nct_vgg19_check_prototxt(nullptr, argv[2]) != NCT_OK) { printf("Error: %s\n", nct_model_last_error()); return 1; }
+        printf("ok\n");
+        return 0;
+    }
     CmdLine cl;
     Config cfg;
     nct_params_default(&cfg.prm);
-    int gpu = 0, ngpus = 1, seed = 1, inflight = 1, levels = 5, resume = 0, feat16 = 0, vis = 0;
+    int gpu = 0, ngpus = 1, seed = 1, inflight = 1, levels = 5, resume = 0, feat16 = 0, vis = 0, io = -1, pin = 1;
     cl.add("m", cfg.model_dir, "Directory of network models.");
     cl.add("i", cfg.input_dir, "Input directory of content and style images and pairs.txt.");
     cl.add("o", cfg.output_dir, "Output directory of result images.");
@@ -318,12 +412,14 @@ int main(int argc, char** argv) {
     cl.add("l", cfg.prm.local_weight, "Weight of local constraitn (default: 0.001).");
     cl.add("w", cfg.prm.wls_lambda_init, "Initial value of WLS weight (default: 0.0234375).");
     cl.add("gpus", ngpus, "[extension] number of GPUs to shard pairs.txt over, starting at -g (default: 1).");
-    cl.add("inflight", inflight, "[extension] pairs in flight per GPU, one context + host thread each (default: 1; 2-3 raises throughput ~20 %).");
+    cl.add("inflight", inflight, "[extension] pairs in flight per GPU, one context + host thread each (default: 1; 2-4 raises throughput ~20 %).");
+    cl.add("io", io, "[extension] threads of the shared decode/encode pool (default -1: two per GPU, at most the machine's; 0: every GPU worker does its own file I/O).");
+    cl.add("pin", pin, "[extension] 1 = pin each GPU's worker and I/O threads to the CPUs of the GPU's NUMA node (sysfs local_cpulist); 0 = leave the scheduler alone.");
     cl.add("seed", seed, "[extension] seed of the counter-based RNG (default: 1).");
     cl.add("levels", levels, "[extension] pyramid levels to run, coarse to fine: 5 = the full L=5..1 loop, 1 = L=5 only.");
-    cl.add("resume", resume, "[extension] 1 = skip pairs whose output file exists; every pair appends a JSON line to <output>/status.jsonl.");
+    cl.add("resume", resume, "[extension] 1 = skip pairs whose output file exists and is a complete PNG; every pair appends a JSON line to <output>/status.jsonl.");
     cl.add("vis", vis, "[extension] 1 = the reference's ENABLE_VIS dumps per level (flow maps, level images, error heat map, coefficient and cluster images) next to the output.");
-    cl.add("feat16", feat16, "[extension] 1 = fp16 PatchMatch feature tiles (fp32 accumulate); not bit-identical to the default.");
+    cl.add("feat16", feat16, "[extension] 1 = fp16 PatchMatch feature tiles (fp32 accumulate); not bit-identical to the default (about 45 dB against it).");
     if (!cl.parse(argc, argv)) return -1;
     cfg.prm.seed = (uint32_t)seed;
     cfg.prm.levels = levels < 1 ? 1 : (levels > 5 ? 5 : levels);
@@ -334,6 +430,10 @@ int main(int argc, char** argv) {
     if (ngpus < 1) ngpus = 1;
     if (inflight < 1) inflight = 1;
     if (inflight > 8) inflight = 8;
+    const int nworkers = ngpus * inflight;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (io < 0) io = std::min(2 * ngpus, hw > 0 ? hw : 2 * ngpus);
+    if (io > 64) io = 64;
 
     mkdir(cfg.output_dir.c_str(), 0777);                                    // main.cu:458
     const std::string pairsFile = cfg.input_dir + "/pairs.txt";
@@ -344,28 +444,73 @@ int main(int argc, char** argv) {
     while (fscanf(fp, "%259s %259s %f\n", a, b, &w) == 3) pairs.push_back({a, b, w});
     fclose(fp);
 
-    // model path: <model_dir>/vgg19/VGG_ILSVRC_19_layers.caffemodel (main.cu:575-580; '\\' or '/' accepted in model_dir)
-    const std::string model = cfg.model_dir + "/vgg19/VGG_ILSVRC_19_layers.caffemodel";
-    // one context (streams, arena, weights) per worker; worker j runs on GPU j mod G, so -inflight K gives every GPU K independent pairs
-    // whose launch-latency-bound phases (coarse pyramid levels, solver reductions) overlap with the other pairs' heavy kernels
-    const int nworkers = ngpus * inflight;
+    // model: <model_dir>/vgg19/VGG_ILSVRC_19_layers_deploy.prototxt + VGG_ILSVRC_19_layers.caffemodel (main.cu:575-580; '\\' or '/' accepted in model_dir).
+    // The topology is built into the library, so the prototxt is only checked: a directory that describes another network is refused, a missing file is noted.
+    const std::string proto = cfg.model_dir + "/vgg19/VGG_ILSVRC_19_layers_deploy.prototxt", model = cfg.model_dir + "/vgg19/VGG_ILSVRC_19_layers.caffemodel";
+    struct stat pst;
+    if (stat(proto.c_str(), &pst) == 0) {
+        if (nct_vgg19_check_prototxt(nullptr, proto.c_str()) != NCT_OK) { printf("Error: %s\n", nct_model_last_error()); return -1; }
+    } else printf("Note: %s not found; using the library's built-in VGG19 topology (conv1_1 ... relu5_1).\n", proto.c_str());
+
+    // test hook: NCT_DEVICE_OVERRIDE=d runs every logical GPU of -gpus N on HIP device d (the N > 1 host path on a 1-GPU box)
+    const char* ovr = getenv("NCT_DEVICE_OVERRIDE");
+    auto device_of = [&](int g) { return ovr && *ovr ? atoi(ovr) : gpu + g; };
+    // one context (streams, arena) per worker; worker j runs on GPU j mod G, so -inflight K gives every GPU K independent pairs whose
+    // launch-latency-bound phases (coarse pyramid levels, solver reductions) overlap with the other pairs' heavy kernels.
+    // Weights: the 575 MB caffemodel is parsed ONCE per process, uploaded ONCE per device, and every other context of that device shares the read-only copy
+    // (the reference parses it twice, main.cu:581-582; round 2 of this CLI parsed and uploaded it once per worker).
     std::vector<nct_ctx*> ctxs(nworkers, nullptr);
+    nct_model* host_model = nullptr;
+    if (nct_model_parse_caffemodel(model.c_str(), &host_model) != NCT_OK) { printf("Error: %s\n", nct_model_last_error()); return -1; }
+    int uploads = 0;
     for (int j = 0; j < nworkers; ++j) {
-        const int g = j % ngpus;
-        if (nct_create(gpu + g, &ctxs[j]) != NCT_OK) { printf("Error: %s\n", nct_last_error(nullptr)); return -1; }
-        if (j < ngpus) { char name[256]; nct_device_name(ctxs[j], name, sizeof name); printf("Set device %d: %s.\n", gpu + g, name); }
-        if (nct_vgg19_load_caffemodel(ctxs[j], model.c_str()) != NCT_OK) { printf("Error: %s\n", nct_last_error(ctxs[j])); return -1; }
+        const int g = j % ngpus, dev = device_of(g);
+        if (nct_create(dev, &ctxs[j]) != NCT_OK) { printf("Error: %s\n", nct_last_error(nullptr)); return -1; }
+        if (j < ngpus) { char name[256]; nct_device_name(ctxs[j], name, sizeof name); printf("Set device %d: %s.\n", dev, name); }
+        int owner = -1;
+        for (int k = 0; k < j; ++k) if (device_of(k % ngpus) == dev) { owner = k; break; }
+        const int rc = owner < 0 ? (++uploads, nct_vgg19_load_model(ctxs[j], host_model)) : nct_vgg19_share_weights(ctxs[j], ctxs[owner]);
+        if (rc != NCT_OK) { printf("Error: %s\n", nct_last_error(ctxs[j])); return -1; }
     }
+    nct_model_free(host_model);
+    { size_t wb = 0; nct_vgg19_weights_info(ctxs[0], nullptr, &wb, nullptr);
+      printf("VGG19 weights: parsed once, %d device cop%s of %.1f MB shared by %d context(s).\n", uploads, uploads == 1 ? "y" : "ies", wb / 1e6, nworkers); }
+
+    // NUMA placement: the CPUs next to each GPU (sysfs), for its workers and its share of the I/O pool
+    std::vector<affinity::GpuLocality> loc(ngpus);
+    if (pin)
+        for (int g = 0; g < ngpus; ++g) {
+            char addr[32];
+            if (nct_device_pci_bus_id(device_of(g), addr, sizeof addr) != NCT_OK) continue;
+            loc[g] = affinity::gpu_locality(addr);
+            if (!loc[g].cpus.empty()) printf("GPU %d (%s): NUMA node %d, host threads pinned to CPUs %s.\n", device_of(g), addr, loc[g].numa_node, affinity::cpus_to_string(loc[g].cpus).c_str());
+        }
+
     const auto t0 = std::chrono::steady_clock::now();
-    // pairs are independent and of mixed sizes: every worker takes the next unprocessed pair from a shared counter (work stealing
-    // inside the node, BASELINE config 5); which worker runs a pair has no influence on its result
+    // pairs are independent and of mixed sizes: every worker takes the next decoded pair (work stealing inside the node, BASELINE config 5);
+    // which worker runs a pair has no influence on its result
+    std::vector<std::thread> threads;
+    Pipeline P; P.total = pairs.size(); P.cap = (size_t)std::max(2, 2 * nworkers);
     std::atomic<size_t> next{0};
-    std::vector<std::thread> workers;
-    for (int j = 0; j < nworkers; ++j)
-        workers.emplace_back([&, j] { for (size_t i; (i = next.fetch_add(1)) < pairs.size();) process(ctxs[j], cfg, pairs[i], i); });
-    for (auto& t : workers) t.join();
+    if (io > 0) {
+        for (int t = 0; t < io; ++t) threads.emplace_back([&, t] { if (pin) affinity::pin_current_thread(loc[t % ngpus].cpus); io_thread(P, cfg, pairs); });
+        for (int j = 0; j < nworkers; ++j) threads.emplace_back([&, j] { if (pin) affinity::pin_current_thread(loc[j % ngpus].cpus); gpu_worker(P, ctxs[j], cfg); });
+    } else {
+        for (int j = 0; j < nworkers; ++j)
+            threads.emplace_back([&, j] {
+                if (pin) affinity::pin_current_thread(loc[j % ngpus].cpus);
+                for (size_t i; (i = next.fetch_add(1)) < pairs.size();) {
+                    Job job; job.index = i; job.p = pairs[i];
+                    load_pair(cfg, job);
+                    if (job.state == Job::LOADED) run_pair(ctxs[j], cfg, job);
+                    if (job.state == Job::LOADED) store_pair(job);
+                    finish(cfg, job);
+                }
+            });
+    }
+    for (auto& t : threads) t.join();
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("Processed %zu pair(s) on %d GPU(s), %d in flight each, in %.3f sec (%.3f pairs/sec).\n", pairs.size(), ngpus, inflight, sec, pairs.empty() ? 0.0 : pairs.size() / sec);
+    printf("Processed %zu pair(s) on %d GPU(s), %d in flight each, %d I/O thread(s), in %.3f sec (%.3f pairs/sec).\n", pairs.size(), ngpus, inflight, io, sec, pairs.empty() ? 0.0 : pairs.size() / sec);
     for (auto* c : ctxs) nct_destroy(c);
     return 0;
 }

@@ -115,12 +115,28 @@ inline bool write(const std::string& path, const uint8_t* bgr, int h, int w, std
     ihdr[0] = ww >> 24; ihdr[1] = ww >> 16; ihdr[2] = ww >> 8; ihdr[3] = ww; ihdr[4] = hh >> 24; ihdr[5] = hh >> 16; ihdr[6] = hh >> 8; ihdr[7] = hh;
     ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
     chunk("IHDR", ihdr, 13); chunk("IDAT", comp.data(), (uint32_t)clen); chunk("IEND", nullptr, 0);
-    FILE* f = fopen(path.c_str(), "wb");
+    // written under a temporary name and renamed: a run killed mid-write (or a full disk) never leaves a truncated file under the final name,
+    // which -resume would take for a finished pair
+    const std::string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) { err = "cannot create"; return false; }
-    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { err = "short write"; remove(tmp.c_str()); return false; }
+    if (rename(tmp.c_str(), path.c_str()) != 0) { err = "cannot rename the finished file into place"; remove(tmp.c_str()); return false; }
+    return true;
+}
+
+// -resume: is `path` a complete PNG? (signature, IHDR first, an IEND chunk closing the file) — without decoding it
+inline bool looks_complete(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint8_t head[24], tail[12];
+    bool ok = fread(head, 1, 24, f) == 24 && fseek(f, -12, SEEK_END) == 0 && fread(tail, 1, 12, f) == 12;
     fclose(f);
-    if (!ok) err = "short write";
-    return ok;
+    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    static const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
+    return ok && !memcmp(head, sig, 8) && !memcmp(head + 12, "IHDR", 4) && !memcmp(tail, iend, 12);
 }
 
 }  // namespace pngio

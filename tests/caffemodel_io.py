@@ -86,3 +86,35 @@ def synthetic_vgg19(seed=19, nlayers=13, bias_scale=0.0):
         ws.append(np.ascontiguousarray(w))
         bs.append((rng.standard_normal(VGG_COUT[i]).astype(np.float32) * np.float32(bias_scale)) if bias_scale else np.zeros(VGG_COUT[i], np.float32))
     return ws, bs
+
+
+def write_deploy_prototxt(path, v1=False, drop=None, num_output=None, extra_tail=True):
+    """A deploy prototxt of the VGG19 topology in protobuf text format (own writer; the reference ships one under demo/model/vgg19/): `layer` messages with string
+    types, or V1 `layers` with enum types. drop: name of a layer to leave out; num_output: {conv name: value} overrides — for the negative tests."""
+    names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv3_4", "conv4_1", "conv4_2", "conv4_3", "conv4_4",
+             "conv5_1", "conv5_2", "conv5_3", "conv5_4"]
+    cout = [64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512, 512]
+    pool_after = {"conv1_2": "pool1", "conv2_2": "pool2", "conv3_4": "pool3", "conv4_4": "pool4", "conv5_4": "pool5"}
+    kw = "layers" if v1 else "layer"
+    ty = (lambda s_: {"Convolution": "CONVOLUTION", "ReLU": "RELU", "Pooling": "POOLING", "InnerProduct": "INNER_PRODUCT"}[s_]) if v1 else (lambda s_: '"%s"' % s_)
+    out = ['name: "VGG_ILSVRC_19_layer"', 'input: "data"', "# comment line", "input_shape {", "  dim: 1", "  dim: 3", "  dim: 224", "  dim: 224", "}"]
+    cur = "data"
+    for i, n in enumerate(names):
+        if not extra_tail and i > 12:
+            break
+        no = (num_output or {}).get(n, cout[i])
+        if n != drop:
+            out += [f"{kw} {{", f'  bottom: "{cur}"', f'  top: "{n}"', f'  name: "{n}"', f"  type: {ty('Convolution')}", "  convolution_param {", f"    num_output: {no}", "    pad: 1",
+                    "    kernel_size: 3", "  }", "}"]
+            cur = n
+        r = "relu" + n[4:]
+        if r != drop:
+            out += [f"{kw} {{", f'  bottom: "{cur}"', f'  top: "{cur}"', f'  name: "{r}"', f"  type: {ty('ReLU')}", "}"]
+        if n in pool_after and pool_after[n] != drop and (extra_tail or i < 12):
+            pn = pool_after[n]
+            out += [f"{kw} {{", f'  bottom: "{cur}"', f'  top: "{pn}"', f'  name: "{pn}"', f"  type: {ty('Pooling')}", "  pooling_param {", "    pool: MAX", "    kernel_size: 2", "    stride: 2", "  }", "}"]
+            cur = pn
+    if extra_tail:
+        out += [f"{kw} {{", f'  bottom: "{cur}"', '  top: "fc6"', '  name: "fc6"', f"  type: {ty('InnerProduct')}", "  inner_product_param {", "    num_output: 4096", "  }", "}"]
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")

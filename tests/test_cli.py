@@ -177,6 +177,54 @@ def test_decoders_survive_mutated_files_under_sanitizers(tmp_path):
     assert decoded + rejected == 20000 and decoded > 1000 and rejected > 1000
 
 
+def test_gpu_locality_from_sysfs(tmp_path):
+    """`-pin`: the CPUs next to a GPU come from /sys/bus/pci/devices/<addr>/{numa_node,local_cpulist} (host/affinity.h); checked against a fake sysfs tree
+    through the CLI's self-test hook (NCT_SYSFS_ROOT), incl. the cpulist grammar and the node-cpulist fallback."""
+    root = tmp_path / "sys"
+    d = root / "bus" / "pci" / "devices" / "0000:c1:00.0"; d.mkdir(parents=True)
+    (d / "numa_node").write_text("1\n"); (d / "local_cpulist").write_text("32-63,160-191\n")
+    env = dict(os.environ, NCT_SYSFS_ROOT=str(root))
+    r = subprocess.run([BIN, "--gpu-locality", "0000:c1:00.0"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "1 32-63,160-191"
+    d2 = root / "bus" / "pci" / "devices" / "0000:05:00.0"; d2.mkdir(parents=True)
+    (d2 / "numa_node").write_text("0\n"); (d2 / "local_cpulist").write_text("\n")          # empty list -> falls back to the node's cpulist
+    n0 = root / "devices" / "system" / "node" / "node0"; n0.mkdir(parents=True); (n0 / "cpulist").write_text("0-3,8\n")
+    r = subprocess.run([BIN, "--gpu-locality", "0000:05:00.0"], capture_output=True, text=True, env=env)
+    assert r.stdout.strip() == "0 0-3,8"
+    r = subprocess.run([BIN, "--gpu-locality", "0000:ff:00.0"], capture_output=True, text=True, env=env)      # unknown device: no pinning, no failure
+    assert r.returncode == 0 and r.stdout.strip() == "-1"
+    (d / "local_cpulist").write_text("7-3\n")                                                   # malformed range -> ignored
+    r = subprocess.run([BIN, "--gpu-locality", "0000:c1:00.0"], capture_output=True, text=True, env=env)
+    assert r.stdout.strip() == "1"
+
+
+def test_deploy_prototxt_check(tmp_path):
+    """Classifier builds its Net from the deploy prototxt (Classifier.cpp:16); the library's topology is built in, so the file is checked: the VGG19 files pass
+    (V2 `layer` + V1 `layers` spelling, comments, trailing fc layers ignored), anything that is another network up to relu5_1 is refused with a reason."""
+    from caffemodel_io import write_deploy_prototxt
+    ok = tmp_path / "ok.prototxt"; write_deploy_prototxt(str(ok))
+    assert run("--check-prototxt", str(ok)).stdout.strip() == "ok"
+    write_deploy_prototxt(str(ok), v1=True)
+    assert run("--check-prototxt", str(ok)).stdout.strip() == "ok"
+    write_deploy_prototxt(str(ok), extra_tail=False)                       # a file that stops at relu5_1 is enough
+    assert run("--check-prototxt", str(ok)).stdout.strip() == "ok"
+    for kw, needle in ((dict(drop="conv3_3"), "unexpected ReLU 'relu3_3'"), (dict(num_output={"conv2_1": 96}), "conv2_1 is num_output 96"),
+                       (dict(drop="pool2"), "no 2x2 max pool after conv2_2"), (dict(drop="relu4_2"), "conv4_2 is not followed by a ReLU")):
+        bad = tmp_path / "bad.prototxt"; write_deploy_prototxt(str(bad), **kw)
+        r = run("--check-prototxt", str(bad))
+        assert r.returncode == 1 and needle in r.stdout, (kw, r.stdout)
+    (tmp_path / "junk.prototxt").write_text("layer { name: \"conv1_1\" type: \"Convolution\" ")      # unterminated message
+    r = run("--check-prototxt", str(tmp_path / "junk.prototxt"))
+    assert r.returncode == 1 and "not protobuf text format" in r.stdout
+    r = run("--check-prototxt", str(tmp_path / "absent.prototxt"))
+    assert r.returncode == 1 and "cannot open" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/demo/model/vgg19/VGG_ILSVRC_19_layers_deploy.prototxt"), reason="reference model dir not mounted")
+def test_deploy_prototxt_check_accepts_the_reference_file():
+    assert run("--check-prototxt", "/root/reference/demo/model/vgg19/VGG_ILSVRC_19_layers_deploy.prototxt").stdout.strip() == "ok"
+
+
 @pytest.mark.gpu
 def test_cli_batch_matches_library(tmp_path, ctx):
     from caffemodel_io import synthetic_vgg19, write_caffemodel
@@ -259,7 +307,8 @@ def test_cli_shrink_jpeg_resume_levels(tmp_path, ctx):
     exp = ctx.process_pair(ctx.resize_u8c3(dec, 1000, 636), small, prm)
     assert np.array_equal(got, exp)
     st = [json.loads(l) for l in (out / "status.jsonl").read_text().splitlines()]
-    assert [s["status"] for s in st] == ["done", "done"] and st[0]["output"].endswith("big_small_2.00.png")
+    assert [s["status"] for s in st] == ["done", "done"]            # (the I/O pool finishes pairs in any order: look pairs up by index)
+    assert {s["pair"]: os.path.basename(s["output"]) for s in st} == {0: "big_small_2.00.png", 1: "small_big_1.00.png"}
     mtime = os.path.getmtime(out / "big_small_2.00.png")
     os.remove(out / "small_big_1.00.png")
     r = run(*args, "-resume", "1")
@@ -341,3 +390,80 @@ def test_cli_vis_dumps(tmp_path, ctx, oracle):
     kn = load("a_b_2.00_knn_2.png"); ah, aw = lv["dims"][2][:2]
     yy, xx = np.meshgrid(np.minimum(np.arange(ah) // 4, lab0.shape[0] - 1), np.minimum(np.arange(aw) // 4, lab0.shape[1] - 1), indexing="ij")
     assert np.array_equal(kn, cl[yy, xx])
+
+
+@pytest.mark.gpu
+def test_cli_two_logical_gpus_io_pool_shared_weights(tmp_path, ctx):
+    """The 8-GPU host path on one GPU: `-gpus 2 -inflight 2` with NCT_DEVICE_OVERRIDE=0 (every logical GPU on device 0) — four worker contexts, ONE parse of
+    the caffemodel and ONE device copy of the weights shared by all of them, pairs decoded/encoded by the I/O pool (`-io 3`), the prototxt read and checked;
+    the files equal `-io 0` (workers doing their own I/O) and the library, whatever worker ran a pair. A prototxt describing another net is refused."""
+    from caffemodel_io import synthetic_vgg19, write_caffemodel, write_deploy_prototxt
+    ws, bs = synthetic_vgg19(19)
+    mdir = tmp_path / "model" / "vgg19"; mdir.mkdir(parents=True)
+    write_caffemodel(str(mdir / "VGG_ILSVRC_19_layers.caffemodel"), ws, bs)
+    write_deploy_prototxt(str(mdir / "VGG_ILSVRC_19_layers_deploy.prototxt"))
+    inp = tmp_path / "in"; inp.mkdir()
+    imgs, lines = {}, []
+    for i, (h, w) in enumerate([(64, 64), (72, 56), (48, 80), (96, 64), (64, 96), (80, 80), (56, 72)]):
+        imgs[i] = (synth.image(30 + i, h, w), synth.image(40 + i, w, h))
+        Image.fromarray(imgs[i][0][..., ::-1].copy()).save(inp / f"s{i}.png"); Image.fromarray(imgs[i][1][..., ::-1].copy()).save(inp / f"r{i}.png")
+        lines.append(f"s{i}.png r{i}.png 2.0\n")
+    (inp / "pairs.txt").write_text("".join(lines))
+    env = dict(os.environ, NCT_DEVICE_OVERRIDE="0")
+    outs = {}
+    for io in ("3", "0"):
+        out = tmp_path / f"out_io{io}"
+        r = subprocess.run([BIN, "-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(out), "-gpus", "2", "-inflight", "2", "-io", io], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "VGG19 weights: parsed once, 1 device copy of" in r.stdout and "shared by 4 context(s)" in r.stdout
+        assert f"on 2 GPU(s), 2 in flight each, {io} I/O thread(s)" in r.stdout and "not found" not in r.stdout
+        assert r.stdout.count("Final output file:") == 7 and not [n for n in os.listdir(out) if n.endswith(".tmp")]
+        outs[io] = {n: np.asarray(Image.open(out / n).convert("RGB"))[..., ::-1] for n in sorted(os.listdir(out)) if n.endswith(".png")}
+    assert list(outs["3"]) == list(outs["0"]) and len(outs["3"]) == 7
+    ctx.vgg19_load_raw(ws, bs)
+    for i in range(7):
+        n = f"s{i}_r{i}_2.00.png"
+        assert np.array_equal(outs["3"][n], outs["0"][n]), n
+        if i < 3:
+            assert np.array_equal(outs["3"][n], ctx.process_pair(*imgs[i])), n
+    # -resume: a truncated output (killed run) is redone, a complete one skipped
+    out = tmp_path / "out_io3"
+    full = (out / "s0_r0_2.00.png").read_bytes()
+    (out / "s1_r1_2.00.png").write_bytes(full[: len(full) // 2])
+    r = subprocess.run([BIN, "-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(out), "-resume", "1"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.count("Skipping (-resume)") == 6 and r.stdout.count("Final output file:") == 1
+    assert np.array_equal(np.asarray(Image.open(out / "s1_r1_2.00.png").convert("RGB"))[..., ::-1], outs["0"]["s1_r1_2.00.png"])
+    write_deploy_prototxt(str(mdir / "VGG_ILSVRC_19_layers_deploy.prototxt"), num_output={"conv4_1": 256})
+    r = subprocess.run([BIN, "-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(tmp_path / "o2")], capture_output=True, text=True, env=env)
+    assert r.returncode == 255 and "conv4_1 is num_output 256" in r.stdout
+
+
+@pytest.mark.gpu
+def test_contexts_share_one_weight_copy(ctx, tmp_path):
+    """nct_model_parse_caffemodel + nct_vgg19_load_model + nct_vgg19_share_weights: N contexts on one GPU hold ONE device copy (same address, sharers = N), a
+    sharing context computes the same features, reloading into a sharer detaches it, and the copy outlives the context that uploaded it."""
+    from caffemodel_io import synthetic_vgg19, write_caffemodel
+    ws, bs = synthetic_vgg19(19)
+    path = str(tmp_path / "m.caffemodel"); write_caffemodel(path, ws, bs, fmt="v1")
+    model = nct.Model(path)
+    a = nct.Context(0); a.vgg19_load_model(model); model.close()
+    others = [nct.Context(0) for _ in range(3)]
+    for o in others:
+        o.vgg19_share_weights(a)
+    ia = a.vgg19_weights_info()
+    assert ia["sharers"] == 4 and 45e6 < ia["bytes"] < 60e6
+    assert all(o.vgg19_weights_info()["id"] == ia["id"] for o in others)
+    img = synth.image(9, 40, 48)
+    fa = a.vgg19_features(img, 5)
+    a.close()                                                       # the uploader goes away: the copy stays with its remaining users
+    assert others[0].vgg19_weights_info()["sharers"] == 3
+    fo = others[0].vgg19_features(img, 5)
+    assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(fa, fo))
+    others[1].vgg19_load_raw(ws, bs)                                # a reload never writes into a shared copy
+    assert others[1].vgg19_weights_info()["id"] != ia["id"] and others[0].vgg19_weights_info()["sharers"] == 2
+    with pytest.raises(nct.NctError):
+        nct.Context(0).vgg19_share_weights(nct.Context(0))          # nothing loaded in the source
+    with pytest.raises(nct.NctError):
+        nct.Model(str(tmp_path / "absent.caffemodel"))
+    for o in others:
+        o.close()
