@@ -78,7 +78,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="[test hook] torch.distributed backend (gloo exercises the N>1 path on a 1-GPU box)")
     ap.add_argument("--device-override", type=int, default=-1, help="[test hook] run every rank on this device instead of LOCAL_RANK")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle on the full 700x700 pair (minutes)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="time the oracle on the full SxS pair even on a small host (the default from 32 host threads on: ~2 min)")
+    ap.add_argument("--cpu-baseline-sample", action="store_true", help="time the oracle on the bounded 350x350 sample only (seconds) and scale by pixel count")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 PMC passes (traffic falls back to profiles/)")
     ap.add_argument("--no-latency-flag", action="store_true", help="skip the two extra single-pair runs with NCT_FLAG_LATENCY (kernel-trace runs: keeps the launch count per pair comparable)")
@@ -280,10 +281,12 @@ def main():
         "build_id": lib_build_id(),
     }
     res["vgg_mfma"] = vgg_mfma(src.shape[0], src.shape[1], ref.shape[0], ref.shape[1], prm.levels, stages["vgg_ms"])
+    if rank == 0 and not args.no_roofline and not args.no_pmc and world == 1 and wl == "pair700" and S == 700:
+        res["vgg_mfma"].update(vgg_mfma_util(local_rank))
     if rank == 0 and not args.no_roofline and prm.levels == 5:
         res["roofline"] = patchmatch_roofline(nct, ctx, prm, src.shape, ref.shape, local_rank, live_pmc=not args.no_pmc and wl == "pair700" and S == 700 and world == 1)
     if rank == 0 and not args.no_cpu_baseline and world == 1:               # the CPU port is timed on rank 0 of the 1-GPU run only
-        res["cpu_baseline"] = cpu_baseline(synth, ws, bs, src.shape[0], full=args.cpu_baseline_full)
+        res["cpu_baseline"] = cpu_baseline(synth, ws, bs, src.shape[0], full=(args.cpu_baseline_full or (os.cpu_count() or 1) >= 32) and not args.cpu_baseline_sample)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
@@ -374,6 +377,7 @@ def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
         pmc, how = pmc_traffic(device, live_pmc)
         if pmc is not None:
             traffic = pmc["corrected_bytes_per_launch"]["total"]
+    footprint = nq * C * 4 + nq * 16
     achieved = (traffic if traffic is not None else alg / n_launch) / launch_s / 1e9
     return {"bound": "hbm", "kernel": f"k_pm_step<1, 1, 2, 2, 8> (C=64, 8x8 queries per workgroup, 8 lanes per query, {sshape[1]}x{sshape[0]} <-> {rshape[1]}x{rshape[0]}, both directions per launch, pipeline features)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -382,9 +386,12 @@ def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
             "traffic_source": how, "pmc": pmc, "launches": n_launch, "avg_launch_ms": 1e3 * launch_s, "evals": evals,
             "algorithmic_bytes_per_launch": alg / n_launch, "algorithmic_GBs": alg_gbs,
             "traffic_over_algorithmic": None if traffic is None else traffic / (alg / n_launch),
+            # what the launch must touch at least once: both feature maps (read as query regions and as candidate tiles) + both NNF / distance fields in and out
+            "footprint_bytes": footprint, "restream_factor": None if traffic is None else traffic / footprint,
             "l1_frac": None if not (pmc and pmc.get("l1")) else pmc["l1"]["frac_of_l1_return_bandwidth"],
-            "note": "frac is the DRAM-side demand; the kernel itself is latency bound close to what the 256 L1s can return (l1_frac, 64 B/clk/CU): "
-                    "overlapping candidate tiles are served by L1/L2, so the no-reuse byte model (algorithmic_GBs) exceeds the HBM peak; DESIGN.md 3.2"}
+            "note": "traffic = L2-miss (fabric-side) bytes: FETCH_SIZE counts Infinity-Cache (MALL) hits as well, and the level's 251 MB footprint fits the 256 MiB MALL, so the "
+                    "true HBM demand is <= frac; restream_factor = traffic / footprint. Overlapping candidate tiles are served by L1/L2, so the no-reuse byte model "
+                    "(algorithmic_GBs) exceeds the HBM peak; DESIGN.md 3.2"}
 
 
 def vgg_mfma(sh, sw, rh, rw, levels, vgg_ms):
@@ -408,6 +415,34 @@ def vgg_mfma(sh, sw, rh, rw, levels, vgg_ms):
     tf = per_pair / (vgg_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "k_conv3x3_mfma (v_mfma_f32_32x32x2_f32), all forwards of a pair", "flops_per_pair": per_pair,
             "stage_ms": vgg_ms, "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
+
+
+def vgg_mfma_util(device):
+    """SQ_VALU_MFMA_BUSY_CYCLES of the conv kernel as shipped: two counter-only rocprofv3 passes over scripts/vgg_only.py (three 700x700 forwards to conv5_1);
+    utilisation = MFMA-busy cycles / (launch cycles x 1024 SIMDs), launch cycles = GRBM_GUI_ACTIVE / 8 XCDs, summed over all conv launches (FLOP-weighted by
+    construction) and for the conv4_x launches alone (the 244-workgroup layers, one round on 256 CUs)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {"mfma_util": None, "mfma_util_source": "rocprofv3 not on PATH"}
+    try:
+        import csv, glob
+        tot = {}
+        for ctrs in (("SQ_VALU_MFMA_BUSY_CYCLES",), ("GRBM_GUI_ACTIVE",)):
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                env = dict(os.environ, TMPDIR="/tmp", HIP_VISIBLE_DEVICES=str(device))
+                subprocess.run([exe, "--pmc", *ctrs, "--kernel-trace", "-d", td, "-o", "c", "--output-format", "csv", "--", sys.executable, os.path.join(REPO, "scripts", "vgg_only.py")],
+                               cwd=REPO, env=env, check=True, capture_output=True, timeout=300)
+                f = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+                for r in csv.DictReader(open(f[0])):
+                    if r["Kernel_Name"].startswith("void k_conv3x3_mfma") and r["Counter_Name"] == ctrs[0]:
+                        key = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))
+                        tot.setdefault(key, {}).setdefault(ctrs[0], []).append(float(r["Counter_Value"]))
+        busy = sum(sum(v["SQ_VALU_MFMA_BUSY_CYCLES"]) for v in tot.values())
+        cyc = sum(sum(v["GRBM_GUI_ACTIVE"]) for v in tot.values()) / 8.0
+        per = {f"{k[0].replace('void ', '')} grid {k[1]}": round(sum(v["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(v["GRBM_GUI_ACTIVE"]) / 8.0 * 1024), 4) for k, v in sorted(tot.items())}
+        return {"mfma_util": busy / (cyc * 1024), "mfma_util_per_layer_group": per, "mfma_util_source": "live rocprofv3 passes inside bench.py (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"}
+    except Exception as e:      # noqa: BLE001
+        return {"mfma_util": None, "mfma_util_source": f"PMC pass failed: {type(e).__name__}: {str(e)[:120]}"}
 
 
 def cpu_baseline(synth, ws, bs, S, full=False):
@@ -437,9 +472,13 @@ def cpu_baseline(synth, ws, bs, S, full=False):
                      f"{S}x{S} by pixel count ({1 / scale:.2f}x; full-size check: profiles/README.md); one {n1}x{n1} pair on 1 thread: {dt1:.2f} s",
            "value_1thread": scale1 / dt1, "sample_seconds": dt, "sample_seconds_1thread": dt1}
     if full:
+        # the real SxS pair, once: the reported value (the scaled sample stays beside it as a cross-check of the scaling law)
         dtf = run(S, threads)
+        res["value_scaled_sample"] = res["value"]
+        res["value"] = 1.0 / dtf
         res["full_pair_seconds"] = dtf
-        res["value_full_pair"] = 1.0 / dtf
+        res["sample"] = (f"oracle orc_process_pair on the full {S}x{S} bench pair (L=5->1, same synthetic VGG19): {dtf:.1f} s on {threads} OpenMP threads; cross-checks: one {n}x{n} pair "
+                         f"{dt:.2f} s (scaled by pixel count: {1 / res['value_scaled_sample']:.1f} s), one {n1}x{n1} pair on 1 thread {dt1:.2f} s")
     return res
 
 

@@ -11,8 +11,8 @@
  *  - a context is bound to ONE GPU and is NOT thread-safe; use one context per worker thread / process.
  *    The context owns every device allocation (cached arena, reused across calls and pairs).
  *  - "host" entry points take host pointers and are synchronous. Feature tensors are CHW fp32 exactly like the
- *    reference kernels' arguments (`float* a1`, Caffe blob layout). `*_dev` variants (nct_dev.h section below)
- *    work on device pointers in the library's internal channel-last (HWC) layout.
+ *    reference kernels' arguments (`float* a1`, Caffe blob layout). The `*_dev` variants (section "device-pointer seams"
+ *    below) work on device pointers in the library's internal channel-last (HWC) layout and do not synchronise.
  *  - NNF element = uint32 `(y << 12) | x` (GeneralizedPatchMatch.cu:24-34), row-major (ah x aw).
  *  - there is NO CPU fallback: without a usable HIP device nct_create fails with NCT_ERR_NO_DEVICE.
  */
@@ -221,6 +221,32 @@ int nct_pair_upload(nct_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, const 
 int nct_pair_run(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing);
 int nct_pair_run_levels(nct_ctx* ctx, const nct_params* prm, nct_pair_timing* timing, const nct_pair_levels* levels);   /* + host copies of the intermediates */
 int nct_pair_download(nct_ctx* ctx, uint8_t* out_bgr);
+
+/* ---- device-pointer seams: the same operations on buffers that stay in HBM between calls (main.cu:204-316 keeps Ndata_C1, ann_device, ... on the device
+ * across these kernels; an integrator replacing single seams should not pay H2D + D2H + a synchronise per call). Buffers come from the context's arena
+ * (nct_dev_alloc / nct_dev_free; any device pointer of the context's GPU works). Calls are enqueued on the context's stream in call order and return
+ * immediately; nct_dev_download and nct_synchronize wait. Features: channel-last HWC fp32 (nct_chw_to_hwc_dev converts a Caffe blob once); `unit_norm` = 1
+ * tells nct_patchmatch_bidir_dev that both maps hold unit vectors (output of nct_feat_normalize_dev), which enables the exact row-wise rejection.
+ * Chained like the reference's level loop they reproduce nct_pair_run_levels bit for bit (tests/test_gpu_pipeline.py::test_dev_seams_chain_equals_pipeline). */
+int nct_dev_alloc(nct_ctx* ctx, size_t bytes, void** out);
+int nct_dev_free(nct_ctx* ctx, void* p);
+int nct_dev_upload(nct_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int nct_dev_download(nct_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int nct_chw_to_hwc_dev(nct_ctx* ctx, const float* src_chw, float* dst_hwc, int C, int H, int W);
+int nct_hwc_to_chw_dev(nct_ctx* ctx, const float* src_hwc, float* dst_chw, int C, int H, int W);
+int nct_vgg19_features_dev(nct_ctx* ctx, const uint8_t* d_bgr, int h, int w, int stride, int deepest_tap, float* const* d_taps_chw, int* dims);   /* main.cu:94,102,426 */
+int nct_feat_normalize_dev(nct_ctx* ctx, const float* src_hwc, float* dst_hwc, float* resp, int C, int H, int W);                                    /* main.cu:265,274,313 */
+int nct_nnf_init_dev(nct_ctx* ctx, uint32_t* nnf, int ah, int aw, int bh, int bw);                                                                    /* main.cu:232-233 */
+int nct_nnf_upsample_dev(nct_ctx* ctx, const uint32_t* nnf_half, uint32_t* nnf, int ah, int aw, int bh, int bw, int ah_half, int aw_half);           /* main.cu:240-250 */
+int nct_patchmatch_dev(nct_ctx* ctx, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw, int patch, int iters, int rs_max,
+                       uint32_t seed, uint32_t* nnf, float* dist);                                                                                     /* main.cu:283 */
+int nct_patchmatch_bidir_dev(nct_ctx* ctx, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw, int patch, int iters, int rs_max,
+                             uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, int unit_norm);              /* main.cu:283-284 */
+int nct_bds_vote_features_dev(nct_ctx* ctx, const uint32_t* ann, const uint32_t* bnn, const float* pin_hwc, float* pout_hwc, float* pw, int C, int ah, int aw,
+                              int bh, int bw, int patch, float w_coherence, float w_complete);                                                         /* main.cu:303-311 */
+int nct_bds_vote_image_dev(nct_ctx* ctx, const uint8_t* b_bgr, const uint32_t* ann, const uint32_t* bnn, int ah, int aw, int bh, int bw, int patch,
+                           double w_coherence, double w_complete, uint8_t* out_bgr);                                                                   /* main.cu:291 */
+int nct_feature_distance_dev(nct_ctx* ctx, const float* a_hwc, const float* b_hwc, float* err, int C, int H, int W);                                  /* main.cu:316 */
 
 /* ---- measurement hooks (bench.py / rocprof): device-resident PatchMatch on synthetic features ----
  * nct_pm_bench_setup uploads + normalises two CHW feature maps once; nct_pm_bench_run re-initialises the NNF

@@ -84,6 +84,21 @@ SIGNATURES = {
     "nct_pair_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nct_pair_run_levels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nct_pair_download": (C.c_int, [C.c_void_p, _u8p]),
+    "nct_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "nct_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nct_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "nct_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "nct_chw_to_hwc_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "nct_hwc_to_chw_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "nct_vgg19_features_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    "nct_feat_normalize_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "nct_nnf_init_dev": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4),
+    "nct_nnf_upsample_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6),
+    "nct_patchmatch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_uint32, C.c_void_p, C.c_void_p]),
+    "nct_patchmatch_bidir_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "nct_bds_vote_features_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_float]),
+    "nct_bds_vote_image_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_double, C.c_double, C.c_void_p]),
+    "nct_feature_distance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "nct_pm_bench_setup": (C.c_int, [C.c_void_p, _f32p, _f32p] + [C.c_int] * 5),
     "nct_pm_bench_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
     "nct_pm_bench_run_bidir": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -142,6 +157,7 @@ class Model:
     """host-side parsed caffemodel (nct_model): parse the file once per process, upload it once per GPU (Context.vgg19_load_model)."""
 
     def __init__(self, path):
+        self._m = None
         m = C.c_void_p()
         rc = lib().nct_model_parse_caffemodel(os.fsencode(path), C.byref(m))
         if rc != 0:
@@ -286,6 +302,30 @@ class Context:
 
     def vgg19_load_caffemodel(self, path):
         self._chk(self._l.nct_vgg19_load_caffemodel(self._h, os.fsencode(path)))
+
+    # ---- device-pointer seams (nct_dev.cpp): buffers are plain integers (device addresses); nothing synchronises until dev_download / synchronize
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self._l.nct_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, p):
+        self._chk(self._l.nct_dev_free(self._h, p))
+
+    def dev_upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        p = self.dev_alloc(a.nbytes)
+        self._chk(self._l.nct_dev_upload(self._h, p, a.ctypes.data, a.nbytes))
+        return p
+
+    def dev_download(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        self._chk(self._l.nct_dev_download(self._h, out.ctypes.data, p, out.nbytes))
+        return out
+
+    def dev_call(self, name, *args):
+        """nct_<name>_dev(ctx, *args)"""
+        self._chk(getattr(self._l, "nct_" + name + "_dev")(self._h, *args))
 
     def vgg19_load_model(self, model):
         """model: a Model (nct_model_parse_caffemodel) — upload the host copy to this context's GPU"""
