@@ -40,3 +40,32 @@ def test_demo_batch_against_reference_results(tmp_path):
                         "--json", str(tmp_path / "report.json"), "--min-ssim", "0.5"], capture_output=True, text=True)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_demo_dry_run_on_the_demo_geometry(tmp_path):
+    """SURVEY §8(f)-2 readiness: the whole harness on a generated stand-in of the reference's demo batch — the demo's image sizes and PNG colour types (five RGBA
+    inputs: alpha must be dropped like cv::imread does), `in/` sub-directory, the 9-line pairs.txt with the BDS sweep 0/1/2/4/8, `<src>_<ref>_<bds>.png` naming —
+    with synthetic weights; the CLI's files must equal the library's results (L-inf 0). The real-weights run stays gated on $NCT_MODEL_DIR."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "demo_validate.py"), "--weights", "synthetic", "--scale", "0.5", "--out", str(tmp_path / "out"),
+                        "--json", str(tmp_path / "report.json")], capture_output=True, text=True)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    import json
+    rep = json.load(open(tmp_path / "report.json"))
+    assert len(rep) == 9 and all(x["linf"] == 0 for x in rep)
+    assert sorted(x["name"] for x in rep)[:2] == ["in0_tar0_2.00.png", "in1_tar1_2.00.png"] and "in4_tar4_8.00.png" in [x["name"] for x in rep]
+
+
+def test_demo_geometry_matches_the_reference_demo():
+    """the stand-in's sizes / colour types are the demo's (checked where the reference is mounted)"""
+    import demo_validate as dv
+    d = "/root/reference/demo/example/in"
+    if not os.path.isdir(d):
+        pytest.skip("reference demo not mounted")
+    from PIL import Image
+    for name, (w, h, mode) in dv.DEMO_GEOMETRY.items():
+        im = Image.open(os.path.join(d, name + ".png"))
+        assert im.size == (w, h) and im.mode == mode, name
+    lines = [l.split() for l in open("/root/reference/demo/example/pairs.txt") if l.strip()]
+    assert [("in/%s.png" % a, "in/%s.png" % b, c) for a, b, c in dv.DEMO_PAIRS] == [(l[0], l[1], float(l[2])) for l in lines]
