@@ -76,13 +76,20 @@ def test_bench_two_ranks_draw_tickets_from_the_store():
     assert abs(d["value"] - 6 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
 
 
+def _golden_sum_700():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pair700_oracle.json")))["700"]["sum"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("wl", ["batch64", "mixed256", "pair256l5"])
 def test_bench_other_workloads(wl):
     """BASELINE configs 3 / 5 / 1 as bench workloads, at reduced batch sizes: strong-scaling lines with host-in -> host-out steps."""
     extra = ["--batch", "6"] if wl != "pair256l5" else []
     if wl == "batch64":
-        extra += ["--size", "96"]
+        extra = ["--batch", "2"]            # config 3's batch path carrying REAL 700x700 pairs (two of the 64), not a shrunken stand-in
     d = _run("--workload", wl, "--steps", "1", "--warmup", "0", "--inflight", "2", "--no-cpu-baseline", "--no-roofline", *extra, timeout=1200)
     assert d["config"]["name"] == wl and d["value"] > 0
     assert d["scaling"] == ("weak" if wl == "pair256l5" else "strong")
+    if wl == "batch64":
+        assert "700x700" in d["config"]["workload"] and d["config"]["pairs_per_gpu_per_step"] == 2 and d["output_checksum"] == _golden_sum_700()

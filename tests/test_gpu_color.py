@@ -15,11 +15,16 @@ def test_lab_conversions_exact(ctx, oracle):
     assert np.array_equal(lab, oracle.bgr2lab(x))
     allc = np.stack(np.meshgrid(np.arange(0, 256, 5), np.arange(0, 256, 5), np.arange(0, 256, 5), indexing="ij"), -1).reshape(-1, 3).astype(np.uint8)
     assert np.array_equal(ctx.bgr2lab(allc), oracle.bgr2lab(allc))
-    back_g, back_o = ctx.lab2bgr(lab), oracle.lab2bgr(lab)
-    # float path (spline inverse gamma): identical formula; allow <=1 LSB on a vanishing fraction from fma/rounding differences
-    d = np.abs(back_g.astype(int) - back_o.astype(int))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3
-    assert np.array_equal(ctx.lab2bgr(allc), oracle.lab2bgr(allc)) or np.abs(ctx.lab2bgr(allc).astype(int) - oracle.lab2bgr(allc).astype(int)).max() <= 1
+    # Lab -> BGR, both forms of Lab2RGB_f: the float path is the same sequence of IEEE operations on both sides (-ffp-contract=off, the
+    # spline table built by the same code), so the bytes are identical — on random Lab triples, on a 5-step lattice and on EVERY triple of the dark / saturated
+    # corner where the two forms part (L_u8 <= 24, all a, all b)
+    import nct
+    dark = np.stack(np.meshgrid(np.arange(0, 25), np.arange(256), np.arange(256), indexing="ij"), -1).reshape(-1, 3).astype(np.uint8)
+    for form in (nct.LAB2BGR_PIECEWISE, nct.LAB2BGR_CUBE):
+        for t in (lab, allc, dark):
+            assert np.array_equal(ctx.lab2bgr(t, form=form), oracle.lab2bgr(t, form=form)), form
+    assert np.array_equal(ctx.lab2bgr(lab), oracle.lab2bgr(lab, form=0))                      # the default is the piecewise form
+    assert not np.array_equal(ctx.lab2bgr(dark, form=0), ctx.lab2bgr(dark, form=1))
 
 
 @pytest.mark.parametrize("dims", [(700, 700, 350, 350), (175, 175, 88, 88), (113, 170, 57, 85), (60, 47, 31, 23), (30, 40, 30, 40), (452, 680, 226, 340)])
