@@ -313,7 +313,8 @@ def pmc_traffic(device, live):
                                    cwd=REPO, env=env, check=True, capture_output=True, timeout=300)
                     for ctr in ctrs:
                         vals[ctr] = read_pmc_csv(td, ctr)
-            return finish_pmc(vals, bid, "live rocprofv3 passes inside bench.py"), "live"
+            out = finish_pmc(vals, bid, "live rocprofv3 passes inside bench.py")
+            return out, "live"
         except Exception as e:      # noqa: BLE001 — fall back to the recorded passes
             why = f"live PMC failed: {type(e).__name__}: {str(e)[:120]}"
     elif live:
@@ -330,9 +331,11 @@ def read_pmc_csv(td, ctr):
     import csv, glob
     f = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
     rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == ctr]
-    v = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"].startswith("void k_pm_step<1, 1,")]
+    pm = sorted((r for r in rows if r["Kernel_Name"].startswith("void k_pm_step<1, 1,")), key=lambda r: int(r["Dispatch_Id"]))
+    v = [float(r["Counter_Value"]) for r in pm]
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in pm]          # us, this pass's own kernel trace
     norm = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"].startswith("k_normalize(")]
-    return {"dispatches": len(v), "mean": sum(v) / len(v), "normalize_max": max(norm) if norm else None}
+    return {"dispatches": len(v), "mean": sum(v) / len(v), "normalize_max": max(norm) if norm else None, "per_dispatch": v, "per_dispatch_us": dur}
 
 
 def finish_pmc(vals, bid, how):
@@ -350,7 +353,20 @@ def finish_pmc(vals, bid, how):
         cyc = vals["GRBM_GUI_ACTIVE"]["mean"] / 8.0
         l1 = {"vmem_read_instructions_per_launch": vals["SQ_INSTS_VMEM_RD"]["mean"], "bytes_per_launch_upper_bound": vals["SQ_INSTS_VMEM_RD"]["mean"] * 1024.0,
               "launch_cycles": cyc, "frac_of_l1_return_bandwidth": vals["SQ_INSTS_VMEM_RD"]["mean"] * 1024.0 / (cyc * 256 * 64)}
-    return {"build_id": bid, "how": how, "kernel": "k_pm_step<1, 1, 2, 2, 8>", "dispatches": vals["FETCH_SIZE"]["dispatches"],
+    # The 41 launches of a level are not alike: step 0 evaluates the initial field, steps with jump 8 / 4 / 2 only propagate (mostly L1/L2 hits: neighbouring
+    # queries propose overlapping tiles), every fourth step (jump 1) adds the random search, whose candidates lie up to +-32 px away and miss L2 — those launches
+    # are the bandwidth-bound ones. Per class: fabric-side bytes (FETCH_SIZE x 2; writes are < 1 %) over the launch durations of the same counter pass.
+    by_step = None
+    fs = vals["FETCH_SIZE"]
+    if fs.get("per_dispatch") and len(fs["per_dispatch"]) % 41 == 0:
+        cls = {"init": [], "propagation": [], "random_search": []}
+        for i, (kb, us) in enumerate(zip(fs["per_dispatch"], fs["per_dispatch_us"])):
+            k = i % 41
+            cls["init" if k == 0 else ("random_search" if k % 4 == 0 else "propagation")].append((kb * 2048.0, us))
+        by_step = {name: {"launches_per_level": len(v) // (len(fs["per_dispatch"]) // 41), "avg_launch_us": sum(u for _, u in v) / len(v), "fabric_bytes_per_launch": sum(b for b, _ in v) / len(v),
+                          "fabric_GBs": sum(b for b, _ in v) / sum(u for _, u in v) / 1e3, "frac_of_hbm_peak": sum(b for b, _ in v) / sum(u for _, u in v) / 1e3 / HBM_PEAK_GBS}
+                   for name, v in cls.items() if v}
+    return {"build_id": bid, "how": how, "kernel": "k_pm_step<1, 1, 2, 2, 8>", "dispatches": vals["FETCH_SIZE"]["dispatches"], "by_step": by_step,
             "FETCH_SIZE_KB_per_dispatch_raw": vals["FETCH_SIZE"]["mean"], "WRITE_SIZE_KB_per_dispatch_raw": vals["WRITE_SIZE"]["mean"],
             "calibration": cal, "corrected_bytes_per_launch": {"fetch": fetch, "write": write, "total": fetch + write}, "l1": l1}
 
@@ -389,6 +405,8 @@ def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
             # what the launch must touch at least once: both feature maps (read as query regions and as candidate tiles) + both NNF / distance fields in and out
             "footprint_bytes": footprint, "restream_factor": None if traffic is None else traffic / footprint,
             "l1_frac": None if not (pmc and pmc.get("l1")) else pmc["l1"]["frac_of_l1_return_bandwidth"],
+            # frac averages 41 unlike launches; the random-search launches (every fourth: jump 1) are the bandwidth-bound ones
+            "frac_random_search_launches": None if not (pmc and pmc.get("by_step")) else pmc["by_step"]["random_search"]["frac_of_hbm_peak"],
             "note": "traffic = L2-miss (fabric-side) bytes: FETCH_SIZE counts Infinity-Cache (MALL) hits as well, and the level's 251 MB footprint fits the 256 MiB MALL, so the "
                     "true HBM demand is <= frac; restream_factor = traffic / footprint. Overlapping candidate tiles are served by L1/L2, so the no-reuse byte model "
                     "(algorithmic_GBs) exceeds the HBM peak; DESIGN.md 3.2"}
