@@ -39,8 +39,8 @@ int nctk_hwc_to_chw(nct_ctx* ctx, hipStream_t s, const float* src, float* dst, i
 // ---------------------------------------------------------------- N1 normalise
 // Summation order (must match oracle/orc_nnf.c): lane v of the 16-lane row owns float4 chunks v, v+16, …;
 // one fmaf chain per lane; 16-lane butterfly.
-// dst_h (nullable): the same values rounded to fp16 (round-to-nearest-even), HWC — the shadow map the PatchMatch prefilter reads
-// (k_patchmatch.hip); |x - fp16(x)| <= 2^-11 |x| for |x| >= 2^-14 and <= 2^-25 below, which is what its rejection bound relies on.
+// dst_h (nullable): the same values rounded to fp16 (round-to-nearest-even), HWC — the candidate tiles of the opt-in reduced-precision mode
+// (NCT_FLAG_FEAT16, k_patchmatch.hip NCT_PM_FP16: fp32 accumulate, results differ from the fp32 path; there is no fp16 prefilter in the product).
 __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dis_out,
                                                    int C, int HW, uint2* __restrict__ dst_h) {
     int pix = blockIdx.x * 16 + (threadIdx.x >> 4);

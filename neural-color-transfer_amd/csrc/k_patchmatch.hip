@@ -475,10 +475,12 @@ template <int NCH, int MODE>
 static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, int tstep, int strip, unsigned long long* counter) {
     constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY, LPQ = PMLanes<NCH>::LPQ;
     const size_t lds = NCH >= 1 ? (size_t)(4 * TQX + 2) * (4 * TQY + 2) * NCH * 16 * sizeof(float4) : 0;      // region pixels x C/4 float4
-    // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device; set with the init step
-    // of every run (mode 0), i.e. once per PatchMatch and per device the context lives on
-    if (lds > 32768 && mode == 0)
+    // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device: set once per context (= per device) and instantiation
+    constexpr unsigned abit = 1u << ((NCH > 8 ? 9 : NCH) * 3 + MODE);
+    if (lds > 32768 && !(ctx->pm_attr_mask & abit)) {
         NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE, TQX, TQY, LPQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->pm_attr_mask |= abit;
+    }
     hipLaunchKernelGGL((k_pm_step<NCH, MODE, TQX, TQY, LPQ>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, tstep, strip, counter);
     NCT_LAUNCH_CHECK();
     return 0;

@@ -29,8 +29,9 @@ struct nct_ctx {
     void* vgg = nullptr;              // struct vgg_weights* (nct_vgg.cpp)
     void* cvt = nullptr;              // struct cvt_dev* (k_cvt.hip): colour-conversion LUTs on the device
     void* pair = nullptr;             // struct pair_state* (nct_pipeline.cpp): device-resident source/reference/result images
-    unsigned long long* d_counter = nullptr;   // device counters of the pm kernels (profiling passes): [0] evaluations, [1] exact fp32 re-evaluations
-                                                // behind the fp16 prefilter, [2] accepted candidates; 4 slots per pyramid level in pair runs
+    unsigned long long* d_counter = nullptr;   // device counters of the pm kernels (NCT_FLAG_COUNT_EVALS): [0] distance evaluations performed, [1] accepted candidates;
+                                                // 4 slots per pyramid level in pair runs (nct_pipeline.cpp reads [4 l] and [4 l + 1])
+    unsigned pm_attr_mask = 0;                 // k_pm_step instantiations whose dynamic-LDS opt-in has been set on this context's device
     // stage clock: events recorded on the main stream at stage boundaries, read once after the pair's final synchronise
     // (no host syncs in between: see nct_pair_timing in nct.h)
     int wls_split = 0;                          // NCT_FLAG_LATENCY of the running pair: a- and b-half of the WLS solve on two streams

@@ -138,7 +138,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     // the enqueueing of everything below — until the VGG forwards and k-means have finished
     MARK(ST_CLUSTER, 0);
 
-    // ---- K1 for all five levels on the side stream: the kNN graph of a level depends only on the level image of S and on the
+    // ---- K1 for the levels that run (nct_params.levels) on the side stream: the kNN graph of a level depends only on the level image of S and on the
     // labels (main.cu:351-359), not on the correspondence, so it overlaps with PatchMatch / votes / solvers of the main stream
     // (whose many small launches leave most CUs idle). Scratch released meanwhile stays reserved until the join (nct_internal.h).
     std::vector<DevBuf<uint8_t>*> slab(5, nullptr);
@@ -258,7 +258,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
             MARK(ST_VGG, l);
         }
     }
-    // the side stream holds the kNN graphs of all five levels; levels that did not run still have to finish before their buffers go back
+    // the side stream's kNN graphs (one per level that ran) finish before their buffers go back (Cleanup3 synchronises stream2)
     NCT_HIP(hipStreamSynchronize(s));
     if (timing) {
         timing->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
