@@ -126,8 +126,12 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "VGG_ILSVRC_19_layers.caffemodel")
         write_caffemodel(path, ws, bs, fmt="v1")
-        for c in ctxs:
-            c.vgg19_load_caffemodel(path)
+        # parsed once per process, uploaded once per GPU; the other contexts in flight on this GPU share the read-only device copy (as the CLI does)
+        model = nct.Model(path)
+        ctxs[0].vgg19_load_model(model)
+        model.close()
+        for c in ctxs[1:]:
+            c.vgg19_share_weights(ctxs[0])
 
     prm = nct.Params.default()
     wl = args.workload
