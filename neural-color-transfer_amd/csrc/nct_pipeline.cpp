@@ -208,7 +208,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
 #ifndef NCT_PIPE_PM_EXACT_MODE
 #define NCT_PIPE_PM_EXACT_MODE NCT_PM_ROWREJECT
 #endif
-        const int pm_mode = (feat16 && C >= 128) ? NCT_PM_FP16 : NCT_PIPE_PM_EXACT_MODE;
+        const int pm_mode = (feat16 && C >= 256) ? NCT_PM_FP16 : NCT_PIPE_PM_EXACT_MODE;
         rc = nctk_patchmatch_bidir(ctx, s, na, nb, (const uint16_t*)na_h, (const uint16_t*)nb_h, C, ah[l], aw[l], bh[l], bw[l], prm->pm_iters, rs_range[l], seed_ab, seed_ba,
                                    ann, annd, bnn, bnnd, pm_mode, count ? ctx->d_counter + 4 * l : nullptr); if (rc) return rc;
         MARK(ST_PM, l);
