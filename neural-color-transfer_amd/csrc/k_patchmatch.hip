@@ -29,10 +29,19 @@
 #include <climits>
 #include <hip/hip_fp16.h>
 
-// workgroups per CU (= waves per SIMD) the C = 64 kernels are compiled for: the level is latency bound (a wave walks its candidates one after
-// the other), five waves per SIMD hide more of it than four: 16.0 vs 17.4 ms per pair; six (80 registers, spills) 19.1 ms; C = 128 at five: 10.4 vs 8.5 ms
+// workgroups per CU (= waves per SIMD) the C = 64 kernels are compiled for. Round 2: five (92 registers) beat four, 16.0 vs 17.4 ms per pair, six (80, spills) 19.1 ms.
+// Round 3: with two patch rows per round trip (pm_dist8 STAGE 1: 109 registers) four waves beat five-with-one-row: 13.0 vs 14.6 ms (five with spills: 15.3); C = 128 at five: 10.4 vs 8.5 ms
 #ifndef NCT_PM_OCC8
-#define NCT_PM_OCC8 5
+#define NCT_PM_OCC8 4
+#endif
+#ifndef NCT_PM_FAR_MAG
+#define NCT_PM_FAR_MAG 16       // random samples drawn with this radius or more are "far" (mostly rejected after their first row)
+#endif
+#ifndef NCT_PM_FAR_STAGE
+#define NCT_PM_FAR_STAGE 1
+#endif
+#ifndef NCT_PM_NEAR_STAGE
+#define NCT_PM_NEAR_STAGE 1
 #endif
 #ifndef NCT_PM_FAST_MAX
 #define NCT_PM_FAST_MAX 2
@@ -75,7 +84,12 @@ __global__ void k_pm_interleave64(const float4* __restrict__ src, float4* __rest
     dst[(size_t)px * 16 + l + 8] = make_float4(a.z, b.z, a.w, b.w);
 }
 // B, a_lds: interleaved layout; l = lane of the query's 8-lane group. Same contract as pm_dist below.
-template <int MODE, int RW>
+// STAGE: how the three patch rows of an interior candidate are fetched. The level is bound by the latency of DEPENDENT fetches (row -> partial sum -> test -> next row), so:
+//   0  one row at a time, rejection test after each of the first two (three round trips for a survivor);
+//   1  the first row alone (most far random samples stop here), then the other two TOGETHER (two round trips);
+//   2  the whole tile at once (one round trip): for candidates that are rarely rejected early — propagated matches and near random samples (radius < NCT_PM_FAR_MAG).
+// The fmaf chains run in the same order in every form, and an early return only ever replaces a value that could not win: same bits.
+template <int MODE, int RW, int STAGE = 0>
 __device__ __forceinline__ float pm_dist8(const float* __restrict__ B, const PMGeom& g, int ax, int ay, unsigned amask, int bx, int by, int l,
                                           const float4* __restrict__ a_lds, int lx, int ly, float need) {
     constexpr bool EX = MODE == NCT_PM_ROWREJECT;
@@ -85,16 +99,42 @@ __device__ __forceinline__ float pm_dist8(const float* __restrict__ B, const PMG
         const float4* pbc = reinterpret_cast<const float4*>(B) + (size_t)(unsigned)(by * g.bw + bx) * C4 + l;
         const float4* pac = a_lds + ((ly + 1) * RW + (lx + 1)) * C4 + l;
         pm_f2 acc = {0.f, 0.f};
+        if constexpr (STAGE == 0 || !EX) {
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {                 // one patch row at a time; with EX a hopeless candidate stops after a row
-            const float4* pbr = pbc + dy * g.bw * C4;
-            const float4* par = pac + dy * RW * C4;
+            for (int dy = -1; dy <= 1; ++dy) {                 // one patch row at a time; with EX a hopeless candidate stops after a row
+                const float4* pbr = pbc + dy * g.bw * C4;
+                const float4* par = pac + dy * RW * C4;
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) acc = pk_dot4_acc(par[dx * C4], par[dx * C4 + 8], pbr[dx * C4], pbr[dx * C4 + 8], acc);
-            if (EX && dy < 1 && need > -FLT_MAX) {
-                const float rem = dy < 0 ? 6.0007f : 3.0004f;
-                if (half8_sum(acc.x, acc.y) + rem < need) return FLT_MAX;
+                for (int dx = -1; dx <= 1; ++dx) acc = pk_dot4_acc(par[dx * C4], par[dx * C4 + 8], pbr[dx * C4], pbr[dx * C4 + 8], acc);
+                if (EX && dy < 1 && need > -FLT_MAX) {
+                    const float rem = dy < 0 ? 6.0007f : 3.0004f;
+                    if (half8_sum(acc.x, acc.y) + rem < need) return FLT_MAX;
+                }
             }
+        } else {
+            float4 t[3][3][2];                                 // [row][dx][half of the pixel record]
+            if constexpr (STAGE == 2) {
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) { t[dy + 1][dx + 1][0] = pbc[(dy * g.bw + dx) * C4]; t[dy + 1][dx + 1][1] = pbc[(dy * g.bw + dx) * C4 + 8]; }
+            } else {
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) { t[0][dx + 1][0] = pbc[(-g.bw + dx) * C4]; t[0][dx + 1][1] = pbc[(-g.bw + dx) * C4 + 8]; }
+            }
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) acc = pk_dot4_acc(pac[(-RW + dx) * C4], pac[(-RW + dx) * C4 + 8], t[0][dx + 1][0], t[0][dx + 1][1], acc);
+            if constexpr (STAGE == 1) {
+                if (need > -FLT_MAX && half8_sum(acc.x, acc.y) + 6.0007f < need) return FLT_MAX;
+#pragma unroll
+                for (int dy = 0; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) { t[dy + 1][dx + 1][0] = pbc[(dy * g.bw + dx) * C4]; t[dy + 1][dx + 1][1] = pbc[(dy * g.bw + dx) * C4 + 8]; }
+            }
+#pragma unroll
+            for (int dy = 0; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) acc = pk_dot4_acc(pac[(dy * RW + dx) * C4], pac[(dy * RW + dx) * C4 + 8], t[dy + 1][dx + 1][0], t[dy + 1][dx + 1][1], acc);
         }
         const float sfull = half8_sum(acc.x, acc.y);
         if (EX && need > -FLT_MAX && sfull + 1e-4f < need) return FLT_MAX;
@@ -199,8 +239,8 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
             const float4* pac = a_lds + ((ly + 1) * RW + (lx + 1)) * C4 + v;
             float facc = 0.f;
             if constexpr (EX) {
-                // one patch row at a time; a hopeless candidate stops after a row
-                // (margins: a tap of unit vectors adds <= 1 + 2e-6, fp32 accumulation error < 1e-4)
+                // one patch row at a time; a hopeless candidate stops after a row (margins: a tap of unit vectors adds <= 1 + 2e-6, fp32 accumulation
+                // error < 1e-4). Two rows per round trip as in pm_dist8 measured slower here: 6.56 vs 6.25 ms for the C = 128 level
 #pragma unroll
                 for (int dy = -1; dy <= 1; ++dy) {
                     const float4* pbr = pbc + dy * g.bw * C4;
@@ -412,7 +452,7 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
             int mag = rs_start;
             const int ncand = nprop + nrand;
             for (int k = 0; k < ncand; ++k) {
-                int xp, yp; bool valid; float rr;
+                int xp, yp; bool valid; float rr; bool far = false;
                 if (k < nprop) {
                     const uint32_t c = k == 0 ? cl0 : (k == 1 ? cl1 : (k == 2 ? cl2 : cl3));
                     xp = nnf_x(c); yp = nnf_y(c);
@@ -433,13 +473,18 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
                     const int rx = (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)wy);
                     xp = xmin + (rx == wx ? 0 : rx);
                     yp = ymin + (ry == wy ? 0 : ry);
+                    far = mag >= NCT_PM_FAR_MAG;
                     mag >>= 1;
                     valid = true; rr = FLT_MIN;
                 }
                 if (valid) {
                     // to win, -sum/9 (+rr) < dbest, i.e. sum > -9 dbest: unreachable sums are cut off (unit-norm features only)
                     float d;
-                    if constexpr (LPQ == 8) d = pm_dist8<MODE, RW>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                    if constexpr (LPQ == 8) {
+                        // (wave-uniform branch: the search radius is the same for every query of a step)
+                        if (far) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                        else d = pm_dist8<MODE, RW, NCT_PM_NEAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                    }
                     else d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
                     if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
                     if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; if (live && v == 0) ++naccept; }
