@@ -8,7 +8,7 @@
 //  * the hierarchy needs no Galerkin triple products: with 2x2 aggregates and piecewise-constant interpolation, P^T A P of a
 //    weighted 5-point graph Laplacian + diagonal is again one (coarse data term = sum of the 4 fine ones, coarse edge = sum of
 //    the fine edges crossing between the two aggregates);
-//  * smoother = two Chebyshev-weighted Jacobi sweeps (0.58, 2.64) — order independent, so the result is reproducible; one cycle is two tile-fused
+//  * smoother = MG_NS Chebyshev-weighted Jacobi sweeps per leg (round 3: three — 0.53, 0.97, 5.10; rounds 1-2: two) — order independent, so the result is reproducible; one cycle is two tile-fused
 //    launches per level (k_mg_down / k_mg_up, iterates exchanged through LDS) and ONE workgroup for all levels <= 512 pixels;
 //  * vectors are planar [6][pixels]: on a regular 5-point stencil the neighbours of consecutive pixels are consecutive, so
 //    every load/store of a wave is one fully coalesced segment per right-hand side;
@@ -33,12 +33,19 @@ namespace {
 // is still a symmetric preconditioner. Against omega = 0.8 twice (round 1): 63/47/34/27/27 instead of 74/56/42/34/34 PCG iterations on the
 // five solves of a 700x700 pair (-17 %) at the same cost per cycle; [lambda_max/4, lambda_max] (0.562, 1.39) gave -8 %, wider intervals
 // than /20 nothing more (scripts: NCT_MG_W1 / NCT_MG_W2 builds). The coarsest grid keeps 60 sweeps at 0.8.
-#ifndef NCT_MG_W1
-#define NCT_MG_W1 0.5808
-#define NCT_MG_W2 2.6437
+// Round 3: MG_NS = 3 sweeps per leg with the degree-3 weights on [lambda_max / 30, lambda_max] (0.5346, 0.9677, 5.0974): 60/41/29/22/22 instead of 71/53/39/31/31 iterations
+// (-24 %) for legs that cost ~1.3x (halo 3 instead of 2) — and, at rtol 1e-7, the same 8-bit result. Degree 4 (0.5193, 0.7153, 1.5340, 8.0502 on [lambda_max / 40, lambda_max]):
+// -35 % iterations, legs ~1.7x. NCT_MG_NS selects 2 / 3 / 4 at build time (the oracle mirrors it: orc_set_mg_smoother).
+#ifndef NCT_MG_NS
+#define NCT_MG_NS 3
 #endif
-constexpr double OMEGA = NCT_MG_W1;
-constexpr float MG_R2 = (float)(NCT_MG_W2 / NCT_MG_W1), MG_R0 = (float)(0.8 / NCT_MG_W1);   // second-sweep and coarsest-grid weights relative to the first (fdinv = omega_1 / diag)
+constexpr int MG_NS = NCT_MG_NS;
+static_assert(MG_NS >= 2 && MG_NS <= 4, "2, 3 or 4 smoothing sweeps per leg");
+constexpr double MG_W[4] = {MG_NS == 2 ? 0.5808 : (MG_NS == 3 ? 0.5346 : 0.5193), MG_NS == 2 ? 2.6437 : (MG_NS == 3 ? 0.9677 : 0.7153), MG_NS == 3 ? 5.0974 : 1.5340, 8.0502};
+constexpr double OMEGA = MG_W[0];
+// weight of sweep k relative to the first (fdinv = omega_0 / diag is what the levels store); coarsest grid: 0.8
+__host__ __device__ constexpr float mg_rk(int k) { return (float)(MG_W[k] / MG_W[0]); }
+constexpr float MG_R0 = (float)(0.8 / MG_W[0]);
 constexpr int NQMAX = 6;      // right-hand sides of a solve: 6 (a and b of the 3 Lab channels) or 3 + 3 on two streams (template parameter NQ)
 #ifndef NCT_MG_TXB
 #define NCT_MG_TXB 48
@@ -235,42 +242,49 @@ __device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= c.w3 * s_v[q * LN + p - LW]; }
 }
-constexpr int mg_threads(int TX, int TY) { return ((TX + 4) * (TY + 4) + 63) / 64 * 64; }
+constexpr int mg_threads(int TX, int TY) { return ((TX + 2 * MG_NS) * (TY + 2 * MG_NS) + 63) / 64 * 64; }
 // TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below.
+// One thread per pixel of the tile + MG_NS-pixel halo. Sweep k produces its iterate on the tile + (MG_NS - k)-pixel halo from the previous one (exchanged through LDS,
+// two arrays in ping-pong); halo pixels are recomputed by the neighbouring tiles with the same expressions, hence bit-identical.
 template <int NQ, int TX, int TY, typename TB>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc) {
     if (st->nactive == 0) return;
-    constexpr int LW = TX + 4, LH = TY + 4, LN = LW * LH;
-    __shared__ vf s_a[NQ * LN], s_b[NQ * LN];            // s_a: x1, later the residual b - M x ; s_b: x
+    constexpr int HL = MG_NS, LW = TX + 2 * HL, LH = TY + 2 * HL, LN = LW * LH;
+    __shared__ vf s_a[NQ * LN], s_b[NQ * LN];
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const int p = threadIdx.x;
     const int ly = p / LW, lx = p - ly * LW;
-    const int gy = y0 + ly - 2, gx = x0 + lx - 2;
+    const int gy = y0 + ly - HL, gx = x0 + lx - HL;
     const bool valid = p < LN && gy >= 0 && gy < F.H && gx >= 0 && gx < F.W;
-    const bool ring1 = valid && lx >= 1 && lx <= TX + 2 && ly >= 1 && ly <= TY + 2;     // tile + 1-pixel halo
-    const bool interior = valid && lx >= 2 && lx <= TX + 1 && ly >= 2 && ly <= TY + 1;
+    auto ring = [&](int k) { return valid && lx >= k && lx <= TX + 2 * HL - 1 - k && ly >= k && ly <= TY + 2 * HL - 1 - k; };   // tile + (HL - k)-pixel halo
+    const bool interior = ring(HL);
     const int i = gy * F.W + gx;
-    vf bq[NQ], x1[NQ]; PxCoef c;
+    vf bq[NQ], xk[NQ]; PxCoef c;
     if (valid) {
         c = px_coef(F, gy, gx);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * F.n + i]; x1[q] = bq[q] * c.dinv; s_a[q * LN + p] = x1[q]; }
+        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * F.n + i]; xk[q] = bq[q] * c.dinv; s_a[q * LN + p] = xk[q]; }     // sweep 0 (from zero)
     }
     __syncthreads();
-    if (ring1) {
-        vf y[NQ]; lds_op<NQ, LW, LN>(c, s_a, p, y);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const vf v = x1[q] + (bq[q] - y[q]) * (c.dinv * MG_R2);
-            s_b[q * LN + p] = v;
-            if (interior) x[(size_t)q * F.n + i] = v;
+    for (int k = 1; k < MG_NS; ++k) {
+        vf* src = (k & 1) ? s_a : s_b; vf* dst = (k & 1) ? s_b : s_a;
+        if (ring(k)) {
+            vf y[NQ]; lds_op<NQ, LW, LN>(c, src, p, y);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                xk[q] = xk[q] + (bq[q] - y[q]) * (c.dinv * mg_rk(k));
+                dst[q * LN + p] = xk[q];
+                if (k == MG_NS - 1 && interior) x[(size_t)q * F.n + i] = xk[q];
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
+    vf* xs = (MG_NS & 1) ? s_a : s_b; vf* rs = (MG_NS & 1) ? s_b : s_a;       // the smoothed iterate (on the tile + 1) and where the residual goes
     if (interior) {
-        vf yv[NQ]; lds_op<NQ, LW, LN>(c, s_b, p, yv);
+        vf yv[NQ]; lds_op<NQ, LW, LN>(c, xs, p, yv);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) s_a[q * LN + p] = bq[q] - yv[q];
+        for (int q = 0; q < NQ; ++q) rs[q * LN + p] = bq[q] - yv[q];
     }
     __syncthreads();
     if (p < (TX / 2) * (TY / 2)) {
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
                 const int yy = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
                 if (yy < F.H && xx < F.W) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) acc[q] += s_a[q * LN + (yy - y0 + 2) * LW + (xx - x0 + 2)];
+                    for (int q = 0; q < NQ; ++q) acc[q] += rs[q * LN + (yy - y0 + HL) * LW + (xx - x0 + HL)];
                 }
             }
 #pragma unroll
@@ -298,35 +312,35 @@ template <int NQ, int TX, int TY, typename TB>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __restrict__ st, Lvl L, const TB* __restrict__ b, const vf* __restrict__ x, int Wc, int nc,
                                                               const vf* __restrict__ ec, vf* __restrict__ xo) {
     if (st->nactive == 0) return;
-    constexpr int LW = TX + 4, LH = TY + 4, LN = LW * LH;
-    __shared__ vf s_a[NQ * LN], s_b[NQ * LN];            // s_a: xe ; s_b: x2
+    constexpr int HL = MG_NS, LW = TX + 2 * HL, LH = TY + 2 * HL, LN = LW * LH;
+    __shared__ vf s_a[NQ * LN], s_b[NQ * LN];
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const int p = threadIdx.x;
     const int ly = p / LW, lx = p - ly * LW;
-    const int gy = y0 + ly - 2, gx = x0 + lx - 2;
+    const int gy = y0 + ly - HL, gx = x0 + lx - HL;
     const bool valid = p < LN && gy >= 0 && gy < L.H && gx >= 0 && gx < L.W;
-    const bool ring1 = valid && lx >= 1 && lx <= TX + 2 && ly >= 1 && ly <= TY + 2;
-    const bool interior = valid && lx >= 2 && lx <= TX + 1 && ly >= 2 && ly <= TY + 1;
+    auto ring = [&](int k) { return valid && lx >= k && lx <= TX + 2 * HL - 1 - k && ly >= k && ly <= TY + 2 * HL - 1 - k; };
     const int i = gy * L.W + gx;
-    vf bq[NQ], xe[NQ]; PxCoef c;
+    vf bq[NQ], xk[NQ]; PxCoef c;
     if (valid) {
         c = px_coef(L, gy, gx);
         const int ip = (gy >> 1) * Wc + (gx >> 1);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * L.n + i]; xe[q] = x[(size_t)q * L.n + i] + ec[(size_t)q * nc + ip]; s_a[q * LN + p] = xe[q]; }
+        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * L.n + i]; xk[q] = x[(size_t)q * L.n + i] + ec[(size_t)q * nc + ip]; s_a[q * LN + p] = xk[q]; }   // xe = x + e_coarse(parent)
     }
     __syncthreads();
-    vf x2[NQ];
-    if (ring1) {
-        vf y[NQ]; lds_op<NQ, LW, LN>(c, s_a, p, y);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { x2[q] = xe[q] + (bq[q] - y[q]) * c.dinv; s_b[q * LN + p] = x2[q]; }
-    }
-    __syncthreads();
-    if (interior) {
-        vf y[NQ]; lds_op<NQ, LW, LN>(c, s_b, p, y);
+    for (int k = 0; k < MG_NS; ++k) {
+        vf* src = (k & 1) ? s_b : s_a; vf* dst = (k & 1) ? s_a : s_b;
+        if (ring(k + 1)) {
+            vf y[NQ]; lds_op<NQ, LW, LN>(c, src, p, y);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) xo[(size_t)q * L.n + i] = x2[q] + (bq[q] - y[q]) * (c.dinv * MG_R2);
+            for (int q = 0; q < NQ; ++q) {
+                xk[q] = xk[q] + (bq[q] - y[q]) * (k == 0 ? c.dinv : c.dinv * mg_rk(k));
+                if (k == MG_NS - 1) xo[(size_t)q * L.n + i] = xk[q]; else dst[q * LN + p] = xk[q];
+            }
+        }
+        if (k < MG_NS - 1) __syncthreads();
     }
 }
 // Middle + tail of the V-cycle in ONE launch, one 1024-thread workgroup PER RIGHT-HAND SIDE: the first fused level has <= 4096 pixels
@@ -432,27 +446,35 @@ __device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __
     if constexpr (D + 1 < MID_LV) {
         const Lvl& C = P.lv[D + 1];
         MidCoef c[PPT]; vf x[PPT];
-        // ---- down: x1 = b*dinv ; x = x1 + (b - M x1)*dinv ; res = b - M x
+        // ---- down: MG_NS sweeps from zero (x_1 = b*dinv ; x_{s+1} = x_s + (b - M x_s)*dinv*rk(s)), iterates in ping-pong through sA / sB ; res = b - M x
 #pragma unroll
         for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) { c[k] = mid_coef(L, i); sA[i] = bval(k, i) * c[k].dinv; } }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = t + k * MID_T;
-            if (i < n) {
-                const vf bk = bval(k, i), x1 = bk * c[k].dinv, xv = x1 + (bk - mid_op(c[k], sA, i, W)) * (c[k].dinv * MG_R2);
-                sB[i] = xv;
-                if constexpr (INLDS) sx0[i] = xv; else x[k] = xv;
-            }
-        }
-        __syncthreads();
+        for (int sw = 1; sw < MG_NS; ++sw) {
+            vf* src = (sw & 1) ? sA : sB; vf* dst = (sw & 1) ? sB : sA;
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) sA[i] = bval(k, i) - mid_op(c[k], sB, i, W); }
+            for (int k = 0; k < PPT; ++k) {
+                const int i = t + k * MID_T;
+                if (i < n) {
+                    vf xs; const vf y = mid_op(c[k], src, i, W, &xs);
+                    const vf xv = xs + (bval(k, i) - y) * (c[k].dinv * mg_rk(sw));
+                    dst[i] = xv;
+                    if (sw == MG_NS - 1) { if constexpr (INLDS) sx0[i] = xv; else x[k] = xv; }
+                }
+            }
+            __syncthreads();
+        }
+        {
+            vf* xs = (MG_NS & 1) ? sA : sB; vf* rs = (MG_NS & 1) ? sB : sA;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) rs[i] = bval(k, i) - mid_op(c[k], xs, i, W); }
+        }
         __syncthreads();
         constexpr int CPT = mid_ppt(D + 1);
         vf bc[CPT];
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) { const int I = t + k * MID_T; bc[k] = I < C.n ? mid_restrict(sA, I, C.W, W, L.H) : 0.f; }
+        for (int k = 0; k < CPT; ++k) { const int I = t + k * MID_T; bc[k] = I < C.n ? mid_restrict((MG_NS & 1) ? sB : sA, I, C.W, W, L.H) : 0.f; }
         __syncthreads();                                      // the residual array is free again
         mid_level<D + 1>(P, q, t, sA, sB, sC, sb0, sx0, bc, sweeps);    // its correction arrives in sC
         // ---- up: xe = x + e_coarse(parent) ; x2 = xe + (b - M xe)*dinv ; xo = x2 + (b - M x2)*dinv
@@ -471,23 +493,22 @@ __device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __
                 sA[i] = xk + sC[(gy >> 1) * C.W + (gx >> 1)];
             }
         }
-        __syncthreads();
+        __syncthreads();                                      // (from here on every thread has finished reading the child's correction in sC)
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = t + k * MID_T;
-            if (i < n) { vf xe; const vf y = mid_op(c[k], sA, i, W, &xe); sB[i] = xe + (bval(k, i) - y) * c[k].dinv; }
-        }
-        __syncthreads();                                      // every thread has also finished reading the child's correction in sC
+        for (int sw = 0; sw < MG_NS; ++sw) {
+            vf* src = (sw & 1) ? sB : sA; vf* dst = (sw & 1) ? sA : sB;
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = t + k * MID_T;
-            if (i < n) {
-                vf x2; const vf y = mid_op(c[k], sB, i, W, &x2);
-                const vf v = x2 + (bval(k, i) - y) * (c[k].dinv * MG_R2);
-                if (D == 0) L.x2[(size_t)q * n + i] = v; else sC[i] = v;
+            for (int k = 0; k < PPT; ++k) {
+                const int i = t + k * MID_T;
+                if (i < n) {
+                    vf xs; const vf y = mid_op(c[k], src, i, W, &xs);
+                    const vf v = xs + (bval(k, i) - y) * (sw == 0 ? c[k].dinv : c[k].dinv * mg_rk(sw));
+                    if (sw < MG_NS - 1) dst[i] = v;
+                    else if (D == 0) L.x2[(size_t)q * n + i] = v; else sC[i] = v;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 __global__ __launch_bounds__(MID_T) void k_mg_mid(const PState* __restrict__ st, MidPack P, int sweeps) {

@@ -17,9 +17,6 @@ void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha,
 #define NQ 6
 /* two Chebyshev-weighted Jacobi sweeps per leg (k_wls_mg.hip: NCT_MG_W1 / NCT_MG_W2); fdinv = (float)(W1 / diag), the second sweep and the
  * coarsest grid scale it in fp32 exactly as the kernels do */
-static const double OMEGA = 0.5808, OMEGA2 = 2.6437;
-#define MG_R2 ((float)(OMEGA2 / OMEGA))
-#define MG_R0 ((float)(0.8 / OMEGA))
 typedef struct { int H, W, n; double *r, *wx, *wy, *diag; float *fdiag, *fdinv, *fwx, *fwy, *b, *x, *x2; } lvl_t;   /* fdinv = (float)(omega / diag) */
 
 static void tree256(double* s) { for (int off = 128; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) s[t] += s[t + off]; }
@@ -59,19 +56,48 @@ static void canon_sum(const double* v, int n, int nq, double* out) {
     if (r_ + 1 < H_) { const float w_ = (L)->fwy[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + W_, q); } \
     if (r_ > 0) { const float w_ = (L)->fwy[(i) - W_]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - W_, q); } } while (0)
 
+/* Smoother: NS damped-Jacobi sweeps per leg with Chebyshev weights (k_wls_mg.hip: MG_NS, MG_W[]); fdinv = (float)(W[0] / diag), sweep k scales it in fp32 by
+ * (float)(W[k] / W[0]) exactly as the kernels do. orc_set_mg_smoother selects one of the shipped / experimental sets (design experiments; the default is the product's). */
+static int MG_NS = 3;
+static double MG_W[8] = {0.5346, 0.9677, 5.0974};
+static float mg_rk(int k) { return (float)(MG_W[k] / MG_W[0]); }
+void orc_set_mg_smoother(int ns) {
+    static const double w2[2] = {0.5808, 2.6437}, w3[3] = {0.5346, 0.9677, 5.0974}, w4[4] = {0.5193, 0.7153, 1.5340, 8.0502};
+    const double* w = ns == 2 ? w2 : (ns == 4 ? w4 : w3);
+    MG_NS = ns == 2 || ns == 4 ? ns : 3;
+    for (int k = 0; k < MG_NS; ++k) MG_W[k] = w[k];
+}
+int orc_get_mg_smoother(void) { return MG_NS; }
+
+/* one Jacobi sweep on level L: out = in + (rhs - M in) * (fdinv * rk); in == NULL means "from zero": out = rhs * fdinv (rk = 1). rhs: fp64 residual (rounded on load) at level 0 */
+static void mg_sweep(const lvl_t* L, const double* r0, const float* in, float* out, float rk) {
+#define BVS(j, q) (r0 ? (float)r0[(size_t)(j) * NQ + (q)] : L->b[(size_t)(j) * NQ + (q)])
+    if (!in) {
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < L->n; ++i) for (int q = 0; q < NQ; ++q) out[(size_t)i * NQ + q] = BVS(i, q) * L->fdinv[i];
+        return;
+    }
+#define INV(j, q) (in[(size_t)(j) * NQ + (q)])
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < L->n; ++i) {
+        float y[NQ]; LVL_OPF(L, i, INV, y);
+        const float d = rk == 1.0f ? L->fdinv[i] : L->fdinv[i] * rk;
+        for (int q = 0; q < NQ; ++q) { const float t = BVS(i, q) - y[q]; const float u = t * d; out[(size_t)i * NQ + q] = in[(size_t)i * NQ + q] + u; }
+    }
+#undef INV
+}
+
 /* z = lv[0].x (fp32) for the fp64 residual r0 (rounded to fp32 on load) */
 static void vcycle(lvl_t* lv, int nl, const double* r0) {
     for (int l = 0; l < nl - 1; ++l) {
         lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
+        const double* rr = l == 0 ? r0 : NULL;
+        /* pre-smoothing from zero: NS sweeps, the result in L->x */
+        float* cur = (MG_NS & 1) ? L->x : L->x2; float* oth = (MG_NS & 1) ? L->x2 : L->x;
+        mg_sweep(L, rr, NULL, cur, 1.0f);
+        for (int k = 1; k < MG_NS; ++k) { mg_sweep(L, rr, cur, oth, mg_rk(k)); float* t = cur; cur = oth; oth = t; }
+        /* cur == L->x */
 #define BV(j, q) (l == 0 ? (float)r0[(size_t)(j) * NQ + (q)] : L->b[(size_t)(j) * NQ + (q)])
-#define X1(j, q) (BV(j, q) * L->fdinv[j])
-#pragma omp parallel for schedule(static)
-        for (int i = 0; i < L->n; ++i) {
-            float y[NQ]; LVL_OPF(L, i, X1, y);
-            const float d = L->fdinv[i] * MG_R2;
-            for (int q = 0; q < NQ; ++q) { const float x1 = X1(i, q); const float t = BV(i, q) - y[q]; const float u = t * d; L->x[(size_t)i * NQ + q] = x1 + u; }
-        }
-#undef X1
 #define XV(j, q) (L->x[(size_t)(j) * NQ + (q)])
 #pragma omp parallel for schedule(static)
         for (int I = 0; I < C->n; ++I) {
@@ -94,11 +120,12 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
         lvl_t* L = &lv[nl - 1];
         float* cur = L->x; float* nxt = L->x2;
         memset(cur, 0, sizeof(float) * (size_t)L->n * NQ);
+        const float r0c = (float)(0.8 / MG_W[0]);
         for (int s = 0; s < 60; ++s) {
 #define CV(j, q) (cur[(size_t)(j) * NQ + (q)])
             for (int i = 0; i < L->n; ++i) {
                 float y[NQ]; LVL_OPF(L, i, CV, y);
-                const float d = L->fdinv[i] * MG_R0;
+                const float d = L->fdinv[i] * r0c;
                 for (int q = 0; q < NQ; ++q) { const float t = L->b[(size_t)i * NQ + q] - y[q]; const float u = t * d; nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + u; }
             }
 #undef CV
@@ -109,26 +136,24 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
     for (int l = nl - 2; l >= 0; --l) {
         lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
         const int Wc = C->W;
-#define BV(j, q) (l == 0 ? (float)r0[(size_t)(j) * NQ + (q)] : L->b[(size_t)(j) * NQ + (q)])
-#define XE(j, q) (L->x[(size_t)(j) * NQ + (q)] + C->x[(size_t)((((j) / L->W) >> 1) * Wc + ((((j) % L->W)) >> 1)) * NQ + (q)])
+        const double* rr = l == 0 ? r0 : NULL;
+        /* xe = x + e_coarse(parent), then NS sweeps; the result ends in L->x */
+        float* cur = (MG_NS & 1) ? L->x2 : L->x; float* oth = (MG_NS & 1) ? L->x : L->x2;
+        if (cur != L->x) {
 #pragma omp parallel for schedule(static)
-        for (int i = 0; i < L->n; ++i) {
-            float y[NQ]; LVL_OPF(L, i, XE, y);
-            const float d = L->fdinv[i];
-            for (int q = 0; q < NQ; ++q) { const float xe = XE(i, q); const float t = BV(i, q) - y[q]; const float u = t * d; L->x2[(size_t)i * NQ + q] = xe + u; }
-        }
-#undef XE
-#define X2(j, q) (L->x2[(size_t)(j) * NQ + (q)])
+            for (int j = 0; j < L->n; ++j) for (int q = 0; q < NQ; ++q) cur[(size_t)j * NQ + q] = L->x[(size_t)j * NQ + q] + C->x[(size_t)(((j / L->W) >> 1) * Wc + ((j % L->W) >> 1)) * NQ + q];
+        } else {
 #pragma omp parallel for schedule(static)
-        for (int i = 0; i < L->n; ++i) {
-            float y[NQ]; LVL_OPF(L, i, X2, y);
-            const float d = L->fdinv[i] * MG_R2;
-            for (int q = 0; q < NQ; ++q) { const float t = BV(i, q) - y[q]; const float u = t * d; L->x[(size_t)i * NQ + q] = L->x2[(size_t)i * NQ + q] + u; }
+            for (int j = 0; j < L->n; ++j) for (int q = 0; q < NQ; ++q) L->x[(size_t)j * NQ + q] = L->x[(size_t)j * NQ + q] + C->x[(size_t)(((j / L->W) >> 1) * Wc + ((j % L->W) >> 1)) * NQ + q];
         }
-#undef X2
-#undef BV
+        for (int k = 0; k < MG_NS; ++k) { mg_sweep(L, rr, cur, oth, k == 0 ? 1.0f : mg_rk(k)); float* t = cur; cur = oth; oth = t; }
     }
 }
+#undef BVS
+
+/* diagnostic: iteration counts (max over the right-hand sides) of the solves since the last reset */
+static int g_wls_log[64], g_wls_log_n = 0;
+int orc_wls_log(int* out, int reset) { const int n = g_wls_log_n; if (out) memcpy(out, g_wls_log, sizeof(int) * (size_t)n); if (reset) g_wls_log_n = 0; return n; }
 
 /* a,b: full-res [N][3] in (x0) / out. iters_out[6] nullable. Returns max iterations, or -1 if not converged. */
 int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double rtol, int* iters_out) {
@@ -173,7 +198,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
             if (y + 1 < L->H) a00 += L->wy[i];
             if (y > 0) a00 += L->wy[i - L->W];
             L->diag[i] = a00;
-            L->fdiag[i] = (float)a00; L->fdinv[i] = (float)(OMEGA / a00); L->fwx[i] = (float)L->wx[i]; L->fwy[i] = (float)L->wy[i];
+            L->fdiag[i] = (float)a00; L->fdinv[i] = (float)(MG_W[0] / a00); L->fwx[i] = (float)L->wx[i]; L->fwy[i] = (float)L->wy[i];
         }
     }
     lvl_t* F = &lv[0];
@@ -242,6 +267,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     for (int i = 0; i < n; ++i) for (int q = 0; q < NQ; ++q) { if (q < 3) a[(size_t)i * 3 + q] = x6[(size_t)i * NQ + q]; else b[(size_t)i * 3 + q - 3] = x6[(size_t)i * NQ + q]; }
     if (iters_out) memcpy(iters_out, iters, sizeof iters);
     int mx = 0; for (int q = 0; q < 6; ++q) if (iters[q] > mx) mx = iters[q];
+    if (g_wls_log_n < 64) g_wls_log[g_wls_log_n++] = mx;
     for (int l = 0; l < nl; ++l) { free(lv[l].r); free(lv[l].wx); free(lv[l].wy); free(lv[l].diag); free(lv[l].fdiag); free(lv[l].fdinv); free(lv[l].fwx); free(lv[l].fwy); free(lv[l].b); free(lv[l].x); free(lv[l].x2); }
     free(x6); free(r); free(p); free(sv); free(w); free(acc);
     return any ? -1 : mx;
