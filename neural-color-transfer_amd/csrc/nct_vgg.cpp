@@ -186,6 +186,7 @@ struct TxtTok { const char* p; const char* end; bool ok = true;
 };
 // parses `field: value` / `field { ... }` pairs of one message body until '}' (or the end of the file at depth 0)
 bool parse_msg(TxtTok& t, int depth, TxtLayer* L, std::vector<TxtLayer>* layers, const std::string& path_in_layer) {
+    if (depth > 32) return false;              // model directories are user input: bounded recursion on deeply nested braces
     for (;;) {
         t.ws();
         if (t.p >= t.end) return depth == 0;
