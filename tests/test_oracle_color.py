@@ -329,3 +329,24 @@ def test_knn_matches_reference_nanoflann(oracle):
                     checked += 1
                     exact_ids += int(ids[i, t] == keep[t][1])
         assert exact_ids == checked and checked > (n if name == "smooth" else 100), (name, exact_ids, checked)
+
+
+def test_mg_smoother_degree_changes_iterations_not_the_solution(oracle):
+    """S2 preconditioner: the V-cycle's Chebyshev-weighted Jacobi smoother runs MG_NS sweeps per leg (k_wls_mg.hip / orc_wls_mg.c; the product's default is 3). The degree
+    only changes how fast PCG converges — at the solver's tolerance the solutions of the 2-, 3- and 4-sweep cycles agree far below an 8-bit step and the 8-bit results are equal;
+    more sweeps need fewer iterations."""
+    err, s, g, ids, ws = _s1_inputs(oracle, h=24, w=24)
+    full = synth.image(3, 96, 96)
+    assert oracle.l.orc_get_mg_smoother() == 3
+    res = {}
+    try:
+        for ns in (2, 3, 4):
+            oracle.l.orc_set_mg_smoother(ns)
+            res[ns] = oracle.local_color_transfer(err, s, g, full, ids, ws, layer=2, want_stages=True)
+    finally:
+        oracle.l.orc_set_mg_smoother(3)
+    it = {ns: int(res[ns][1]["wls_iters"].max()) for ns in res}
+    assert it[2] > it[3] >= it[4] > 3, it
+    for ns in (2, 4):
+        assert np.allclose(res[ns][1]["ab_wls"], res[3][1]["ab_wls"], rtol=0, atol=5e-6)
+        assert np.array_equal(res[ns][0], res[3][0])
