@@ -3,17 +3,17 @@
 // layers/base_conv_layer.cpp:257-283), in-place ReLU (layers/relu_layer.cpp:14-17), MAX pooling with ceil-mode
 // output size and clipped windows (layers/pooling_layer.cpp:90-93,147-165); preprocessing Classifier.cpp:211-275.
 //
-// MI355X design — im2col-free implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32, = a k-ordered fmaf chain, so the
-// result is bit-identical to oracle/orc_vgg.c):
-//   D[cout][pixel] += W[cout][k] * In[k][pixel],  k = ci*9 + tap ascending, two k per MFMA.
-//   * A operand = weights pre-packed K-major ([k][cout]): lane (i = l&31, half = l>>5) reads Wp[k0+half][m0+i] — a
-//     coalesced 128-B row segment per half-wave;
-//   * B operand = activations in planar CHW: lane (j = l&31, half) reads In[ci][y+dy][x0+j+dx] — 32 consecutive
-//     pixels of one plane, again a coalesced 128-B segment. No im2col buffer, no LDS round trip: an f32 MFMA needs only
-//     512 B of operands per 4096 FLOP, each wave register-tiles 2x2 MFMA tiles (64 cout x 64 pixels, 64 accumulators)
-//     and the 9 taps of a channel re-hit the same L1 lines, so the L1/L2 path feeds the matrix pipe without barriers;
-//   * the D fragment has pixels on lanes and couts on registers, so every store instruction writes 32 consecutive
-//     pixels of one output plane (coalesced), with bias + ReLU fused.
+// MI355X design — im2col-free implicit GEMM on the two-block f32 MFMA v_mfma_f32_32x32x1_2b_f32 (exact f32: one fmaf per output element and k, k ascending,
+// so the result is bit-identical to oracle/orc_vgg.c):
+//   D[cout][pixel] += W[cout][k] * In[k][pixel],  k = ci*9 + tap ascending, one k per MFMA, two 32-pixel blocks per MFMA.
+//   * B operand = activations in planar CHW: lane = pixel (64 consecutive pixels per wave), the three dx taps of an input row come from ONE 12-byte
+//     buffer load (x-1, x, x+1): six vector-memory instructions per channel pair and wave for the activations;
+//   * A operand = weights pre-packed per channel pair so that lane (i = l&31, h = l>>5) fetches its nine values k = 2 s + h with two 16-byte loads and one
+//     4-byte load, coalesced over the 32 couts of a half wave; cbsz:1 abid:h hands half h's value to both pixel blocks;
+//   * no im2col buffer and no LDS round trip: an f32 MFMA needs 512 B of operands per 4096 FLOP, every wave register-tiles 64 couts x 64 pixels
+//     (64 accumulators) and runs a two-stage register pipeline (operands of the next channel pair in flight under the 36 MFMAs of this one);
+//   * the D fragment has pixels on lanes and couts on registers, so every store instruction writes 32 consecutive pixels of one output plane,
+//     with bias + ReLU (+ the following 2x2 max-pool where the tile shape fits the map) fused.
 // Roofline: MFMA (f32 peak 157.3 TF). FLOPs = 2*9*Cin*Cout*H*W per layer.
 #include "nct_internal.h"
 #include "nct_device.h"
@@ -33,171 +33,268 @@ __global__ void k_vgg_preprocess(const uint8_t* __restrict__ bgr, int stride, fl
 }
 
 // ---------------------------------------------------------------- conv3x3 pad1 stride1 + bias + ReLU
-// Pixels are tiled in 1-D (row-major pixel index p = y*W + x): a 32-pixel MFMA column tile is 32 consecutive pixels (it may wrap
-// over a row end — validity is per lane anyway), a wave owns two consecutive ones plus two 32-cout row tiles, a workgroup =
-// 4 waves = WCO along cout x (4/WCO) along pixels. 1-D tiling wastes no lanes on ragged 2-D tile edges: conv4_x at 88x88 needs
+// Pixels are tiled in 1-D (row-major pixel index p = y*W + x): a wave owns 64 consecutive pixels (the run may wrap over a row end — validity is per lane anyway)
+// and 64 couts, a workgroup = 4 waves = WCO along cout x (4/WCO) along pixels. 1-D tiling wastes no lanes on ragged 2-D tile edges: conv4_x at 88x88 needs
 // 61 x 4 = 244 workgroups (one per CU, one round) where 16x8 tiles needed 264 — 8 CUs with two workgroups doubled the layer time.
-struct ConvGeom { int Cin, Cout, H, W, npx_blocks, nblk_n; };
+struct ConvGeom { int Cin, Cout, H, W, npx_blocks, nblk_n, tiles_x, Ho, Wo; };   // tiles_x, Ho, Wo: fused 2x2 pooling only
 #ifndef NCT_CONV_PT1_BELOW
 #define NCT_CONV_PT1_BELOW 128
 #endif
 
-// WCO = waves along cout (1 => block covers 64 cout x 256 px; 2 => 128 cout x 128 px); PT = 32-pixel tiles per wave (2, or 1 for the
-// layers whose grid would otherwise leave SIMDs with a single wave: half the pixels per workgroup, twice the workgroups)
-template <int WCO, int PT>
-__global__ __launch_bounds__(256) void k_conv3x3_mfma(const float* __restrict__ in, const float* __restrict__ wp /*[Cin*9][Cout]*/,
-                                                      const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int relu) {
+// The kernel. Rounds 1-2 used v_mfma_f32_32x32x2_f32 (lane halves = two k values): every tap of every pixel tile was its own 4-byte load, 24 vector-memory
+// instructions per 36 MFMAs, MFMA busy 0.61-0.68 (git history: k_conv3x3_mfma). Round 3: v_mfma_f32_32x32x1_2b_f32 multiplies two independent 32x32 blocks
+// by ONE k each (still an exact fmaf per element, k ascending: bit-identical). Block = lane half, so a wave's 64 lanes are 64 consecutive PIXELS (block 0 = pixels 0..31, block 1 = 32..63) and every lane needs ALL 18
+// k values of a channel pair for its own pixel: the three dx taps of an input row are the three dwords of ONE unaligned 12-byte load (x-1, x, x+1), six
+// loads per channel pair instead of eighteen. The A operand (32 couts x one k) is the same for both blocks: the weights stay packed as for the 32x32x2
+// kernel — lane half h holds k = 2 s + h — and cbsz:1 abid:h broadcasts half h's value to both blocks. 36 MFMAs per channel pair as before, 12 vector-memory
+// instructions instead of 24, and no per-load address selects: the loads go through a buffer descriptor over the whole input, so the one dword before the
+// first plane / behind the last one that edge lanes touch is range-checked away by the hardware (per dword: scripts/probes/bufload_probe.hip) and rows
+// outside the image read the neighbouring plane or nothing — all of those taps are zeroed by the tap masks (selects, never multiplies).
+// voffset is unsigned, so offsets carry a bias of one row + one pixel (soffset = plane offset - bias); plane 0 of the first pair cannot be biased and is
+// fetched in the prologue with the window of the x == 0 lanes moved one pixel right and rotated back.
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+
+// WCO = waves along cout; CT = 32-cout tiles per wave (2: 64 couts x 64 px per wave; 1: 32 x 64, for grids that would otherwise be too small).
+// POOL = the following 2x2/2 max-pool (ceil mode, clipped windows: k_maxpool2x2) in the epilogue: the wave's 64 pixels are then a 32 x 2 tile (block 0 = row 2 ty,
+// block 1 = row 2 ty + 1), so a pooling window is two registers of one lane (vertical) and two neighbouring lanes (horizontal, one DPP quad_perm); only the pooled
+// map is written. The K loop does not change: every lane fetches the rows of its own pixel.
+template <int WCO, int CT, bool POOL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_conv3x3_mfma2b(const float* __restrict__ in, const float* __restrict__ wp /*packed, see k_pack_weights*/,
+                                                        const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int relu) {
     constexpr int WPX = 4 / WCO;             // waves along pixels
-    constexpr int BLK_PX = WPX * 32 * PT;    // pixels covered by a workgroup
+    constexpr int BLK_PX = WPX * 64;
+    constexpr int BLK_CO = WCO * 32 * CT;
     const int HW = g.H * g.W;
-    // block -> (pixel block, cout block); blocks of one pixel block differ by multiples of 8 => same XCD/L2
-    int bid = blockIdx.x;
-    const int np = g.npx_blocks;
     int pt, nb;
     {
-        const int grp = bid / (8 * g.nblk_n), rem = bid - grp * 8 * g.nblk_n;
+        const int bid = blockIdx.x, grp = bid / (8 * g.nblk_n), rem = bid - grp * 8 * g.nblk_n;
         nb = rem >> 3; pt = grp * 8 + (rem & 7);
     }
-    if (pt >= np) return;
+    if (pt >= g.npx_blocks) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, l31 = lane & 31;
     const int wco = wave % WCO, wpx = wave / WCO;
-    const int m0 = nb * (64 * WCO) + wco * 64;                 // first cout of this wave
-    const int p0 = pt * BLK_PX + wpx * 32 * PT + l31, p1 = p0 + 32; // this lane's pixel in tile 0 / tile 1
-    const bool live0 = p0 < HW, live1 = PT == 2 && p1 < HW;
-    const int pc0 = live0 ? p0 : HW - 1, pc1 = live1 ? p1 : HW - 1;
-    const int y0 = pc0 / g.W, x0 = pc0 - y0 * g.W, y1 = pc1 / g.W, x1 = pc1 - y1 * g.W;
-
-    // per-lane tap tables for the 9 k-steps of a channel pair (k = 2s + half within 18)
-    // out-of-image taps read the (in-bounds) own pixel instead and are zeroed by a select: no divergent branches in the K loop
-    // (one offset table for both pixel tiles: an out-of-image tap is redirected to the lane's own pixel of that channel by a select on the
-    //  ADDRESS, nine registers fewer than a table per tile — the difference between two and three waves per SIMD)
-    int boff[9]; unsigned vm0 = 0, vm1 = 0;
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {
-        const int k = 2 * s + half;
-        const int ci = k / 9, tap = k - 9 * ci, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        boff[s] = ci * HW + dy * g.W + dx;
-        const bool v0 = live0 && (x0 + dx) >= 0 && (x0 + dx) < g.W && (y0 + dy) >= 0 && (y0 + dy) < g.H;
-        const bool v1 = live1 && (x1 + dx) >= 0 && (x1 + dx) < g.W && (y1 + dy) >= 0 && (y1 + dy) < g.H;
-        vm0 |= (unsigned)v0 << s; vm1 |= (unsigned)v1 << s;
+    const int m0 = nb * BLK_CO + wco * 32 * CT;                 // first cout of this wave
+    int y, x, tile_y = 0, tile_x = 0; bool live;                // this lane's pixel
+    if constexpr (POOL) {
+        const int wt = pt * WPX + wpx;                          // wave tile, row-major over (row pairs, 32-pixel column tiles)
+        tile_y = wt / g.tiles_x; tile_x = wt - tile_y * g.tiles_x;
+        y = 2 * tile_y + half; x = 32 * tile_x + l31;
+        live = y < g.H && x < g.W;
+    } else {
+        const int p = pt * BLK_PX + wpx * 64 + lane;
+        live = p < HW;
+        const int pc = live ? p : 0;
+        y = pc / g.W; x = pc - y * g.W;
     }
-    auto own = [&](int s) { return s < 4 ? 0 : (s > 4 ? HW : half * HW); };      // ci * HW of k-step s (k = 2 s + half, ci = k / 9)
-    const float* b0p = in + pc0;
-    const float* b1p = in + pc1;
-    const float4* ap4 = reinterpret_cast<const float4*>(wp) + (size_t)half * g.Cout + m0 + l31;       // s 0..3 of the pair; + 2 Cout float4: s 4..7
-    const float* ap1 = wp + (size_t)16 * g.Cout + (size_t)half * g.Cout + m0 + l31;                  // s 8
+    const int bias_px = g.H >= 2 ? g.W + 1 : 1;              // one row + one pixel; a one-row map (the tail of a tiny pyramid) has no room for the row: its dy taps are masked anyway
+    const unsigned plane_bytes = (unsigned)HW * 4u, bias_bytes = (unsigned)bias_px * 4u;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (unsigned)g.Cin * plane_bytes, 0x00020000);
 
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};   // [cout tile][pixel tile]
-    // Software pipeline in registers: the 36 operands of channel pair c2+2 are requested before the 36 MFMAs of pair c2 issue
-    // (36 x 64 = 2304 cycles of matrix work cover the L1/L2 latency of the next pair even at one wave per SIMD).
-    // Two register sets in ping-pong, no copies: while the 36 MFMAs of one channel pair issue (36 x 64 = 2304 cycles of matrix work),
-    // the 36 operand loads of the next pair are in flight. load_pair only ISSUES loads (raw values); the out-of-image select is
-    // applied right before each MFMA group, so the only s_waitcnt in front of an MFMA block is for loads issued a whole block
-    // earlier. (Selects or register copies directly behind the loads put the full L2 latency in front of every block: the conv
-    // layers ran at 55-60 % MFMA utilisation that way.)
-    struct ASet { float4 q0, q1; float s8; };               // the nine A values of a pair: s 0..3, s 4..7, s 8
-    ASet a0x, a1x, a0y, a1y; float b0x[9], b1x[9], b0y[9], b1y[9];
-    auto load_pair = [&](ASet& a0, ASet& a1, float (&b0)[9], float (&b1)[9]) {
-        a0.q0 = ap4[0]; a1.q0 = ap4[32];
-        a0.q1 = ap4[(size_t)2 * g.Cout]; a1.q1 = ap4[(size_t)2 * g.Cout + 32];
-        a0.s8 = ap1[0]; a1.s8 = ap1[32];
+    unsigned voff[3];                        // biased byte offset of (row y + r - 1, pixel x - 1) inside a plane; dead lanes: out of range
+    bool rowv[3];
 #pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            b0[s] = b0p[((vm0 >> s) & 1u) ? boff[s] : own(s)];
-            if constexpr (PT == 2) b1[s] = b1p[((vm1 >> s) & 1u) ? boff[s] : own(s)];
-        }
+    for (int r = 0; r < 3; ++r) {
+        voff[r] = live ? (unsigned)(((y + r - 1) * g.W + x - 1 + bias_px) * 4) : 0xFFF00000u;       // >= 0 for every row inside the image
+        rowv[r] = live && (y + r - 1) >= 0 && (y + r - 1) < g.H;
+    }
+    const bool xl = x > 0, xr = x < g.W - 1;
+    auto tapv = [&](int r, int d) { return d == 0 ? (rowv[r] && xl) : (d == 2 ? (rowv[r] && xr) : rowv[r]); };
+    bool tm[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tm[t] = tapv(t / 3, t % 3);
+
+    const float4* ap4 = reinterpret_cast<const float4*>(wp) + (size_t)half * g.Cout + m0 + l31;
+    const float* ap1 = wp + (size_t)16 * g.Cout + (size_t)half * g.Cout + m0 + l31;
+    unsigned soff = plane_bytes - bias_bytes;              // plane 1 (the prologue fetches plane 0 unbiased)
+
+    f32x32 acc0 = {0}, acc1 = {0};           // [cout tile]: registers 0..15 = pixel block 0, 16..31 = block 1
+    struct ASet { float4 q0, q1; float s8; };
+    struct BSet { u32x3 r[2][3]; };
+    ASet a0x, a1x, a0y, a1y; BSet bx, by;
+    // operands are requested in the order the 36 MFMAs of the pair consume them (k = 0..17: A s 0..3 + plane 0 rows, A s 4..7 + plane 1 rows, A s 8), so every
+    // load has the same distance — one whole half iteration — to its first use (with the six A loads first, the first activation row of the next pair had only half of it)
+    auto bload = [&](unsigned so, int r) { return __builtin_amdgcn_raw_buffer_load_b96(rs, voff[r], so, 0); };
+    auto load_pair = [&](ASet& a0, ASet& a1, BSet& b) {          // channels (soff - plane + bias) / plane and the next one
+#ifndef NCT_CONV_TIMING_SKIP
+#define NCT_CONV_TIMING_SKIP 0                                   // timing experiments only (results wrong): 1 = K loop without the A stream, 2 = without the B stream, 3 = neither
+#endif
+        constexpr bool LA = !(NCT_CONV_TIMING_SKIP & 1), LB = !(NCT_CONV_TIMING_SKIP & 2);
+#ifndef NCT_CONV_ORDER
+#define NCT_CONV_ORDER 0
+#endif
+        auto la = [&](int part) {
+            if constexpr (LA) {
+                if (part == 0) { a0.q0 = ap4[0]; if constexpr (CT == 2) a1.q0 = ap4[32]; }
+                if (part == 1) { a0.q1 = ap4[(size_t)2 * g.Cout]; if constexpr (CT == 2) a1.q1 = ap4[(size_t)2 * g.Cout + 32]; }
+                if (part == 2) { a0.s8 = ap1[0]; if constexpr (CT == 2) a1.s8 = ap1[32]; }
+            }
+        };
+        auto lb = [&](int ci) {
+            if constexpr (LB) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) b.r[ci][r] = bload(ci ? soff : soff - plane_bytes, r);
+            }
+        };
+        if constexpr (NCT_CONV_ORDER == 0) { la(0); la(1); la(2); lb(0); lb(1); }            // weights first
+        else if constexpr (NCT_CONV_ORDER == 1) { lb(0); la(0); la(1); lb(1); la(2); }        // roughly as consumed
+        else { lb(0); lb(1); la(0); la(1); la(2); }                                          // activations first
         ap4 += (size_t)18 * g.Cout / 4;
         ap1 += (size_t)18 * g.Cout;
-        b0p += (size_t)2 * HW;
-        b1p += (size_t)2 * HW;
+        soff += 2u * plane_bytes;
     };
     auto aval = [](const ASet& a, int s) -> float {
         switch (s) { case 0: return a.q0.x; case 1: return a.q0.y; case 2: return a.q0.z; case 3: return a.q0.w;
                      case 4: return a.q1.x; case 5: return a.q1.y; case 6: return a.q1.z; case 7: return a.q1.w; default: return a.s8; }
     };
-    auto mma_pair = [&](const ASet& a0, const ASet& a1, const float (&b0)[9], const float (&b1)[9]) {
+    auto mma_pair = [&](const ASet& a0, const ASet& a1, const BSet& b) {
 #pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            const float x0 = ((vm0 >> s) & 1u) ? b0[s] : 0.f;
-            const float av0 = aval(a0, s), av1 = aval(a1, s);
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, x0, acc00, 0, 0, 0);
-            if constexpr (PT == 2) {
-                const float x1 = ((vm1 >> s) & 1u) ? b1[s] : 0.f;
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, x1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, x0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, x1, acc11, 0, 0, 0);
+        for (int k = 0; k < 18; ++k) {
+            const int ci = k / 9, t = k - 9 * ci, r = t / 3, d = t - 3 * r, s = k >> 1;
+            const float bv = tm[t] ? __uint_as_float(b.r[ci][r][d]) : 0.f;
+            if (k & 1) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x1f32(aval(a0, s), bv, acc0, 1, 1, 0);
+                if constexpr (CT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x1f32(aval(a1, s), bv, acc1, 1, 1, 0);
             } else {
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, x0, acc10, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x1f32(aval(a0, s), bv, acc0, 1, 0, 0);
+                if constexpr (CT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x1f32(aval(a1, s), bv, acc1, 1, 0, 0);
             }
         }
     };
-    // schedule of one half iteration: MFMA, load, MFMA, load, ... — the 36 loads ride in the shadow of the 36 MFMAs instead of
-    // draining the matrix pipe while they issue in one burst
+#ifndef NCT_CONV_SCHED
+#define NCT_CONV_SCHED 0
+#endif
     auto interleave = [] {
-        if constexpr (PT == 2) {                                       // 36 MFMAs, 24 loads (6 A + 18 B)
+        if constexpr (NCT_CONV_SCHED == 2) return;
+        if constexpr (CT == 2) {                                       // 36 MFMAs, 12 loads (6 A + 6 B)
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one VMEM read
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NCT_CONV_SCHED == 1 ? 1 : 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NCT_CONV_SCHED == 1 ? 2 : 1, 0);
             }
-        } else {                                                       // 18 MFMAs, 15 loads (6 A + 9 B)
+        } else {                                                       // 18 MFMAs, 9 loads (3 A + 6 B)
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
     };
-    load_pair(a0x, a1x, b0x, b1x);
+    // prologue: channel pair 0. Plane 0 has no room for the bias in front of it: unbiased offsets, x == 0 lanes fetch (x, x+1, x+2) and rotate.
+    {
+        a0x.q0 = ap4[0]; a0x.q1 = ap4[(size_t)2 * g.Cout]; a0x.s8 = ap1[0];
+        if constexpr (CT == 2) { a1x.q0 = ap4[32]; a1x.q1 = ap4[(size_t)2 * g.Cout + 32]; a1x.s8 = ap1[32]; }
+        ap4 += (size_t)18 * g.Cout / 4;
+        ap1 += (size_t)18 * g.Cout;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const unsigned v0 = voff[r] - bias_bytes + (xl ? 0u : 4u);          // rows above the image wrap to out-of-range values: they read zeros and are masked
+            u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, v0, 0, 0);
+            if (!xl) { t.z = t.y; t.y = t.x; }
+            bx.r[0][r] = t;
+            bx.r[1][r] = __builtin_amdgcn_raw_buffer_load_b96(rs, voff[r], soff, 0);
+        }
+        soff += 2u * plane_bytes;
+    }
     int c2 = 0;
     for (; c2 + 4 <= g.Cin; c2 += 4) {
-        load_pair(a0y, a1y, b0y, b1y);                            // channels c2+2, c2+3
-        mma_pair(a0x, a1x, b0x, b1x);
+        load_pair(a0y, a1y, by);                                  // channels c2+2, c2+3
+        mma_pair(a0x, a1x, bx);
         interleave();
         __builtin_amdgcn_sched_barrier(0);
-        // channels c2+4, c2+5 — unconditionally: a branch around these loads makes the waitcnt pass assume they were NOT issued and
-        // drain everything inside the next MFMA block. Past the last pair the pointers are rewound and the (unused) loads re-read it.
-        if (c2 + 4 >= g.Cin) { ap4 -= (size_t)18 * g.Cout / 4; ap1 -= (size_t)18 * g.Cout; b0p -= (size_t)2 * HW; b1p -= (size_t)2 * HW; }
-        load_pair(a0x, a1x, b0x, b1x);
-        mma_pair(a0y, a1y, b0y, b1y);
+        // channels c2+4, c2+5 — unconditionally (see k_conv3x3_mfma); past the last pair the pointers are rewound and the unused loads re-read it
+        if (c2 + 4 >= g.Cin) { ap4 -= (size_t)18 * g.Cout / 4; ap1 -= (size_t)18 * g.Cout; soff -= 2u * plane_bytes; }
+        load_pair(a0x, a1x, bx);
+        mma_pair(a0y, a1y, by);
         interleave();
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (c2 < g.Cin) mma_pair(a0x, a1x, b0x, b1x);                 // odd number of channel pairs
+    if (c2 < g.Cin) mma_pair(a0x, a1x, bx);                       // odd number of channel pairs
 
-    // epilogue: D row (cout) = (r&3) + 8*(r>>2) + 4*half, D col (pixel) = l31
+    // epilogue: register 16 b + r of a tile = (cout row (r&3) + 8 (r>>2) + 4 half, pixel 32 b + l31)
+    if constexpr (POOL) {
+        const int xx = 32 * tile_x + l31, y0 = 2 * tile_y;                   // column of this lane in both blocks (whatever its half), top row of the tile
+        const bool ok0 = y0 < g.H && xx < g.W, ok1 = y0 + 1 < g.H && xx < g.W;
+        const size_t po = (size_t)tile_y * g.Wo + (xx >> 1), pn = (size_t)g.Ho * g.Wo;
+        const bool writer = ok0 && !(l31 & 1);
+        auto pool4 = [&](float top, float bot) {                            // window order of the Caffe loop: (y0, x), (y0, x+1), (y0+1, x), (y0+1, x+1); clipped = skipped
+            top = ok0 ? top : -3.402823466e+38f; bot = ok1 ? bot : -3.402823466e+38f;
+            const float top_r = dpp_rot<0xB1>(top), bot_r = dpp_rot<0xB1>(bot);          // quad_perm:[1,0,3,2]: the odd neighbour's values in the even lane
+            float m = -3.402823466e+38f;
+            m = top > m ? top : m; m = top_r > m ? top_r : m; m = bot > m ? bot : m; m = bot_r > m ? bot_r : m;
+            return m;
+        };
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int co0 = m0 + row, co1 = m0 + 32 + row;
-        const float bb0 = bias[co0], bb1 = bias[co1];
-        float v00 = acc00[r] + bb0, v01 = acc01[r] + bb0, v10 = acc10[r] + bb1, v11 = acc11[r] + bb1;
-        if (relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
-        if (live0) { out[(size_t)co0 * HW + p0] = v00; out[(size_t)co1 * HW + p0] = v10; }
-        if constexpr (PT == 2) { if (live1) { out[(size_t)co0 * HW + p1] = v01; out[(size_t)co1 * HW + p1] = v11; } }
+        for (int r = 0; r < 16; ++r) {
+            const int co0 = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float bb0 = bias[co0];
+            float t0 = acc0[r] + bb0, u0 = acc0[16 + r] + bb0;
+            if (relu) { t0 = fmaxf(t0, 0.f); u0 = fmaxf(u0, 0.f); }
+            const float m0v = pool4(t0, u0);
+            if (writer) out[(size_t)co0 * pn + po] = m0v;
+            if constexpr (CT == 2) {
+                const float bb1 = bias[co0 + 32];
+                float t1 = acc1[r] + bb1, u1 = acc1[16 + r] + bb1;
+                if (relu) { t1 = fmaxf(t1, 0.f); u1 = fmaxf(u1, 0.f); }
+                const float m1v = pool4(t1, u1);
+                if (writer) out[(size_t)(co0 + 32) * pn + po] = m1v;
+            }
+        }
+    } else {
+        const int pw = pt * BLK_PX + wpx * 64;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int pp = pw + 32 * b + l31;
+            const bool lv = pp < HW;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co0 = m0 + row;
+                float v0 = acc0[16 * b + r] + bias[co0];
+                if (relu) v0 = fmaxf(v0, 0.f);
+                if (lv) out[(size_t)co0 * HW + pp] = v0;
+                if constexpr (CT == 2) {
+                    float v1 = acc1[16 * b + r] + bias[co0 + 32];
+                    if (relu) v1 = fmaxf(v1, 0.f);
+                    if (lv) out[(size_t)(co0 + 32) * HW + pp] = v1;
+                }
+            }
+        }
     }
 }
 
+// Does the 32 x 2 tile of the fused-pool form fit a H x W map? (auto rule: at most 4 % more wave tiles than the 1-D tiling — 700^2, 350^2: +0.6 %; 175^2, 88^2: +9 %, not fused)
+bool nctk_conv3x3_pool_fits(int H, int W) {
+    const long t2 = (long)cdiv(W, 32) * cdiv(H, 2), t1 = cdiv(H * W, 64);
+    return t2 * 100 <= t1 * 104;
+}
+
+// pool = 1: `out` receives only the 2x2/2 max-pooled map [Cout][(H-1)/2+1][(W-1)/2+1] (what nctk_maxpool2x2 would make of the conv output)
 int nctk_conv3x3(nct_ctx* ctx, hipStream_t s, const float* in, const float* wp, const float* bias, float* out,
-                 int Cin, int Cout, int H, int W, int relu) {
+                 int Cin, int Cout, int H, int W, int relu, int pool) {
     NCT_REQUIRE((Cin & 1) == 0 && (Cout & 63) == 0, "conv3x3: Cin=%d must be even (pad) and Cout=%d a multiple of 64", Cin, Cout);
+    NCT_REQUIRE((size_t)Cin * H * W * 4 < ((size_t)1 << 32), "conv3x3: input of %d x %d x %d floats exceeds the 4 GB a buffer descriptor addresses", Cin, H, W);
     const int WCO = (Cout % 128 == 0) ? 2 : 1;
-    // two pixel tiles per wave (best operand reuse) unless that grid has fewer than 512 workgroups (two per CU): then one tile per wave
-    const int full_blocks = cdiv(H * W, (4 / WCO) * 64) * (Cout / (64 * WCO));
-    const int PT = full_blocks >= NCT_CONV_PT1_BELOW ? 2 : 1;
-    const int blk_px = (4 / WCO) * 32 * PT;
-    ConvGeom g{Cin, Cout, H, W, cdiv(H * W, blk_px), Cout / (64 * WCO)};
-    const int nblocks = cdiv(g.npx_blocks, 8) * 8 * g.nblk_n;
-    if (WCO == 2 && PT == 2)      hipLaunchKernelGGL((k_conv3x3_mfma<2, 2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
-    else if (WCO == 2)            hipLaunchKernelGGL((k_conv3x3_mfma<2, 1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
-    else if (PT == 2)             hipLaunchKernelGGL((k_conv3x3_mfma<1, 2>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
-    else                          hipLaunchKernelGGL((k_conv3x3_mfma<1, 1>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);
+    const int tiles_x = cdiv(W, 32), ntiles = pool ? tiles_x * cdiv(H, 2) : cdiv(H * W, 64);         // 64-pixel wave tiles
+    // 64 couts x 64 px per wave unless that grid has fewer than NCT_CONV_PT1_BELOW workgroups: then 32 couts per wave, four waves along cout
+    const int full_blocks = cdiv(ntiles, 4 / WCO) * (Cout / (64 * WCO));
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+#define NCT_CONV_LAUNCH(wco, ct, wpx, nblk_n_)                                                                                                    \
+    do {                                                                                                                                          \
+        ConvGeom g{Cin, Cout, H, W, cdiv(ntiles, wpx), nblk_n_, tiles_x, Ho, Wo};                                                                  \
+        const int nblocks = cdiv(g.npx_blocks, 8) * 8 * g.nblk_n;                                                                                 \
+        if (pool) hipLaunchKernelGGL((k_conv3x3_mfma2b<wco, ct, true>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);             \
+        else      hipLaunchKernelGGL((k_conv3x3_mfma2b<wco, ct, false>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);            \
+    } while (0)
+    if (full_blocks >= NCT_CONV_PT1_BELOW) {
+        if (WCO == 2) NCT_CONV_LAUNCH(2, 2, 2, Cout / 128);
+        else          NCT_CONV_LAUNCH(1, 2, 4, Cout / 64);
+    } else if (Cout % 128 == 0) NCT_CONV_LAUNCH(4, 1, 1, Cout / 128);
+    else                        NCT_CONV_LAUNCH(2, 1, 2, Cout / 64);
+#undef NCT_CONV_LAUNCH
     NCT_LAUNCH_CHECK();
     return 0;
 }

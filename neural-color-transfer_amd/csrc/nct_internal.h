@@ -36,6 +36,7 @@ struct nct_ctx {
     // (no host syncs in between: see nct_pair_timing in nct.h)
     int wls_split = 0;                          // NCT_FLAG_LATENCY of the running pair: a- and b-half of the WLS solve on two streams
     int wls_graph = 0;                          // experiment hook (env NCT_WLS_GRAPH=1): replay the PCG iteration batch as a HIP graph
+    int conv_pool_fuse = -1;                    // VGG: 2x2 max-pool inside the conv epilogue: -1 = where the tile shape fits the map (nctk_conv3x3_pool_fits), 0 never, 1 always (NCT_CONV_POOL_FUSE; tests)
     double wls_rtol = 1e-7;                     // relative residual at which the WLS solve stops. 1e-7: the 8-bit result of every level equals the EXACT solve's on the
                                                 // full-size fixtures (1e-6: 55.4 / 50.1 dB; +4.3 ms per 700x700 pair; DESIGN.md §4 rtol sweep). Experiment hook: env NCT_WLS_RTOL
     int wls_maxit = 5000;                       // iteration budget of the WLS solve (test hook: env NCT_WLS_MAXIT)

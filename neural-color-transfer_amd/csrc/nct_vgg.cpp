@@ -16,7 +16,8 @@
 #include <fcntl.h>
 #include <unistd.h>
 
-int nctk_conv3x3(nct_ctx*, hipStream_t, const float* in, const float* wp, const float* bias, float* out, int Cin, int Cout, int H, int W, int relu);
+int nctk_conv3x3(nct_ctx*, hipStream_t, const float* in, const float* wp, const float* bias, float* out, int Cin, int Cout, int H, int W, int relu, int pool);
+bool nctk_conv3x3_pool_fits(int H, int W);
 int nctk_maxpool2x2(nct_ctx*, hipStream_t, const float* in, float* out, int C, int H, int W);
 int nctk_vgg_preprocess(nct_ctx*, hipStream_t, const uint8_t* bgr, int stride, float* out, int H, int W);
 int nctk_pack_weights(nct_ctx*, hipStream_t, const float* w, float* wp, int Cout, int Cin, int Cin_pad);
@@ -369,11 +370,15 @@ int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H,
         float* dst;
         if (tap >= 0 && d_taps && d_taps[tap]) dst = d_taps[tap];
         else dst = (cur == pp[0]) ? pp[1] : pp[0];
-        rc = nctk_conv3x3(ctx, s, cur, v->wp[i], v->bias[i], dst, (kCin[i] + 1) & ~1, kCout[i], h, w, 1);
+        // a pooled layer is never a tap (taps are conv*_1): where the tile shape fits, the pool rides in the conv epilogue and the unpooled map is never written
+        const bool pooled = kPoolAfter[i] && i < last;
+        const bool fuse = pooled && tap < 0 && (ctx->conv_pool_fuse == 1 || (ctx->conv_pool_fuse < 0 && nctk_conv3x3_pool_fits(h, w)));
+        rc = nctk_conv3x3(ctx, s, cur, v->wp[i], v->bias[i], dst, (kCin[i] + 1) & ~1, kCout[i], h, w, 1, fuse ? 1 : 0);
         if (rc) return rc;
         cur = dst;
         if (tap >= 0 && dims) { dims[tap * 3 + 0] = kCout[i]; dims[tap * 3 + 1] = h; dims[tap * 3 + 2] = w; }
-        if (kPoolAfter[i] && i < last) {
+        if (fuse) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+        else if (pooled) {
             float* pd = (cur == pp[0]) ? pp[1] : pp[0];
             rc = nctk_maxpool2x2(ctx, s, cur, pd, kCout[i], h, w);
             if (rc) return rc;
@@ -431,7 +436,7 @@ int nct_conv3x3_relu(nct_ctx* ctx, const float* in_chw, int Cin, int H, int W, c
     NCT_HIP(hipMemcpyAsync(db, bias, sizeof(float) * Cout, hipMemcpyHostToDevice, ctx->stream));
     int rc = nctk_pack_weights(ctx, ctx->stream, dw, dwp, Cout, Cin, cin_pad);
     if (rc) return rc;
-    rc = nctk_conv3x3(ctx, ctx->stream, din, dwp, db, dout, cin_pad, Cout, H, W, relu);
+    rc = nctk_conv3x3(ctx, ctx->stream, din, dwp, db, dout, cin_pad, Cout, H, W, relu, 0);
     if (rc) return rc;
     NCT_HIP(hipMemcpyAsync(out_chw, dout, sizeof(float) * Cout * hw, hipMemcpyDeviceToHost, ctx->stream));
     NCT_HIP(hipStreamSynchronize(ctx->stream));

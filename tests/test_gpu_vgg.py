@@ -14,7 +14,7 @@ def bits(a):
 
 
 CONV_CASES = [(3, 64, 17, 23), (64, 64, 40, 70), (64, 128, 33, 35), (128, 256, 20, 45), (256, 512, 11, 13), (512, 512, 9, 16),
-              (4, 64, 2, 2), (64, 64, 180, 200), (128, 128, 5, 177)]
+              (4, 64, 2, 2), (64, 64, 180, 200), (128, 128, 5, 177), (64, 128, 2, 67), (6, 64, 130, 2)]
 
 
 @pytest.mark.parametrize("shape", CONV_CASES)
@@ -73,6 +73,23 @@ def test_vgg19_features_bit_exact(ctx, oracle, weights, hw):
     # stopping at a shallower tap gives the same shallow taps
     g2 = ctx.vgg19_features(img, 2)
     assert len(g2) == 2 and np.array_equal(bits(g2[1]), bits(o[1]))
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("hw", [(40, 52), (71, 45), (66, 96), (2, 2)])
+def test_vgg19_pool_in_conv_epilogue_bit_exact(oracle, weights, monkeypatch, hw, fuse):
+    """conv1_2 / 2_2 / 3_4 / 4_4 with the following 2x2 max-pool inside the conv epilogue (32 x 2 pixel tiles; forced on — the default only fuses where that tile
+    shape fits the map, i.e. at 700^2 and 350^2 of the bench pair — and forced off): same bits as Caffe's conv + ceil-mode clipped pooling, odd sizes included."""
+    import nct
+    monkeypatch.setenv("NCT_CONV_POOL_FUSE", fuse)
+    ws, bs = weights
+    img = synth.image(11, *hw)
+    with nct.Context(0) as c:
+        c.vgg19_load_raw(ws, bs)
+        g = c.vgg19_features(img, 5)
+    o = oracle.vgg19_features(img, ws, bs, 5)
+    for t in range(5):
+        assert g[t].shape == o[t].shape and np.array_equal(bits(g[t]), bits(o[t])), f"tap {t + 1}"
 
 
 @pytest.mark.parametrize("fmt,unpacked", [("v1", False), ("v2", False), ("v1", True)])
