@@ -435,7 +435,7 @@ def vgg_mfma(sh, sw, rh, rw, levels, vgg_ms):
     cs, cr = cum_flops(sh, sw), cum_flops(rh, rw)
     per_pair = cs[tap_conv[4]] + cr[tap_conv[4]] + sum(cs[tap_conv[t]] for t in range(4 - (levels - 1), 4))
     tf = per_pair / (vgg_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_conv3x3_mfma (v_mfma_f32_32x32x2_f32), all forwards of a pair", "flops_per_pair": per_pair,
+    return {"bound": "mfma", "kernel": "k_conv3x3_mfma2b (v_mfma_f32_32x32x1_2b_f32), all forwards of a pair", "flops_per_pair": per_pair,
             "stage_ms": vgg_ms, "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
 
 
