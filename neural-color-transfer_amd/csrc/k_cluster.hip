@@ -250,11 +250,18 @@ __global__ void k_cell_masks(const int* __restrict__ labels, int lh, int lw, uns
 }
 
 // ---- (cluster, colour-cell) membership entries: key = cluster << 3*cb | cell(L,a,b), value = pixel id. The cell edge is 2^cs Lab
-// units (cb = 8 - cs bits per axis): 32-unit cells (8^3) below 3k pixels, 16-unit below 12k, 8-unit below 100k, 4-unit cells (64^3)
-// above, where an 8-unit cell already holds dozens of points and rings 0-1 (always visited) would scan 8x more than needed.
+// units (cb = 8 - cs bits per axis): 32-unit cells (8^3) below 3k pixels, 16-unit below 12k, 8-unit below 100k, 2-unit cells (128^3)
+// above: the search is bound by the points it scans in rings 0-1 (4-unit cells: 2.3 ms at 700x700, 8-unit 6.7, 16-unit 23, 2-unit 1.4).
 __device__ __forceinline__ unsigned cell_key(int l, unsigned col, int cs) {
     const int cb = 8 - cs;
     return ((unsigned)l << (3 * cb)) | (((col >> 16) & 255u) >> cs) << (2 * cb) | (((col >> 8) & 255u) >> cs) << cb | ((col & 255u) >> cs);
+}
+// sort key of an entry = cell_key << 3 cs | the colour's position INSIDE its cell (28 bits for every cs): entries of a cell come out ordered by colour, so the 64 queries of
+// a wave are (nearly) the same colour — they prune the same neighbouring cells and pass the distance pre-filter together (the search loops are per-thread: what one lane
+// cannot skip, the whole wave walks). The order inside a cell does not enter any result.
+__device__ __forceinline__ unsigned entry_key(int l, unsigned col, int cs) {
+    const unsigned m = (1u << cs) - 1u;
+    return (cell_key(l, col, cs) << (3 * cs)) | (((col >> 16) & m) << (2 * cs)) | (((col >> 8) & m) << cs) | (col & m);
 }
 __global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* __restrict__ lab, int lw, int lh, int h, int w, int samples, int nlabels_host, const int* __restrict__ nlabels_dev, int cs,
                               int* __restrict__ count, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
@@ -275,15 +282,18 @@ __global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* 
         int base = 0;
         if (lane == leader) base = atomicAdd(count, __popcll(bal));
         base = __shfl(base, leader);
-        if (in) { const int pos = base + __popcll(bal & ((1ull << lane) - 1ull)); keys[pos] = cell_key(l, col, cs); vals[pos] = (unsigned)i; }
+        if (in) { const int pos = base + __popcll(bal & ((1ull << lane) - 1ull)); keys[pos] = entry_key(l, col, cs); vals[pos] = (unsigned)i; }
     }
 }
 // start[k] = first sorted entry with key >= k, k in [0, nkeys]
-__global__ void k_knn_cell_starts(const unsigned* __restrict__ keys, int m, int* __restrict__ start, int nkeys) {
+// lo/hi (nullable): start table of the 64x coarser cells (keys >> 6) — the search for cell k then stays inside its coarse cell's few entries. With 2-unit cells the
+// table has 33.5 M entries, most of them empty cells: a full binary search per cell cost 287 us at 700x700.
+__global__ void k_knn_cell_starts(const unsigned* __restrict__ keys, int m, int* __restrict__ start, int nkeys, int shift, const int* __restrict__ coarse) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > nkeys) return;
     int lo = 0, hi = m;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < (unsigned)k) lo = mid + 1; else hi = mid; }
+    if (coarse) { lo = coarse[k >> 6]; hi = coarse[(k >> 6) + 1]; }
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((keys[mid] >> shift) < (unsigned)k) lo = mid + 1; else hi = mid; }
     start[k] = lo;
 }
 
@@ -312,7 +322,7 @@ __device__ __forceinline__ void knn_grid_entry(int e, const unsigned* __restrict
                                                const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
                                                int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
     const int cb = 8 - cs, CELLS = 1 << cb; const unsigned cmask = (unsigned)CELLS - 1u;
-    const unsigned key = keys[e];
+    const unsigned key = keys[e] >> (3 * cs);
     const int id = (int)vals[e];
     const int l = (int)(key >> (3 * cb));
     const int cz = (int)((key >> (2 * cb)) & cmask), cy = (int)((key >> cb) & cmask), cx = (int)(key & cmask);
@@ -340,19 +350,32 @@ __device__ __forceinline__ void knn_grid_entry(int e, const unsigned* __restrict
         }
     };
     const int base = l << (3 * cb);
+    // Cells that cannot hold a winner are not scanned (round 3): along an axis, a point in cell c differs from the query's coordinate q by at least gap(c) = the distance
+    // from q to the cell's interval (0 for the query's own cell), so every point of cell (z, y, x) has d^2 >= gap_z^2 + gap_y^2 + gap_x^2; a cell whose bound EXCEEDS the
+    // current (k+1)-th best d^2 can be skipped — its points lose to it even on ties. The bound only tightens while scanning, and the final set is the k+1 smallest under
+    // the total order (dist, id) whatever the order of the scan: same ids as the brute-force oracle. With the query's own cell scanned first (a 4-unit cell holds a median of
+    // 89 points at 700x700, the 9th-nearest colour is 1-2 units away) most of the 26 cells of ring 1 drop out: ~2400 -> a few hundred points scanned per query.
+    const int qz = (int)((pc >> 16) & 255u), qy = (int)((pc >> 8) & 255u), qx = (int)(pc & 255u);   // key order: (col >> 16) is the most significant axis
+    auto gap = [&](int q, int c) { const int lo = c << cs, hi = lo + (1 << cs) - 1; return q < lo ? lo - q : (q > hi ? q - hi : 0); };
     for (int r = 0; r < CELLS; ++r) {
         if (r > 0) { const int bound = (r - 1) * (1 << cs) + 1; if (bq[KNN_K] < bound * bound) break; }
         for (int dz = -r; dz <= r; ++dz) {
             const int z = cz + dz; if (z < 0 || z >= CELLS) continue;
+            const int gz = gap(qz, z);
             for (int dy = -r; dy <= r; ++dy) {
                 const int yy = cy + dy; if (yy < 0 || yy >= CELLS) continue;
+                const int gy = gap(qy, yy), gzy = gz * gz + gy * gy;
+                if (gzy > bq[KNN_K]) continue;
                 const int row = base | (z << (2 * cb)) | (yy << cb);
-                if (max(abs(dz), abs(dy)) == r) {                       // full x range of the shell face
-                    const int x0 = max(cx - r, 0), x1 = min(cx + r, CELLS - 1);
+                if (max(abs(dz), abs(dy)) == r) {                       // full x range of the shell face, minus the cells at its ends that are too far
+                    int x0 = max(cx - r, 0), x1 = min(cx + r, CELLS - 1);
+                    while (x0 < x1 && gzy + gap(qx, x0) * gap(qx, x0) > bq[KNN_K]) ++x0;
+                    while (x1 > x0 && gzy + gap(qx, x1) * gap(qx, x1) > bq[KNN_K]) --x1;
+                    if (gzy + gap(qx, x0) * gap(qx, x0) > bq[KNN_K]) continue;              // x0 == x1 and that cell is too far as well
                     scan(start[row | x0], start[(row | x1) + 1]);
                 } else {                                                 // only the two end cells
-                    if (cx - r >= 0) scan(start[row | (cx - r)], start[(row | (cx - r)) + 1]);
-                    if (cx + r < CELLS) scan(start[row | (cx + r)], start[(row | (cx + r)) + 1]);
+                    if (cx - r >= 0 && gzy + gap(qx, cx - r) * gap(qx, cx - r) <= bq[KNN_K]) scan(start[row | (cx - r)], start[(row | (cx - r)) + 1]);
+                    if (cx + r < CELLS && gzy + gap(qx, cx + r) * gap(qx, cx + r) <= bq[KNN_K]) scan(start[row | (cx + r)], start[(row | (cx + r)) + 1]);
                 }
             }
         }
@@ -418,14 +441,14 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     const int n = h * w;
     // cell edge 2^cs Lab units, chosen so that a cell holds a handful of points: sparse (coarse-level) point sets in fine cells make a
     // query walk thousands of empty cells before it has seen k+1 points
-    const int cs = n >= 100000 ? 2 : n >= 12000 ? 3 : n >= 3000 ? 4 : 5, cb = 8 - cs;
+    const int cs = n >= 100000 ? 1 : n >= 12000 ? 3 : n >= 3000 ? 4 : 5, cb = 8 - cs;
     const int cap = n * KNN_SLOTS, nkeys = 16 << (3 * cb);
-    const unsigned key_sentinel = 1u << (3 * cb + 4);      // sorts after every real key (16 clusters x cells)
+    const unsigned key_sentinel = 1u << 28;                 // sorts after every real key (16 clusters x cells x in-cell position = 4 + 3 cb + 3 cs = 28 bits)
     DevBuf<unsigned> mask(ctx, (size_t)lh * lw), keys(ctx, cap), vals(ctx, cap), keys_s(ctx, cap), vals_s(ctx, cap);
     DevBuf<unsigned> cols(ctx, cap);
-    DevBuf<int> count(ctx, 1), start(ctx, nkeys + 2), nslot(ctx, n), cand_id(ctx, (size_t)n * KNN_SLOTS * KNN_K);
+    DevBuf<int> count(ctx, 1), start(ctx, nkeys + 2), cstart(ctx, (nkeys >> 6) + 4), nslot(ctx, n), cand_id(ctx, (size_t)n * KNN_SLOTS * KNN_K);
     DevBuf<double> cand_d(ctx, (size_t)n * KNN_SLOTS * KNN_K);
-    if (!mask.ok() || !keys.ok() || !vals.ok() || !keys_s.ok() || !vals_s.ok() || !cols.ok() || !count.ok() || !start.ok() || !nslot.ok() || !cand_id.ok() || !cand_d.ok()) return NCT_ERR_HIP;
+    if (!mask.ok() || !keys.ok() || !vals.ok() || !keys_s.ok() || !vals_s.ok() || !cols.ok() || !count.ok() || !start.ok() || !cstart.ok() || !nslot.ok() || !cand_id.ok() || !cand_d.ok()) return NCT_ERR_HIP;
     NCT_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
     NCT_HIP(hipMemsetAsync(nslot, 0, sizeof(int) * n, s));
     NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)(unsigned*)keys, (int)key_sentinel, cap, s));       // unused slots sort to the end
@@ -435,11 +458,16 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
                        (int*)count, (unsigned*)keys, (unsigned*)vals);
     NCT_LAUNCH_CHECK();
     size_t tmp_bytes = 0;
-    NCT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 3 * cb + 5, s));
+    NCT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 29, s));
     DevBuf<char> tmp(ctx, tmp_bytes ? tmp_bytes : 16);
     if (!tmp.ok()) return NCT_ERR_HIP;
-    NCT_HIP(rocprim::radix_sort_pairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 3 * cb + 5, s));
-    hipLaunchKernelGGL(k_knn_cell_starts, dim3(cdiv(nkeys + 1, 256)), dim3(256), 0, s, (const unsigned*)keys_s, cap, (int*)start, nkeys);
+    NCT_HIP(rocprim::radix_sort_pairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 29, s));
+    if (nkeys >= (1 << 22)) {                            // two stages: 64x coarser cells first
+        hipLaunchKernelGGL(k_knn_cell_starts, dim3(cdiv((nkeys >> 6) + 2, 256)), dim3(256), 0, s, (const unsigned*)keys_s, cap, (int*)cstart, (nkeys >> 6) + 1, 3 * cs + 6, (const int*)nullptr);
+        NCT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_knn_cell_starts, dim3(cdiv(nkeys + 1, 256)), dim3(256), 0, s, (const unsigned*)keys_s, cap, (int*)start, nkeys, 3 * cs, (const int*)cstart);
+    } else
+        hipLaunchKernelGGL(k_knn_cell_starts, dim3(cdiv(nkeys + 1, 256)), dim3(256), 0, s, (const unsigned*)keys_s, cap, (int*)start, nkeys, 3 * cs, (const int*)nullptr);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_entry_colours, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, (const int*)count, (const unsigned*)vals_s, (unsigned*)cols);
     NCT_LAUNCH_CHECK();
