@@ -113,33 +113,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     struct ASet { float4 q0, q1; float s8; };
     struct BSet { u32x3 r[2][3]; };
     ASet a0x, a1x, a0y, a1y; BSet bx, by;
-    // operands are requested in the order the 36 MFMAs of the pair consume them (k = 0..17: A s 0..3 + plane 0 rows, A s 4..7 + plane 1 rows, A s 8), so every
-    // load has the same distance — one whole half iteration — to its first use (with the six A loads first, the first activation row of the next pair had only half of it)
+    // weights first, then the activation rows (requesting them in the order the MFMAs consume them, or activations first, measured 3-5 % slower: DESIGN.md 9)
     auto bload = [&](unsigned so, int r) { return __builtin_amdgcn_raw_buffer_load_b96(rs, voff[r], so, 0); };
-    auto load_pair = [&](ASet& a0, ASet& a1, BSet& b) {          // channels (soff - plane + bias) / plane and the next one
 #ifndef NCT_CONV_TIMING_SKIP
 #define NCT_CONV_TIMING_SKIP 0                                   // timing experiments only (results wrong): 1 = K loop without the A stream, 2 = without the B stream, 3 = neither
 #endif
+    auto load_pair = [&](ASet& a0, ASet& a1, BSet& b) {          // channels (soff - plane + bias) / plane and the next one
         constexpr bool LA = !(NCT_CONV_TIMING_SKIP & 1), LB = !(NCT_CONV_TIMING_SKIP & 2);
-#ifndef NCT_CONV_ORDER
-#define NCT_CONV_ORDER 0
-#endif
-        auto la = [&](int part) {
-            if constexpr (LA) {
-                if (part == 0) { a0.q0 = ap4[0]; if constexpr (CT == 2) a1.q0 = ap4[32]; }
-                if (part == 1) { a0.q1 = ap4[(size_t)2 * g.Cout]; if constexpr (CT == 2) a1.q1 = ap4[(size_t)2 * g.Cout + 32]; }
-                if (part == 2) { a0.s8 = ap1[0]; if constexpr (CT == 2) a1.s8 = ap1[32]; }
-            }
-        };
-        auto lb = [&](int ci) {
-            if constexpr (LB) {
+        if constexpr (LA) {
+            a0.q0 = ap4[0]; a0.q1 = ap4[(size_t)2 * g.Cout]; a0.s8 = ap1[0];
+            if constexpr (CT == 2) { a1.q0 = ap4[32]; a1.q1 = ap4[(size_t)2 * g.Cout + 32]; a1.s8 = ap1[32]; }
+        }
+        if constexpr (LB) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) b.r[ci][r] = bload(ci ? soff : soff - plane_bytes, r);
-            }
-        };
-        if constexpr (NCT_CONV_ORDER == 0) { la(0); la(1); la(2); lb(0); lb(1); }            // weights first
-        else if constexpr (NCT_CONV_ORDER == 1) { lb(0); la(0); la(1); lb(1); la(2); }        // roughly as consumed
-        else { lb(0); lb(1); la(0); la(1); la(2); }                                          // activations first
+            for (int r = 0; r < 3; ++r) { b.r[0][r] = bload(soff - plane_bytes, r); b.r[1][r] = bload(soff, r); }
+        }
         ap4 += (size_t)18 * g.Cout / 4;
         ap1 += (size_t)18 * g.Cout;
         soff += 2u * plane_bytes;
