@@ -69,8 +69,8 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="pair700", choices=WORKLOADS)
     ap.add_argument("--size", type=int, default=0, help="[test hook] image side for the pair* workloads (0 = the workload's own)")
     ap.add_argument("--inflight", type=int, default=4, help="independent pairs in flight per GPU (contexts + host threads)")
