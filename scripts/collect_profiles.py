@@ -119,9 +119,10 @@ if os.path.exists(pm_all):
 
 vg = os.path.join(src, "vgg_mfma_by_grid.txt")
 if os.path.exists(vg):
-    V = [f"# round 3 — MFMA counters of the shipped conv kernel `k_conv3x3_mfma` (VGG19 forward 700x700 -> conv5_1, three forwards; two counter-only passes), build {bench['build_id']}", "",
+    V = [f"# round 3 — MFMA counters of the shipped conv kernel `k_conv3x3_mfma2b<WCO, CT, POOL>` (VGG19 forward 700x700 -> conv5_1, three forwards; two counter-only passes), build {bench['build_id']}", "",
          "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (launch cycles x 1024 SIMDs), launch cycles = GRBM_GUI_ACTIVE / 8 XCDs (`scripts/pmc_by_grid.py`; the grid size tells the layers apart:",
-         "491520 = conv1_x at 700^2, 245760 = conv2_x, 122880 = conv3_x, 65536 = conv4_x, 32768 = conv5_1). bench.py repeats the two passes live (`vgg_mfma.mfma_util`:",
+         "491520 = conv1_1 at 700^2, 493568 = conv1_2 + pool, 245760 = conv2_1, 247808 = conv2_2 + pool, 122880 = conv3_x, 65536 = conv4_x, 32768 = conv5_1). The cycle base is the GRBM counter's, so the",
+         "shares compare layers and builds, not an absolute peak fraction (conv5_1's 124 workgroups could not exceed 0.48). bench.py repeats the two passes live (`vgg_mfma.mfma_util`:",
          f"{bench['vgg_mfma'].get('mfma_util')} over all conv launches).", "", "```"] + [l.rstrip("\n") for l in open(vg)] + ["```"]
     open(os.path.join(dst, f"{R}_pmc_vgg_mfma.md"), "w").write("\n".join(V) + "\n")
 

@@ -1,4 +1,4 @@
-"""VGG19 forward only (700x700 -> conv5_1, synthetic weights): used under rocprofv3 --pmc for the MFMA counters of k_conv3x3_mfma."""
+"""VGG19 forward only (700x700 -> conv5_1, synthetic weights): used under rocprofv3 --pmc for the MFMA counters of k_conv3x3_mfma2b."""
 import sys
 sys.path.insert(0, "tests"); sys.path.insert(0, "neural-color-transfer_amd/python")
 import nct, synth
