@@ -61,7 +61,8 @@ def test_kmeans_blobs(ctx, oracle):
     assert gn == on == 10 and np.array_equal(gl, ol)
 
 
-@pytest.mark.parametrize("case", [(12, 14, 6, 7, 2), (32, 32, 16, 16, 2), (64, 60, 16, 15, 4), (40, 40, 5, 5, 8)])
+# the last two cases reach the 8-unit cells (n >= 12 000) and the 2-unit cells with the two-stage start table (n >= 100 000) of k_knn_grid; a third of each image is one flat colour
+@pytest.mark.parametrize("case", [(12, 14, 6, 7, 2), (32, 32, 16, 16, 2), (64, 60, 16, 15, 4), (40, 40, 5, 5, 8), (120, 110, 15, 14, 8), (320, 324, 20, 21, 16)])
 def test_knn_graph(ctx, oracle, case):
     h, w, lh, lw, samples = case
     img = synth.image(9, h, w)

@@ -14,7 +14,7 @@ def bits(a):
 
 
 CONV_CASES = [(3, 64, 17, 23), (64, 64, 40, 70), (64, 128, 33, 35), (128, 256, 20, 45), (256, 512, 11, 13), (512, 512, 9, 16),
-              (4, 64, 2, 2), (64, 64, 180, 200), (128, 128, 5, 177), (64, 128, 2, 67), (6, 64, 130, 2)]
+              (4, 64, 2, 2), (64, 64, 180, 200), (128, 128, 5, 177), (64, 128, 2, 67), (6, 64, 130, 2), (32, 128, 131, 129)]       # the last one: the 128-cout x 128-px workgroup form (>= 128 workgroups)
 
 
 @pytest.mark.parametrize("shape", CONV_CASES)
