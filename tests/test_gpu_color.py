@@ -88,7 +88,9 @@ def _level_case(seed, H, W, h, w, nlab_grid, samples, oracle):
     return err, s_lvl, g_lvl, s_full, ids, ws
 
 
-@pytest.mark.parametrize("case", [(48, 48, 12, 12, (3, 3), 4, 2), (40, 56, 20, 28, (5, 7), 4, 3), (32, 32, 32, 32, (2, 2), 16, 4)])
+# the last case (136 896 pixels at the level) runs the forms the bandwidth-bound levels use: workgroup-shared in-edge gathers and unfused scalar steps in S1, 48x8 V-cycle tiles in S2,
+# 2-unit kNN cells
+@pytest.mark.parametrize("case", [(48, 48, 12, 12, (3, 3), 4, 2), (40, 56, 20, 28, (5, 7), 4, 3), (32, 32, 32, 32, (2, 2), 16, 4), (372, 368, 372, 368, (23, 23), 16, 4)])
 def test_local_color_transfer_stages(ctx, oracle, case):
     H, W, h, w, grid, samples, layer = case
     err, s_lvl, g_lvl, s_full, ids, ws = _level_case(20 + layer, H, W, h, w, grid, samples, oracle)
