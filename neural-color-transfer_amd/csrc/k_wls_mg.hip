@@ -224,11 +224,12 @@ __device__ __forceinline__ PxCoef px_coef(const Lvl& L, int gy, int gx) {
     c.w0 = c.r ? L.fwx[i] : 0.f; c.w1 = c.l ? L.fwx[i - 1] : 0.f; c.w2 = c.dn ? L.fwy[i] : 0.f; c.w3 = c.up ? L.fwy[i - L.W] : 0.f;
     return c;
 }
-// y = M v at the pixel stored at LDS position p of a grid with row pitch LW (same operation order as lvl_op: +x, -x, +y, -y)
+// y = M v at the pixel stored at LDS position p of a grid with row pitch LW (same operation order as lvl_op: +x, -x, +y, -y). `own` = the thread's own value of v,
+// which it wrote to s_v[.. + p] itself and still holds in registers (a fifth of the stencil's LDS reads)
 template <int NQ, int LW, int LN>
-__device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s_v, int p, vf (&y)[NQ]) {
+__device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s_v, int p, const vf (&own)[NQ], vf (&y)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) y[q] = c.d * s_v[q * LN + p];
+    for (int q = 0; q < NQ; ++q) y[q] = c.d * own[q];
     if (c.r) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= c.w0 * s_v[q * LN + p + 1]; }
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
     for (int k = 1; k < MG_NS; ++k) {
         vf* src = (k & 1) ? s_a : s_b; vf* dst = (k & 1) ? s_b : s_a;
         if (ring(k)) {
-            vf y[NQ]; lds_op<NQ, LW, LN>(c, src, p, y);
+            vf y[NQ]; lds_op<NQ, LW, LN>(c, src, p, xk, y);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 xk[q] = xk[q] + (bq[q] - y[q]) * (c.dinv * mg_rk(k));
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
     }
     vf* xs = (MG_NS & 1) ? s_a : s_b; vf* rs = (MG_NS & 1) ? s_b : s_a;       // the smoothed iterate (on the tile + 1) and where the residual goes
     if (interior) {
-        vf yv[NQ]; lds_op<NQ, LW, LN>(c, xs, p, yv);
+        vf yv[NQ]; lds_op<NQ, LW, LN>(c, xs, p, xk, yv);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) rs[q * LN + p] = bq[q] - yv[q];
     }
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
     for (int k = 0; k < MG_NS; ++k) {
         vf* src = (k & 1) ? s_b : s_a; vf* dst = (k & 1) ? s_a : s_b;
         if (ring(k + 1)) {
-            vf y[NQ]; lds_op<NQ, LW, LN>(c, src, p, y);
+            vf y[NQ]; lds_op<NQ, LW, LN>(c, src, p, xk, y);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 xk[q] = xk[q] + (bq[q] - y[q]) * (k == 0 ? c.dinv : c.dinv * mg_rk(k));
