@@ -356,6 +356,31 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
     const int v = lane;                                     // LPQ 16: the lane's channel chunk; LPQ 8: its 32-byte record of the interleaved pixel
     const int ox = tx * 4 * TQX, oy = ty * 4 * TQY;        // origin of the workgroup's query tile
 
+    constexpr int NSX = 4 * TQX / QW, NSUB = NSX * (4 * TQY / QH);
+    // The NNF word, distance and four neighbour words of a pass's query do not depend on the previous pass: they are requested one pass ahead, so the dependent chain of a
+    // pass is candidate rows only (the chain — NNF words -> first row -> other rows, per pass, per round of resident workgroups — is what a late propagation launch costs)
+    struct QIn { uint32_t vbest; float d; uint32_t vnb[4]; };
+    auto qfetch = [&](int sub, QIn& q) {
+        const int sx = sub % NSX, sy = sub / NSX;
+        const int qx = ox + sx * QW + (grp % QW), qy = oy + sy * QH + (grp / QW);
+        const int ax = qx < g.aw ? qx : g.aw - 1, ay = qy < g.ah ? qy : g.ah - 1;
+        const int qi = ay * g.aw + ax;
+        q.vbest = nnf_in[qi];
+        if (mode != 0) {
+            q.d = d_in[qi];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int nx = ax + ((k == 0) ? -jump : (k == 1 ? jump : 0)), ny = ay + ((k == 2) ? -jump : (k == 3 ? jump : 0));
+                q.vnb[k] = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
+            }
+        }
+    };
+    // (C = 64 only: at C = 128 the six extra registers cost the fourth wave per SIMD — 6.98 vs 6.22 ms for that level, 11.4 with the first pass's words requested early as
+    //  well. The first pass's words are requested in front of the staging loop, whose barrier they then fly under.)
+    constexpr bool AHEAD = LPQ == 8 && NSUB > 1;
+    QIn qnext;
+    if constexpr (AHEAD) qfetch(0, qnext);
+
     // stage the region of A that the queries of this workgroup read (their 3x3 tiles overlap) into LDS once per launch. Without it every
     // evaluation re-reads its 9*C*4-byte query tile through L1.
     extern __shared__ float4 s_a[];
@@ -374,9 +399,11 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
     if (jump == 1) for (int mag = rs_start; mag >= 1; mag >>= 1) ++nrand;
     unsigned nevals = 0, naccept = 0;
 
-    constexpr int NSX = 4 * TQX / QW, NSUB = NSX * (4 * TQY / QH);
+    QIn qcur;
 #pragma unroll 1
     for (int sub = 0; sub < NSUB; ++sub) {
+        if constexpr (AHEAD) { qcur = qnext; if (sub + 1 < NSUB) qfetch(sub + 1, qnext); }
+        else qfetch(sub, qcur);
         const int sx = sub % NSX, sy = sub / NSX;
         const int qx = ox + sx * QW + (grp % QW), qy = oy + sy * QH + (grp / QW);
         if (NSUB > 1 && ox + sx * QW >= g.aw) continue;                 // sub-tile entirely outside the image (uniform over the workgroup)
@@ -399,7 +426,7 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
             amask |= ((yy >= 0 && yy < g.ah && xx >= 0 && xx < g.aw) ? 1u : 0u) << t;
         }
 
-        const uint32_t vbest = nnf_in[qi];
+        const uint32_t vbest = qcur.vbest;
         int xbest = nnf_x(vbest), ybest = nnf_y(vbest);
         const int x0 = xbest, y0 = ybest;
         float dbest;
@@ -411,15 +438,9 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
             if (dbest >= cut) dbest = cut;
             if (live && v == 0) nevals += 1;
         } else {
-            dbest = d_in[qi];
-            // the four neighbours' matches are independent of the evaluations: all four loads are issued together, in front of the candidate walk
-            // (inside the loop each would be one more dependent round trip per candidate)
-            uint32_t vnb[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int nx = ax + ((k == 0) ? -jump : (k == 1 ? jump : 0)), ny = ay + ((k == 2) ? -jump : (k == 3 ? jump : 0));
-                vnb[k] = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
-            }
+            dbest = qcur.d;
+            // the four neighbours' matches are independent of the evaluations (inside the candidate loop each would be one more dependent round trip per candidate)
+            const uint32_t (&vnb)[4] = qcur.vnb;
             // ---- propagation candidates: 0 left, 1 right, 2 up, 3 down — the neighbour's match shifted back by the jump. Each query first packs the
             // candidates that can still win into a short list (in that order), then the wave walks the lists round by round: with most candidates
             // dropping out (below) a wave needs max-over-its-queries rounds instead of four, and no round is spent on a slot whose queries all sit out.
