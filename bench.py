@@ -246,9 +246,11 @@ def main():
 
     # single-pair latency (nothing else on the GPU) and per-stage device times of one more pair
     ctx.pair_run(prm)
-    t1 = time.perf_counter()
-    ctx.pair_run(prm)
-    single_pair_s = time.perf_counter() - t1
+    single_pair_s = float("inf")
+    for _ in range(3):                       # best of three: a single sample carries the box's hiccups (105.8 vs 97-98 ms seen once)
+        t1 = time.perf_counter()
+        ctx.pair_run(prm)
+        single_pair_s = min(single_pair_s, time.perf_counter() - t1)
     # the same pair with NCT_FLAG_LATENCY (a-/b-halves of the WLS solves on two streams: more launches, same bytes, same result)
     plat = nct.Params.default()
     for k, _ in nct.Params._fields_:
