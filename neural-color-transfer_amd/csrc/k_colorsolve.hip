@@ -315,17 +315,25 @@ __global__ void k_cg_beta(const double* __restrict__ partial, int nb, CGState* _
     }
 }
 // thread per pixel (both parts): p (interleaved [pixel][6]) is one contiguous 48-byte record per thread, r ([part][pixel][3]) two dense streams
+// (the CG scalars are read once up front and every operand of the pixel is requested before the first store: 22 -> 16 us at 700x700 against a loop that re-read
+// st->active / st->vb per component and alternated loads and stores)
 __global__ __launch_bounds__(256) void k_s1_dir(int n, const CGState* __restrict__ st, const double* __restrict__ r, double* __restrict__ p, int first) {
+    bool act[3]; double vb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { act[c] = st->active[c] != 0; vb[c] = st->vb[c]; }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    double rv[6], pv[6];
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { rv[part * 3 + c] = r[((size_t)part * n + i) * 3 + c]; pv[part * 3 + c] = first ? 0.0 : p[(size_t)i * 6 + part * 3 + c]; }
 #pragma unroll
     for (int part = 0; part < 2; ++part)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (!st->active[c]) continue;
-            const size_t j = (size_t)i * 6 + part * 3 + c;
-            const double rv = r[((size_t)part * n + i) * 3 + c];
-            p[j] = first ? rv : st->vb[c] * p[j] + rv;
+            if (!act[c]) continue;
+            p[(size_t)i * 6 + part * 3 + c] = first ? rv[part * 3 + c] : vb[c] * pv[part * 3 + c] + rv[part * 3 + c];
         }
 }
 // ---- fused variants for levels with few partial sums (nb <= S1_FUSE_NB): the two single-workgroup kernels of an iteration
@@ -337,6 +345,15 @@ constexpr int S1_FUSE_NB = 512;
 // beta step + direction update, thread per pixel: state_out = beta(state_in, partial_rr); p = r + vb p   (first: state_out = state_in, p = r)
 __global__ __launch_bounds__(256) void k_s1_dir_f(int n, int nb, const double* __restrict__ partial_rr, const CGState* __restrict__ sin, CGState* __restrict__ sout,
                                                   double tol2, const double* __restrict__ r, double* __restrict__ p, int first) {
+    // the pixel's operands do not depend on the scalars: they are requested in front of the reduction that produces those (a chain of its own) and fly under it
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double rv[6], pv[6];
+    if (i < n) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { rv[part * 3 + c] = r[((size_t)part * n + i) * 3 + c]; pv[part * 3 + c] = first ? 0.0 : p[(size_t)i * 6 + part * 3 + c]; }
+    }
     double vb[3]; int act[3];
     if (first) {
 #pragma unroll
@@ -356,34 +373,44 @@ __global__ __launch_bounds__(256) void k_s1_dir_f(int n, int nb, const double* _
             sout->iters[c] = sin->iters[c] + (a ? 1 : 0); sout->active[c] = act[c];
         }
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
 #pragma unroll
     for (int part = 0; part < 2; ++part)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (!act[c]) continue;
-            const size_t j = (size_t)i * 6 + part * 3 + c;
-            const double rv = r[((size_t)part * n + i) * 3 + c];
-            p[j] = first ? rv : vb[c] * p[j] + rv;
+            p[(size_t)i * 6 + part * 3 + c] = first ? rv[part * 3 + c] : vb[c] * pv[part * 3 + c] + rv[part * 3 + c];
         }
 }
 // alpha step + solution/residual update: va = r1 / (p.Ap) from partial_pap ; x += va p ; r -= va Ap ; partial_rr = r.r
 __global__ __launch_bounds__(256) void k_s1_update_f(int n, int nb, const double* __restrict__ partial_pap, const CGState* __restrict__ st, const double* __restrict__ p,
                                                      const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r, double* __restrict__ partial_rr) {
-    double sm[3]; final_reduce<3>(partial_pap, nb, sm);
     const int i = blockIdx.x * 256 + threadIdx.x;
+    double pv[6], av[6], xv[6], rv[6];                           // requested in front of the reduction (see k_s1_dir_f)
+    bool act[3]; double r1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { act[c] = st->active[c] != 0; r1[c] = st->r1[c]; }
+    if (i < n) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t j = ((size_t)part * n + i) * 3 + c;
+                pv[part * 3 + c] = p[(size_t)i * 6 + part * 3 + c]; av[part * 3 + c] = Ap[j]; xv[part * 3 + c] = x[j]; rv[part * 3 + c] = r[j];
+            }
+    }
+    double sm[3]; final_reduce<3>(partial_pap, nb, sm);
     double acc[3] = {0, 0, 0};
     if (i < n) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (!st->active[c]) continue;
-            const double va = st->r1[c] / sm[c];
+            if (!act[c]) continue;
+            const double va = r1[c] / sm[c];
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
                 const size_t j = ((size_t)part * n + i) * 3 + c;
-                x[j] += va * p[(size_t)i * 6 + part * 3 + c];
-                const double rn = r[j] - va * Ap[j];
+                x[j] = xv[part * 3 + c] + va * pv[part * 3 + c];
+                const double rn = rv[part * 3 + c] - va * av[part * 3 + c];
                 r[j] = rn; acc[c] += rn * rn;
             }
         }
@@ -399,18 +426,28 @@ __global__ void k_pack6(int n, const double* __restrict__ x, double* __restrict_
 }
 __global__ __launch_bounds__(256) void k_s1_update(int n, const CGState* __restrict__ st, const double* __restrict__ p, const double* __restrict__ Ap,
                                                    double* __restrict__ x, double* __restrict__ r, double* __restrict__ partial) {
+    bool act[3]; double va[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { act[c] = st->active[c] != 0; va[c] = st->va[c]; }
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[3] = {0, 0, 0};
     if (i < n) {
+        double pv[6], av[6], xv[6], rv[6];                       // every operand of the pixel is requested before the first store
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t j = ((size_t)part * n + i) * 3 + c;
+                pv[part * 3 + c] = p[(size_t)i * 6 + part * 3 + c]; av[part * 3 + c] = Ap[j]; xv[part * 3 + c] = x[j]; rv[part * 3 + c] = r[j];
+            }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (!st->active[c]) continue;
-            const double va = st->va[c];
+            if (!act[c]) continue;
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
                 const size_t j = ((size_t)part * n + i) * 3 + c;
-                x[j] += va * p[(size_t)i * 6 + part * 3 + c];
-                const double rn = r[j] - va * Ap[j];
+                x[j] = xv[part * 3 + c] + va[c] * pv[part * 3 + c];
+                const double rn = rv[part * 3 + c] - va[c] * av[part * 3 + c];
                 r[j] = rn; acc[c] += rn * rn;
             }
         }
