@@ -35,7 +35,8 @@ if os.path.exists(sweep) and os.path.getsize(sweep) > 10:
 # ---- per-kernel table of the one-pair-in-flight profiled run
 prof = jline("prof_bench.json")
 rows = list(csv.DictReader(open(os.path.join(src, "prof", "b_kernel_stats.csv"))))
-pairs = 3 * 4          # context warm-up + (1 warm-up + 2 timed) steps + host-to-host + latency / stage / roofline pairs, one in flight: see bench.py
+pairs = 3 * 4 + 2      # context warm-up + (1 warm-up + 2 timed) steps + host-to-host + the single-pair latency (warm run + best of three) / latency-flag / stage / roofline pairs,
+                       # one in flight: see bench.py
 calls = sum(int(r["Calls"]) for r in rows)
 total = sum(int(r["TotalDurationNs"]) for r in rows)
 pm = [r for r in rows if r["Name"].startswith("void k_pm_step<1, 1,")][0]
