@@ -55,10 +55,20 @@ constexpr int NQMAX = 6;      // right-hand sides of a solve: 6 (a and b of the 
 // The PCG itself (and the hierarchy construction) is fp64; the V-cycle — a fixed linear preconditioner, whose accuracy does not
 // limit the accuracy of the solution — runs in fp32 on rounded copies of the level operators: half the bytes on the two
 // bandwidth-bound levels, same iteration counts (scripts/mg_convergence_experiments.py).
+//
+// Hierarchy (round 4; rounds 1-3: 2x2 aggregation with piecewise-constant transfer, 174 PCG iterations per 700x700 pair): VERTEX-CENTRED coarsening —
+// coarse point (Y, X) IS fine point (2Y, 2X) — with OPERATOR-DEPENDENT interpolation (black-box multigrid, Alcouffe/Brandt/Dendy/Painter): a fine point on
+// a coarse grid line interpolates from its two coarse neighbours with the weights of the stencil collapsed across the line, a fine point in the middle of
+// a coarse cell solves its own equation for its 8 neighbours. Restriction = transpose, coarse operators = Galerkin products P^T A P: symmetric 9-point
+// stencils kept as the diagonal and the four forward couplings (+x, +y, +x+y, -x+y), all in the form w = -A(i, j) so that level 0 keeps (diag, wx, wy).
+// The edge-aware weights vary by 10^4 between neighbouring edges, which a piecewise-constant transfer cannot follow; this one halves the iteration count.
 typedef float vf;
-struct Lvl { int H, W, n; double *r, *wx, *wy, *diag;      // fp64 operator: data term, edge weights, diagonal
-             vf *fdiag, *fdinv, *fwx, *fwy;                // fp32 copies; fdinv = (float)(omega / diag)
-             vf *b, *x, *x2; };                            // V-cycle vectors, planar [6][n]
+struct Lvl { int H, W, n, nine;                                  // nine: 9-point stencil (every level but the finest)
+             double *d, *wE, *wS, *wSE, *wSW, *pa, *pb;          // fp64 operator: (A v)_i = d_i v_i - sum_k w_ik v_k; forward couplings, 0 where the neighbour does not exist; transfer weights
+             vf *fd, *fdinv, *fE, *fS, *fSE, *fSW, *fpa, *fpb;   // fp32 copies; fdinv = (float)(omega_0 / dt), dt = the safe smoother diagonal (k_mg_finish)
+             vf *b, *x, *x2; };                                  // V-cycle vectors, planar [6][n]
+// pa / pb of a fine point = its interpolation weights: (even y, odd x): from the W / E coarse point; (odd y, even x): from the N / S one; (odd, odd): pa = 1 / d
+// (the cell centre is eliminated exactly); coarse points: unused.
 
 // State of the 6 right-hand sides of the single-reduction (Chronopoulos-Gear) PCG, double buffered: the update kernel of iteration k
 // reads st[k & 1] and (workgroup 0) writes st[(k + 1) & 1]. nactive = number of systems still iterating: the host polls it only every
@@ -146,123 +156,223 @@ __device__ __forceinline__ void mg_final_reduce_strided(const double* __restrict
     __syncthreads();
 }
 
-// y = M v at pixel i of a level (diag*v - sum_w w*v_nbr, neighbour order +x, -x, +y, -y)
+// y = M v at pixel i of the FINE level (5-point: diag*v - sum_w w*v_nbr, neighbour order +x, -x, +y, -y)
 template <int NQ, typename F>
 __device__ __forceinline__ void lvl_op(const Lvl& L, int i, F&& val /* val(j, q) */, double (&y)[NQ]) {
     const int W = L.W, H = L.H;
     const int r = i / W, c = i - r * W;
-    const double d = L.diag[i];
+    const double d = L.d[i];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) y[q] = d * val(i, q);
-    if (c + 1 < W) { const double w = L.wx[i];
+    if (c + 1 < W) { const double w = L.wE[i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(i + 1, q); }
-    if (c > 0) { const double w = L.wx[i - 1];
+    if (c > 0) { const double w = L.wE[i - 1];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(i - 1, q); }
-    if (r + 1 < H) { const double w = L.wy[i];
+    if (r + 1 < H) { const double w = L.wS[i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(i + W, q); }
-    if (r > 0) { const double w = L.wy[i - W];
+    if (r > 0) { const double w = L.wS[i - W];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) y[q] -= w * val(i - W, q); }
 }
 
-// ---- hierarchy construction
-__global__ void k_mg_coarsen(Lvl F, Lvl C) {
-    const int I = blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= C.n) return;
-    const int Y = I / C.W, X = I - Y * C.W;
-    const int y0 = 2 * Y, x0 = 2 * X;
-    const bool x1ok = x0 + 1 < F.W, y1ok = y0 + 1 < F.H;
-    double rs = F.r[y0 * F.W + x0];
-    if (x1ok) rs += F.r[y0 * F.W + x0 + 1];
-    if (y1ok) rs += F.r[(y0 + 1) * F.W + x0];
-    if (x1ok && y1ok) rs += F.r[(y0 + 1) * F.W + x0 + 1];
-    double ex = 0.0, ey = 0.0;
-    if (x0 + 2 < F.W) {                       // fine edges (x0+1 -> x0+2) of both rows
-        ex = F.wx[y0 * F.W + x0 + 1];
-        if (y1ok) ex += F.wx[(y0 + 1) * F.W + x0 + 1];
-    }
-    if (y0 + 2 < F.H) {
-        ey = F.wy[(y0 + 1) * F.W + x0];
-        if (x1ok) ey += F.wy[(y0 + 1) * F.W + x0 + 1];
-    }
-    C.r[I] = rs; C.wx[I] = ex; C.wy[I] = ey;
+// ---- hierarchy construction (fp64; the oracle mirrors every expression: oracle/orc_wls_mg.c mg_weights / mg_pstencil / mg_galerkin / mg_finish)
+// neighbour k of a pixel: E, W, S, N, SE, SW, NE, NW
+__device__ __forceinline__ int nb_dy(int k) { return k == 2 || k == 4 || k == 5 ? 1 : (k == 3 || k == 6 || k == 7 ? -1 : 0); }
+__device__ __forceinline__ int nb_dx(int k) { return k == 0 || k == 4 || k == 6 ? 1 : (k == 1 || k == 5 || k == 7 ? -1 : 0); }
+// existence mask of the 8 neighbours of (r, c) on level L (diagonals only on 9-point levels)
+__device__ __forceinline__ unsigned nb_mask(const Lvl& L, int r, int c) {
+    const bool xr = c + 1 < L.W, xl = c > 0, yd = r + 1 < L.H, yu = r > 0;
+    unsigned m = (xr ? 1u : 0u) | (xl ? 2u : 0u) | (yd ? 4u : 0u) | (yu ? 8u : 0u);
+    if (L.nine) m |= (xr && yd ? 16u : 0u) | (xl && yd ? 32u : 0u) | (xr && yu ? 64u : 0u) | (xl && yu ? 128u : 0u);
+    return m;
 }
-__global__ void k_mg_diag(Lvl L) {
+// the 8 couplings of pixel (r, c), 0 where the neighbour does not exist
+__device__ __forceinline__ void coup8(const Lvl& L, int r, int c, double (&w)[8]) {
+    const int W = L.W, i = r * W + c;
+    const unsigned m = nb_mask(L, r, c);
+    w[0] = (m & 1u) ? L.wE[i] : 0.0; w[1] = (m & 2u) ? L.wE[i - 1] : 0.0; w[2] = (m & 4u) ? L.wS[i] : 0.0; w[3] = (m & 8u) ? L.wS[i - W] : 0.0;
+    w[4] = (m & 16u) ? L.wSE[i] : 0.0; w[5] = (m & 32u) ? L.wSW[i] : 0.0; w[6] = (m & 64u) ? L.wSW[i - W + 1] : 0.0; w[7] = (m & 128u) ? L.wSE[i - W - 1] : 0.0;
+}
+// level 0: diagonal of the reference's system (accumulated in its order: data term, +x, -x, +y, -y) and the fp32 copies
+__global__ void k_mg_diag(Lvl L, const double* __restrict__ rough) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.n) return;
     const int y = i / L.W, x = i - y * L.W;
     double a00 = 0.0;
-    a00 += L.r[i];
-    if (x + 1 < L.W) a00 += L.wx[i];
-    if (x > 0) a00 += L.wx[i - 1];
-    if (y + 1 < L.H) a00 += L.wy[i];
-    if (y > 0) a00 += L.wy[i - L.W];
-    L.diag[i] = a00;
-    L.fdiag[i] = (vf)a00; L.fdinv[i] = (vf)(OMEGA / a00); L.fwx[i] = (vf)L.wx[i]; L.fwy[i] = (vf)L.wy[i];
+    a00 += rough[i];
+    if (x + 1 < L.W) a00 += L.wE[i];
+    if (x > 0) a00 += L.wE[i - 1];
+    if (y + 1 < L.H) a00 += L.wS[i];
+    if (y > 0) a00 += L.wS[i - L.W];
+    L.d[i] = a00;
+    L.fd[i] = (vf)a00; L.fdinv[i] = (vf)(OMEGA / a00); L.fE[i] = (vf)L.wE[i]; L.fS[i] = (vf)L.wS[i];
+}
+// interpolation weights towards the next coarser level: the stencil collapsed across the coarse grid line
+__global__ void k_mg_weights(Lvl L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    const int r = i / L.W, c = i - r * L.W;
+    double w[8]; coup8(L, r, c, w);
+    const double d = L.d[i];
+    double pa = 0.0, pb = 0.0;
+    if (!(r & 1) && (c & 1)) { const double den = (d - w[2]) - w[3]; pa = ((w[1] + w[5]) + w[7]) / den; pb = ((w[0] + w[4]) + w[6]) / den; }
+    else if ((r & 1) && !(c & 1)) { const double den = (d - w[0]) - w[1]; pa = ((w[3] + w[6]) + w[7]) / den; pb = ((w[2] + w[4]) + w[5]) / den; }
+    else if ((r & 1) && (c & 1)) pa = 1.0 / d;
+    L.pa[i] = pa; L.pb[i] = pb; L.fpa[i] = (vf)pa; L.fpb[i] = (vf)pb;
+}
+// column I of P as a 3x3 block around fine point (2Y, 2X): pst[I*9 + (dy+1)*3 + dx+1]
+__global__ void k_mg_pstencil(Lvl L, Lvl C, double* __restrict__ pst_out) {
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= C.n) return;
+    const int Y = I / C.W, X = I - Y * C.W;
+    const int W = L.W, H = L.H, r = 2 * Y, c = 2 * X, f = r * W + c;
+    double pst[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pst[k] = 0.0;
+    pst[4] = 1.0;
+    if (c > 0) pst[3] = L.pb[f - 1];
+    if (c + 1 < W) pst[5] = L.pa[f + 1];
+    if (r > 0) pst[1] = L.pb[f - W];
+    if (r + 1 < H) pst[7] = L.pa[f + W];
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy += 2)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx += 2) {
+            const int y = r + dy, x = c + dx;
+            if (y < 0 || y >= H || x < 0 || x >= W) continue;
+            double w[8]; coup8(L, y, x, w);
+            const double wdiag = dy < 0 ? (dx < 0 ? w[4] : w[5]) : (dx < 0 ? w[6] : w[7]);
+            const double wvert = dy < 0 ? w[2] : w[3];
+            const double whor = dx < 0 ? w[0] : w[1];
+            pst[(dy + 1) * 3 + dx + 1] = ((wdiag + wvert * pst[3 + dx + 1]) + whor * pst[(dy + 1) * 3 + 1]) * L.pa[y * W + x];
+        }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pst_out[(size_t)I * 9 + k] = pst[k];
+}
+// Galerkin product: A_c(I, J) = sum over the fine points i of block(I), row-major, of pst_I(i) * (A pst_J)(i) for J = I and its four forward neighbours
+__global__ void k_mg_galerkin(Lvl L, Lvl C, const double* __restrict__ pst) {
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= C.n) return;
+    const int Wc = C.W, Hc = C.H, Y = I / Wc, X = I - Y * Wc;
+    const int W = L.W, H = L.H;
+    // J = (Y + JY[j], X + JX[j]): self, E, S, SE, SW
+    const int JY[5] = {0, 0, 1, 1, 1}, JX[5] = {0, 1, 0, 1, -1};
+    bool jok[5]; double acc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { const int yj = Y + JY[j], xj = X + JX[j]; jok[j] = yj < Hc && xj >= 0 && xj < Wc; acc[j] = 0.0; }
+    const double* pI = pst + (size_t)I * 9;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int y = 2 * Y + dy, x = 2 * X + dx;
+            if (y < 0 || y >= H || x < 0 || x >= W) continue;
+            const double pi = pI[(dy + 1) * 3 + dx + 1];
+            double w[8]; coup8(L, y, x, w);
+            const unsigned m = nb_mask(L, y, x);
+            const double di = L.d[y * W + x];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (!jok[j]) continue;
+                const double* pJ = pst + (size_t)(I + JY[j] * Wc + JX[j]) * 9;
+                const int ry = dy - 2 * JY[j], rx = dx - 2 * JX[j];                 // position of fine point i relative to block J
+                double au = (ry >= -1 && ry <= 1 && rx >= -1 && rx <= 1) ? di * pJ[(ry + 1) * 3 + rx + 1] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (!(m & (1u << k))) continue;
+                    const int ky = ry + nb_dy(k), kx = rx + nb_dx(k);
+                    if (ky < -1 || ky > 1 || kx < -1 || kx > 1) continue;
+                    au -= w[k] * pJ[(ky + 1) * 3 + kx + 1];
+                }
+                acc[j] += pi * au;
+            }
+        }
+    C.d[I] = acc[0];
+    C.wE[I] = jok[1] ? -acc[1] : 0.0;
+    C.wS[I] = jok[2] ? -acc[2] : 0.0;
+    C.wSE[I] = jok[3] ? -acc[3] : 0.0;
+    C.wSW[I] = jok[4] ? -acc[4] : 0.0;
+}
+// 9-point levels: fp32 copies and the safe smoother diagonal dt = max(d, (|d| + sum |w|) / 2) — Gershgorin keeps lambda_max(dt^-1 A) <= 2 where a Galerkin
+// stencil has couplings of the wrong sign; dt = d on M-matrix rows
+__global__ void k_mg_finish(Lvl L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    const int r = i / L.W, c = i - r * L.W;
+    const double d = L.d[i];
+    double w[8]; coup8(L, r, c, w);
+    double s = fabs(d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += fabs(w[k]);
+    const double h = 0.5 * s, dt = h > d ? h : d;
+    L.fd[i] = (vf)d; L.fdinv[i] = (vf)(OMEGA / dt); L.fE[i] = (vf)L.wE[i]; L.fS[i] = (vf)L.wS[i]; L.fSE[i] = (vf)L.wSE[i]; L.fSW[i] = (vf)L.wSW[i];
 }
 
 // ---- V-cycle (fp32, vectors planar [6][n])
 // tile-fused legs: every intermediate iterate of a leg lives in LDS for a TX x TY fine tile plus a halo (recomputed by the
 // neighbouring tiles with the same expressions, hence bit-identical) instead of making a round trip through global memory and a
 // launch per sweep:
-//   down: x1 = b*dinv ; x = x1 + (b - M x1)*dinv (two damped-Jacobi sweeps from zero) ; coarse rhs = sum over the 2x2 aggregate
-//         of (b - M x), fine pixels in the order (0,0),(0,1),(1,0),(1,1)
-//   up:   xe = x + e_coarse(parent) ; x2 = xe + (b - M xe)*dinv ; xo = x2 + (b - M x2)*dinv
-// One thread per pixel of the tile + 2-pixel halo: it loads ITS pixel's right-hand side, coefficients and inputs once (all loads of
-// a leg are issued in the first phase), the first iterate is exchanged through LDS on the halo-2 grid, the second on the halo-1
-// grid, the result is produced on the tile. (Recomputing the first iterate at the 5 stencil points from global memory instead
-// cost 40-75 loads per thread and ~28 us per leg at 700x700.)
-struct PxCoef { vf d, dinv, w0, w1, w2, w3; bool r, l, dn, up; };    // diag, omega/diag, weights to +x, -x, +y, -y and their existence
+//   down: x1 = b*dinv ; x_{k+1} = x_k + (b - M x_k)*dinv*rk (MG_NS Chebyshev-weighted Jacobi sweeps from zero) ; res = b - M x ; coarse rhs = P^T res
+//   up:   xe = x + P e_coarse ; MG_NS more sweeps
+// One thread per pixel of the tile + halo: it loads ITS pixel's right-hand side, coefficients and inputs once (all loads of a leg are issued in the
+// first phase), iterates are exchanged through two LDS arrays in ping-pong. Tiles start at even coordinates, so a tile owns the coarse points
+// (even, even) inside it. The transfers reach one pixel further than the smoother on ONE side (the coarse point at the tile's left / top edge
+// gathers from the line point in front of it; for an even sweep count the up leg's outermost column needs the coarse point behind it), so the
+// thread grid has MG_NS + 1 halo pixels on that side and MG_NS on the other: (TX + 2 MG_NS + 1) x (TY + 2 MG_NS + 1) threads.
+struct PxCoef { vf d, dinv, w[8], pa, pb; unsigned ex; };    // diag, omega/dt, couplings E W S N SE SW NE NW (0 where absent), transfer weights, existence mask
+template <bool NINE>
 __device__ __forceinline__ PxCoef px_coef(const Lvl& L, int gy, int gx) {
-    const int i = gy * L.W + gx;
+    const int i = gy * L.W + gx, W = L.W;
     PxCoef c;
-    c.r = gx + 1 < L.W; c.l = gx > 0; c.dn = gy + 1 < L.H; c.up = gy > 0;
-    c.d = L.fdiag[i]; c.dinv = L.fdinv[i];
-    c.w0 = c.r ? L.fwx[i] : 0.f; c.w1 = c.l ? L.fwx[i - 1] : 0.f; c.w2 = c.dn ? L.fwy[i] : 0.f; c.w3 = c.up ? L.fwy[i - L.W] : 0.f;
+    const bool xr = gx + 1 < W, xl = gx > 0, yd = gy + 1 < L.H, yu = gy > 0;
+    c.ex = (xr ? 1u : 0u) | (xl ? 2u : 0u) | (yd ? 4u : 0u) | (yu ? 8u : 0u);
+    c.d = L.fd[i]; c.dinv = L.fdinv[i]; c.pa = L.fpa[i]; c.pb = L.fpb[i];
+    c.w[0] = xr ? L.fE[i] : 0.f; c.w[1] = xl ? L.fE[i - 1] : 0.f; c.w[2] = yd ? L.fS[i] : 0.f; c.w[3] = yu ? L.fS[i - W] : 0.f;
+    if (NINE) {
+        c.ex |= (xr && yd ? 16u : 0u) | (xl && yd ? 32u : 0u) | (xr && yu ? 64u : 0u) | (xl && yu ? 128u : 0u);
+        c.w[4] = (xr && yd) ? L.fSE[i] : 0.f; c.w[5] = (xl && yd) ? L.fSW[i] : 0.f; c.w[6] = (xr && yu) ? L.fSW[i - W + 1] : 0.f; c.w[7] = (xl && yu) ? L.fSE[i - W - 1] : 0.f;
+    } else { c.w[4] = c.w[5] = c.w[6] = c.w[7] = 0.f; }
     return c;
 }
-// y = M v at the pixel stored at LDS position p of a grid with row pitch LW (same operation order as lvl_op: +x, -x, +y, -y). `own` = the thread's own value of v,
-// which it wrote to s_v[.. + p] itself and still holds in registers (a fifth of the stencil's LDS reads)
-template <int NQ, int LW, int LN>
+template <int LW> __device__ __forceinline__ constexpr int lds_off(int k) {
+    return k == 0 ? 1 : k == 1 ? -1 : k == 2 ? LW : k == 3 ? -LW : k == 4 ? LW + 1 : k == 5 ? LW - 1 : k == 6 ? -LW + 1 : -LW - 1;
+}
+// y = M v at the pixel stored at LDS position p of a grid with row pitch LW (neighbour order E, W, S, N, SE, SW, NE, NW). `own` = the thread's own value of v,
+// which it wrote to s_v[.. + p] itself and still holds in registers
+template <int NQ, int LW, int LN, bool NINE>
 __device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s_v, int p, const vf (&own)[NQ], vf (&y)[NQ]) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) y[q] = c.d * own[q];
-    if (c.r) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= c.w0 * s_v[q * LN + p + 1]; }
-    if (c.l) {
+    for (int k = 0; k < (NINE ? 8 : 4); ++k)
+        if (c.ex & (1u << k)) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= c.w1 * s_v[q * LN + p - 1]; }
-    if (c.dn) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= c.w2 * s_v[q * LN + p + LW]; }
-    if (c.up) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= c.w3 * s_v[q * LN + p - LW]; }
+            for (int q = 0; q < NQ; ++q) y[q] -= c.w[k] * s_v[q * LN + p + lds_off<LW>(k)];
+        }
 }
-constexpr int mg_threads(int TX, int TY) { return ((TX + 2 * MG_NS) * (TY + 2 * MG_NS) + 63) / 64 * 64; }
+constexpr int mg_threads(int TX, int TY) { return ((TX + 2 * MG_NS + 1) * (TY + 2 * MG_NS + 1) + 63) / 64 * 64; }
 // TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below.
-// One thread per pixel of the tile + MG_NS-pixel halo. Sweep k produces its iterate on the tile + (MG_NS - k)-pixel halo from the previous one (exchanged through LDS,
-// two arrays in ping-pong); halo pixels are recomputed by the neighbouring tiles with the same expressions, hence bit-identical.
-template <int NQ, int TX, int TY, typename TB>
+// Sweep k produces its iterate on ring(k) = the thread grid shrunk by k from every side; the residual lives on ring(MG_NS) = the tile + one pixel to the left / top.
+// Restriction R = P^T in three steps (oracle: mg_restrict): cell centres t = res / d ; every other point res' = res + sum over its adjacent centres of w t ;
+// coarse point = res' + pa(E pt) res'(E pt) + pb(W pt) res'(W pt) + pa(S pt) res'(S pt) + pb(N pt) res'(N pt), the products formed by the line points.
+template <int NQ, int TX, int TY, typename TB, bool NINE>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc) {
     if (st->nactive == 0) return;
-    constexpr int HL = MG_NS, LW = TX + 2 * HL, LH = TY + 2 * HL, LN = LW * LH;
+    constexpr int HA = MG_NS + 1, HB = MG_NS, LW = TX + HA + HB, LH = TY + HA + HB, LN = LW * LH;
     __shared__ vf s_a[NQ * LN], s_b[NQ * LN];
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const int p = threadIdx.x;
     const int ly = p / LW, lx = p - ly * LW;
-    const int gy = y0 + ly - HL, gx = x0 + lx - HL;
+    const int gy = y0 + ly - HA, gx = x0 + lx - HA;
     const bool valid = p < LN && gy >= 0 && gy < F.H && gx >= 0 && gx < F.W;
-    auto ring = [&](int k) { return valid && lx >= k && lx <= TX + 2 * HL - 1 - k && ly >= k && ly <= TY + 2 * HL - 1 - k; };   // tile + (HL - k)-pixel halo
-    const bool interior = ring(HL);
+    auto ring = [&](int k) { return valid && lx >= k && lx <= LW - 1 - k && ly >= k && ly <= LH - 1 - k; };
+    const bool interior = valid && lx >= HA && lx < HA + TX && ly >= HA && ly < HA + TY;
+    const bool oy = (gy & 1) != 0, ox = (gx & 1) != 0;
     const int i = gy * F.W + gx;
     vf bq[NQ], xk[NQ]; PxCoef c;
     if (valid) {
-        c = px_coef(F, gy, gx);
+        c = px_coef<NINE>(F, gy, gx);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * F.n + i]; xk[q] = bq[q] * c.dinv; s_a[q * LN + p] = xk[q]; }     // sweep 0 (from zero)
     }
@@ -271,7 +381,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
     for (int k = 1; k < MG_NS; ++k) {
         vf* src = (k & 1) ? s_a : s_b; vf* dst = (k & 1) ? s_b : s_a;
         if (ring(k)) {
-            vf y[NQ]; lds_op<NQ, LW, LN>(c, src, p, xk, y);
+            vf y[NQ]; lds_op<NQ, LW, LN, NINE>(c, src, p, xk, y);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 xk[q] = xk[q] + (bq[q] - y[q]) * (c.dinv * mg_rk(k));
@@ -281,60 +391,110 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
         }
         __syncthreads();
     }
-    vf* xs = (MG_NS & 1) ? s_a : s_b; vf* rs = (MG_NS & 1) ? s_b : s_a;       // the smoothed iterate (on the tile + 1) and where the residual goes
-    if (interior) {
-        vf yv[NQ]; lds_op<NQ, LW, LN>(c, xs, p, xk, yv);
+    vf* xs = (MG_NS & 1) ? s_a : s_b; vf* rs = (MG_NS & 1) ? s_b : s_a;       // the smoothed iterate, and the array nobody reads any more
+    const bool inres = ring(MG_NS);
+    vf res[NQ];
+    if (inres) {
+        vf yv[NQ]; lds_op<NQ, LW, LN, NINE>(c, xs, p, xk, yv);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) rs[q * LN + p] = bq[q] - yv[q];
+        for (int q = 0; q < NQ; ++q) { res[q] = bq[q] - yv[q]; if (oy && ox) rs[q * LN + p] = res[q] * c.pa; }
+    }
+    __syncthreads();                                                           // from here on xs is free as well
+    if (inres && !(oy && ox)) {
+        // adjacent cell centres: line point on a row (even y, odd x): S, N ; on a column: E, W ; coarse point: SE, SW, NE, NW
+        const int k0 = (!oy && ox) ? 2 : ((oy && !ox) ? 0 : 4), k1 = (!oy && !ox) ? 8 : k0 + 2;
+#pragma unroll
+        for (int k = 0; k < (NINE ? 8 : 4); ++k)
+            if (k >= k0 && k < k1 && (c.ex & (1u << k))) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) res[q] += c.w[k] * rs[q * LN + p + lds_off<LW>(k)];
+            }
+        if (oy != ox) {                                                        // (t is read at centre positions only, these are line positions)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { xs[q * LN + p] = c.pa * res[q]; rs[q * LN + p] = c.pb * res[q]; }      // towards its first (W / N) and second (E / S) coarse point
+        }
     }
     __syncthreads();
-    if (p < (TX / 2) * (TY / 2)) {
-        const int cy = p / (TX / 2), cx = p - cy * (TX / 2);
-        const int Y = y0 / 2 + cy, X = x0 / 2 + cx;
-        if (Y < C.H && X < C.W) {
-            vf acc[NQ];
+    if (interior && !oy && !ox) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int yy = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
-                if (yy < F.H && xx < F.W) {
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) acc[q] += rs[q * LN + (yy - y0 + HL) * LW + (xx - x0 + HL)];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) bc[(size_t)q * C.n + Y * C.W + X] = acc[q];
+        for (int q = 0; q < NQ; ++q) {
+            vf acc = res[q];
+            if (c.ex & 1u) acc += xs[q * LN + p + 1];
+            if (c.ex & 2u) acc += rs[q * LN + p - 1];
+            if (c.ex & 4u) acc += xs[q * LN + p + LW];
+            if (c.ex & 8u) acc += rs[q * LN + p - LW];
+            bc[(size_t)q * C.n + (gy >> 1) * C.W + (gx >> 1)] = acc;
         }
     }
 }
+// Prolongation (oracle: mg_prolong): coarse points copy e_c; line points pa e(W|N) + pb e(E|S); cell centres (sum_k w_k e_k) / d over their 8 neighbours.
 // xo must not alias x (neighbouring tiles still read x for their halo)
-template <int NQ, int TX, int TY, typename TB>
+template <int NQ, int TX, int TY, typename TB, bool NINE>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __restrict__ st, Lvl L, const TB* __restrict__ b, const vf* __restrict__ x, int Wc, int nc,
                                                               const vf* __restrict__ ec, vf* __restrict__ xo) {
     if (st->nactive == 0) return;
-    constexpr int HL = MG_NS, LW = TX + 2 * HL, LH = TY + 2 * HL, LN = LW * LH;
+    constexpr bool ODD = (MG_NS & 1) != 0;
+    constexpr int HA = ODD ? MG_NS + 1 : MG_NS, HB = ODD ? MG_NS : MG_NS + 1, LW = TX + HA + HB, LH = TY + HA + HB, LN = LW * LH;
+    constexpr int OL = ODD ? 1 : 0, OR = ODD ? 0 : 1;                          // xe lives on the grid minus its first (odd sweep count) / last (even) row and column
     __shared__ vf s_a[NQ * LN], s_b[NQ * LN];
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const int p = threadIdx.x;
     const int ly = p / LW, lx = p - ly * LW;
-    const int gy = y0 + ly - HL, gx = x0 + lx - HL;
+    const int gy = y0 + ly - HA, gx = x0 + lx - HA;
     const bool valid = p < LN && gy >= 0 && gy < L.H && gx >= 0 && gx < L.W;
-    auto ring = [&](int k) { return valid && lx >= k && lx <= TX + 2 * HL - 1 - k && ly >= k && ly <= TY + 2 * HL - 1 - k; };
+    auto ring = [&](int k) { return valid && lx >= OL + k && lx <= LW - 1 - OR - k && ly >= OL + k && ly <= LH - 1 - OR - k; };
+    const bool oy = (gy & 1) != 0, ox = (gx & 1) != 0;
     const int i = gy * L.W + gx;
     vf bq[NQ], xk[NQ]; PxCoef c;
     if (valid) {
-        c = px_coef(L, gy, gx);
-        const int ip = (gy >> 1) * Wc + (gx >> 1);
+        c = px_coef<NINE>(L, gy, gx);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * L.n + i]; xk[q] = x[(size_t)q * L.n + i] + ec[(size_t)q * nc + ip]; s_a[q * LN + p] = xk[q]; }   // xe = x + e_coarse(parent)
+        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * L.n + i]; xk[q] = x[(size_t)q * L.n + i]; }
+        if (!oy && !ox) {
+            const int ip = (gy >> 1) * Wc + (gx >> 1);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) s_a[q * LN + p] = ec[(size_t)q * nc + ip];
+        }
+    }
+    __syncthreads();
+    if (valid && oy != ox) {
+        const int stp = ox ? 1 : LW;
+        const bool first_in = ox ? lx >= 1 : ly >= 1;
+        const bool second_ex = ox ? (c.ex & 1u) != 0 : (c.ex & 4u) != 0, second_in = ox ? lx + 1 <= LW - 1 : ly + 1 <= LH - 1;
+        if (first_in && (!second_ex || second_in)) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                vf v = c.pa * s_a[q * LN + p - stp];
+                if (second_ex) v += c.pb * s_a[q * LN + p + stp];
+                s_a[q * LN + p] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (valid && oy && ox && lx >= 1 && lx <= LW - 2 && ly >= 1 && ly <= LH - 2) {
+        vf acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < (NINE ? 8 : 4); ++k)
+            if (c.ex & (1u << k)) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] += c.w[k] * s_a[q * LN + p + lds_off<LW>(k)];
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s_a[q * LN + p] = acc[q] * c.pa;
+    }
+    __syncthreads();
+    if (ring(0)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { xk[q] = xk[q] + s_a[q * LN + p]; s_a[q * LN + p] = xk[q]; }      // xe = x + P e_coarse
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < MG_NS; ++k) {
         vf* src = (k & 1) ? s_b : s_a; vf* dst = (k & 1) ? s_a : s_b;
         if (ring(k + 1)) {
-            vf y[NQ]; lds_op<NQ, LW, LN>(c, src, p, xk, y);
+            vf y[NQ]; lds_op<NQ, LW, LN, NINE>(c, src, p, xk, y);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 xk[q] = xk[q] + (bq[q] - y[q]) * (k == 0 ? c.dinv : c.dinv * mg_rk(k));
@@ -344,197 +504,37 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
         if (k < MG_NS - 1) __syncthreads();
     }
 }
-// Middle + tail of the V-cycle in ONE launch, one 1024-thread workgroup PER RIGHT-HAND SIDE: the first fused level has <= 4096 pixels
-// (44x44 at 700x700, 63x63 at 1000x1000), the deeper ones <= 1024 (22x22, 11x11, 6x6). The six systems share the operator but not a single
-// value, so no workgroup ever waits for another and the whole sub-cycle needs only __syncthreads(). Everything a level needs for the way
-// back up (right-hand side, pre-smoothed iterate, stencil coefficients of the deeper levels) stays in REGISTERS of the thread that owns
-// the pixel; iterates are exchanged through whole-grid LDS arrays (no halos); coefficients come from global memory once per level (the
-// first fused level re-reads them for the up leg) and all those loads are issued at the start. A first version that re-read
-// coefficients and iterates from global memory in each of its 35 barrier-separated phases was SLOWER than the launches it replaced
-//  — a single workgroup has nothing to hide a global round trip with.
-// Replaces round 1's single-workgroup tail (<= 512 pixels, all six systems in one workgroup: 12.5 us) plus the k_mg_down / k_mg_up
-// launches of the 44x44 level. Same expressions and operation order (+x, -x, +y, -y; children (0,0),(0,1),(1,0),(1,1)) as k_mg_down /
-// k_mg_up, so the cycle is bit-identical. lv[0] is the first fused level: its rhs lv[0].b was written by the restriction above it, its
-// correction goes to lv[0].x2. The coarsest grid (n <= 64) is solved by `sweeps` damped-Jacobi sweeps from zero by one wave (one lane per
-// unknown, the iterate in a register, neighbours through ds_bpermute).
-// Pixels per thread of the first / second fused level. 8 / 2 would take the 88x88 level of a 700x700 pair into the launch as well (two
-// launches fewer per cycle), but 8 pixels x 7 coefficient registers do not fit the 128 VGPRs of a 1024-thread workgroup next to the deeper
-// levels' state: 59 (NCT_MID_LDS0: right-hand side and iterate of depth 0 in LDS) to 92 spilled registers, +14 us per call, 40.5 vs 37.1 ms
-// of WLS per pair.
-#ifndef NCT_MID_P0
-#define NCT_MID_P0 4
-#define NCT_MID_P1 1
-#endif
-#ifndef NCT_MID_LDS0
-#define NCT_MID_LDS0 0      // 1: depth 0 keeps its right-hand side and pre-smoothed iterate in LDS instead of registers
-#endif
-constexpr int MID_T = 1024, MID_P0 = NCT_MID_P0, MID_P1 = NCT_MID_P1, MID_N0 = MID_T * MID_P0, MID_N1 = MID_T * MID_P1, MID_N2 = MID_T, MID_LV = MID_P0 > 4 ? 7 : 6;
-constexpr int mid_ppt(int D) { return D == 0 ? MID_P0 : (D == 1 ? MID_P1 : 1); }      // pixels per thread at depth D of the fused sub-cycle
-struct MidPack { Lvl lv[MID_LV]; int nl; };
-struct MidCoef { vf d, dinv, w0, w1, w2, w3; unsigned flags; };      // flags: 1 = +x exists, 2 = -x, 4 = +y, 8 = -y
-__device__ __forceinline__ MidCoef mid_coef(const Lvl& L, int i) {
-    const int gy = i / L.W, gx = i - gy * L.W;
-    MidCoef c;
-    const bool r = gx + 1 < L.W, l = gx > 0, dn = gy + 1 < L.H, up = gy > 0;
-    c.flags = (r ? 1u : 0u) | (l ? 2u : 0u) | (dn ? 4u : 0u) | (up ? 8u : 0u);
-    c.d = L.fdiag[i]; c.dinv = L.fdinv[i];
-    c.w0 = r ? L.fwx[i] : 0.f; c.w1 = l ? L.fwx[i - 1] : 0.f; c.w2 = dn ? L.fwy[i] : 0.f; c.w3 = up ? L.fwy[i - L.W] : 0.f;
-    return c;
-}
-__device__ __forceinline__ vf mid_op(const MidCoef& c, const vf* __restrict__ s_v, int i, int W, vf* centre = nullptr) {
-    const vf v0 = s_v[i];
-    if (centre) *centre = v0;
-    vf y = c.d * v0;
-    if (c.flags & 1u) y -= c.w0 * s_v[i + 1];
-    if (c.flags & 2u) y -= c.w1 * s_v[i - 1];
-    if (c.flags & 4u) y -= c.w2 * s_v[i + W];
-    if (c.flags & 8u) y -= c.w3 * s_v[i - W];
-    return y;
-}
-// restricted residual of coarse pixel I: children of the fine grid (Wf x Hf) in the order (0,0),(0,1),(1,0),(1,1)
-__device__ __forceinline__ vf mid_restrict(const vf* __restrict__ s_res, int I, int Wc, int Wf, int Hf) {
-    const int Y = I / Wc, X = I - Y * Wc;
-    vf acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int yy = 2 * Y + (k >> 1), xx = 2 * X + (k & 1);
-        if (yy < Hf && xx < Wf) acc += s_res[yy * Wf + xx];
-    }
-    return acc;
-}
-// Level D of the fused sub-cycle. In: this level's right-hand side b[] in registers (pixel i = t + k * MID_T). Out: this level's correction
-// in s_out (LDS, n values) — or in global L.x2 for D == 0. sA / sB: exchange arrays (>= n); sC: the child's correction (n_child values).
-template <int D>
-__device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __restrict__ sA, vf* __restrict__ sB, vf* __restrict__ sC,
-                                          vf* __restrict__ sb0, vf* __restrict__ sx0, const vf (&breg)[mid_ppt(D)], int sweeps) {
-    constexpr int PPT = mid_ppt(D);
-    constexpr bool INLDS = D == 0 && NCT_MID_LDS0 != 0;
-    const Lvl& L = P.lv[D];
-    const int n = L.n, W = L.W;
-    auto bval = [&](int k, int i) -> vf { if constexpr (INLDS) return sb0[i]; else return breg[k]; };
-    if (D == P.nl - 1) {
-        // ---- coarsest grid: wave 0, one lane per unknown (same code as the single-workgroup tail of round 1)
-        if (t < n) sA[t] = bval(0, t);
-        __syncthreads();
-        if (t < 64) {
-            const int i = t, H = L.H;
-            const bool live = i < n;
-            const int r = live ? i / W : 0, c = live ? i - r * W : 0;
-            vf bq = 0, d = 0, dv = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-            const bool has_r = live && c + 1 < W, has_l = live && c > 0, has_d = live && r + 1 < H, has_u = live && r > 0;
-            if (live) {
-                bq = sA[i]; d = L.fdiag[i]; dv = L.fdinv[i];
-                if (has_r) w0 = L.fwx[i];
-                if (has_l) w1 = L.fwx[i - 1];
-                if (has_d) w2 = L.fwy[i];
-                if (has_u) w3 = L.fwy[i - W];
-            }
-            vf x = 0.0f;
-            for (int s = 0; s < sweeps; ++s) {
-                const vf xr = __shfl(x, (i + 1) & 63), xl = __shfl(x, (i - 1) & 63), xd = __shfl(x, (i + W) & 63), xu = __shfl(x, (i - W) & 63);
-                vf y = d * x;
-                if (has_r) y -= w0 * xr;
-                if (has_l) y -= w1 * xl;
-                if (has_d) y -= w2 * xd;
-                if (has_u) y -= w3 * xu;
-                if (live) x = x + (bq - y) * (dv * MG_R0);
-            }
-            if (live) { if (D == 0) L.x2[(size_t)q * n + i] = x; else sC[i] = x; }
-        }
-        __syncthreads();
-        return;
-    }
-    if constexpr (D + 1 < MID_LV) {
-        const Lvl& C = P.lv[D + 1];
-        MidCoef c[PPT]; vf x[PPT];
-        // ---- down: MG_NS sweeps from zero (x_1 = b*dinv ; x_{s+1} = x_s + (b - M x_s)*dinv*rk(s)), iterates in ping-pong through sA / sB ; res = b - M x
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) { c[k] = mid_coef(L, i); sA[i] = bval(k, i) * c[k].dinv; } }
-        __syncthreads();
-#pragma unroll
-        for (int sw = 1; sw < MG_NS; ++sw) {
-            vf* src = (sw & 1) ? sA : sB; vf* dst = (sw & 1) ? sB : sA;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int i = t + k * MID_T;
-                if (i < n) {
-                    vf xs; const vf y = mid_op(c[k], src, i, W, &xs);
-                    const vf xv = xs + (bval(k, i) - y) * (c[k].dinv * mg_rk(sw));
-                    dst[i] = xv;
-                    if (sw == MG_NS - 1) { if constexpr (INLDS) sx0[i] = xv; else x[k] = xv; }
-                }
-            }
-            __syncthreads();
-        }
-        {
-            vf* xs = (MG_NS & 1) ? sA : sB; vf* rs = (MG_NS & 1) ? sB : sA;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) rs[i] = bval(k, i) - mid_op(c[k], xs, i, W); }
-        }
-        __syncthreads();
-        constexpr int CPT = mid_ppt(D + 1);
-        vf bc[CPT];
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) { const int I = t + k * MID_T; bc[k] = I < C.n ? mid_restrict((MG_NS & 1) ? sB : sA, I, C.W, W, L.H) : 0.f; }
-        __syncthreads();                                      // the residual array is free again
-        mid_level<D + 1>(P, q, t, sA, sB, sC, sb0, sx0, bc, sweeps);    // its correction arrives in sC
-        // ---- up: xe = x + e_coarse(parent) ; x2 = xe + (b - M xe)*dinv ; xo = x2 + (b - M x2)*dinv
-        if constexpr (D == 0) {                                // the first fused level does not keep its coefficients across the deeper levels
-            asm volatile("" ::: "memory");                     // (a real reload: without the clobber the first loads' registers stay live)
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) c[k] = mid_coef(L, i); }
-        }
-        // (the iterates xe and x2 of the own pixel are read back from the exchange arrays, where the operator reads them anyway)
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = t + k * MID_T;
-            if (i < n) {
-                const int gy = i / W, gx = i - gy * W;
-                vf xk; if constexpr (INLDS) xk = sx0[i]; else xk = x[k];
-                sA[i] = xk + sC[(gy >> 1) * C.W + (gx >> 1)];
-            }
-        }
-        __syncthreads();                                      // (from here on every thread has finished reading the child's correction in sC)
-#pragma unroll
-        for (int sw = 0; sw < MG_NS; ++sw) {
-            vf* src = (sw & 1) ? sB : sA; vf* dst = (sw & 1) ? sA : sB;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int i = t + k * MID_T;
-                if (i < n) {
-                    vf xs; const vf y = mid_op(c[k], src, i, W, &xs);
-                    const vf v = xs + (bval(k, i) - y) * (sw == 0 ? c[k].dinv : c[k].dinv * mg_rk(sw));
-                    if (sw < MG_NS - 1) dst[i] = v;
-                    else if (D == 0) L.x2[(size_t)q * n + i] = v; else sC[i] = v;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-__global__ __launch_bounds__(MID_T) void k_mg_mid(const PState* __restrict__ st, MidPack P, int sweeps) {
+// Coarsest grid (n <= 64, 9-point): `sweeps` damped-Jacobi (0.8) sweeps from zero, one wave per right-hand side, one lane per unknown, the iterate in a
+// register, neighbours through ds_bpermute. Its correction goes to L.x2.
+__global__ __launch_bounds__(64) void k_mg_coarsest(const PState* __restrict__ st, Lvl L, int sweeps) {
     if (st->nactive == 0) return;
-    __shared__ vf sA[MID_N0], sB[MID_N0], sC[MID_N1];
-    const int q = blockIdx.x, t = threadIdx.x;
-    const Lvl& L0 = P.lv[0];
-    vf b[MID_P0];
-#if NCT_MID_LDS0
-    __shared__ vf sb0[MID_N0], sx0[MID_N0];
+    const int q = blockIdx.x, i = threadIdx.x, n = L.n, W = L.W;
+    const bool live = i < n;
+    const int r = live ? i / W : 0, c = live ? i - r * W : 0;
+    vf bq = 0.f, d = 0.f, dv = 0.f, w[8]; unsigned ex = 0;
 #pragma unroll
-    for (int k = 0; k < MID_P0; ++k) { const int i = t + k * MID_T; b[k] = 0.f; if (i < L0.n) sb0[i] = L0.b[(size_t)q * L0.n + i]; }
-    mid_level<0>(P, q, t, sA, sB, sC, sb0, sx0, b, sweeps);         // each thread reads back only what it wrote: no barrier needed
-#else
+    for (int k = 0; k < 8; ++k) w[k] = 0.f;
+    if (live) { const PxCoef pc = px_coef<true>(L, r, c); d = pc.d; dv = pc.dinv; ex = pc.ex; bq = L.b[(size_t)q * n + i];
 #pragma unroll
-    for (int k = 0; k < MID_P0; ++k) { const int i = t + k * MID_T; b[k] = i < L0.n ? L0.b[(size_t)q * L0.n + i] : 0.f; }
-    mid_level<0>(P, q, t, sA, sB, sC, nullptr, nullptr, b, sweeps);
-#endif
+        for (int k = 0; k < 8; ++k) w[k] = pc.w[k]; }
+    vf x = 0.0f;
+    for (int s = 0; s < sweeps; ++s) {
+        vf y = d * x;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const vf xn = __shfl(x, (i + nb_dy(k) * W + nb_dx(k)) & 63);
+            if (ex & (1u << k)) y -= w[k] * xn;
+        }
+        if (live) x = x + (bq - y) * (dv * MG_R0);
+    }
+    if (live) L.x2[(size_t)q * n + i] = x;
 }
 
 // ---- PCG pieces at the fine level
 
 // x6 = interleave(X); r = rough*x0 - M x0 ; partial: rr, bb (12)
 template <int NQ>
-__global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restrict__ X /*[2][n][3]*/, double* __restrict__ x6, double* __restrict__ r, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restrict__ rough, const double* __restrict__ X /*[2][n][3]*/, double* __restrict__ x6, double* __restrict__ r, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[2 * NQ];
 #pragma unroll
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restri
     if (i < L.n) {
         auto xv = [&](int j, int q) { return X[((size_t)(q / 3) * L.n + j) * 3 + (q % 3)]; };
         double y[NQ]; lvl_op<NQ>(L, i, xv, y);
-        const double rg = L.r[i];
+        const double rg = rough[i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const double x0 = xv(i, q);
@@ -657,6 +657,7 @@ struct PartBufs {
     double *x6, *r, *p, *sv, *w, *partial, *sums; PState* st;      // Krylov vectors [NQ][N], reduction scratch, double-buffered state
     std::vector<Lvl> lv;                                            // the shared operator hierarchy with THIS part's V-cycle vectors (b, x, x2)
     PState* hst; hipEvent_t ev[2];                                  // two page-locked read-back slots and their events
+    const double* rough;                                            // the data term (right-hand side = rough * x0)
     int maxit, graph;
     int iters[NQMAX];
 };
@@ -670,52 +671,39 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     PState* st = B.st;                                 // st[0] / st[1]; `cur` = the state the iteration being enqueued reads
     const PState* cur = st;
     const double rtol2 = rtol * rtol;
-    hipLaunchKernelGGL(k_pcg_start<NQ>, dim3(nb), dim3(256), 0, s, F, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
+    hipLaunchKernelGGL(k_pcg_start<NQ>, dim3(nb), dim3(256), 0, s, F, B.rough, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
     hipLaunchKernelGGL(k_pcg_start_fin<NQ>, dim3(1), dim3(256), 0, s, (const double*)partial, nb, st, rtol2); LCHK();
 
-    // z = Vcycle(r). Levels 0..nl-2 run the tile-fused down/up legs (2 launches per level), the coarsest grid one 6-wave kernel.
-    // res[l] = where level l's correction ends up (the up leg cannot write in place: neighbouring tiles still read lv[l].x).
-    // The deepest levels run in k_mg_mid, one workgroup per right-hand side (round 1's tail — ONE workgroup for all six systems — had to stop
-    // at 512 pixels: with the 44x44 level it took 157 us per cycle).
-    // tail0 = first level of the fused middle + tail (k_mg_mid): the deepest run of levels whose first has <= MID_N0 pixels and the others
-    // <= MID_N1, at most MID_LV of them; never the fine level (its right-hand side is the fp64 PCG residual and its tiles fill the chip)
-    int tail0 = nl - 1;
-    auto mid_fits = [&](int first) {                     // levels first .. nl-1 as depths 0 .. of k_mg_mid
-        if (nl - first > MID_LV) return false;
-        for (int l = first; l < nl; ++l) { const int d = l - first; if (lv[l].n > (d == 0 ? MID_N0 : (d == 1 ? MID_N1 : MID_N2))) return false; }
-        return true;
-    };
-    while (tail0 > 1 && mid_fits(tail0 - 1)) --tail0;
-    MidPack pack; memset(&pack, 0, sizeof pack); pack.nl = nl - tail0;
-    for (int l = tail0; l < nl; ++l) pack.lv[l - tail0] = lv[l];
-    // Tile shapes: bandwidth-bound levels use TXB x TYB tiles; below 100k pixels the legs are latency bound, so a 16x8 tile whose
-    // haloed footprint (18x10) fits one pass of the 256 threads keeps the dependent load chains short and spreads over more CUs.
+    // z = Vcycle(r). Levels 0..nl-2 run the tile-fused down/up legs (2 launches per level), the coarsest grid one wave per right-hand side.
+    // lv[l].x2 = where level l's correction ends up (the up leg cannot write in place: neighbouring tiles still read lv[l].x).
+    // Tile shapes: bandwidth-bound levels use TXB x TYB tiles; below 100k pixels the legs are latency bound, so a 16x8 tile keeps the
+    // dependent load chains short and spreads over more CUs.
     constexpr int TXB = NCT_MG_TXB, TYB = NCT_MG_TYB;
     auto down = [&](int l) {
         const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
         if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
-            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, double, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, double, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
         } else {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
-            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, vf, true>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, vf, true>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
         }
     };
     auto up = [&](int l, const vf* ec) {
         const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
         const int Wc = lv[l + 1].W, nc = lv[l + 1].n;
         if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, double>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, double>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, double, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, double, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
         } else {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, vf>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, vf>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, vf, true>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, vf, true>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
         }
     };
     auto vcycle = [&]() -> int {
-        for (int l = 0; l < tail0; ++l) { down(l); LCHK(); }
-        hipLaunchKernelGGL(k_mg_mid, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60); LCHK();
-        for (int l = tail0 - 1; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
+        for (int l = 0; l < nl - 1; ++l) { down(l); LCHK(); }
+        hipLaunchKernelGGL(k_mg_coarsest, dim3(NQ), dim3(64), 0, s, cur, lv[nl - 1], 60); LCHK();
+        for (int l = nl - 2; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
         return 0;
     };
     const vf* z = lv[0].x2;
@@ -797,22 +785,38 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     {
         int h = H, w = W;
         for (int l = 0;; ++l) {
-            Lvl L; memset(&L, 0, sizeof L); L.H = h; L.W = w; L.n = h * w;
-            if (l == 0) { L.r = (double*)rough; L.wx = (double*)wx; L.wy = (double*)wy; }
-            else { L.r = newd(L.n); L.wx = newd(L.n); L.wy = newd(L.n); }
-            L.diag = newd(L.n); L.fdiag = newf(L.n); L.fdinv = newf(L.n); L.fwx = newf(L.n); L.fwy = newf(L.n);
+            Lvl L; memset(&L, 0, sizeof L); L.H = h; L.W = w; L.n = h * w; L.nine = l > 0 ? 1 : 0;
+            const bool last = L.n <= 64 || (h <= 8 && w <= 8) || l >= 15;
+            if (l == 0) { L.wE = (double*)wx; L.wS = (double*)wy; }
+            else { L.wE = newd(L.n); L.wS = newd(L.n); L.wSE = newd(L.n); L.wSW = newd(L.n); L.fSE = newf(L.n); L.fSW = newf(L.n);
+                   if (!L.wE || !L.wS || !L.wSE || !L.wSW || !L.fSE || !L.fSW) return NCT_ERR_HIP; }
+            L.d = newd(L.n); L.fd = newf(L.n); L.fdinv = newf(L.n); L.fE = newf(L.n); L.fS = newf(L.n);
+            if (!last) { L.pa = newd(L.n); L.pb = newd(L.n); }
+            L.fpa = newf(L.n); L.fpb = newf(L.n);                  // (the coarsest level never reads them, but px_coef loads them)
             L.b = l == 0 ? nullptr : newf((size_t)L.n * nq0); L.x = newf((size_t)L.n * nq0); L.x2 = newf((size_t)L.n * nq0);
-            if (!L.r || !L.wx || !L.wy || !L.diag || !L.fdiag || !L.fdinv || !L.fwx || !L.fwy || (l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
+            if (!L.d || !L.fd || !L.fdinv || !L.fE || !L.fS || (!last && (!L.pa || !L.pb)) || !L.fpa || !L.fpb || (l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
             lv.push_back(L);
-            if (L.n <= 64 || (h <= 8 && w <= 8) || lv.size() >= 16) break;
+            if (last) break;
             h = (h + 1) / 2; w = (w + 1) / 2;
         }
         if (lv.back().n > 64 || lv.size() < 2) return ctx->fail(NCT_ERR_INVALID, "wls: unsupported grid %dx%d (coarsest level %d)", W, H, lv.back().n);
     }
     const int nl = (int)lv.size();
-    for (int l = 0; l < nl; ++l) {
-        if (l > 0) { hipLaunchKernelGGL(k_mg_coarsen, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l - 1], lv[l]); LCHK(); }
-        hipLaunchKernelGGL(k_mg_diag, dim3(cdiv(lv[l].n, 256)), dim3(256), 0, s, lv[l]); LCHK();
+    {
+        double* pst = newd((size_t)lv[1].n * 9);                  // columns of P as 3x3 blocks, reused level by level
+        if (!pst) return NCT_ERR_HIP;
+        hipLaunchKernelGGL(k_mg_diag, dim3(cdiv(lv[0].n, 256)), dim3(256), 0, s, lv[0], rough); LCHK();
+        for (int l = 0; l < nl; ++l) {
+            const dim3 g(cdiv(lv[l].n, 256));
+            if (l > 0) {
+                const dim3 gc(cdiv(lv[l].n, 128));
+                hipLaunchKernelGGL(k_mg_pstencil, gc, dim3(128), 0, s, lv[l - 1], lv[l], pst); LCHK();
+                hipLaunchKernelGGL(k_mg_galerkin, gc, dim3(128), 0, s, lv[l - 1], lv[l], (const double*)pst); LCHK();
+                hipLaunchKernelGGL(k_mg_finish, g, dim3(256), 0, s, lv[l]); LCHK();
+            }
+            if (l + 1 < nl) { hipLaunchKernelGGL(k_mg_weights, g, dim3(256), 0, s, lv[l]); LCHK(); }
+            else { NCT_HIP(hipMemsetAsync(lv[l].fpa, 0, sizeof(vf) * lv[l].n, s)); NCT_HIP(hipMemsetAsync(lv[l].fpb, 0, sizeof(vf) * lv[l].n, s)); }
+        }
     }
     const int N = lv[0].n, nb = cdiv(N, 256);
     static_assert(4 * sizeof(PState) <= 4096, "pinned read-back area too small");
@@ -832,7 +836,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             if ((l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
         }
         B.hst = (PState*)ctx->pinned + 2 * h; B.ev[0] = ctx->ev_poll[2 * h]; B.ev[1] = ctx->ev_poll[2 * h + 1];
-        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph;
+        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph; B.rough = rough;
         memset(B.iters, 0, sizeof B.iters);
     }
     if (!split) {

@@ -1,23 +1,33 @@
 /* oracle/orc_wls_mg.c — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
  *
  * S2 (ColorTransfer.cpp:951-1125): canonical-order restatement of the product's multigrid-preconditioned CG for the WLS
- * system (diag(r) + L_g) x = r x0 with 6 right-hand sides. The reference solves this system exactly (MKL PARDISO);
- * this solver converges to 1e-8 relative residual and is cross-checked against the exact solve (banded Cholesky / PARDISO
- * fixture) in tests/test_oracle_color.py. It exists in this exact arithmetic order so that the 8-bit result of the GPU
- * path can be compared bit-for-bit (see orc_color_canon.c for why that matters: S1 downstream is chaotic).
- * Hierarchy: 2x2 aggregation (coarse data term = sum of the 4 fine ones, coarse edge = sum of the crossing fine edges), built in
- * fp64; V(2,2) cycle, Chebyshev-weighted Jacobi (omega 0.5808 then 2.6437), 60 Jacobi sweeps (0.8) on the coarsest grid — the cycle runs in fp32 on rounded copies
- * of the level operators (it is only the preconditioner; the CG recurrences, the operator and every dot product stay fp64);
- * two-stage 256-wide tree reductions. */
+ * system (diag(r) + L_g) x = r x0 with 6 right-hand sides. The reference solves this system exactly (MKL PARDISO,
+ * SparseSolver_CPU.cpp:104-286); this solver converges to 1e-7 relative residual and is cross-checked against the exact solve
+ * (banded Cholesky / PARDISO fixture) in tests/test_oracle_color.py. It exists in this exact arithmetic order so that the
+ * 8-bit result of the GPU path can be compared bit-for-bit (see orc_color_canon.c for why that matters: S1 downstream is chaotic).
+ *
+ * Hierarchy (round 4; rounds 1-3: 2x2 aggregation with piecewise-constant transfer): VERTEX-CENTRED coarsening — coarse point
+ * (Y, X) IS fine point (2Y, 2X) — with OPERATOR-DEPENDENT interpolation (the black-box multigrid of Alcouffe/Brandt/Dendy/Painter):
+ *   fine points on a coarse grid line interpolate from their two coarse neighbours with weights from the stencil collapsed across
+ *   the line (w_W / (d - w_N - w_S) ...), fine points in the middle of a coarse cell solve their own equation for the 8 neighbours;
+ * restriction = transpose, coarse operators = Galerkin products P^T A P: symmetric 9-point stencils, stored as the diagonal and the
+ * four forward couplings (+x, +y, +x+y, -x+y), all as w = -A(i,j) so that level 0 keeps the 5-point (diag, wx, wy) form.
+ * Built in fp64; the V(NS,NS) cycle runs in fp32 on rounded copies (it is only the preconditioner; the CG recurrences, the
+ * operator and every dot product stay fp64). Smoother: NS Chebyshev-weighted Jacobi sweeps per leg on the "safe" diagonal
+ * dt = max(d, (d + sum |w|) / 2) (Gershgorin: lambda_max(dt^-1 A) <= 2 also where a Galerkin stencil has couplings of the wrong
+ * sign; dt = d for M-matrix rows, i.e. everywhere on level 0); 60 Jacobi sweeps (0.8) on the coarsest grid; two-stage 256-wide
+ * tree reductions. */
 #include "orc_common.h"
 #include <stdio.h>
 
 void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double* diag, double* wx, double* wy);
 
 #define NQ 6
-/* two Chebyshev-weighted Jacobi sweeps per leg (k_wls_mg.hip: NCT_MG_W1 / NCT_MG_W2); fdinv = (float)(W1 / diag), the second sweep and the
- * coarsest grid scale it in fp32 exactly as the kernels do */
-typedef struct { int H, W, n; double *r, *wx, *wy, *diag; float *fdiag, *fdinv, *fwx, *fwy, *b, *x, *x2; } lvl_t;   /* fdinv = (float)(omega / diag) */
+/* w-notation: (A v)_i = d_i v_i - sum_k w_ik v_k ; forward couplings wE = w(i, i+1), wS = w(i, i+W), wSE = w(i, i+W+1), wSW = w(i, i+W-1),
+ * zero where the neighbour does not exist. Level 0: wSE = wSW = NULL (5-point). pa / pb: interpolation weights of the transfer to the next
+ * coarser level — (even y, odd x): to the W / E coarse point; (odd y, even x): to the N / S one; (odd, odd): pa = 1 / d. */
+typedef struct { int H, W, n, nine; double *d, *wE, *wS, *wSE, *wSW, *pa, *pb;
+                 float *fd, *fdinv, *fE, *fS, *fSE, *fSW, *fpa, *fpb, *b, *x, *x2; } lvl_t;   /* fdinv = (float)(omega_0 / dt) */
 
 static void tree256(double* s) { for (int off = 128; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) s[t] += s[t + off]; }
 static void canon_sum(const double* v, int n, int nq, double* out) {
@@ -38,25 +48,36 @@ static void canon_sum(const double* v, int n, int nq, double* out) {
     free(partial);
 }
 
-/* y = M v at pixel i; VAL(j,q) is an expression giving v_j[q] */
+/* the 8 couplings of pixel (r, c) in the order E, W, S, N, SE, SW, NE, NW (0 where the neighbour does not exist); fp64 and fp32 forms */
+#define COUP8(TYPE, L, E_, S_, SE_, SW_, r, c, w) do { \
+    const int W_ = (L)->W, H_ = (L)->H, i_ = (r) * W_ + (c); const int xr = (c) + 1 < W_, xl = (c) > 0, yd = (r) + 1 < H_, yu = (r) > 0; \
+    (w)[0] = xr ? (L)->E_[i_] : (TYPE)0; (w)[1] = xl ? (L)->E_[i_ - 1] : (TYPE)0; (w)[2] = yd ? (L)->S_[i_] : (TYPE)0; (w)[3] = yu ? (L)->S_[i_ - W_] : (TYPE)0; \
+    if ((L)->nine) { (w)[4] = (xr && yd) ? (L)->SE_[i_] : (TYPE)0; (w)[5] = (xl && yd) ? (L)->SW_[i_] : (TYPE)0; \
+                     (w)[6] = (xr && yu) ? (L)->SW_[i_ - W_ + 1] : (TYPE)0; (w)[7] = (xl && yu) ? (L)->SE_[i_ - W_ - 1] : (TYPE)0; } \
+    else { (w)[4] = (w)[5] = (w)[6] = (w)[7] = (TYPE)0; } } while (0)
+static const int OFFY[8] = {0, 0, 1, -1, 1, 1, -1, -1}, OFFX[8] = {1, -1, 0, 0, 1, -1, 1, -1};
+static int nbr_ok(const lvl_t* L, int r, int c, int k) { const int y = r + OFFY[k], x = c + OFFX[k]; return y >= 0 && y < L->H && x >= 0 && x < L->W && (k < 4 || L->nine); }
+
+/* fp64 fine-level operator (5-point), neighbour order +x, -x, +y, -y */
 #define LVL_OP(L, i, VAL, y) do { \
-    const int W_ = (L)->W, H_ = (L)->H; const int r_ = (i) / W_, c_ = (i) - r_ * W_; const double d_ = (L)->diag[i]; \
+    const int W_ = (L)->W, H_ = (L)->H; const int r_ = (i) / W_, c_ = (i) - r_ * W_; const double d_ = (L)->d[i]; \
     for (int q = 0; q < NQ; ++q) (y)[q] = d_ * VAL((i), q); \
-    if (c_ + 1 < W_) { const double w_ = (L)->wx[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + 1, q); } \
-    if (c_ > 0) { const double w_ = (L)->wx[(i) - 1]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - 1, q); } \
-    if (r_ + 1 < H_) { const double w_ = (L)->wy[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + W_, q); } \
-    if (r_ > 0) { const double w_ = (L)->wy[(i) - W_]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - W_, q); } } while (0)
+    if (c_ + 1 < W_) { const double w_ = (L)->wE[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + 1, q); } \
+    if (c_ > 0) { const double w_ = (L)->wE[(i) - 1]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - 1, q); } \
+    if (r_ + 1 < H_) { const double w_ = (L)->wS[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + W_, q); } \
+    if (r_ > 0) { const double w_ = (L)->wS[(i) - W_]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - W_, q); } } while (0)
 
-/* fp32 stencil of a level; VAL(j,q) is a float expression giving v_j[q]; every operation is a float operation */
-#define LVL_OPF(L, i, VAL, y) do { \
-    const int W_ = (L)->W, H_ = (L)->H; const int r_ = (i) / W_, c_ = (i) - r_ * W_; const float d_ = (L)->fdiag[i]; \
-    for (int q = 0; q < NQ; ++q) (y)[q] = d_ * VAL((i), q); \
-    if (c_ + 1 < W_) { const float w_ = (L)->fwx[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + 1, q); } \
-    if (c_ > 0) { const float w_ = (L)->fwx[(i) - 1]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - 1, q); } \
-    if (r_ + 1 < H_) { const float w_ = (L)->fwy[i]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) + W_, q); } \
-    if (r_ > 0) { const float w_ = (L)->fwy[(i) - W_]; for (int q = 0; q < NQ; ++q) (y)[q] -= w_ * VAL((i) - W_, q); } } while (0)
+/* fp32 stencil of a level: y = d v_i - sum_k w_k v_k over the existing neighbours in the order E, W, S, N, SE, SW, NE, NW; every operation is a float operation */
+static void opf(const lvl_t* L, int i, const float* v, float* y) {
+    const int W = L->W, r = i / W, c = i - r * W;
+    float w[8]; COUP8(float, L, fE, fS, fSE, fSW, r, c, w);
+    const float d = L->fd[i];
+    for (int q = 0; q < NQ; ++q) y[q] = d * v[(size_t)i * NQ + q];
+    for (int k = 0; k < 8; ++k)
+        if (nbr_ok(L, r, c, k)) { const int j = i + OFFY[k] * W + OFFX[k]; for (int q = 0; q < NQ; ++q) y[q] -= w[k] * v[(size_t)j * NQ + q]; }
+}
 
-/* Smoother: NS damped-Jacobi sweeps per leg with Chebyshev weights (k_wls_mg.hip: MG_NS, MG_W[]); fdinv = (float)(W[0] / diag), sweep k scales it in fp32 by
+/* Smoother: NS damped-Jacobi sweeps per leg with Chebyshev weights (k_wls_mg.hip: MG_NS, MG_W[]); fdinv = (float)(W[0] / dt), sweep k scales it in fp32 by
  * (float)(W[k] / W[0]) exactly as the kernels do. orc_set_mg_smoother selects one of the shipped / experimental sets (design experiments; the default is the product's). */
 static int MG_NS = 3;
 static double MG_W[8] = {0.5346, 0.9677, 5.0974};
@@ -77,18 +98,85 @@ static void mg_sweep(const lvl_t* L, const double* r0, const float* in, float* o
         for (int i = 0; i < L->n; ++i) for (int q = 0; q < NQ; ++q) out[(size_t)i * NQ + q] = BVS(i, q) * L->fdinv[i];
         return;
     }
-#define INV(j, q) (in[(size_t)(j) * NQ + (q)])
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < L->n; ++i) {
-        float y[NQ]; LVL_OPF(L, i, INV, y);
+        float y[NQ]; opf(L, i, in, y);
         const float d = rk == 1.0f ? L->fdinv[i] : L->fdinv[i] * rk;
         for (int q = 0; q < NQ; ++q) { const float t = BVS(i, q) - y[q]; const float u = t * d; out[(size_t)i * NQ + q] = in[(size_t)i * NQ + q] + u; }
     }
-#undef INV
 }
 
-/* z = lv[0].x (fp32) for the fp64 residual r0 (rounded to fp32 on load) */
-static void vcycle(lvl_t* lv, int nl, const double* r0) {
+/* restriction R = P^T of the residual of level L (res, [n][NQ] scratch; t2 a second scratch) into C->b:
+ *   1. cell-centre points (odd, odd): t = res * (1/d)                      (they are eliminated exactly: P's centre rows solve the centre equation)
+ *   2. every other point j: res'(j) = res(j) + sum over the adjacent centres c of w_jc t(c), in the neighbour order E, W, S, N, SE, SW, NE, NW
+ *   3. coarse point I at fine f: b_c(I) = res'(f) + pa(E pt) res'(E pt) + pb(W pt) res'(W pt) + pa(S pt) res'(S pt) + pb(N pt) res'(N pt) */
+static void mg_restrict(const lvl_t* L, lvl_t* C, float* res, float* t2) {
+    const int W = L->W, H = L->H;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < L->n; ++i) {
+        const int r = i / W, c = i - r * W;
+        if ((r & 1) && (c & 1)) for (int q = 0; q < NQ; ++q) t2[(size_t)i * NQ + q] = res[(size_t)i * NQ + q] * L->fpa[i];
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < L->n; ++i) {
+        const int r = i / W, c = i - r * W;
+        if ((r & 1) && (c & 1)) continue;
+        float w[8]; COUP8(float, L, fE, fS, fSE, fSW, r, c, w);
+        float acc[NQ]; for (int q = 0; q < NQ; ++q) acc[q] = res[(size_t)i * NQ + q];
+        for (int k = 0; k < 8; ++k) {
+            if (!nbr_ok(L, r, c, k)) continue;
+            const int y = r + OFFY[k], x = c + OFFX[k];
+            if (!((y & 1) && (x & 1))) continue;
+            const int j = y * W + x;
+            for (int q = 0; q < NQ; ++q) acc[q] += w[k] * t2[(size_t)j * NQ + q];
+        }
+        for (int q = 0; q < NQ; ++q) t2[(size_t)i * NQ + q] = acc[q];          /* non-centre slots of t2 are written only here, centre slots only in step 1 */
+    }
+#pragma omp parallel for schedule(static)
+    for (int I = 0; I < C->n; ++I) {
+        const int Y = I / C->W, X = I - Y * C->W, r = 2 * Y, c = 2 * X, f = r * W + c;
+        float acc[NQ]; for (int q = 0; q < NQ; ++q) acc[q] = t2[(size_t)f * NQ + q];
+        if (c + 1 < W) { const float p = L->fpa[f + 1]; for (int q = 0; q < NQ; ++q) acc[q] += p * t2[(size_t)(f + 1) * NQ + q]; }
+        if (c > 0) { const float p = L->fpb[f - 1]; for (int q = 0; q < NQ; ++q) acc[q] += p * t2[(size_t)(f - 1) * NQ + q]; }
+        if (r + 1 < H) { const float p = L->fpa[f + W]; for (int q = 0; q < NQ; ++q) acc[q] += p * t2[(size_t)(f + W) * NQ + q]; }
+        if (r > 0) { const float p = L->fpb[f - W]; for (int q = 0; q < NQ; ++q) acc[q] += p * t2[(size_t)(f - W) * NQ + q]; }
+        for (int q = 0; q < NQ; ++q) C->b[(size_t)I * NQ + q] = acc[q];
+    }
+}
+/* prolongation e = P ec on level L (e: [n][NQ]):  coarse points copy; line points pa e(W|N) + pb e(E|S); centres (sum_k w_ck e_k) * (1/d), k = E, W, S, N, SE, SW, NE, NW */
+static void mg_prolong(const lvl_t* L, const lvl_t* C, const float* ec, float* e) {
+    const int W = L->W, H = L->H, Wc = C->W;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < L->n; ++i) {
+        const int r = i / W, c = i - r * W;
+        if (!(r & 1) && !(c & 1)) for (int q = 0; q < NQ; ++q) e[(size_t)i * NQ + q] = ec[(size_t)((r >> 1) * Wc + (c >> 1)) * NQ + q];
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < L->n; ++i) {
+        const int r = i / W, c = i - r * W;
+        if (((r & 1) ^ (c & 1)) == 0) continue;
+        const int st = (c & 1) ? 1 : W;                      /* (even y, odd x): W / E neighbours; (odd y, even x): N / S */
+        const int has2 = (c & 1) ? c + 1 < W : r + 1 < H;
+        for (int q = 0; q < NQ; ++q) {
+            float v = L->fpa[i] * e[(size_t)(i - st) * NQ + q];
+            if (has2) v += L->fpb[i] * e[(size_t)(i + st) * NQ + q];
+            e[(size_t)i * NQ + q] = v;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < L->n; ++i) {
+        const int r = i / W, c = i - r * W;
+        if (!((r & 1) && (c & 1))) continue;
+        float w[8]; COUP8(float, L, fE, fS, fSE, fSW, r, c, w);
+        float acc[NQ] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 8; ++k)
+            if (nbr_ok(L, r, c, k)) { const int j = i + OFFY[k] * W + OFFX[k]; for (int q = 0; q < NQ; ++q) acc[q] += w[k] * e[(size_t)j * NQ + q]; }
+        for (int q = 0; q < NQ; ++q) e[(size_t)i * NQ + q] = acc[q] * L->fpa[i];
+    }
+}
+
+/* z = lv[0].x (fp32) for the fp64 residual r0 (rounded to fp32 on load). scr1/scr2: [n0][NQ] float scratch */
+static void vcycle(lvl_t* lv, int nl, const double* r0, float* scr1, float* scr2) {
     for (int l = 0; l < nl - 1; ++l) {
         lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
         const double* rr = l == 0 ? r0 : NULL;
@@ -96,25 +184,13 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
         float* cur = (MG_NS & 1) ? L->x : L->x2; float* oth = (MG_NS & 1) ? L->x2 : L->x;
         mg_sweep(L, rr, NULL, cur, 1.0f);
         for (int k = 1; k < MG_NS; ++k) { mg_sweep(L, rr, cur, oth, mg_rk(k)); float* t = cur; cur = oth; oth = t; }
-        /* cur == L->x */
-#define BV(j, q) (l == 0 ? (float)r0[(size_t)(j) * NQ + (q)] : L->b[(size_t)(j) * NQ + (q)])
-#define XV(j, q) (L->x[(size_t)(j) * NQ + (q)])
+        /* cur == L->x ; residual, then restriction */
 #pragma omp parallel for schedule(static)
-        for (int I = 0; I < C->n; ++I) {
-            const int Y = I / C->W, X = I - Y * C->W;
-            float acc[NQ] = {0, 0, 0, 0, 0, 0};
-            for (int t = 0; t < 4; ++t) {
-                const int y = 2 * Y + (t >> 1), xx = 2 * X + (t & 1);
-                if (y < L->H && xx < L->W) {
-                    const int i = y * L->W + xx;
-                    float yv[NQ]; LVL_OPF(L, i, XV, yv);
-                    for (int q = 0; q < NQ; ++q) { const float t2 = BV(i, q) - yv[q]; acc[q] += t2; }
-                }
-            }
-            for (int q = 0; q < NQ; ++q) C->b[(size_t)I * NQ + q] = acc[q];
+        for (int i = 0; i < L->n; ++i) {
+            float yv[NQ]; opf(L, i, L->x, yv);
+            for (int q = 0; q < NQ; ++q) scr1[(size_t)i * NQ + q] = (l == 0 ? (float)r0[(size_t)i * NQ + q] : L->b[(size_t)i * NQ + q]) - yv[q];
         }
-#undef XV
-#undef BV
+        mg_restrict(L, C, scr1, scr2);
     }
     {   /* coarsest: 60 Jacobi sweeps from zero */
         lvl_t* L = &lv[nl - 1];
@@ -122,34 +198,122 @@ static void vcycle(lvl_t* lv, int nl, const double* r0) {
         memset(cur, 0, sizeof(float) * (size_t)L->n * NQ);
         const float r0c = (float)(0.8 / MG_W[0]);
         for (int s = 0; s < 60; ++s) {
-#define CV(j, q) (cur[(size_t)(j) * NQ + (q)])
             for (int i = 0; i < L->n; ++i) {
-                float y[NQ]; LVL_OPF(L, i, CV, y);
+                float y[NQ]; opf(L, i, cur, y);
                 const float d = L->fdinv[i] * r0c;
                 for (int q = 0; q < NQ; ++q) { const float t = L->b[(size_t)i * NQ + q] - y[q]; const float u = t * d; nxt[(size_t)i * NQ + q] = cur[(size_t)i * NQ + q] + u; }
             }
-#undef CV
             float* t = cur; cur = nxt; nxt = t;
         }
         /* 60 is even: the result is back in L->x */
     }
     for (int l = nl - 2; l >= 0; --l) {
         lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
-        const int Wc = C->W;
         const double* rr = l == 0 ? r0 : NULL;
-        /* xe = x + e_coarse(parent), then NS sweeps; the result ends in L->x */
+        /* xe = x + P e_coarse, then NS sweeps; the result ends in L->x */
+        mg_prolong(L, C, C->x, scr1);
         float* cur = (MG_NS & 1) ? L->x2 : L->x; float* oth = (MG_NS & 1) ? L->x : L->x2;
-        if (cur != L->x) {
 #pragma omp parallel for schedule(static)
-            for (int j = 0; j < L->n; ++j) for (int q = 0; q < NQ; ++q) cur[(size_t)j * NQ + q] = L->x[(size_t)j * NQ + q] + C->x[(size_t)(((j / L->W) >> 1) * Wc + ((j % L->W) >> 1)) * NQ + q];
-        } else {
-#pragma omp parallel for schedule(static)
-            for (int j = 0; j < L->n; ++j) for (int q = 0; q < NQ; ++q) L->x[(size_t)j * NQ + q] = L->x[(size_t)j * NQ + q] + C->x[(size_t)(((j / L->W) >> 1) * Wc + ((j % L->W) >> 1)) * NQ + q];
-        }
+        for (int j = 0; j < L->n; ++j) for (int q = 0; q < NQ; ++q) cur[(size_t)j * NQ + q] = L->x[(size_t)j * NQ + q] + scr1[(size_t)j * NQ + q];
         for (int k = 0; k < MG_NS; ++k) { mg_sweep(L, rr, cur, oth, k == 0 ? 1.0f : mg_rk(k)); float* t = cur; cur = oth; oth = t; }
     }
 }
 #undef BVS
+
+/* ---- hierarchy construction (fp64) */
+/* interpolation weights of level L (k_mg_weights): collapse the stencil across the coarse grid line */
+static void mg_weights(lvl_t* L) {
+    const int W = L->W;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < L->n; ++i) {
+        const int r = i / W, c = i - r * W;
+        double w[8]; COUP8(double, L, wE, wS, wSE, wSW, r, c, w);
+        const double d = L->d[i];
+        double pa = 0.0, pb = 0.0;
+        if (!(r & 1) && (c & 1)) { const double den = (d - w[2]) - w[3]; pa = ((w[1] + w[5]) + w[7]) / den; pb = ((w[0] + w[4]) + w[6]) / den; }           /* W: W+SW+NW ; E: E+SE+NE */
+        else if ((r & 1) && !(c & 1)) { const double den = (d - w[0]) - w[1]; pa = ((w[3] + w[6]) + w[7]) / den; pb = ((w[2] + w[4]) + w[5]) / den; }      /* N: N+NE+NW ; S: S+SE+SW */
+        else if ((r & 1) && (c & 1)) pa = 1.0 / d;
+        L->pa[i] = pa; L->pb[i] = pb;
+    }
+}
+/* the 3x3 block of column I of P around fine point (2Y, 2X): pst[(dy+1)*3 + dx+1], 0 outside the grid (k_mg_pstencil) */
+static void mg_pstencil(const lvl_t* L, int Y, int X, double* pst) {
+    const int W = L->W, H = L->H, r = 2 * Y, c = 2 * X, f = r * W + c;
+    for (int k = 0; k < 9; ++k) pst[k] = 0.0;
+    pst[4] = 1.0;
+    if (c > 0) pst[3] = L->pb[f - 1];
+    if (c + 1 < W) pst[5] = L->pa[f + 1];
+    if (r > 0) pst[1] = L->pb[f - W];
+    if (r + 1 < H) pst[7] = L->pa[f + W];
+    for (int dy = -1; dy <= 1; dy += 2)
+        for (int dx = -1; dx <= 1; dx += 2) {
+            const int y = r + dy, x = c + dx;
+            if (y < 0 || y >= H || x < 0 || x >= W) continue;
+            double w[8]; COUP8(double, L, wE, wS, wSE, wSW, y, x, w);
+            /* couplings of the centre (y, x) towards (-dy, -dx) [the coarse point], (-dy, 0) [the line point (r, x)], (0, -dx) [the line point (y, c)] */
+            const double wdiag = dy < 0 ? (dx < 0 ? w[4] : w[5]) : (dx < 0 ? w[6] : w[7]);
+            const double wvert = dy < 0 ? w[2] : w[3];
+            const double whor = dx < 0 ? w[0] : w[1];
+            pst[(dy + 1) * 3 + dx + 1] = ((wdiag + wvert * pst[3 + dx + 1]) + whor * pst[(dy + 1) * 3 + 1]) * L->pa[y * W + x];
+        }
+}
+/* Galerkin product (k_mg_galerkin): A_c(I, J) = sum over i in block(I), row-major, of pst_I(i) * (A pst_J)(i),  (A u)(i) = d_i u_i - sum_k w_ik u_k, k = E, W, S, N, SE, SW, NE, NW */
+static double galerkin_entry(const lvl_t* L, int Y, int X, const double* pI, int YJ, int XJ, const double* pJ) {
+    const int W = L->W, H = L->H;
+    double acc = 0.0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int y = 2 * Y + dy, x = 2 * X + dx;
+            if (y < 0 || y >= H || x < 0 || x >= W) continue;
+            const double pi = pI[(dy + 1) * 3 + dx + 1];
+            const int ry = y - 2 * YJ, rx = x - 2 * XJ;                       /* position of fine point i relative to block J */
+            double w[8]; COUP8(double, L, wE, wS, wSE, wSW, y, x, w);
+            double au = (ry >= -1 && ry <= 1 && rx >= -1 && rx <= 1) ? L->d[y * W + x] * pJ[(ry + 1) * 3 + rx + 1] : 0.0;
+            for (int k = 0; k < 8; ++k) {
+                if (!nbr_ok(L, y, x, k)) continue;
+                const int ky = ry + OFFY[k], kx = rx + OFFX[k];
+                if (ky < -1 || ky > 1 || kx < -1 || kx > 1) continue;
+                au -= w[k] * pJ[(ky + 1) * 3 + kx + 1];
+            }
+            acc += pi * au;
+        }
+    return acc;
+}
+static void mg_galerkin(const lvl_t* L, lvl_t* C) {
+    const int Wc = C->W, Hc = C->H;
+    double* pst = (double*)malloc(sizeof(double) * 9 * (size_t)C->n);
+#pragma omp parallel for schedule(static)
+    for (int I = 0; I < C->n; ++I) mg_pstencil(L, I / Wc, I % Wc, pst + (size_t)I * 9);
+#pragma omp parallel for schedule(static)
+    for (int I = 0; I < C->n; ++I) {
+        const int Y = I / Wc, X = I - Y * Wc;
+        const double* pI = pst + (size_t)I * 9;
+        C->d[I] = galerkin_entry(L, Y, X, pI, Y, X, pI);
+        C->wE[I] = X + 1 < Wc ? -galerkin_entry(L, Y, X, pI, Y, X + 1, pst + (size_t)(I + 1) * 9) : 0.0;
+        C->wS[I] = Y + 1 < Hc ? -galerkin_entry(L, Y, X, pI, Y + 1, X, pst + (size_t)(I + Wc) * 9) : 0.0;
+        C->wSE[I] = (X + 1 < Wc && Y + 1 < Hc) ? -galerkin_entry(L, Y, X, pI, Y + 1, X + 1, pst + (size_t)(I + Wc + 1) * 9) : 0.0;
+        C->wSW[I] = (X > 0 && Y + 1 < Hc) ? -galerkin_entry(L, Y, X, pI, Y + 1, X - 1, pst + (size_t)(I + Wc - 1) * 9) : 0.0;
+    }
+    free(pst);
+}
+/* fp32 copies + the safe smoother diagonal (k_mg_finish) */
+static void mg_finish(lvl_t* L, int with_transfer) {
+    const int W = L->W;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < L->n; ++i) {
+        const int r = i / W, c = i - r * W;
+        const double d = L->d[i];
+        double dt = d;
+        if (L->nine) {
+            double w[8]; COUP8(double, L, wE, wS, wSE, wSW, r, c, w);
+            double s = fabs(d); for (int k = 0; k < 8; ++k) s += fabs(w[k]);
+            const double h = 0.5 * s; dt = h > d ? h : d;
+        }
+        L->fd[i] = (float)d; L->fdinv[i] = (float)(MG_W[0] / dt); L->fE[i] = (float)L->wE[i]; L->fS[i] = (float)L->wS[i];
+        if (L->nine) { L->fSE[i] = (float)L->wSE[i]; L->fSW[i] = (float)L->wSW[i]; }
+        if (with_transfer) { L->fpa[i] = (float)L->pa[i]; L->fpb[i] = (float)L->pb[i]; }
+    }
+}
 
 /* diagnostic: iteration counts (max over the right-hand sides) of the solves since the last reset */
 static int g_wls_log[64], g_wls_log_n = 0;
@@ -160,49 +324,27 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     lvl_t lv[16]; int nl = 0;
     { int h = H, w = W;
       for (;;) {
-          lvl_t* L = &lv[nl]; L->H = h; L->W = w; L->n = h * w;
-          L->r = (double*)malloc(sizeof(double) * L->n); L->wx = (double*)malloc(sizeof(double) * L->n); L->wy = (double*)malloc(sizeof(double) * L->n);
-          L->diag = (double*)malloc(sizeof(double) * L->n);
-          L->fdiag = (float*)malloc(sizeof(float) * L->n); L->fdinv = (float*)malloc(sizeof(float) * L->n); L->fwx = (float*)malloc(sizeof(float) * L->n); L->fwy = (float*)malloc(sizeof(float) * L->n);
-          L->b = (float*)malloc(sizeof(float) * (size_t)L->n * NQ); L->x = (float*)malloc(sizeof(float) * (size_t)L->n * NQ); L->x2 = (float*)malloc(sizeof(float) * (size_t)L->n * NQ);
+          lvl_t* L = &lv[nl]; memset(L, 0, sizeof *L); L->H = h; L->W = w; L->n = h * w; L->nine = nl > 0;
+          const size_t n = (size_t)L->n;
+          L->d = (double*)malloc(sizeof(double) * n); L->wE = (double*)malloc(sizeof(double) * n); L->wS = (double*)malloc(sizeof(double) * n);
+          L->pa = (double*)calloc(n, sizeof(double)); L->pb = (double*)calloc(n, sizeof(double));
+          L->fd = (float*)malloc(sizeof(float) * n); L->fdinv = (float*)malloc(sizeof(float) * n); L->fE = (float*)malloc(sizeof(float) * n); L->fS = (float*)malloc(sizeof(float) * n);
+          L->fpa = (float*)calloc(n, sizeof(float)); L->fpb = (float*)calloc(n, sizeof(float));
+          if (L->nine) { L->wSE = (double*)malloc(sizeof(double) * n); L->wSW = (double*)malloc(sizeof(double) * n); L->fSE = (float*)malloc(sizeof(float) * n); L->fSW = (float*)malloc(sizeof(float) * n); }
+          L->b = (float*)malloc(sizeof(float) * n * NQ); L->x = (float*)malloc(sizeof(float) * n * NQ); L->x2 = (float*)malloc(sizeof(float) * n * NQ);
           ++nl;
           if (L->n <= 64 || (h <= 8 && w <= 8) || nl >= 16) break;
           h = (h + 1) / 2; w = (w + 1) / 2;
       } }
-    { double* dtmp = (double*)malloc(sizeof(double) * lv[0].n);
-      orc_wls_system(lab, H, W, lamda, alpha, roughness, dtmp, lv[0].wx, lv[0].wy);
-      memcpy(lv[0].r, roughness, sizeof(double) * lv[0].n); free(dtmp); }
+    orc_wls_system(lab, H, W, lamda, alpha, roughness, lv[0].d, lv[0].wE, lv[0].wS);      /* d = r + the 4 weights, accumulated in the order r, +x, -x, +y, -y */
     for (int l = 0; l < nl; ++l) {
-        lvl_t* L = &lv[l];
-        if (l > 0) {
-            lvl_t* F = &lv[l - 1];
-            for (int I = 0; I < L->n; ++I) {
-                const int Y = I / L->W, X = I - Y * L->W, y0 = 2 * Y, x0 = 2 * X;
-                const int x1ok = x0 + 1 < F->W, y1ok = y0 + 1 < F->H;
-                double rs = F->r[y0 * F->W + x0];
-                if (x1ok) rs += F->r[y0 * F->W + x0 + 1];
-                if (y1ok) rs += F->r[(y0 + 1) * F->W + x0];
-                if (x1ok && y1ok) rs += F->r[(y0 + 1) * F->W + x0 + 1];
-                double ex = 0.0, ey = 0.0;
-                if (x0 + 2 < F->W) { ex = F->wx[y0 * F->W + x0 + 1]; if (y1ok) ex += F->wx[(y0 + 1) * F->W + x0 + 1]; }
-                if (y0 + 2 < F->H) { ey = F->wy[(y0 + 1) * F->W + x0]; if (x1ok) ey += F->wy[(y0 + 1) * F->W + x0 + 1]; }
-                L->r[I] = rs; L->wx[I] = ex; L->wy[I] = ey;
-            }
-        }
-        for (int i = 0; i < L->n; ++i) {
-            const int y = i / L->W, x = i - y * L->W;
-            double a00 = 0.0;
-            a00 += L->r[i];
-            if (x + 1 < L->W) a00 += L->wx[i];
-            if (x > 0) a00 += L->wx[i - 1];
-            if (y + 1 < L->H) a00 += L->wy[i];
-            if (y > 0) a00 += L->wy[i - L->W];
-            L->diag[i] = a00;
-            L->fdiag[i] = (float)a00; L->fdinv[i] = (float)(MG_W[0] / a00); L->fwx[i] = (float)L->wx[i]; L->fwy[i] = (float)L->wy[i];
-        }
+        if (l > 0) mg_galerkin(&lv[l - 1], &lv[l]);
+        if (l + 1 < nl) mg_weights(&lv[l]);
+        mg_finish(&lv[l], l + 1 < nl);
     }
     lvl_t* F = &lv[0];
     const int n = F->n;
+    float* scr1 = (float*)malloc(sizeof(float) * (size_t)n * NQ); float* scr2 = (float*)malloc(sizeof(float) * (size_t)n * NQ);
     double* x6 = (double*)malloc(sizeof(double) * (size_t)n * NQ); double* r = (double*)malloc(sizeof(double) * (size_t)n * NQ);
     double* p = (double*)calloc((size_t)n * NQ, sizeof(double)); double* sv = (double*)calloc((size_t)n * NQ, sizeof(double));
     double* w = (double*)malloc(sizeof(double) * (size_t)n * NQ);
@@ -213,7 +355,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
 #define X0(j, q) ((q) < 3 ? a[(size_t)(j) * 3 + (q)] : b[(size_t)(j) * 3 + (q) - 3])
     for (int i = 0; i < n; ++i) {
         double y[NQ]; LVL_OP(F, i, X0, y);
-        const double rg = F->r[i];
+        const double rg = roughness[i];
         for (int q = 0; q < NQ; ++q) {
             const double x0 = X0(i, q), bq = rg * x0, rv = bq - y[q];
             x6[(size_t)i * NQ + q] = x0; r[(size_t)i * NQ + q] = rv;
@@ -229,7 +371,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     const int maxit = 5000;
     while (any && it < maxit) {
         const int first = it == 0;
-        vcycle(lv, nl, r);                                             /* u = F->x (fp32), widened exactly below */
+        vcycle(lv, nl, r, scr1, scr2);                                 /* u = F->x (fp32), widened exactly below */
 #define UV(j, q) ((double)F->x[(size_t)(j) * NQ + (q)])
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < n; ++i) {
@@ -268,7 +410,8 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     if (iters_out) memcpy(iters_out, iters, sizeof iters);
     int mx = 0; for (int q = 0; q < 6; ++q) if (iters[q] > mx) mx = iters[q];
     if (g_wls_log_n < 64) g_wls_log[g_wls_log_n++] = mx;
-    for (int l = 0; l < nl; ++l) { free(lv[l].r); free(lv[l].wx); free(lv[l].wy); free(lv[l].diag); free(lv[l].fdiag); free(lv[l].fdinv); free(lv[l].fwx); free(lv[l].fwy); free(lv[l].b); free(lv[l].x); free(lv[l].x2); }
-    free(x6); free(r); free(p); free(sv); free(w); free(acc);
+    for (int l = 0; l < nl; ++l) { lvl_t* L = &lv[l]; free(L->d); free(L->wE); free(L->wS); free(L->wSE); free(L->wSW); free(L->pa); free(L->pb); free(L->fd); free(L->fdinv); free(L->fE); free(L->fS);
+                                   free(L->fSE); free(L->fSW); free(L->fpa); free(L->fpb); free(L->b); free(L->x); free(L->x2); }
+    free(scr1); free(scr2); free(x6); free(r); free(p); free(sv); free(w); free(acc);
     return any ? -1 : mx;
 }
