@@ -48,8 +48,8 @@ __host__ __device__ constexpr float mg_rk(int k) { return (float)(MG_W[k] / MG_W
 constexpr float MG_R0 = (float)(0.8 / MG_W[0]);
 constexpr int NQMAX = 6;      // right-hand sides of a solve: 6 (a and b of the 3 Lab channels) or 3 + 3 on two streams (template parameter NQ)
 #ifndef NCT_MG_TXB
-#define NCT_MG_TXB 48
-#define NCT_MG_TYB 8
+#define NCT_MG_TXB 32
+#define NCT_MG_TYB 16
 #endif
 
 // The PCG itself (and the hierarchy construction) is fp64; the V-cycle — a fixed linear preconditioner, whose accuracy does not
@@ -64,11 +64,13 @@ constexpr int NQMAX = 6;      // right-hand sides of a solve: 6 (a and b of the 
 // The edge-aware weights vary by 10^4 between neighbouring edges, which a piecewise-constant transfer cannot follow; this one halves the iteration count.
 typedef float vf;
 struct Lvl { int H, W, n, nine;                                  // nine: 9-point stencil (every level but the finest)
-             double *d, *wE, *wS, *wSE, *wSW, *pa, *pb;          // fp64 operator: (A v)_i = d_i v_i - sum_k w_ik v_k; forward couplings, 0 where the neighbour does not exist; transfer weights
-             vf *fd, *fdinv, *fE, *fS, *fSE, *fSW, *fpa, *fpb;   // fp32 copies; fdinv = (float)(omega_0 / dt), dt = the safe smoother diagonal (k_mg_finish)
+             double *d, *wE, *wS, *wSE, *wSW, *pa, *pb;          // fp64 operator: (A v)_i = d_i v_i - sum_k w_ik v_k; forward couplings, 0 where the neighbour does not exist; line weights
+             vf *fd, *fdinv, *fE, *fS, *fSE, *fSW;               // fp32 copies; fdinv = (float)(omega_0 / dt), dt = the safe smoother diagonal (k_mg_finish)
+             vf *fpst, *fpw;                                     // transfer to the next coarser level: fpst[I][9] = column I of P as a 3x3 block (restriction reads it),
+                                                                 // fpw[4][n] = the same numbers per FINE point, one plane per parent NW, NE, SW, SE / W, E / N, S (prolongation)
              vf *b, *x, *x2; };                                  // V-cycle vectors, planar [6][n]
-// pa / pb of a fine point = its interpolation weights: (even y, odd x): from the W / E coarse point; (odd y, even x): from the N / S one; (odd, odd): pa = 1 / d
-// (the cell centre is eliminated exactly); coarse points: unused.
+// pa / pb (fp64, construction only) of a fine point on a coarse grid line = its weights from the W / E (even y, odd x) or N / S (odd y, even x) coarse point;
+// of a cell centre (odd, odd): pa = 1 / d (the centre is eliminated exactly). k_mg_pstencil turns them into the columns of P.
 
 // State of the 6 right-hand sides of the single-reduction (Chronopoulos-Gear) PCG, double buffered: the update kernel of iteration k
 // reads st[k & 1] and (workgroup 0) writes st[(k + 1) & 1]. nactive = number of systems still iterating: the host polls it only every
@@ -221,10 +223,10 @@ __global__ void k_mg_weights(Lvl L) {
     if (!(r & 1) && (c & 1)) { const double den = (d - w[2]) - w[3]; pa = ((w[1] + w[5]) + w[7]) / den; pb = ((w[0] + w[4]) + w[6]) / den; }
     else if ((r & 1) && !(c & 1)) { const double den = (d - w[0]) - w[1]; pa = ((w[3] + w[6]) + w[7]) / den; pb = ((w[2] + w[4]) + w[5]) / den; }
     else if ((r & 1) && (c & 1)) pa = 1.0 / d;
-    L.pa[i] = pa; L.pb[i] = pb; L.fpa[i] = (vf)pa; L.fpb[i] = (vf)pb;
+    L.pa[i] = pa; L.pb[i] = pb;
 }
 // column I of P as a 3x3 block around fine point (2Y, 2X): pst[I*9 + (dy+1)*3 + dx+1]
-__global__ void k_mg_pstencil(Lvl L, Lvl C, double* __restrict__ pst_out) {
+__global__ void k_mg_pstencil(Lvl L, Lvl C, double* __restrict__ pst_out) {      // also L.fpst = (float) of it: THE transfer weights of the cycle
     const int I = blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= C.n) return;
     const int Y = I / C.W, X = I - Y * C.W;
@@ -250,7 +252,25 @@ __global__ void k_mg_pstencil(Lvl L, Lvl C, double* __restrict__ pst_out) {
             pst[(dy + 1) * 3 + dx + 1] = ((wdiag + wvert * pst[3 + dx + 1]) + whor * pst[(dy + 1) * 3 + 1]) * L.pa[y * W + x];
         }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) pst_out[(size_t)I * 9 + k] = pst[k];
+    for (int k = 0; k < 9; ++k) { pst_out[(size_t)I * 9 + k] = pst[k]; L.fpst[(size_t)I * 9 + k] = (vf)pst[k]; }
+}
+// the same weights per fine point: plane s = parent s of the point in the order NW, NE, SW, SE (cell centre) / W, E / N, S (line points); 0 for absent parents and coarse points
+__global__ void k_mg_pweights(Lvl L, Lvl C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    const int r = i / L.W, c = i - r * L.W;
+    const int Y0 = r >> 1, X0 = c >> 1, ny = (r & 1) ? 2 : 1, nx = (c & 1) ? 2 : 1;
+    vf pw[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ny * nx > 1) {
+        int sl = 0;
+        for (int jy = 0; jy < ny; ++jy)
+            for (int jx = 0; jx < nx; ++jx, ++sl) {
+                const int Y = Y0 + jy, X = X0 + jx;
+                if (Y < C.H && X < C.W) pw[sl] = L.fpst[(size_t)(Y * C.W + X) * 9 + (r - 2 * Y + 1) * 3 + (c - 2 * X + 1)];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) L.fpw[(size_t)k * L.n + i] = pw[k];
 }
 // Galerkin product: A_c(I, J) = sum over the fine points i of block(I), row-major, of pst_I(i) * (A pst_J)(i) for J = I and its four forward neighbours
 __global__ void k_mg_galerkin(Lvl L, Lvl C, const double* __restrict__ pst) {
@@ -320,14 +340,14 @@ __global__ void k_mg_finish(Lvl L) {
 // (even, even) inside it. The transfers reach one pixel further than the smoother on ONE side (the coarse point at the tile's left / top edge
 // gathers from the line point in front of it; for an even sweep count the up leg's outermost column needs the coarse point behind it), so the
 // thread grid has MG_NS + 1 halo pixels on that side and MG_NS on the other: (TX + 2 MG_NS + 1) x (TY + 2 MG_NS + 1) threads.
-struct PxCoef { vf d, dinv, w[8], pa, pb; unsigned ex; };    // diag, omega/dt, couplings E W S N SE SW NE NW (0 where absent), transfer weights, existence mask
+struct PxCoef { vf d, dinv, w[8]; unsigned ex; };    // diag, omega/dt, couplings E W S N SE SW NE NW (0 where absent), existence mask (diagonal bits on 9-point levels only)
 template <bool NINE>
 __device__ __forceinline__ PxCoef px_coef(const Lvl& L, int gy, int gx) {
     const int i = gy * L.W + gx, W = L.W;
     PxCoef c;
     const bool xr = gx + 1 < W, xl = gx > 0, yd = gy + 1 < L.H, yu = gy > 0;
     c.ex = (xr ? 1u : 0u) | (xl ? 2u : 0u) | (yd ? 4u : 0u) | (yu ? 8u : 0u);
-    c.d = L.fd[i]; c.dinv = L.fdinv[i]; c.pa = L.fpa[i]; c.pb = L.fpb[i];
+    c.d = L.fd[i]; c.dinv = L.fdinv[i];
     c.w[0] = xr ? L.fE[i] : 0.f; c.w[1] = xl ? L.fE[i - 1] : 0.f; c.w[2] = yd ? L.fS[i] : 0.f; c.w[3] = yu ? L.fS[i - W] : 0.f;
     if (NINE) {
         c.ex |= (xr && yd ? 16u : 0u) | (xl && yd ? 32u : 0u) | (xr && yu ? 64u : 0u) | (xl && yu ? 128u : 0u);
@@ -354,8 +374,7 @@ __device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s
 constexpr int mg_threads(int TX, int TY) { return ((TX + 2 * MG_NS + 1) * (TY + 2 * MG_NS + 1) + 63) / 64 * 64; }
 // TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below.
 // Sweep k produces its iterate on ring(k) = the thread grid shrunk by k from every side; the residual lives on ring(MG_NS) = the tile + one pixel to the left / top.
-// Restriction R = P^T in three steps (oracle: mg_restrict): cell centres t = res / d ; every other point res' = res + sum over its adjacent centres of w t ;
-// coarse point = res' + pa(E pt) res'(E pt) + pb(W pt) res'(W pt) + pa(S pt) res'(S pt) + pb(N pt) res'(N pt), the products formed by the line points.
+// Restriction R = P^T (oracle: mg_restrict): the thread of a coarse point sums fpst[I][k] * res over the 3x3 block around it, row-major.
 template <int NQ, int TX, int TY, typename TB, bool NINE>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc) {
     if (st->nactive == 0) return;
@@ -368,11 +387,16 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
     const bool valid = p < LN && gy >= 0 && gy < F.H && gx >= 0 && gx < F.W;
     auto ring = [&](int k) { return valid && lx >= k && lx <= LW - 1 - k && ly >= k && ly <= LH - 1 - k; };
     const bool interior = valid && lx >= HA && lx < HA + TX && ly >= HA && ly < HA + TY;
-    const bool oy = (gy & 1) != 0, ox = (gx & 1) != 0;
+    const bool coarse = interior && !(gy & 1) && !(gx & 1);                    // this thread's pixel IS a coarse point: it gathers the restricted residual
     const int i = gy * F.W + gx;
-    vf bq[NQ], xk[NQ]; PxCoef c;
+    vf bq[NQ], xk[NQ], ps[9]; PxCoef c;
     if (valid) {
         c = px_coef<NINE>(F, gy, gx);
+        if (coarse) {
+            const vf* pp = F.fpst + (size_t)((gy >> 1) * C.W + (gx >> 1)) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) ps[k] = pp[k];
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * F.n + i]; xk[q] = bq[q] * c.dinv; s_a[q * LN + p] = xk[q]; }     // sweep 0 (from zero)
     }
@@ -391,43 +415,30 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
         }
         __syncthreads();
     }
-    vf* xs = (MG_NS & 1) ? s_a : s_b; vf* rs = (MG_NS & 1) ? s_b : s_a;       // the smoothed iterate, and the array nobody reads any more
-    const bool inres = ring(MG_NS);
-    vf res[NQ];
-    if (inres) {
+    vf* xs = (MG_NS & 1) ? s_a : s_b; vf* rs = (MG_NS & 1) ? s_b : s_a;       // the smoothed iterate, and where the residual goes
+    if (ring(MG_NS)) {
         vf yv[NQ]; lds_op<NQ, LW, LN, NINE>(c, xs, p, xk, yv);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { res[q] = bq[q] - yv[q]; if (oy && ox) rs[q * LN + p] = res[q] * c.pa; }
-    }
-    __syncthreads();                                                           // from here on xs is free as well
-    if (inres && !(oy && ox)) {
-        // adjacent cell centres: line point on a row (even y, odd x): S, N ; on a column: E, W ; coarse point: SE, SW, NE, NW
-        const int k0 = (!oy && ox) ? 2 : ((oy && !ox) ? 0 : 4), k1 = (!oy && !ox) ? 8 : k0 + 2;
-#pragma unroll
-        for (int k = 0; k < (NINE ? 8 : 4); ++k)
-            if (k >= k0 && k < k1 && (c.ex & (1u << k))) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) res[q] += c.w[k] * rs[q * LN + p + lds_off<LW>(k)];
-            }
-        if (oy != ox) {                                                        // (t is read at centre positions only, these are line positions)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) { xs[q * LN + p] = c.pa * res[q]; rs[q * LN + p] = c.pb * res[q]; }      // towards its first (W / N) and second (E / S) coarse point
-        }
+        for (int q = 0; q < NQ; ++q) rs[q * LN + p] = bq[q] - yv[q];
     }
     __syncthreads();
-    if (interior && !oy && !ox) {
+    if (coarse) {
+        const bool xr = (c.ex & 1u) != 0, xl = (c.ex & 2u) != 0, yd = (c.ex & 4u) != 0, yu = (c.ex & 8u) != 0;
+        const bool in[9] = {xl && yu, yu, xr && yu, xl, true, xr, xl && yd, yd, xr && yd};
+        vf acc[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            vf acc = res[q];
-            if (c.ex & 1u) acc += xs[q * LN + p + 1];
-            if (c.ex & 2u) acc += rs[q * LN + p - 1];
-            if (c.ex & 4u) acc += xs[q * LN + p + LW];
-            if (c.ex & 8u) acc += rs[q * LN + p - LW];
-            bc[(size_t)q * C.n + (gy >> 1) * C.W + (gx >> 1)] = acc;
-        }
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            if (in[k]) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] += ps[k] * rs[q * LN + p + (k / 3 - 1) * LW + (k % 3 - 1)];
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) bc[(size_t)q * C.n + (gy >> 1) * C.W + (gx >> 1)] = acc[q];
     }
 }
-// Prolongation (oracle: mg_prolong): coarse points copy e_c; line points pa e(W|N) + pb e(E|S); cell centres (sum_k w_k e_k) / d over their 8 neighbours.
+// Prolongation (oracle: mg_prolong): coarse points copy e_c; every other point ((p0 e0 + p1 e1) + p2 e2) + p3 e3 over its existing coarse parents NW, NE, SW, SE (W, E / N, S on a line).
 // xo must not alias x (neighbouring tiles still read x for their halo)
 template <int NQ, int TX, int TY, typename TB, bool NINE>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __restrict__ st, Lvl L, const TB* __restrict__ b, const vf* __restrict__ x, int Wc, int nc,
@@ -445,9 +456,11 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
     auto ring = [&](int k) { return valid && lx >= OL + k && lx <= LW - 1 - OR - k && ly >= OL + k && ly <= LH - 1 - OR - k; };
     const bool oy = (gy & 1) != 0, ox = (gx & 1) != 0;
     const int i = gy * L.W + gx;
-    vf bq[NQ], xk[NQ]; PxCoef c;
+    vf bq[NQ], xk[NQ], pw[4]; PxCoef c;
     if (valid) {
         c = px_coef<NINE>(L, gy, gx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[k] = L.fpw[(size_t)k * L.n + i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * L.n + i]; xk[q] = x[(size_t)q * L.n + i]; }
         if (!oy && !ox) {
@@ -457,42 +470,30 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
         }
     }
     __syncthreads();
-    if (valid && oy != ox) {
-        const int stp = ox ? 1 : LW;
-        const bool first_in = ox ? lx >= 1 : ly >= 1;
-        const bool second_ex = ox ? (c.ex & 1u) != 0 : (c.ex & 4u) != 0, second_in = ox ? lx + 1 <= LW - 1 : ly + 1 <= LH - 1;
-        if (first_in && (!second_ex || second_in)) {
+    if (ring(0)) {                                                             // xe = x + P e_coarse -> s_b (s_a keeps the coarse values the neighbours still read)
+        const bool xr = (c.ex & 1u) != 0, yd = (c.ex & 4u) != 0;
+        // parents in the order NW, NE, SW, SE (centre) / W, E (row line point) / N, S (column line point): LDS offsets and existence of the 2nd .. 4th
+        const int o0 = -(oy ? LW : 0) - (ox ? 1 : 0);
+        const int o1 = (oy && ox) ? -LW + 1 : (ox ? 1 : LW);
+        const bool e1 = (oy && ox) ? xr : (ox ? xr : yd);
+        const bool e2 = oy && ox && yd, e3 = oy && ox && yd && xr;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                vf v = c.pa * s_a[q * LN + p - stp];
-                if (second_ex) v += c.pb * s_a[q * LN + p + stp];
-                s_a[q * LN + p] = v;
+        for (int q = 0; q < NQ; ++q) {
+            vf e;
+            if (!oy && !ox) e = s_a[q * LN + p];
+            else {
+                e = pw[0] * s_a[q * LN + p + o0];
+                if (e1) e += pw[1] * s_a[q * LN + p + o1];
+                if (e2) e += pw[2] * s_a[q * LN + p + LW - 1];
+                if (e3) e += pw[3] * s_a[q * LN + p + LW + 1];
             }
+            xk[q] = xk[q] + e; s_b[q * LN + p] = xk[q];
         }
-    }
-    __syncthreads();
-    if (valid && oy && ox && lx >= 1 && lx <= LW - 2 && ly >= 1 && ly <= LH - 2) {
-        vf acc[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < (NINE ? 8 : 4); ++k)
-            if (c.ex & (1u << k)) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[q] += c.w[k] * s_a[q * LN + p + lds_off<LW>(k)];
-            }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) s_a[q * LN + p] = acc[q] * c.pa;
-    }
-    __syncthreads();
-    if (ring(0)) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { xk[q] = xk[q] + s_a[q * LN + p]; s_a[q * LN + p] = xk[q]; }      // xe = x + P e_coarse
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < MG_NS; ++k) {
-        vf* src = (k & 1) ? s_b : s_a; vf* dst = (k & 1) ? s_a : s_b;
+        vf* src = (k & 1) ? s_a : s_b; vf* dst = (k & 1) ? s_b : s_a;
         if (ring(k + 1)) {
             vf y[NQ]; lds_op<NQ, LW, LN, NINE>(c, src, p, xk, y);
 #pragma unroll
@@ -504,30 +505,213 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
         if (k < MG_NS - 1) __syncthreads();
     }
 }
-// Coarsest grid (n <= 64, 9-point): `sweeps` damped-Jacobi (0.8) sweeps from zero, one wave per right-hand side, one lane per unknown, the iterate in a
-// register, neighbours through ds_bpermute. Its correction goes to L.x2.
-__global__ __launch_bounds__(64) void k_mg_coarsest(const PState* __restrict__ st, Lvl L, int sweeps) {
-    if (st->nactive == 0) return;
-    const int q = blockIdx.x, i = threadIdx.x, n = L.n, W = L.W;
-    const bool live = i < n;
-    const int r = live ? i / W : 0, c = live ? i - r * W : 0;
-    vf bq = 0.f, d = 0.f, dv = 0.f, w[8]; unsigned ex = 0;
+// Middle + tail of the V-cycle in ONE launch, one 1024-thread workgroup PER RIGHT-HAND SIDE: the first fused level has <= 4096 pixels
+// (44x44 at 700x700, 63x63 at 1000x1000), the deeper ones <= 1024 (22x22, 11x11, 6x6). The six systems share the operator but not a single
+// value, so no workgroup ever waits for another and the whole sub-cycle needs only __syncthreads(). Everything a level needs for the way
+// back up (right-hand side, pre-smoothed iterate, stencil coefficients of the deeper levels) stays in REGISTERS of the thread that owns
+// the pixel; iterates are exchanged through whole-grid LDS arrays (no halos); coefficients and transfer weights come from global memory once
+// per level (the first fused level re-reads its coefficients for the up leg) and those loads are issued at the start of the level. (A version
+// that re-read coefficients and iterates from global memory in each of its barrier-separated phases was SLOWER than the launches it replaced
+// — DESIGN.md §9 — a single workgroup has nothing to hide a global round trip with.)
+// Same expressions and operation order as k_mg_down / k_mg_up (stencil E, W, S, N, SE, SW, NE, NW; restriction over the 3x3 block row-major;
+// prolongation over the parents NW, NE, SW, SE), so the cycle is bit-identical to the tile-fused launches it replaces. lv[0] is the first fused
+// level: its rhs lv[0].b was written by the restriction above it, its correction goes to lv[0].x2. The coarsest grid (n <= 64) is solved by
+// `sweeps` damped-Jacobi sweeps from zero by one wave (one lane per unknown, the iterate in a register, neighbours through ds_bpermute).
+// P0 = pixels per thread of the first fused level: 2 (<= 2048 pixels: 44x44 at 700x700; no spills) or 4 (63x63 at 1000x1000; the 9-point coefficients of four pixels
+// beside the deeper levels' state exceed the 128 VGPRs of a 1024-thread workgroup: ~60 spilled registers, still faster than the launches it replaces)
+#ifndef NCT_MID_MAXP0
+#define NCT_MID_MAXP0 1      // largest first fused level, in units of 1024 pixels (1, 2 or 4)
+#endif
+constexpr int MID_T = 1024, MID_P1 = 1, MID_N1 = MID_T * MID_P1, MID_LV = 5;
+// largest level at depth d >= 1 (the first fused level: P0 * 1024); levels shrink ~4x per depth. The levels below the first park their 10 coefficients and 4 prolongation
+// weights per pixel in LDS for the way back up (a workgroup has the CU to itself: 79 KB of the 160 KB), so only right-hand side and iterate stay in registers across the recursion
+constexpr int mid_cap(int d) { return d == 1 ? 1024 : (d == 2 ? 256 : 64); }
+constexpr int mid_stash_off(int d) { return d <= 1 ? 0 : mid_stash_off(d - 1) + 14 * mid_cap(d - 1); }
+constexpr int MID_STASH = mid_stash_off(MID_LV);
+constexpr int mid_ppt(int P0, int D) { return D == 0 ? P0 : (D == 1 ? MID_P1 : 1); }      // pixels per thread at depth D of the fused sub-cycle
+struct MidPack { Lvl lv[MID_LV]; int nl; };
+__device__ __forceinline__ vf mid_op(const PxCoef& c, const vf* __restrict__ s_v, int i, int W, vf* centre = nullptr) {
+    const vf v0 = s_v[i];
+    if (centre) *centre = v0;
+    vf y = c.d * v0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = 0.f;
-    if (live) { const PxCoef pc = px_coef<true>(L, r, c); d = pc.d; dv = pc.dinv; ex = pc.ex; bq = L.b[(size_t)q * n + i];
+    for (int k = 0; k < 8; ++k)
+        if (c.ex & (1u << k)) y -= c.w[k] * s_v[i + nb_dy(k) * W + nb_dx(k)];
+    return y;
+}
+// restricted residual of coarse pixel I of the grid (Wc wide) below the fine grid (Wf x Hf): sum over the 3x3 block around fine point (2Y, 2X), row-major
+__device__ __forceinline__ vf mid_restrict(const vf* __restrict__ s_res, const vf (&ps)[9], int I, int Wc, int Wf, int Hf) {
+    const int Y = I / Wc, X = I - Y * Wc, r = 2 * Y, c = 2 * X;
+    vf acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = pc.w[k]; }
-    vf x = 0.0f;
-    for (int s = 0; s < sweeps; ++s) {
-        vf y = d * x;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const vf xn = __shfl(x, (i + nb_dy(k) * W + nb_dx(k)) & 63);
-            if (ex & (1u << k)) y -= w[k] * xn;
-        }
-        if (live) x = x + (bq - y) * (dv * MG_R0);
+    for (int k = 0; k < 9; ++k) {
+        const int yy = r + k / 3 - 1, xx = c + k % 3 - 1;
+        if (yy >= 0 && yy < Hf && xx >= 0 && xx < Wf) acc += ps[k] * s_res[yy * Wf + xx];
     }
-    if (live) L.x2[(size_t)q * n + i] = x;
+    return acc;
+}
+// P e at fine pixel (gy, gx) from the child's correction s_c (Wc x Hc): the existing parents in the order NW, NE, SW, SE (W, E / N, S on a line)
+__device__ __forceinline__ vf mid_prolong(const vf* __restrict__ s_c, const vf (&pw)[4], int gy, int gx, int Wc, int Hc) {
+    const int Y0 = gy >> 1, X0 = gx >> 1;
+    const bool oy = (gy & 1) != 0, ox = (gx & 1) != 0;
+    if (!oy && !ox) return s_c[Y0 * Wc + X0];
+    const bool xr = X0 + 1 < Wc, yd = Y0 + 1 < Hc;
+    vf e = pw[0] * s_c[Y0 * Wc + X0];
+    if (oy && ox) {
+        if (xr) e += pw[1] * s_c[Y0 * Wc + X0 + 1];
+        if (yd) e += pw[2] * s_c[(Y0 + 1) * Wc + X0];
+        if (yd && xr) e += pw[3] * s_c[(Y0 + 1) * Wc + X0 + 1];
+    } else if (ox) { if (xr) e += pw[1] * s_c[Y0 * Wc + X0 + 1]; }
+    else { if (yd) e += pw[1] * s_c[(Y0 + 1) * Wc + X0]; }
+    return e;
+}
+// Level D of the fused sub-cycle. In: this level's right-hand side b[] in registers (pixel i = t + k * MID_T). Out: this level's correction
+// in sC (LDS, n values) — or in global L.x2 for D == 0. sA / sB: exchange arrays (>= n); sC: the child's correction (n_child values), then this level's own.
+template <int P0, int D>
+__device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __restrict__ sA, vf* __restrict__ sB, vf* __restrict__ sC, vf* __restrict__ sS,
+                                          const vf (&breg)[mid_ppt(P0, D)], int sweeps) {
+    constexpr int PPT = mid_ppt(P0, D);
+    const Lvl& L = P.lv[D];
+    const int n = L.n, W = L.W;
+    if (D == P.nl - 1) {
+        // ---- coarsest grid: wave 0, one lane per unknown
+        if (t < n) sA[t] = breg[0];
+        __syncthreads();
+        if (t < 64) {
+            const int i = t;
+            const bool live = i < n;
+            const int r = live ? i / W : 0, c = live ? i - r * W : 0;
+            vf bq = 0.f, d = 0.f, dv = 0.f, w[8]; unsigned ex = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = 0.f;
+            if (live) { const PxCoef pc = px_coef<true>(L, r, c); d = pc.d; dv = pc.dinv; ex = pc.ex; bq = sA[i];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) w[k] = pc.w[k]; }
+            vf x = 0.0f;
+            for (int s = 0; s < sweeps; ++s) {
+                vf y = d * x;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const vf xn = __shfl(x, (i + nb_dy(k) * W + nb_dx(k)) & 63);
+                    if (ex & (1u << k)) y -= w[k] * xn;
+                }
+                if (live) x = x + (bq - y) * (dv * MG_R0);
+            }
+            if (live) { if (D == 0) L.x2[(size_t)q * n + i] = x; else sC[i] = x; }
+        }
+        __syncthreads();
+        return;
+    }
+    if constexpr (D + 1 < MID_LV) {
+        const Lvl& C = P.lv[D + 1];
+        constexpr int CPT = mid_ppt(P0, D + 1);
+        vf* __restrict__ stash = sS + mid_stash_off(D);       // D >= 1: this level's coefficients and prolongation weights, planar [14][n], parked for the way back up
+        vf x[PPT];
+        {
+            PxCoef c[PPT]; vf ps[CPT][9];
+            // ---- all loads of the level first: coefficients, the P columns of the coarse pixels this thread restricts to, (D >= 1) the prolongation weights
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) c[k] = px_coef<true>(L, i / W, i % W); }
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) { const int I = t + k * MID_T; if (I < C.n) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) ps[k][j] = L.fpst[(size_t)I * 9 + j]; } }
+            if constexpr (D >= 1) {
+                if (t < n) {
+                    vf pw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pw[j] = L.fpw[(size_t)j * n + t];
+                    stash[t] = c[0].d; stash[n + t] = c[0].dinv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) stash[(2 + j) * n + t] = c[0].w[j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) stash[(10 + j) * n + t] = pw[j];
+                }
+            }
+            // ---- down: MG_NS sweeps from zero (x_1 = b*dinv ; x_{s+1} = x_s + (b - M x_s)*dinv*rk(s)), iterates in ping-pong through sA / sB ; res = b - M x
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) sA[i] = breg[k] * c[k].dinv; }
+            __syncthreads();
+#pragma unroll
+            for (int sw = 1; sw < MG_NS; ++sw) {
+                vf* src = (sw & 1) ? sA : sB; vf* dst = (sw & 1) ? sB : sA;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int i = t + k * MID_T;
+                    if (i < n) {
+                        vf xs; const vf y = mid_op(c[k], src, i, W, &xs);
+                        const vf xv = xs + (breg[k] - y) * (c[k].dinv * mg_rk(sw));
+                        dst[i] = xv;
+                        if (sw == MG_NS - 1) x[k] = xv;
+                    }
+                }
+                __syncthreads();
+            }
+            {
+                vf* xs = (MG_NS & 1) ? sA : sB; vf* rs = (MG_NS & 1) ? sB : sA;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) rs[i] = breg[k] - mid_op(c[k], xs, i, W); }
+            }
+            __syncthreads();
+            vf bc[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) { const int I = t + k * MID_T; bc[k] = I < C.n ? mid_restrict((MG_NS & 1) ? sB : sA, ps[k], I, C.W, W, L.H) : 0.f; }
+            __syncthreads();                                      // the residual array is free again
+            asm volatile("" ::: "memory");                        // nothing of this level but b and x stays in registers across the deeper levels
+            mid_level<P0, D + 1>(P, q, t, sA, sB, sC, sS, bc, sweeps);    // its correction arrives in sC
+        }
+        // ---- up: xe = x + P e_child ; MG_NS more sweeps. Coefficients and weights come back from the stash (D >= 1) or from global memory again (D == 0)
+        PxCoef c[PPT]; vf pw[PPT][4];
+        if constexpr (D == 0) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) { const int i = t + k * MID_T; if (i < n) { c[k] = px_coef<true>(L, i / W, i % W);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pw[k][j] = L.fpw[(size_t)j * n + i]; } }
+        } else {
+            if (t < n) {
+                const int gy = t / W, gx = t - gy * W;
+                const bool xr = gx + 1 < W, xl = gx > 0, yd = gy + 1 < L.H, yu = gy > 0;
+                c[0].ex = (xr ? 1u : 0u) | (xl ? 2u : 0u) | (yd ? 4u : 0u) | (yu ? 8u : 0u) | (xr && yd ? 16u : 0u) | (xl && yd ? 32u : 0u) | (xr && yu ? 64u : 0u) | (xl && yu ? 128u : 0u);
+                c[0].d = stash[t]; c[0].dinv = stash[n + t];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c[0].w[j] = stash[(2 + j) * n + t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pw[0][j] = stash[(10 + j) * n + t];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = t + k * MID_T;
+            if (i < n) sA[i] = x[k] + mid_prolong(sC, pw[k], i / W, i % W, C.W, C.H);
+        }
+        __syncthreads();                                      // (from here on every thread has finished reading the child's correction in sC)
+#pragma unroll
+        for (int sw = 0; sw < MG_NS; ++sw) {
+            vf* src = (sw & 1) ? sB : sA; vf* dst = (sw & 1) ? sA : sB;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int i = t + k * MID_T;
+                if (i < n) {
+                    vf xs; const vf y = mid_op(c[k], src, i, W, &xs);
+                    const vf v = xs + (breg[k] - y) * (sw == 0 ? c[k].dinv : c[k].dinv * mg_rk(sw));
+                    if (sw < MG_NS - 1) dst[i] = v;
+                    else if (D == 0) L.x2[(size_t)q * n + i] = v; else sC[i] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+template <int P0>
+__global__ __launch_bounds__(MID_T) void k_mg_mid(const PState* __restrict__ st, MidPack P, int sweeps) {
+    if (st->nactive == 0) return;
+    __shared__ vf sA[MID_T * P0], sB[MID_T * P0], sC[MID_N1], sS[MID_STASH];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const Lvl& L0 = P.lv[0];
+    vf b[P0];
+#pragma unroll
+    for (int k = 0; k < P0; ++k) { const int i = t + k * MID_T; b[k] = i < L0.n ? L0.b[(size_t)q * L0.n + i] : 0.f; }
+    mid_level<P0, 0>(P, q, t, sA, sB, sC, sS, b, sweeps);
 }
 
 // ---- PCG pieces at the fine level
@@ -700,10 +884,24 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
             else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, vf, true>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
         }
     };
+    // tail0 = first level of the fused middle + tail (k_mg_mid): the deepest run of levels whose first has <= 4096 pixels and the others
+    // <= MID_N1, at most MID_LV of them; never the fine level (its right-hand side is the fp64 PCG residual and its tiles fill the chip)
+    int tail0 = nl - 1;
+    auto mid_fits = [&](int first) {                     // levels first .. nl-1 as depths 0 .. of k_mg_mid
+        if (nl - first > MID_LV) return false;
+        for (int l = first; l < nl; ++l) { const int d = l - first; if (lv[l].n > (d == 0 ? NCT_MID_MAXP0 * MID_T : mid_cap(d))) return false; }
+        return true;
+    };
+    while (tail0 > 1 && mid_fits(tail0 - 1)) --tail0;
+    MidPack pack; memset(&pack, 0, sizeof pack); pack.nl = nl - tail0;
+    for (int l = tail0; l < nl; ++l) pack.lv[l - tail0] = lv[l];
     auto vcycle = [&]() -> int {
-        for (int l = 0; l < nl - 1; ++l) { down(l); LCHK(); }
-        hipLaunchKernelGGL(k_mg_coarsest, dim3(NQ), dim3(64), 0, s, cur, lv[nl - 1], 60); LCHK();
-        for (int l = nl - 2; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
+        for (int l = 0; l < tail0; ++l) { down(l); LCHK(); }
+        if (lv[tail0].n <= MID_T)          hipLaunchKernelGGL(k_mg_mid<1>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+        else if (lv[tail0].n <= 2 * MID_T) hipLaunchKernelGGL(k_mg_mid<2>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+        else                               hipLaunchKernelGGL(k_mg_mid<4>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+        LCHK();
+        for (int l = tail0 - 1; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
         return 0;
     };
     const vf* z = lv[0].x2;
@@ -792,9 +990,9 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
                    if (!L.wE || !L.wS || !L.wSE || !L.wSW || !L.fSE || !L.fSW) return NCT_ERR_HIP; }
             L.d = newd(L.n); L.fd = newf(L.n); L.fdinv = newf(L.n); L.fE = newf(L.n); L.fS = newf(L.n);
             if (!last) { L.pa = newd(L.n); L.pb = newd(L.n); }
-            L.fpa = newf(L.n); L.fpb = newf(L.n);                  // (the coarsest level never reads them, but px_coef loads them)
+            if (!last) { L.fpst = newf((size_t)((h + 1) / 2) * ((w + 1) / 2) * 9); L.fpw = newf((size_t)L.n * 4); }
             L.b = l == 0 ? nullptr : newf((size_t)L.n * nq0); L.x = newf((size_t)L.n * nq0); L.x2 = newf((size_t)L.n * nq0);
-            if (!L.d || !L.fd || !L.fdinv || !L.fE || !L.fS || (!last && (!L.pa || !L.pb)) || !L.fpa || !L.fpb || (l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
+            if (!L.d || !L.fd || !L.fdinv || !L.fE || !L.fS || (!last && (!L.pa || !L.pb || !L.fpst || !L.fpw)) || (l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
             lv.push_back(L);
             if (last) break;
             h = (h + 1) / 2; w = (w + 1) / 2;
@@ -811,11 +1009,11 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             if (l > 0) {
                 const dim3 gc(cdiv(lv[l].n, 128));
                 hipLaunchKernelGGL(k_mg_pstencil, gc, dim3(128), 0, s, lv[l - 1], lv[l], pst); LCHK();
+                hipLaunchKernelGGL(k_mg_pweights, dim3(cdiv(lv[l - 1].n, 256)), dim3(256), 0, s, lv[l - 1], lv[l]); LCHK();
                 hipLaunchKernelGGL(k_mg_galerkin, gc, dim3(128), 0, s, lv[l - 1], lv[l], (const double*)pst); LCHK();
                 hipLaunchKernelGGL(k_mg_finish, g, dim3(256), 0, s, lv[l]); LCHK();
             }
             if (l + 1 < nl) { hipLaunchKernelGGL(k_mg_weights, g, dim3(256), 0, s, lv[l]); LCHK(); }
-            else { NCT_HIP(hipMemsetAsync(lv[l].fpa, 0, sizeof(vf) * lv[l].n, s)); NCT_HIP(hipMemsetAsync(lv[l].fpb, 0, sizeof(vf) * lv[l].n, s)); }
         }
     }
     const int N = lv[0].n, nb = cdiv(N, 256);

@@ -27,7 +27,8 @@ void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha,
  * zero where the neighbour does not exist. Level 0: wSE = wSW = NULL (5-point). pa / pb: interpolation weights of the transfer to the next
  * coarser level — (even y, odd x): to the W / E coarse point; (odd y, even x): to the N / S one; (odd, odd): pa = 1 / d. */
 typedef struct { int H, W, n, nine; double *d, *wE, *wS, *wSE, *wSW, *pa, *pb;
-                 float *fd, *fdinv, *fE, *fS, *fSE, *fSW, *fpa, *fpb, *b, *x, *x2; } lvl_t;   /* fdinv = (float)(omega_0 / dt) */
+                 float *fd, *fdinv, *fE, *fS, *fSE, *fSW, *fpst, *b, *x, *x2; } lvl_t;   /* fdinv = (float)(omega_0 / dt); fpst: the columns of P towards the next coarser level as
+                                                                                           3x3 blocks, [n_coarse][9], (float) of mg_pstencil's values: THE transfer weights of the cycle */
 
 static void tree256(double* s) { for (int off = 128; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) s[t] += s[t + off]; }
 static void canon_sum(const double* v, int n, int nq, double* out) {
@@ -106,77 +107,50 @@ static void mg_sweep(const lvl_t* L, const double* r0, const float* in, float* o
     }
 }
 
-/* restriction R = P^T of the residual of level L (res, [n][NQ] scratch; t2 a second scratch) into C->b:
- *   1. cell-centre points (odd, odd): t = res * (1/d)                      (they are eliminated exactly: P's centre rows solve the centre equation)
- *   2. every other point j: res'(j) = res(j) + sum over the adjacent centres c of w_jc t(c), in the neighbour order E, W, S, N, SE, SW, NE, NW
- *   3. coarse point I at fine f: b_c(I) = res'(f) + pa(E pt) res'(E pt) + pb(W pt) res'(W pt) + pa(S pt) res'(S pt) + pb(N pt) res'(N pt) */
-static void mg_restrict(const lvl_t* L, lvl_t* C, float* res, float* t2) {
+/* restriction R = P^T: coarse point I at fine point f = (2Y, 2X):  b_c(I) = sum over the 3x3 block around f, row-major, of fpst[I][k] * res(f + off_k)  (points outside the grid skipped;
+ * the centre weight is 1) */
+static void mg_restrict(const lvl_t* L, lvl_t* C, const float* res) {
     const int W = L->W, H = L->H;
 #pragma omp parallel for schedule(static)
-    for (int i = 0; i < L->n; ++i) {
-        const int r = i / W, c = i - r * W;
-        if ((r & 1) && (c & 1)) for (int q = 0; q < NQ; ++q) t2[(size_t)i * NQ + q] = res[(size_t)i * NQ + q] * L->fpa[i];
-    }
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < L->n; ++i) {
-        const int r = i / W, c = i - r * W;
-        if ((r & 1) && (c & 1)) continue;
-        float w[8]; COUP8(float, L, fE, fS, fSE, fSW, r, c, w);
-        float acc[NQ]; for (int q = 0; q < NQ; ++q) acc[q] = res[(size_t)i * NQ + q];
-        for (int k = 0; k < 8; ++k) {
-            if (!nbr_ok(L, r, c, k)) continue;
-            const int y = r + OFFY[k], x = c + OFFX[k];
-            if (!((y & 1) && (x & 1))) continue;
-            const int j = y * W + x;
-            for (int q = 0; q < NQ; ++q) acc[q] += w[k] * t2[(size_t)j * NQ + q];
-        }
-        for (int q = 0; q < NQ; ++q) t2[(size_t)i * NQ + q] = acc[q];          /* non-centre slots of t2 are written only here, centre slots only in step 1 */
-    }
-#pragma omp parallel for schedule(static)
     for (int I = 0; I < C->n; ++I) {
-        const int Y = I / C->W, X = I - Y * C->W, r = 2 * Y, c = 2 * X, f = r * W + c;
-        float acc[NQ]; for (int q = 0; q < NQ; ++q) acc[q] = t2[(size_t)f * NQ + q];
-        if (c + 1 < W) { const float p = L->fpa[f + 1]; for (int q = 0; q < NQ; ++q) acc[q] += p * t2[(size_t)(f + 1) * NQ + q]; }
-        if (c > 0) { const float p = L->fpb[f - 1]; for (int q = 0; q < NQ; ++q) acc[q] += p * t2[(size_t)(f - 1) * NQ + q]; }
-        if (r + 1 < H) { const float p = L->fpa[f + W]; for (int q = 0; q < NQ; ++q) acc[q] += p * t2[(size_t)(f + W) * NQ + q]; }
-        if (r > 0) { const float p = L->fpb[f - W]; for (int q = 0; q < NQ; ++q) acc[q] += p * t2[(size_t)(f - W) * NQ + q]; }
+        const int Y = I / C->W, X = I - Y * C->W, r = 2 * Y, c = 2 * X;
+        const float* ps = L->fpst + (size_t)I * 9;
+        float acc[NQ] = {0, 0, 0, 0, 0, 0};
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int y = r + dy, x = c + dx;
+                if (y < 0 || y >= H || x < 0 || x >= W) continue;
+                const float p = ps[(dy + 1) * 3 + dx + 1];
+                for (int q = 0; q < NQ; ++q) acc[q] += p * res[(size_t)(y * W + x) * NQ + q];
+            }
         for (int q = 0; q < NQ; ++q) C->b[(size_t)I * NQ + q] = acc[q];
     }
 }
-/* prolongation e = P ec on level L (e: [n][NQ]):  coarse points copy; line points pa e(W|N) + pb e(E|S); centres (sum_k w_ck e_k) * (1/d), k = E, W, S, N, SE, SW, NE, NW */
+/* prolongation e = P ec: a fine point combines its existing coarse parents in the order NW, NE, SW, SE (a point on a coarse grid line has two of them: W, E or N, S; a coarse
+ * point copies): e = ((p0 e0 + p1 e1) + p2 e2) + p3 e3, weight of parent J for fine point i = fpst[J][i - 2J] */
 static void mg_prolong(const lvl_t* L, const lvl_t* C, const float* ec, float* e) {
-    const int W = L->W, H = L->H, Wc = C->W;
+    const int W = L->W, Wc = C->W, Hc = C->H;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < L->n; ++i) {
         const int r = i / W, c = i - r * W;
-        if (!(r & 1) && !(c & 1)) for (int q = 0; q < NQ; ++q) e[(size_t)i * NQ + q] = ec[(size_t)((r >> 1) * Wc + (c >> 1)) * NQ + q];
-    }
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < L->n; ++i) {
-        const int r = i / W, c = i - r * W;
-        if (((r & 1) ^ (c & 1)) == 0) continue;
-        const int st = (c & 1) ? 1 : W;                      /* (even y, odd x): W / E neighbours; (odd y, even x): N / S */
-        const int has2 = (c & 1) ? c + 1 < W : r + 1 < H;
-        for (int q = 0; q < NQ; ++q) {
-            float v = L->fpa[i] * e[(size_t)(i - st) * NQ + q];
-            if (has2) v += L->fpb[i] * e[(size_t)(i + st) * NQ + q];
-            e[(size_t)i * NQ + q] = v;
-        }
-    }
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < L->n; ++i) {
-        const int r = i / W, c = i - r * W;
-        if (!((r & 1) && (c & 1))) continue;
-        float w[8]; COUP8(float, L, fE, fS, fSE, fSW, r, c, w);
-        float acc[NQ] = {0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < 8; ++k)
-            if (nbr_ok(L, r, c, k)) { const int j = i + OFFY[k] * W + OFFX[k]; for (int q = 0; q < NQ; ++q) acc[q] += w[k] * e[(size_t)j * NQ + q]; }
-        for (int q = 0; q < NQ; ++q) e[(size_t)i * NQ + q] = acc[q] * L->fpa[i];
+        const int Y0 = r >> 1, X0 = c >> 1, ny = (r & 1) ? 2 : 1, nx = (c & 1) ? 2 : 1;        /* parents: rows Y0 .. Y0 + ny - 1, columns X0 .. X0 + nx - 1 */
+        float acc[NQ]; int first = 1;
+        for (int jy = 0; jy < ny; ++jy)
+            for (int jx = 0; jx < nx; ++jx) {
+                const int Y = Y0 + jy, X = X0 + jx;
+                if (Y >= Hc || X >= Wc) continue;
+                const int J = Y * Wc + X;
+                if (ny == 1 && nx == 1) { for (int q = 0; q < NQ; ++q) acc[q] = ec[(size_t)J * NQ + q]; first = 0; continue; }
+                const float p = L->fpst[(size_t)J * 9 + (r - 2 * Y + 1) * 3 + (c - 2 * X + 1)];
+                for (int q = 0; q < NQ; ++q) { const float t = p * ec[(size_t)J * NQ + q]; acc[q] = first ? t : acc[q] + t; }
+                first = 0;
+            }
+        for (int q = 0; q < NQ; ++q) e[(size_t)i * NQ + q] = acc[q];
     }
 }
 
-/* z = lv[0].x (fp32) for the fp64 residual r0 (rounded to fp32 on load). scr1/scr2: [n0][NQ] float scratch */
-static void vcycle(lvl_t* lv, int nl, const double* r0, float* scr1, float* scr2) {
+/* z = lv[0].x (fp32) for the fp64 residual r0 (rounded to fp32 on load). scr1: [n0][NQ] float scratch */
+static void vcycle(lvl_t* lv, int nl, const double* r0, float* scr1) {
     for (int l = 0; l < nl - 1; ++l) {
         lvl_t* L = &lv[l]; lvl_t* C = &lv[l + 1];
         const double* rr = l == 0 ? r0 : NULL;
@@ -190,7 +164,7 @@ static void vcycle(lvl_t* lv, int nl, const double* r0, float* scr1, float* scr2
             float yv[NQ]; opf(L, i, L->x, yv);
             for (int q = 0; q < NQ; ++q) scr1[(size_t)i * NQ + q] = (l == 0 ? (float)r0[(size_t)i * NQ + q] : L->b[(size_t)i * NQ + q]) - yv[q];
         }
-        mg_restrict(L, C, scr1, scr2);
+        mg_restrict(L, C, scr1);
     }
     {   /* coarsest: 60 Jacobi sweeps from zero */
         lvl_t* L = &lv[nl - 1];
@@ -279,11 +253,11 @@ static double galerkin_entry(const lvl_t* L, int Y, int X, const double* pI, int
         }
     return acc;
 }
-static void mg_galerkin(const lvl_t* L, lvl_t* C) {
+static void mg_galerkin(lvl_t* L, lvl_t* C) {
     const int Wc = C->W, Hc = C->H;
     double* pst = (double*)malloc(sizeof(double) * 9 * (size_t)C->n);
 #pragma omp parallel for schedule(static)
-    for (int I = 0; I < C->n; ++I) mg_pstencil(L, I / Wc, I % Wc, pst + (size_t)I * 9);
+    for (int I = 0; I < C->n; ++I) { mg_pstencil(L, I / Wc, I % Wc, pst + (size_t)I * 9); for (int k = 0; k < 9; ++k) L->fpst[(size_t)I * 9 + k] = (float)pst[(size_t)I * 9 + k]; }
 #pragma omp parallel for schedule(static)
     for (int I = 0; I < C->n; ++I) {
         const int Y = I / Wc, X = I - Y * Wc;
@@ -297,7 +271,7 @@ static void mg_galerkin(const lvl_t* L, lvl_t* C) {
     free(pst);
 }
 /* fp32 copies + the safe smoother diagonal (k_mg_finish) */
-static void mg_finish(lvl_t* L, int with_transfer) {
+static void mg_finish(lvl_t* L) {
     const int W = L->W;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < L->n; ++i) {
@@ -311,7 +285,6 @@ static void mg_finish(lvl_t* L, int with_transfer) {
         }
         L->fd[i] = (float)d; L->fdinv[i] = (float)(MG_W[0] / dt); L->fE[i] = (float)L->wE[i]; L->fS[i] = (float)L->wS[i];
         if (L->nine) { L->fSE[i] = (float)L->wSE[i]; L->fSW[i] = (float)L->wSW[i]; }
-        if (with_transfer) { L->fpa[i] = (float)L->pa[i]; L->fpb[i] = (float)L->pb[i]; }
     }
 }
 
@@ -329,7 +302,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
           L->d = (double*)malloc(sizeof(double) * n); L->wE = (double*)malloc(sizeof(double) * n); L->wS = (double*)malloc(sizeof(double) * n);
           L->pa = (double*)calloc(n, sizeof(double)); L->pb = (double*)calloc(n, sizeof(double));
           L->fd = (float*)malloc(sizeof(float) * n); L->fdinv = (float*)malloc(sizeof(float) * n); L->fE = (float*)malloc(sizeof(float) * n); L->fS = (float*)malloc(sizeof(float) * n);
-          L->fpa = (float*)calloc(n, sizeof(float)); L->fpb = (float*)calloc(n, sizeof(float));
+          L->fpst = (float*)calloc(9 * ((size_t)((h + 1) / 2) * ((w + 1) / 2)), sizeof(float));
           if (L->nine) { L->wSE = (double*)malloc(sizeof(double) * n); L->wSW = (double*)malloc(sizeof(double) * n); L->fSE = (float*)malloc(sizeof(float) * n); L->fSW = (float*)malloc(sizeof(float) * n); }
           L->b = (float*)malloc(sizeof(float) * n * NQ); L->x = (float*)malloc(sizeof(float) * n * NQ); L->x2 = (float*)malloc(sizeof(float) * n * NQ);
           ++nl;
@@ -338,13 +311,13 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
       } }
     orc_wls_system(lab, H, W, lamda, alpha, roughness, lv[0].d, lv[0].wE, lv[0].wS);      /* d = r + the 4 weights, accumulated in the order r, +x, -x, +y, -y */
     for (int l = 0; l < nl; ++l) {
-        if (l > 0) mg_galerkin(&lv[l - 1], &lv[l]);
+        if (l > 0) mg_galerkin(&lv[l - 1], &lv[l]);       /* also rounds level l-1's transfer weights into lv[l-1].fpst */
         if (l + 1 < nl) mg_weights(&lv[l]);
-        mg_finish(&lv[l], l + 1 < nl);
+        mg_finish(&lv[l]);
     }
     lvl_t* F = &lv[0];
     const int n = F->n;
-    float* scr1 = (float*)malloc(sizeof(float) * (size_t)n * NQ); float* scr2 = (float*)malloc(sizeof(float) * (size_t)n * NQ);
+    float* scr1 = (float*)malloc(sizeof(float) * (size_t)n * NQ);
     double* x6 = (double*)malloc(sizeof(double) * (size_t)n * NQ); double* r = (double*)malloc(sizeof(double) * (size_t)n * NQ);
     double* p = (double*)calloc((size_t)n * NQ, sizeof(double)); double* sv = (double*)calloc((size_t)n * NQ, sizeof(double));
     double* w = (double*)malloc(sizeof(double) * (size_t)n * NQ);
@@ -371,7 +344,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     const int maxit = 5000;
     while (any && it < maxit) {
         const int first = it == 0;
-        vcycle(lv, nl, r, scr1, scr2);                                 /* u = F->x (fp32), widened exactly below */
+        vcycle(lv, nl, r, scr1);                                 /* u = F->x (fp32), widened exactly below */
 #define UV(j, q) ((double)F->x[(size_t)(j) * NQ + (q)])
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < n; ++i) {
@@ -411,7 +384,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     int mx = 0; for (int q = 0; q < 6; ++q) if (iters[q] > mx) mx = iters[q];
     if (g_wls_log_n < 64) g_wls_log[g_wls_log_n++] = mx;
     for (int l = 0; l < nl; ++l) { lvl_t* L = &lv[l]; free(L->d); free(L->wE); free(L->wS); free(L->wSE); free(L->wSW); free(L->pa); free(L->pb); free(L->fd); free(L->fdinv); free(L->fE); free(L->fS);
-                                   free(L->fSE); free(L->fSW); free(L->fpa); free(L->fpb); free(L->b); free(L->x); free(L->x2); }
-    free(scr1); free(scr2); free(x6); free(r); free(p); free(sv); free(w); free(acc);
+                                   free(L->fSE); free(L->fSW); free(L->fpst); free(L->b); free(L->x); free(L->x2); }
+    free(scr1); free(x6); free(r); free(p); free(sv); free(w); free(acc);
     return any ? -1 : mx;
 }

@@ -24,25 +24,40 @@ for name in ("700", "mixed", "1000"):
         g = np.load(p)
         sh, sw, rh, rw = (int(v) for v in g["shape"])
         pairs[name] = (synth.image(1000, sh, sw), synth.image(1001, rh, rw), g)
-out = {"rtol": {}}
-for rtol in ("1e-7", "1e-6", "1e-8", "1e-10"):          # the default first: its result carries the fixture's canonical CRC
+out = {"rtol": {}, "lib": os.environ.get("NCT_LIB", "default")}
+rtols = tuple(os.environ.get("SWEEP_RTOLS", "1e-7,1e-6,1e-8,1e-10").split(","))
+results = {}
+for rtol in rtols:
     os.environ["NCT_WLS_RTOL"] = rtol
     with nct.Context(0) as c:
         c.vgg19_load_raw(ws, bs)
         row = {}
         for name, (src, ref, g) in pairs.items():
             got = c.process_pair(src, ref)
-            if rtol == "1e-7":
-                assert zlib.crc32(got.tobytes()) == int(g["crc_canonical"]), "default-rtol result is not the canonical image"
-                e = got.astype(np.int16).reshape(-1); e[g["idx"]] += g["delta"]; exact[name] = e.astype(np.uint8).reshape(got.shape)
-                assert zlib.crc32(exact[name].tobytes()) == int(g["crc_exact"])
+            results[(rtol, name)] = got
+            if name not in exact and zlib.crc32(got.tobytes()) == int(g["crc_exact"]):
+                exact[name] = got                                  # any run whose CRC is the exact-solve image's IS that image
             c.pair_upload(src, ref)
             prm = nct.Params.default()
             tms = [c.pair_run(prm, want_timing=True) for _ in range(3)]
             best = min(tms, key=lambda t: t["total_ms"])
-            row[name] = {"psnr_min_channel_vs_exact_s2": round(psnr(got, exact[name]), 2), "linf_vs_exact_s2": int(np.abs(got.astype(int) - exact[name].astype(int)).max()),
-                         "bytes_differing": int((got != exact[name]).sum()), "wls_iters_per_level": best["wls_iters"], "wls_ms": round(best["wls_ms"], 2),
-                         "pair_ms": round(best["total_ms"], 2)}
+            row[name] = {"wls_iters_per_level": best["wls_iters"], "wls_ms": round(best["wls_ms"], 2), "pair_ms": round(best["total_ms"], 2)}
         out["rtol"][rtol] = row
-        print(rtol, json.dumps(row), file=sys.stderr, flush=True)
+xdir = os.environ.get("EXACT_DIR")                                 # a sweep of another build left the exact-solve images here / this one leaves them
+if xdir:
+    os.makedirs(xdir, exist_ok=True)
+    for name, (src, ref, g) in pairs.items():
+        f = os.path.join(xdir, f"exact_{name}.npy")
+        if name in exact: np.save(f, exact[name])
+        elif os.path.exists(f):
+            e = np.load(f)
+            if zlib.crc32(e.tobytes()) == int(g["crc_exact"]): exact[name] = e
+for (rtol, name), got in results.items():
+    row = out["rtol"][rtol][name]
+    if name in exact:
+        row.update({"psnr_min_channel_vs_exact_s2": round(psnr(got, exact[name]), 2), "linf_vs_exact_s2": int(np.abs(got.astype(int) - exact[name].astype(int)).max()),
+                    "bytes_differing": int((got != exact[name]).sum())})
+    else:
+        row["bytes_differing"] = "no run reproduced the exact-solve image (CRC) — cannot compare"
+    print(rtol, name, json.dumps(row), file=sys.stderr, flush=True)
 print(json.dumps(out, indent=1))
