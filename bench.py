@@ -22,6 +22,12 @@ Extra objects:
                  x2 gfx950 correction + WRITE_SIZE, separate passes) of THIS build — collected live when rocprofv3 is on PATH, else
                  read from profiles/ only if the recorded build id equals this libnct.so's; `achieved` = traffic / launch time,
                  `frac` = achieved / 8 TB/s. The SURVEY §8d no-reuse byte model is reported next to it (`algorithmic_GBs`).
+  roofline_color — the colour solvers' full-resolution kernels (57 % of a pair in round 3): S1 operator / direction / update and the WLS PCG's finest V-cycle
+                 legs, operator and vector update, each with its compulsory bytes per launch (stated per pixel), the event-timed average of single launches
+                 (NCT_FLAG_TIME_KERNELS: HIP events on the pair's stream around the launch) and the fraction of the 8 TB/s peak; plus SURVEY §8(d)'s per-iteration
+                 byte models over the iteration times.
+  roofline_1000 — the same PatchMatch roofline on BASELINE config 4 (1000x1000: the finest level's 512 MB footprint exceeds the 256 MiB Infinity Cache, so its
+                 fabric-side bytes are HBM bytes), from two live counter passes.
   cpu_baseline — the CPU oracle ("port") end-to-end on a bounded sample of the same workload, on this box's host cores.
   stages_ms    — per-stage device time of one extra pair (events on the stream; not part of the timed region).
 """
@@ -82,6 +88,8 @@ def main():
     ap.add_argument("--cpu-baseline-sample", action="store_true", help="time the oracle on the bounded 350x350 sample only (seconds) and scale by pixel count")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 PMC passes (traffic falls back to profiles/)")
+    ap.add_argument("--no-pmc-1000", action="store_true", help="skip the two counter passes on the 1000x1000 pair (roofline_1000)")
+    ap.add_argument("--no-vary", action="store_true", help="every step re-runs the same resident pairs (rounds 1-3); default: two resident sets of pairs per GPU, alternating step by step")
     ap.add_argument("--no-latency-flag", action="store_true", help="skip the two extra single-pair runs with NCT_FLAG_LATENCY (kernel-trace runs: keeps the launch count per pair comparable)")
     ap.add_argument("--print-launch", action="store_true", help="[test hook] print the torchrun command --gpus N would re-launch with, and exit")
     args = ap.parse_args()
@@ -119,7 +127,8 @@ def main():
     from nct.shard import shard_pairs, timed_region
 
     K = max(1, args.inflight)
-    ctxs = [nct.Context(local_rank) for _ in range(K)]
+    NSETS = 1 if (args.no_vary or not args.workload.startswith("pair")) else 2       # resident input sets per GPU (pair workloads): step i runs set i mod NSETS
+    ctxs = [nct.Context(local_rank) for _ in range(K * NSETS)]
     ctx = ctxs[0]
     # synthetic VGG19 (He-normal, seed 19) serialised as a V1-format caffemodel and loaded through the ingest path
     ws, bs = synthetic_vgg19(19)
@@ -162,19 +171,24 @@ def main():
         # slot k of this rank holds its k-th pair, resident on the device before the timed region starts
         def pair(i):
             return synth.image(1000 + 2 * i, S, S), synth.image(1001 + 2 * i, S, S)
-        my_pairs = shard_pairs(world * K, rank, world)
+        # NSETS x K contexts per GPU, each with its own resident pair (distinct images): step i runs the K pairs of set i mod NSETS, so consecutive steps do not
+        # re-read the same images / features out of a warm Infinity Cache. Pair index of (set, rank, slot) = set * world * K + the rank's share of world * K.
+        my_pairs = [sidx * world * K + pi for sidx in range(NSETS) for pi in shard_pairs(world * K, rank, world)]
         host = [pair(pi) for pi in my_pairs]
         for c, (src, ref) in zip(ctxs, host):
             c.pair_upload(src, ref)
-        elapsed = timed_region(lambda i: run_workers(lambda k: ctxs[k].pair_run(prm)), args.steps, args.warmup, dist=dist, sync=sync,
+        if NSETS > 1 and args.warmup < NSETS:
+            for sidx in range(NSETS):                  # every resident set runs once before the clock (arena blocks, code objects), whatever --warmup says
+                run_workers(lambda k: ctxs[sidx * K + k].pair_run(prm))
+        elapsed = timed_region(lambda i: run_workers(lambda k: ctxs[(i % NSETS) * K + k].pair_run(prm)), args.steps, args.warmup, dist=dist, sync=sync,
                                device=torch.device("cuda", local_rank) if rccl_ranks else None)
         pairs_per_step = world * K
         scaling = "weak"
-        e2 = timed_region(lambda i: run_workers(lambda k: ctxs[k].process_pair(host[k][0], host[k][1], prm)), args.steps, 0, dist=dist, sync=sync,
-                          device=torch.device("cuda", local_rank) if rccl_ranks else None)
+        e2 = timed_region(lambda i: run_workers(lambda k: ctxs[(i % NSETS) * K + k].process_pair(host[(i % NSETS) * K + k][0], host[(i % NSETS) * K + k][1], prm)), args.steps, 0,
+                          dist=dist, sync=sync, device=torch.device("cuda", local_rank) if rccl_ranks else None)
         host_to_host = pairs_per_step * args.steps / e2
         src, ref = host[0]
-        desc = (f"{K} independent {S}x{S} source/reference pair(s) in flight per GPU per step, " +
+        desc = (f"{K} independent {S}x{S} source/reference pair(s) in flight per GPU per step ({NSETS} resident set(s) of distinct pairs, alternating), " +
                 ("L=5 only (BASELINE config 1)" if wl == "pair256l5" else "full L=5->1 pyramid") + ", bds=2.0, Config.h defaults"
                 + {"pair700": " (BASELINE config 2)", "pair1000": " (BASELINE config 4)"}.get(wl, ""))
     else:
@@ -246,11 +260,12 @@ def main():
 
     # single-pair latency (nothing else on the GPU) and per-stage device times of one more pair
     ctx.pair_run(prm)
-    single_pair_s = float("inf")
-    for _ in range(3):                       # best of three: a single sample carries the box's hiccups (105.8 vs 97-98 ms seen once)
+    lat = []
+    for _ in range(5):                       # five samples: a single one carries the box's hiccups (105.8 vs 97-98 ms seen once); median = the headline, min beside it
         t1 = time.perf_counter()
         ctx.pair_run(prm)
-        single_pair_s = min(single_pair_s, time.perf_counter() - t1)
+        lat.append(time.perf_counter() - t1)
+    single_pair_s = sorted(lat)[len(lat) // 2]
     # the same pair with NCT_FLAG_LATENCY (a-/b-halves of the WLS solves on two streams: more launches, same bytes, same result)
     plat = nct.Params.default()
     for k, _ in nct.Params._fields_:
@@ -279,7 +294,9 @@ def main():
                    "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
         "rccl_ranks": rccl_ranks,
         "host_to_host_pairs_per_s": host_to_host,
-        "single_pair_ms": 1e3 * single_pair_s,
+        "value_basis": "inputs resident in HBM when the timed region starts (nct_pair_run; the task contract's definition of `value`). SURVEY 8(d)'s host-in -> host-out "
+                       "wall over the same batches (nct_process_pair: + 2.9 MB of PCIe per pair) = host_to_host_pairs_per_s",
+        "single_pair_ms": 1e3 * single_pair_s, "single_pair_ms_min": 1e3 * min(lat), "single_pair_ms_samples": len(lat),
         "single_pair_latency_flag_ms": None if single_pair_latency_s is None else 1e3 * single_pair_latency_s,
         "stages_ms": stages,
         "output_checksum": int(out.astype(np.uint64).sum()),
@@ -291,6 +308,10 @@ def main():
         res["vgg_mfma"].update(vgg_mfma_util(local_rank))
     if rank == 0 and not args.no_roofline and prm.levels == 5:
         res["roofline"] = patchmatch_roofline(nct, ctx, prm, src.shape, ref.shape, local_rank, live_pmc=not args.no_pmc and wl == "pair700" and S == 700 and world == 1)
+    if rank == 0 and not args.no_roofline and prm.levels == 5:
+        res["roofline_color"] = color_roofline(nct, ctx, prm, src.shape)
+    if rank == 0 and not args.no_roofline and not args.no_pmc and not args.no_pmc_1000 and world == 1 and wl == "pair700" and S == 700:
+        res["roofline_1000"] = patchmatch_roofline_1000(local_rank)
     if rank == 0 and not args.no_cpu_baseline and world == 1:               # the CPU port is timed on rank 0 of the 1-GPU run only
         res["cpu_baseline"] = cpu_baseline(synth, ws, bs, src.shape[0], full=(args.cpu_baseline_full or (os.cpu_count() or 1) >= 32) and not args.cpu_baseline_sample)
     if rank == 0:
@@ -333,11 +354,11 @@ def pmc_traffic(device, live):
     return None, why
 
 
-def read_pmc_csv(td, ctr):
+def read_pmc_csv(td, ctr, prefix="void k_pm_step<1, 1,"):
     import csv, glob
     f = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
     rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == ctr]
-    pm = sorted((r for r in rows if r["Kernel_Name"].startswith("void k_pm_step<1, 1,")), key=lambda r: int(r["Dispatch_Id"]))
+    pm = sorted((r for r in rows if r["Kernel_Name"].startswith(prefix)), key=lambda r: int(r["Dispatch_Id"]))
     v = [float(r["Counter_Value"]) for r in pm]
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in pm]          # us, this pass's own kernel trace
     norm = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"].startswith("k_normalize(")]
@@ -416,6 +437,89 @@ def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
             "note": "traffic = L2-miss (fabric-side) bytes: FETCH_SIZE counts Infinity-Cache (MALL) hits as well, and the level's 251 MB footprint fits the 256 MiB MALL, so the "
                     "true HBM demand is <= frac; restream_factor = traffic / footprint. Overlapping candidate tiles are served by L1/L2, so the no-reuse byte model "
                     "(algorithmic_GBs) exceeds the HBM peak; DESIGN.md 3.2"}
+
+
+def patchmatch_roofline_1000(device):
+    """BASELINE config 4 (one 1000x1000 pair): the finest PatchMatch level's footprint (two 256 MB feature maps + fields = 528 MB) exceeds the 256 MiB Infinity
+    Cache, so the fabric-side bytes of these launches ARE (at least half) HBM bytes — the 700x700 level's 267 MB can be MALL hits. Two counter-only passes
+    (FETCH_SIZE, WRITE_SIZE) over scripts/pair_only.py 1000 2; launch durations from the FETCH_SIZE pass's own kernel trace."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {"frac": None, "why": "rocprofv3 not on PATH"}
+    try:
+        vals = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                env = dict(os.environ, TMPDIR="/tmp", HIP_VISIBLE_DEVICES=str(device))
+                subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", td, "-o", "c", "--output-format", "csv", "--",
+                                sys.executable, os.path.join(REPO, "scripts", "pair_only.py"), "1000", "2"], cwd=REPO, env=env, check=True, capture_output=True, timeout=400)
+                vals[ctr] = read_pmc_csv(td, ctr)
+        fs = vals["FETCH_SIZE"]
+        fetch, write = fs["mean"] * 2048.0, vals["WRITE_SIZE"]["mean"] * 1024.0
+        us = sum(fs["per_dispatch_us"]) / len(fs["per_dispatch_us"])
+        cls = {"init": [], "propagation": [], "random_search": []}
+        if len(fs["per_dispatch"]) % 41 == 0:
+            for i, (kb, u) in enumerate(zip(fs["per_dispatch"], fs["per_dispatch_us"])):
+                k = i % 41
+                cls["init" if k == 0 else ("random_search" if k % 4 == 0 else "propagation")].append((kb * 2048.0, u))
+        by = {n: {"avg_launch_us": sum(u for _, u in v) / len(v), "fabric_bytes_per_launch": sum(b for b, _ in v) / len(v), "frac_of_hbm_peak": sum(b for b, _ in v) / sum(u for _, u in v) / 1e3 / HBM_PEAK_GBS}
+              for n, v in cls.items() if v}
+        nq = 2 * 1000 * 1000
+        foot = nq * 64 * 4 + nq * 16
+        gbs = (fetch + write) / us / 1e3
+        return {"bound": "hbm", "kernel": "k_pm_step<1, 1, 2, 2, 8> at 1000x1000 <-> 1000x1000 (BASELINE config 4), counter-pass launch durations", "dispatches": fs["dispatches"],
+                "traffic": fetch + write, "avg_launch_us": us, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "by_step": by,
+                "footprint_bytes": foot, "footprint_over_mall": foot / (256.0 * 1024 * 1024), "restream_factor": (fetch + write) / foot,
+                "fetch_size_factor": 2.0, "fetch_size_factor_basis": "profiles/round4_fetch_calibration.md: FETCH_SIZE x 1024 / known bytes = 0.50 on a streaming read AND on 8-lane x 16-B tile rows at random pixels",
+                "note": "footprint 2.0x the Infinity Cache: at most half of these bytes can be MALL hits, so HBM demand >= frac / 2 and <= frac; the 700x700 figure (roofline.frac) is fabric-side incl. MALL"}
+    except Exception as e:      # noqa: BLE001
+        return {"frac": None, "why": f"PMC pass failed: {type(e).__name__}: {str(e)[:160]}"}
+
+
+def color_roofline(nct, ctx, prm, sshape):
+    """Event-timed single launches of the full-resolution colour-solver kernels (NCT_FLAG_TIME_KERNELS: 8 iterations of the finest S1 level, 4 iterations of each
+    of the five WLS solves) against their COMPULSORY bytes per launch: what the kernel must read and write once, per pixel of the N = H*W grid, stated here."""
+    p2 = nct.Params.default()
+    for k, _ in nct.Params._fields_:
+        setattr(p2, k, getattr(prm, k))
+    p2.flags |= nct.FLAG_TIME_KERNELS
+    ctx.pair_run(p2, want_timing=True)
+    tm = ctx.pair_run(p2, want_timing=True)
+    us = dict(zip(nct.KT_NAMES, tm["kernel_us"])); ns = dict(zip(nct.KT_NAMES, tm["kernel_samples"]))
+    N = sshape[0] * sshape[1]
+    # bytes per pixel, reads + writes. S1 (3 channels x (a, b) = 6 fp64 unknowns per pixel, kNN k = 8): operator = p of the pixel (48) + 8 out-neighbour records (8 x 48) + in-edge
+    # sources/weights/records (~8 x (4 + 8 + 48)) + 4 raster neighbours (L2 hits, not counted) + coefficients daa/dab/dbb (72) + gx, gy (16) + ids (32) + iw2 (64) + Ap out (48);
+    # WLS (6 right-hand sides): see DESIGN.md 3.4
+    model = {
+        "s1_apply": (48 + 8 * 48 + 8 * 60 + 72 + 16 + 32 + 64 + 48, "p + 8 out-neighbour records + 8 in-edge (src, w, record) + coefficients + Ap"),
+        "s1_dir": (48 + 48 + 48, "r, p in; p out (fp64 x 6)"),
+        "s1_update": (48 * 4 + 48 * 2, "p, Ap, x, r in; x, r out"),
+        "wls_down": (48 + 16 + 24 + 6 + 9, "r (fp64 x 6) + fp32 coefficients in; x (fp32 x 6) + coarse rhs + P columns"),
+        "wls_up": (48 + 24 + 16 + 16 + 6 + 24, "r, x, coefficients, P weights, coarse correction in; z out"),
+        "wls_apply": (24 + 48 + 24 + 48, "z (fp32 x 6), r, fp64 coefficients in; w out"),
+        "wls_update": (48 * 4 + 24 + 48 + 48 * 4, "p, s, x, r, z, w in; p, s, x, r out"),
+    }
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "pixels": N, "kernels": {}}
+    for k, (bpp, what) in model.items():
+        if ns.get(k):
+            gbs = bpp * N / us[k] / 1e3
+            out["kernels"][k] = {"avg_launch_us": us[k], "samples": ns[k], "bytes_per_pixel": bpp, "bytes_per_launch": bpp * N, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes": what}
+    if ns.get("wls_coarse"):
+        out["kernels"]["wls_coarse"] = {"avg_us": us["wls_coarse"], "samples": ns["wls_coarse"], "what": "everything below the finest level of one V-cycle (latency bound: 7 launches)"}
+    it_s1 = sum(us[k] for k in ("s1_apply", "s1_dir", "s1_update") if ns.get(k))
+    it_wls = sum(us[k] for k in ("wls_down", "wls_up", "wls_apply", "wls_update", "wls_coarse") if ns.get(k))
+    # SURVEY 8(d): WLS per PCG iteration ~ (5 nnz + 6 vectors) x 8 B x n per right-hand side; nonlocal CG per iteration 2 passes over ~25 n rows x (2 idx + 2 val) + 4 vectors of 2 n fp64, per channel
+    if it_wls:
+        b = (5 + 6) * 8 * N * 6
+        out["wls_iteration"] = {"us": it_wls, "survey_8d_bytes": b, "survey_8d_GBs": b / it_wls / 1e3, "survey_8d_frac": b / it_wls / 1e3 / HBM_PEAK_GBS,
+                                "compulsory_bytes": sum(model[k][0] for k in ("wls_down", "wls_up", "wls_apply", "wls_update")) * N}
+    if it_s1:
+        b = 3 * (2 * 25 * N * (2 * 4 + 2 * 8) + 4 * 2 * N * 8)
+        out["s1_iteration"] = {"us": it_s1, "survey_8d_bytes": b, "survey_8d_GBs": b / it_s1 / 1e3, "survey_8d_frac": b / it_s1 / 1e3 / HBM_PEAK_GBS,
+                               "compulsory_bytes": sum(model[k][0] for k in ("s1_apply", "s1_dir", "s1_update")) * N,
+                               "note": "the survey's model is the reference's explicit CSR A^T A product; the matrix-free operator moves ~3x fewer bytes, so its survey fraction can exceed 1"}
+    out["dominant"] = max(out["kernels"].items(), key=lambda kv: kv[1].get("avg_launch_us", 0))[0] if out["kernels"] else None
+    return out
 
 
 def vgg_mfma(sh, sw, rh, rw, levels, vgg_ms):

@@ -136,6 +136,8 @@ typedef struct nct_params {
                                      run concurrently on two streams. Same result bit for bit; with several pairs in flight it only adds launches */
 #define NCT_FLAG_LAB2BGR_CUBE 8u  /* CV_Lab2BGR in the older plain-cube form of OpenCV's Lab2RGB_f (no linear branch, no clipping) instead of the default piecewise
                                      form — see nct_lab2bgr_u8_form for which one the reference's own result images show */
+#define NCT_FLAG_TIME_KERNELS 16u /* profiling: HIP events around single launches of the finest level's colour-solver kernels (nct_pair_timing.kernel_us); the
+                                     extra events perturb the pair a little: use a run of its own */
 void nct_params_default(nct_params* p);
 
 /* ---- A1 + third-party (OpenCV 2.4.10) arithmetic used on the path: cvtColor(CV_BGR2Lab / CV_Lab2BGR) on 8U
@@ -203,7 +205,13 @@ typedef struct nct_pair_timing {
     int pm_level_launches[5];
     double vote_level_ms[5], nonlocal_level_ms[5], wls_level_ms[5];   /* the same split per level, for the reference's per-level log lines */
     unsigned long long pm_level_evals[5], pm_level_accepted[5];   /* NCT_FLAG_COUNT_EVALS only, else 0: distance evaluations, accepted candidates */
+    /* NCT_FLAG_TIME_KERNELS only, else 0: average microseconds per launch (HIP events on the pair's stream around kernel_samples[i] single launches) of the
+       colour-solver kernels at full resolution — index NCT_KT_*: the S1 operator / direction / update kernels of the finest level's truncated CG, and the WLS
+       PCG's finest V-cycle legs, operator + dot products, vector update, and everything below the finest level of one V-cycle */
+    double kernel_us[8];
+    int kernel_samples[8];
 } nct_pair_timing;
+enum { NCT_KT_S1_APPLY = 0, NCT_KT_S1_DIR = 1, NCT_KT_S1_UPDATE = 2, NCT_KT_WLS_DOWN = 3, NCT_KT_WLS_UP = 4, NCT_KT_WLS_APPLY = 5, NCT_KT_WLS_UPDATE = 6, NCT_KT_WLS_COARSE = 7 };
 /* per-level intermediates for level-wise validation (all pointers nullable; level 0 = coarsest … 4 = finest; arrays have the level's
  * size ah*aw / bh*bw except `result`, the full-resolution intermediate result after that level, H*W*3 like level_out of the oracle) */
 typedef struct nct_pair_levels {

@@ -587,12 +587,15 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         } else {
             hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2, 3); LCHK();
             for (int k = 1; k <= maxit; ++k) {
-                hipLaunchKernelGGL(k_s1_dir, dim3(nbl), dim3(256), 0, s, n, (const CGState*)st, (const double*)r, (double*)p, k == 1 ? 1 : 0); LCHK();
-                if (coop) hipLaunchKernelGGL(k_s1_apply<true>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial);
-                else      hipLaunchKernelGGL(k_s1_apply<false>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial);
+                const bool kt = ctx->kt_on && layer == 4 && k >= 3 && k < 11;          // NCT_FLAG_TIME_KERNELS: eight iterations of the finest level, one event pair per launch
+#define KT(id, launch) do { if (kt) { int rk_ = ctx->kt_begin(s, id); if (rk_) return rk_; } launch; if (kt) { int rk_ = ctx->kt_end(s); if (rk_) return rk_; } } while (0)
+                KT(NCT_KT_S1_DIR, hipLaunchKernelGGL(k_s1_dir, dim3(nbl), dim3(256), 0, s, n, (const CGState*)st, (const double*)r, (double*)p, k == 1 ? 1 : 0)); LCHK();
+                if (coop) KT(NCT_KT_S1_APPLY, hipLaunchKernelGGL(k_s1_apply<true>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial));
+                else      KT(NCT_KT_S1_APPLY, hipLaunchKernelGGL(k_s1_apply<false>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (double*)Ap, (double*)partial));
                 LCHK();
                 hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st); LCHK();
-                hipLaunchKernelGGL(k_s1_update, dim3(nbl), dim3(256), 0, s, n, (const CGState*)st, (const double*)p, (const double*)Ap, (double*)x, (double*)r, (double*)partial); LCHK();
+                KT(NCT_KT_S1_UPDATE, hipLaunchKernelGGL(k_s1_update, dim3(nbl), dim3(256), 0, s, n, (const CGState*)st, (const double*)p, (const double*)Ap, (double*)x, (double*)r, (double*)partial)); LCHK();
+#undef KT
                 hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (CGState*)st, tol2); LCHK();
             }
         }

@@ -842,6 +842,7 @@ struct PartBufs {
     std::vector<Lvl> lv;                                            // the shared operator hierarchy with THIS part's V-cycle vectors (b, x, x2)
     PState* hst; hipEvent_t ev[2];                                  // two page-locked read-back slots and their events
     const double* rough;                                            // the data term (right-hand side = rough * x0)
+    nct_ctx* kt;                                                    // kernel clock (NCT_FLAG_TIME_KERNELS, unsplit solves only), else null
     int maxit, graph;
     int iters[NQMAX];
 };
@@ -895,7 +896,23 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     while (tail0 > 1 && mid_fits(tail0 - 1)) --tail0;
     MidPack pack; memset(&pack, 0, sizeof pack); pack.nl = nl - tail0;
     for (int l = tail0; l < nl; ++l) pack.lv[l - tail0] = lv[l];
+    bool ktime = false;                                   // this iteration's launches are timed one by one (NCT_FLAG_TIME_KERNELS)
+    auto kt_b = [&](int id) -> int { if (ktime && B.kt->kt_begin(s, id)) return ctx->fail(NCT_ERR_HIP, "%s", B.kt->err.c_str()); return 0; };
+    auto kt_e = [&]() -> int { if (ktime && B.kt->kt_end(s)) return ctx->fail(NCT_ERR_HIP, "%s", B.kt->err.c_str()); return 0; };
     auto vcycle = [&]() -> int {
+        if (ktime) {
+            int rc = kt_b(NCT_KT_WLS_DOWN); if (rc) return rc; down(0); LCHK(); rc = kt_e(); if (rc) return rc;
+            rc = kt_b(NCT_KT_WLS_COARSE); if (rc) return rc;
+            for (int l = 1; l < tail0; ++l) { down(l); LCHK(); }
+            if (lv[tail0].n <= MID_T)          hipLaunchKernelGGL(k_mg_mid<1>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+            else if (lv[tail0].n <= 2 * MID_T) hipLaunchKernelGGL(k_mg_mid<2>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+            else                               hipLaunchKernelGGL(k_mg_mid<4>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+            LCHK();
+            for (int l = tail0 - 1; l >= 1; --l) { up(l, lv[l + 1].x2); LCHK(); }
+            rc = kt_e(); if (rc) return rc;
+            rc = kt_b(NCT_KT_WLS_UP); if (rc) return rc; up(0, lv[1].x2); LCHK(); rc = kt_e(); if (rc) return rc;
+            return 0;
+        }
         for (int l = 0; l < tail0; ++l) { down(l); LCHK(); }
         if (lv[tail0].n <= MID_T)          hipLaunchKernelGGL(k_mg_mid<1>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
         else if (lv[tail0].n <= 2 * MID_T) hipLaunchKernelGGL(k_mg_mid<2>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
@@ -913,11 +930,16 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     auto iteration = [&](int it) -> int {
         cur = st + (it & 1);
         PState* nxt = st + ((it + 1) & 1);
+        ktime = B.kt != nullptr && it >= 2 && it < 6 && tail0 >= 1;
         int rc = vcycle(); if (rc) return rc;
+        rc = kt_b(NCT_KT_WLS_APPLY); if (rc) return rc;
         hipLaunchKernelGGL(k_cg_apply<NQ>, dim3(nb), dim3(256), 0, s, cur, F, z, (const double*)r, (double*)w, (double*)partial); LCHK();
+        rc = kt_e(); if (rc) return rc;
         hipLaunchKernelGGL(k_cg_fin<NQ>, dim3(3), dim3(256), 0, s, cur, (const double*)partial, nb, (double*)sums); LCHK();
+        rc = kt_b(NCT_KT_WLS_UPDATE); if (rc) return rc;
         hipLaunchKernelGGL(k_cg_update<NQ>, dim3(nb), dim3(256), 0, s, N, cur, nxt, (const double*)sums, rtol2, it == 0 ? 1 : 0, z, (const double*)w,
                            (double*)p, (double*)sv, (double*)x6, (double*)r); LCHK();
+        rc = kt_e(); if (rc) return rc;
         cur = nxt;
         return 0;
     };
@@ -1034,7 +1056,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             if ((l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
         }
         B.hst = (PState*)ctx->pinned + 2 * h; B.ev[0] = ctx->ev_poll[2 * h]; B.ev[1] = ctx->ev_poll[2 * h + 1];
-        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph; B.rough = rough;
+        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph; B.rough = rough; B.kt = (ctx->kt_on && !split) ? ctx : nullptr;
         memset(B.iters, 0, sizeof B.iters);
     }
     if (!split) {

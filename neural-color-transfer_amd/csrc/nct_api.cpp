@@ -40,6 +40,23 @@ int nct_ctx::mark(hipStream_t s, int tag) {
     tm_tags.push_back(tag);
     return 0;
 }
+int nct_ctx::kt_begin(hipStream_t s, int id) {
+    if (!kt_on) return 0;
+    const size_t i = 2 * kt_ids.size();
+    while (kt_events.size() < i + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return fail(NCT_ERR_HIP, "hipEventCreate failed");
+        kt_events.push_back(e);
+    }
+    if (hipEventRecord(kt_events[i], s) != hipSuccess) return fail(NCT_ERR_HIP, "hipEventRecord failed");
+    kt_ids.push_back(id);
+    return 0;
+}
+int nct_ctx::kt_end(hipStream_t s) {
+    if (!kt_on || kt_ids.empty()) return 0;
+    if (hipEventRecord(kt_events[2 * kt_ids.size() - 1], s) != hipSuccess) return fail(NCT_ERR_HIP, "hipEventRecord failed");
+    return 0;
+}
 void nct_ctx::release(void* p) {
     if (defer_release) { deferred.push_back(p); return; }
     for (auto& b : blocks) if (b.p == p) { b.used = false; return; }
@@ -115,6 +132,7 @@ void nct_destroy(nct_ctx* ctx) {
     if (ctx->bench_ah16) (void)hipFree(ctx->bench_ah16);
     if (ctx->bench_bh16) (void)hipFree(ctx->bench_bh16);
     for (hipEvent_t e : ctx->tm_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->kt_events) (void)hipEventDestroy(e);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);

@@ -44,6 +44,11 @@ struct nct_ctx {
     std::vector<hipEvent_t> tm_events;          // pool, reused across pairs
     std::vector<int> tm_tags;                   // tag of mark i = the stage that ENDS at event i
     int mark(hipStream_t s, int tag);           // nct_api.cpp; no-op unless tm_on
+    // kernel clock (NCT_FLAG_TIME_KERNELS): event pairs around single launches of the full-resolution colour-solver kernels; sample i = events 2i, 2i+1, id kt_ids[i]
+    bool kt_on = false;
+    std::vector<hipEvent_t> kt_events; std::vector<int> kt_ids;
+    int kt_begin(hipStream_t s, int id);        // nct_api.cpp; no-ops unless kt_on
+    int kt_end(hipStream_t s);
 
     int fail(int code, const char* fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);

@@ -67,7 +67,8 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     if (timing) memset(timing, 0, sizeof *timing);
     auto wall0 = std::chrono::steady_clock::now();
     ctx->tm_on = timing != nullptr; ctx->tm_tags.clear();
-    struct TmOff { nct_ctx* c; ~TmOff() { c->tm_on = false; } } tm_off{ctx};
+    ctx->kt_on = timing != nullptr && (prm->flags & NCT_FLAG_TIME_KERNELS) != 0; ctx->kt_ids.clear();
+    struct TmOff { nct_ctx* c; ~TmOff() { c->tm_on = false; c->kt_on = false; } } tm_off{ctx};
     const int nlevels = prm->levels;
     const bool feat16 = (prm->flags & NCT_FLAG_FEAT16) != 0;
     ctx->wls_split = (prm->flags & NCT_FLAG_LATENCY) ? 1 : 0;
@@ -263,6 +264,13 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     if (timing) {
         timing->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         rc = read_marks(ctx, timing); if (rc) return rc;
+        for (size_t i = 0; i < ctx->kt_ids.size(); ++i) {               // NCT_FLAG_TIME_KERNELS: average the samples per kernel
+            float ms = 0.f;
+            NCT_HIP(hipEventElapsedTime(&ms, ctx->kt_events[2 * i], ctx->kt_events[2 * i + 1]));
+            const int id = ctx->kt_ids[i];
+            if (id >= 0 && id < 8) { timing->kernel_us[id] += 1e3 * ms; timing->kernel_samples[id] += 1; }
+        }
+        for (int id = 0; id < 8; ++id) if (timing->kernel_samples[id]) timing->kernel_us[id] /= timing->kernel_samples[id];
         if (count) {
             unsigned long long h[32];
             NCT_HIP(hipMemcpy(h, ctx->d_counter, sizeof h, hipMemcpyDeviceToHost));

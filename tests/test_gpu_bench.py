@@ -52,7 +52,14 @@ def test_bench_emits_contract_json():
     for k in ("value", "unit", "cores", "kind", "sample", "value_1thread"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
-    assert d["single_pair_ms"] > 0 and d["stages_ms"]["total_ms"] > 0 and d["stages_ms"]["nonlocal_ms"] > 0
+    assert d["single_pair_ms"] > 0 and d["single_pair_ms_min"] <= d["single_pair_ms"] and d["stages_ms"]["total_ms"] > 0 and d["stages_ms"]["nonlocal_ms"] > 0
+    assert "resident" in d["value_basis"]
+    rc = d["roofline_color"]                     # colour-solver kernels: event-timed single launches vs their compulsory bytes (the WLS kernels exist at every size)
+    assert rc["bound"] == "hbm" and rc["pixels"] == 128 * 128
+    for k in ("wls_down", "wls_up", "wls_apply", "wls_update"):
+        e = rc["kernels"][k]
+        assert e["samples"] == 20 and e["avg_launch_us"] > 0 and abs(e["frac"] - e["achieved"] / rc["peak"]) < 1e-9 and e["bytes_per_launch"] == e["bytes_per_pixel"] * 128 * 128
+    assert rc["wls_iteration"]["us"] > 0 and rc["wls_iteration"]["survey_8d_bytes"] == 11 * 8 * 128 * 128 * 6
 
 
 @pytest.mark.gpu
