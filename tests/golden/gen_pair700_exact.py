@@ -10,6 +10,8 @@ plus CRC-32 of both images, so the test can (1) check that the GPU output has th
 image from it, (3) check the rebuilt image's CRC, (4) report L-inf / PSNR of the product against the exact-solve oracle.
 Also stores the per-level intermediate results' CRCs of both runs (level_out) for the level-wise comparison.
 Also refreshes the pair's entry of pair700_oracle.json (CRC-32 and byte sum of the canonical-order result, the fixture the GPU path is pinned to at full size).
+Round 4 adds 700x700 cases off the bench pair's beaten track: the BDS sweep's end points bds = 0 and bds = 8 (demo/example/pairs.txt:5-9) and a second
+pair of seeds — full-size-only code paths (32x16 V-cycle tiles, 2-unit kNN cells, shared in-edge gathers) under other data.
 Runs both oracle variants: ~15 / ~35 / ~5 minutes on 8 cores for 700 / 1000 / mixed."""
 import json, os, sys, time, zlib
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -19,12 +21,16 @@ from caffemodel_io import synthetic_vgg19
 orc = oracle_bind.load()
 orc.l.orc_set_threads(min(32, os.cpu_count() or 1))
 ws, bs = synthetic_vgg19(19)
-CASES = {"700": (700, 700, 700, 700), "1000": (1000, 1000, 1000, 1000), "mixed": (333, 517, 612, 401), "tiny": (64, 56, 48, 64)}
+CASES = {"700": (700, 700, 700, 700), "1000": (1000, 1000, 1000, 1000), "mixed": (333, 517, 612, 401), "tiny": (64, 56, 48, 64),
+         "700_bds0": (700, 700, 700, 700), "700_bds8": (700, 700, 700, 700), "700_seed2": (700, 700, 700, 700)}
+EXTRA = {"700_bds0": dict(bds=0.0), "700_bds8": dict(bds=8.0), "700_seed2": dict(seeds=(1002, 1003))}      # everything else: bds 2.0, seeds 1000 / 1001
 for name in (sys.argv[1:] or ["700"]):
     sh, sw, rh, rw = CASES[name]
-    src, ref = synth.image(1000, sh, sw), synth.image(1001, rh, rw)
-    t = time.time(); canon, canon_lv = orc.process_pair(src, ref, ws, bs, want_levels=True, s2_exact=False); t_c = time.time() - t
-    t = time.time(); exact, exact_lv = orc.process_pair(src, ref, ws, bs, want_levels=True, s2_exact=True); t_e = time.time() - t
+    bds = EXTRA.get(name, {}).get("bds", 2.0); s_seed, r_seed = EXTRA.get(name, {}).get("seeds", (1000, 1001))
+    src, ref = synth.image(s_seed, sh, sw), synth.image(r_seed, rh, rw)
+    prm = {"bds_weight": bds}
+    t = time.time(); canon, canon_lv = orc.process_pair(src, ref, ws, bs, params=prm, want_levels=True, s2_exact=False); t_c = time.time() - t
+    t = time.time(); exact, exact_lv = orc.process_pair(src, ref, ws, bs, params=prm, want_levels=True, s2_exact=True); t_e = time.time() - t
     d = exact.astype(np.int16).reshape(-1) - canon.astype(np.int16).reshape(-1)
     idx = np.flatnonzero(d).astype(np.uint32)
     lv_linf = [int(np.abs(exact_lv[l].astype(int) - canon_lv[l].astype(int)).max()) for l in range(5)]
@@ -32,6 +38,7 @@ for name in (sys.argv[1:] or ["700"]):
     np.savez_compressed(os.path.join(HERE, f"pair_exact_{name}.npz"), shape=np.array([sh, sw, rh, rw]), idx=idx, delta=d[idx].astype(np.int16),
                         crc_canonical=np.uint32(zlib.crc32(canon.tobytes())), crc_exact=np.uint32(zlib.crc32(exact.tobytes())),
                         level_crc_canonical=np.array([zlib.crc32(canon_lv[l].tobytes()) for l in range(5)], np.uint32),
+                        level_crc_exact=np.array([zlib.crc32(exact_lv[l].tobytes()) for l in range(5)], np.uint32), bds=np.float64(bds), seeds=np.array([s_seed, r_seed]),
                         level_linf_exact_vs_canonical=np.array(lv_linf), level_ndiff_exact_vs_canonical=np.array(lv_ndiff),
                         seconds=np.array([t_c, t_e]))
     jpath = os.path.join(HERE, "pair700_oracle.json")

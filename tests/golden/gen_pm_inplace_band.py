@@ -25,7 +25,8 @@ from caffemodel_io import synthetic_vgg19  # noqa: E402
 # (name, C, ah, aw, bh, bw, rs_max, seeds): the 700x700 pyramid's level shapes at conv5_1 / conv3_1 and the 256x256 pair's conv1_1
 CASES = [("44x44x512", 512, 44, 44, 44, 44, 43, (11, 12)),
          ("175x175x256", 256, 175, 175, 175, 175, 10, (13, 14)),
-         ("256x256x64", 64, 256, 256, 256, 256, 32, (15, 16))]
+         ("256x256x64", 64, 256, 256, 256, 256, 32, (15, 16)),
+         ("350x350x128", 128, 350, 350, 350, 350, 21, (17, 18))]      # round 4: the conv2_1 level of the 700x700 pair (rs = 700 / 32), the C = 128 instantiation
 SCHED = {"product_jacobi": 0, "reference_sequential": 1, "reference_lockstep": 2}
 
 
@@ -38,7 +39,13 @@ def psnr(a, b):
 def main():
     orc = oracle_bind.load()
     out = {"generator": "tests/golden/gen_pm_inplace_band.py", "stats": "mean, p5, p25, p50, p75, p95 of annd (negative mean cosine of the best match)", "cases": {}}
+    path = os.path.join(HERE, "pm_inplace_band.json")
+    keep = "--all" not in sys.argv and os.path.exists(path)            # default: compute only what the committed fixture lacks (the cases are independent)
+    if keep:
+        out = json.load(open(path))
     for name, C, ah, aw, bh, bw, rs, (sa, sb) in CASES:
+        if keep and name in out["cases"]:
+            continue
         a = orc.feat_normalize(synth.features(sa, C, ah, aw)); b = orc.feat_normalize(synth.features(sb, C, bh, bw))
         n0 = orc.nnf_init(ah, aw, bh, bw)
         case = {"C": C, "ah": ah, "aw": aw, "bh": bh, "bw": bw, "iters": 10, "rs_max": rs, "feature_seeds": [sa, sb], "pm_seed": 7}
@@ -54,6 +61,9 @@ def main():
             case[sname] = {"stats": [float(v) for v in st], "evals": ev, "improved_frac": float(np.mean(d < d0)), "seconds": round(time.time() - t, 1)}
             print(name, sname, ["%.5f" % v for v in st], ev, "%.1fs" % (time.time() - t), flush=True)
         out["cases"][name] = case
+    if keep and "end_to_end_256" in out:
+        json.dump(out, open(path, "w"), indent=1)
+        return
     # end to end: the whole pair under each schedule (all five levels, both directions), result vs the product schedule's result
     ws, bs = synthetic_vgg19(19)
     S = 256

@@ -176,7 +176,7 @@ def test_patchmatch_fp16_mode_close(ctx):
 
 
 
-@pytest.mark.parametrize("name", ["44x44x512", "175x175x256", "256x256x64"])
+@pytest.mark.parametrize("name", ["44x44x512", "175x175x256", "256x256x64", "350x350x128"])
 def test_patchmatch_energy_within_reference_schedule_band(ctx, oracle, name):
     """SURVEY §8c G4 / DESIGN §4 divergence 1+2, quantified: the product runs PatchMatch as double-buffered Jacobi steps with a counter RNG and a 16-lane fp32
     tree; the reference runs ONE racy in-place launch with sequential channel sums and column-shared cuRAND streams (GeneralizedPatchMatch.cu:677-831). The
