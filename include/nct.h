@@ -232,8 +232,9 @@ int nct_pair_download(nct_ctx* ctx, uint8_t* out_bgr);
 
 /* ---- device-pointer seams: the same operations on buffers that stay in HBM between calls (main.cu:204-316 keeps Ndata_C1, ann_device, ... on the device
  * across these kernels; an integrator replacing single seams should not pay H2D + D2H + a synchronise per call). Buffers come from the context's arena
- * (nct_dev_alloc / nct_dev_free; any device pointer of the context's GPU works). Calls are enqueued on the context's stream in call order and return
- * immediately; nct_dev_download and nct_synchronize wait. Features: channel-last HWC fp32 (nct_chw_to_hwc_dev converts a Caffe blob once); `unit_norm` = 1
+ * (nct_dev_alloc / nct_dev_free; any device pointer of the context's GPU works as an operand). Calls are enqueued on the context's stream in call order and return
+ * immediately; nct_dev_download and nct_synchronize wait. Arena blocks are recycled in the order of THAT stream: use them from another stream (or free them while your own
+ * kernels still read them) only after nct_synchronize. nct_dev_free of a pointer that is not a live nct_dev_alloc block of the context returns NCT_ERR_INVALID. Features: channel-last HWC fp32 (nct_chw_to_hwc_dev converts a Caffe blob once); `unit_norm` = 1
  * tells nct_patchmatch_bidir_dev that both maps hold unit vectors (output of nct_feat_normalize_dev), which enables the exact row-wise rejection.
  * Chained like the reference's level loop they reproduce nct_pair_run_levels bit for bit (tests/test_gpu_pipeline.py::test_dev_seams_chain_equals_pipeline). */
 int nct_dev_alloc(nct_ctx* ctx, size_t bytes, void** out);

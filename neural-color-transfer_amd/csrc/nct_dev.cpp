@@ -17,7 +17,11 @@ int nct_dev_alloc(nct_ctx* ctx, size_t bytes, void** out) {
 }
 int nct_dev_free(nct_ctx* ctx, void* p) {
     CTX_ENTER();
-    if (p) ctx->release(p);
+    if (!p) return NCT_OK;
+    bool mine = false;
+    for (const auto& b : ctx->blocks) if (b.p == p && b.used) { mine = true; break; }
+    NCT_REQUIRE(mine, "dev_free: %p is not a live nct_dev_alloc block of this context", p);      // a foreign or already freed pointer is an error, not a silent no-op
+    ctx->release(p);
     return NCT_OK;
 }
 int nct_dev_upload(nct_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
@@ -69,6 +73,7 @@ int nct_nnf_init_dev(nct_ctx* ctx, uint32_t* nnf, int ah, int aw, int bh, int bw
 int nct_nnf_upsample_dev(nct_ctx* ctx, const uint32_t* nnf_half, uint32_t* nnf, int ah, int aw, int bh, int bw, int ah_half, int aw_half) {
     CTX_ENTER();
     NCT_REQUIRE(nnf_half && nnf && nnf_half != nnf && ah >= 1 && aw >= 1 && bh >= 1 && bw >= 1 && ah_half >= 1 && aw_half >= 1, "nnf_upsample_dev: bad arguments");
+    NCT_REQUIRE(ah < 4096 && aw < 4096 && bh < 4096 && bw < 4096, "nnf_upsample_dev: dims out of range (the NNF word holds 12 bits per coordinate)");
     return nctk_nnf_upsample(ctx, ctx->stream, nnf_half, nnf, ah, aw, bh, bw, ah_half, aw_half);
 }
 
@@ -106,7 +111,7 @@ int nct_bds_vote_image_dev(nct_ctx* ctx, const uint8_t* b_bgr, const uint32_t* a
 }
 int nct_feature_distance_dev(nct_ctx* ctx, const float* a_hwc, const float* b_hwc, float* err, int C, int H, int W) {
     CTX_ENTER();
-    NCT_REQUIRE(a_hwc && b_hwc && err && C > 0 && (C & 3) == 0, "feature_distance_dev: bad arguments");
+    NCT_REQUIRE(a_hwc && b_hwc && err && C > 0 && (C & 3) == 0 && H > 0 && W > 0, "feature_distance_dev: bad arguments");
     return nctk_feature_distance(ctx, ctx->stream, a_hwc, b_hwc, err, C, H * W);
 }
 

@@ -174,7 +174,8 @@ static int parse_caffemodel(const char* path, nct_model& m, std::string& err) {
 // Classifier::Classifier builds the Net from <model_dir>/vgg19/VGG_ILSVRC_19_layers_deploy.prototxt (Classifier.cpp:16, main.cu:575-577). The topology
 // is built into k_vgg.hip, so the file is only CHECKED: a model directory whose prototxt describes another network must not be accepted silently.
 namespace {
-struct TxtLayer { std::string name, type, pool; std::vector<std::string> bottom, top; long num_output = -1, kernel = -1, pad = 0, stride = 1; };
+struct TxtLayer { std::string name, type, pool; std::vector<std::string> bottom, top; long num_output = -1, kernel = -1, pad = 0, stride = 1;
+                  long kernel_h = -1, kernel_w = -1, pad_h = -1, pad_w = -1, stride_h = -1, stride_w = -1; };     // the _h/_w spellings of caffe.proto (ConvolutionParameter 11-14, PoolingParameter 5-10)
 struct TxtTok { const char* p; const char* end; bool ok = true;
     void ws() { while (p < end) { if (*p == '#') { while (p < end && *p != '\n') ++p; } else if (isspace((unsigned char)*p)) ++p; else break; } }
     bool ident(std::string& out) { ws(); const char* s = p; while (p < end && (isalnum((unsigned char)*p) || *p == '_' || *p == '.' || *p == '-' || *p == '+')) ++p; out.assign(s, p); return p > s; }
@@ -217,6 +218,12 @@ bool parse_msg(TxtTok& t, int depth, TxtLayer* L, std::vector<TxtLayer>* layers,
             else if (full == "convolution_param.pad") L->pad = atol(v.c_str());
             else if (full == "convolution_param.stride" || full == "pooling_param.stride") L->stride = atol(v.c_str());
             else if (full == "pooling_param.pool") L->pool = v;
+            else if (full == "convolution_param.kernel_h" || full == "pooling_param.kernel_h") L->kernel_h = atol(v.c_str());
+            else if (full == "convolution_param.kernel_w" || full == "pooling_param.kernel_w") L->kernel_w = atol(v.c_str());
+            else if (full == "convolution_param.pad_h" || full == "pooling_param.pad_h") L->pad_h = atol(v.c_str());
+            else if (full == "convolution_param.pad_w" || full == "pooling_param.pad_w") L->pad_w = atol(v.c_str());
+            else if (full == "convolution_param.stride_h" || full == "pooling_param.stride_h") L->stride_h = atol(v.c_str());
+            else if (full == "convolution_param.stride_w" || full == "pooling_param.stride_w") L->stride_w = atol(v.c_str());
         }
     }
 }
@@ -237,9 +244,19 @@ static int check_prototxt(const char* path, std::string& err) {
     // walk the data path: every conv of the built-in topology up to conv5_1 must be there, in order, 3x3 / pad 1 / stride 1 with the built-in
     // channel count, followed by an in-place ReLU; a 2x2 / stride-2 MAX pool exactly after conv1_2, conv2_2, conv3_4, conv4_4
     int ci = 0; std::string cur = "data"; bool expect_relu = false, expect_pool = false;
-    for (const TxtLayer& L : layers) {
+    for (TxtLayer L : layers) {
         if (ci >= kNeeded && !expect_relu) break;
         const std::string ty = lower(L.type);
+        // square kernels / pads / strides spelled per axis (kernel_h == kernel_w ...) are the same layer; unequal ones are not this network
+        if (L.kernel_h >= 0 || L.kernel_w >= 0) { if (L.kernel_h != L.kernel_w) return fail("prototxt '%s': %s has a non-square kernel", path, L.name.c_str()); L.kernel = L.kernel_h; }
+        if (L.pad_h >= 0 || L.pad_w >= 0) { if (L.pad_h != L.pad_w) return fail("prototxt '%s': %s has unequal pads", path, L.name.c_str()); L.pad = L.pad_h; }
+        if (L.stride_h >= 0 || L.stride_w >= 0) { if (L.stride_h != L.stride_w) return fail("prototxt '%s': %s has unequal strides", path, L.name.c_str()); L.stride = L.stride_h; }
+        if (ty == "input" || ty == "data" || ty == "memorydata" || ty == "dummydata" || ty == "5" || ty == "29") {
+            // the input declared as a layer (the reference's own Caffe ships input_layer.cpp; the demo file uses the legacy `input:` fields): its top is the data path's start
+            if (ci != 0 || L.top.empty()) return fail("prototxt '%s': input layer '%s' inside the network", path, L.name.c_str());
+            cur = L.top[0];
+            continue;
+        }
         if (ty == "convolution" || ty == "4") {
             if (expect_relu) return fail("prototxt '%s': %s is not followed by a ReLU", path, kConvName[ci - 1]);
             if (expect_pool) return fail("prototxt '%s': no 2x2 max pool after %s", path, kConvName[ci - 1]);
@@ -249,8 +266,9 @@ static int check_prototxt(const char* path, std::string& err) {
             if (L.bottom.size() != 1 || L.bottom[0] != cur || L.top.size() != 1) return fail("prototxt '%s': %s does not consume '%s'", path, L.name.c_str(), cur.c_str());
             cur = L.top[0]; expect_relu = true; expect_pool = kPoolAfter[ci]; ++ci;
         } else if (ty == "relu" || ty == "18") {
-            if (!expect_relu || L.bottom.size() != 1 || L.bottom[0] != cur || L.top.size() != 1 || L.top[0] != cur)
+            if (!expect_relu || L.bottom.size() != 1 || L.bottom[0] != cur || L.top.size() != 1)
                 return fail("prototxt '%s': unexpected ReLU '%s'", path, L.name.c_str());
+            cur = L.top[0];                        // in place (top == bottom, the shipped file) or into a blob of its own: the same function
             expect_relu = false;
         } else if (ty == "pooling" || ty == "17") {
             if (!expect_pool || expect_relu) return fail("prototxt '%s': unexpected pooling layer '%s'", path, L.name.c_str());

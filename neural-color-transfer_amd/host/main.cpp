@@ -309,6 +309,7 @@ void run_pair(nct_ctx* ctx, const Config& cfg, Job& j) {
     j.say("VGG19 Time: %lf sec.\n", tm.vgg_ms * 1e-3);
     j.say("**Finished Time: %lf sec.\n", tm.total_ms * 1e-3);
     j.stl.px.clear(); j.stl.px.shrink_to_fit();
+    j.cnt.px.clear(); j.cnt.px.shrink_to_fit();                 // the store stage needs only cnt.h / cnt.w
 }
 
 void store_pair(Job& j) {
@@ -324,6 +325,10 @@ struct Pipeline {
     std::mutex m; std::condition_variable cv;
     std::deque<std::unique_ptr<Job>> ready, results;
     size_t cap = 4, total = 0, next_load = 0, loading = 0, finished = 0;
+    // decoded pixels waiting for a GPU worker: images are queued BEFORE the GPU-side shrink to MAX_SIZE and a decoder accepts up to 64 MP (192 MB), so the queue is
+    // bounded by bytes as well as by count — a new load starts only while the decoded backlog is below byte_cap (or nothing at all is queued or loading)
+    size_t ready_bytes = 0, byte_cap = (size_t)1 << 30;
+    bool may_load() const { return next_load < total && ready.size() + loading < cap && (ready_bytes < byte_cap || ready.size() + loading == 0); }
     bool loads_done() const { return next_load >= total && loading == 0; }
 };
 
@@ -332,9 +337,9 @@ void io_thread(Pipeline& P, const Config& cfg, const std::vector<Pair>& pairs) {
         std::unique_ptr<Job> j; bool store = false; size_t idx = 0;
         {
             std::unique_lock<std::mutex> lk(P.m);
-            P.cv.wait(lk, [&] { return !P.results.empty() || (P.next_load < P.total && P.ready.size() + P.loading < P.cap) || P.finished == P.total; });
+            P.cv.wait(lk, [&] { return !P.results.empty() || P.may_load() || P.finished == P.total; });
             if (!P.results.empty()) { j = std::move(P.results.front()); P.results.pop_front(); store = true; }       // encoding first: it frees memory and unblocks workers
-            else if (P.next_load < P.total && P.ready.size() + P.loading < P.cap) { idx = P.next_load++; ++P.loading; }
+            else if (P.may_load()) { idx = P.next_load++; ++P.loading; }
             else return;                                                                                                 // finished == total
         }
         P.cv.notify_all();
@@ -348,7 +353,7 @@ void io_thread(Pipeline& P, const Config& cfg, const std::vector<Pair>& pairs) {
             if (!go) finish(cfg, *j);
             std::lock_guard<std::mutex> lk(P.m);
             --P.loading;
-            if (go) P.ready.push_back(std::move(j)); else ++P.finished;
+            if (go) { P.ready_bytes += j->cnt.px.size() + j->stl.px.size(); P.ready.push_back(std::move(j)); } else ++P.finished;
         }
         P.cv.notify_all();
     }
@@ -362,6 +367,7 @@ void gpu_worker(Pipeline& P, nct_ctx* ctx, const Config& cfg) {
             P.cv.wait(lk, [&] { return !P.ready.empty() || P.loads_done(); });
             if (P.ready.empty()) return;
             j = std::move(P.ready.front()); P.ready.pop_front();
+            P.ready_bytes -= j->cnt.px.size() + j->stl.px.size();
         }
         P.cv.notify_all();
         run_pair(ctx, cfg, *j);
@@ -491,6 +497,7 @@ int main(int argc, char** argv) {
     // which worker runs a pair has no influence on its result
     std::vector<std::thread> threads;
     Pipeline P; P.total = pairs.size(); P.cap = (size_t)std::max(2, 2 * nworkers);
+    if (const char* e = getenv("NCT_IO_READY_MB")) P.byte_cap = (size_t)std::max(0L, atol(e)) << 20;      // test hook: decoded backlog allowed in front of the GPU workers (default 1 GiB)
     std::atomic<size_t> next{0};
     if (io > 0) {
         for (int t = 0; t < io; ++t) threads.emplace_back([&, t] { if (pin) affinity::pin_current_thread(loc[t % ngpus].cpus); io_thread(P, cfg, pairs); });

@@ -3,6 +3,9 @@
 // (not blended), 16-bit -> 8-bit (high byte), grayscale replicated, palette expanded. Non-interlaced files only.
 #pragma once
 #include <zlib.h>
+#include <atomic>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -117,9 +120,13 @@ inline bool write(const std::string& path, const uint8_t* bgr, int h, int w, std
     chunk("IHDR", ihdr, 13); chunk("IDAT", comp.data(), (uint32_t)clen); chunk("IEND", nullptr, 0);
     // written under a temporary name and renamed: a run killed mid-write (or a full disk) never leaves a truncated file under the final name,
     // which -resume would take for a finished pair
-    const std::string tmp = path + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f) { err = "cannot create"; return false; }
+    // The temporary name is unique per writer (pid + a process-wide counter) and created exclusively: two pairs.txt lines that map to the same output name may be
+    // encoded concurrently by the I/O pool, and a stale file of a killed run must not be appended to. The last finished writer wins the rename.
+    static std::atomic<unsigned long> seq{0};
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(seq.fetch_add(1));
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0644);
+    FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+    if (!f) { if (fd >= 0) close(fd); err = "cannot create"; return false; }
     bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
     ok = (fclose(f) == 0) && ok;
     if (!ok) { err = "short write"; remove(tmp.c_str()); return false; }

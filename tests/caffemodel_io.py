@@ -88,9 +88,11 @@ def synthetic_vgg19(seed=19, nlayers=13, bias_scale=0.0):
     return ws, bs
 
 
-def write_deploy_prototxt(path, v1=False, drop=None, num_output=None, extra_tail=True):
+def write_deploy_prototxt(path, v1=False, drop=None, num_output=None, extra_tail=True, input_layer=False, per_axis=False, relu_in_place=True, kernel_hw=None):
     """A deploy prototxt of the VGG19 topology in protobuf text format (own writer; the reference ships one under demo/model/vgg19/): `layer` messages with string
-    types, or V1 `layers` with enum types. drop: name of a layer to leave out; num_output: {conv name: value} overrides — for the negative tests."""
+    types, or V1 `layers` with enum types. drop: name of a layer to leave out; num_output: {conv name: value} overrides — for the negative tests.
+    input_layer: declare the input as `layer { type: "Input" }` (input_layer.cpp) instead of the legacy `input:` fields; per_axis: spell kernel / pad as kernel_h, kernel_w,
+    pad_h, pad_w; relu_in_place=False: every ReLU writes a blob of its own; kernel_hw: {conv name: (h, w)} (non-square kernels, negative test)."""
     names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv3_4", "conv4_1", "conv4_2", "conv4_3", "conv4_4",
              "conv5_1", "conv5_2", "conv5_3", "conv5_4"]
     cout = [64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512, 512]
@@ -98,18 +100,23 @@ def write_deploy_prototxt(path, v1=False, drop=None, num_output=None, extra_tail
     kw = "layers" if v1 else "layer"
     ty = (lambda s_: {"Convolution": "CONVOLUTION", "ReLU": "RELU", "Pooling": "POOLING", "InnerProduct": "INNER_PRODUCT"}[s_]) if v1 else (lambda s_: '"%s"' % s_)
     out = ['name: "VGG_ILSVRC_19_layer"', 'input: "data"', "# comment line", "input_shape {", "  dim: 1", "  dim: 3", "  dim: 224", "  dim: 224", "}"]
+    if input_layer and not v1:
+        out = ['name: "VGG_ILSVRC_19_layer"', "layer {", '  name: "data"', '  type: "Input"', '  top: "data"', "  input_param { shape: { dim: 1 dim: 3 dim: 224 dim: 224 } }", "}"]
     cur = "data"
     for i, n in enumerate(names):
         if not extra_tail and i > 12:
             break
         no = (num_output or {}).get(n, cout[i])
         if n != drop:
-            out += [f"{kw} {{", f'  bottom: "{cur}"', f'  top: "{n}"', f'  name: "{n}"', f"  type: {ty('Convolution')}", "  convolution_param {", f"    num_output: {no}", "    pad: 1",
-                    "    kernel_size: 3", "  }", "}"]
+            kh, kw_ = (kernel_hw or {}).get(n, (3, 3))
+            geom = ["    pad_h: 1", "    pad_w: 1", f"    kernel_h: {kh}", f"    kernel_w: {kw_}"] if (per_axis or (kh, kw_) != (3, 3)) else ["    pad: 1", "    kernel_size: 3"]
+            out += [f"{kw} {{", f'  bottom: "{cur}"', f'  top: "{n}"', f'  name: "{n}"', f"  type: {ty('Convolution')}", "  convolution_param {", f"    num_output: {no}"] + geom + ["  }", "}"]
             cur = n
         r = "relu" + n[4:]
         if r != drop:
-            out += [f"{kw} {{", f'  bottom: "{cur}"', f'  top: "{cur}"', f'  name: "{r}"', f"  type: {ty('ReLU')}", "}"]
+            rt = cur if relu_in_place else r
+            out += [f"{kw} {{", f'  bottom: "{cur}"', f'  top: "{rt}"', f'  name: "{r}"', f"  type: {ty('ReLU')}", "}"]
+            cur = rt
         if n in pool_after and pool_after[n] != drop and (extra_tail or i < 12):
             pn = pool_after[n]
             out += [f"{kw} {{", f'  bottom: "{cur}"', f'  top: "{pn}"', f'  name: "{pn}"', f"  type: {ty('Pooling')}", "  pooling_param {", "    pool: MAX", "    kernel_size: 2", "    stride: 2", "  }", "}"]

@@ -208,6 +208,15 @@ def test_deploy_prototxt_check(tmp_path):
     assert run("--check-prototxt", str(ok)).stdout.strip() == "ok"
     write_deploy_prototxt(str(ok), extra_tail=False)                       # a file that stops at relu5_1 is enough
     assert run("--check-prototxt", str(ok)).stdout.strip() == "ok"
+    # spellings the reference's own Caffe accepts for the same network: the input as an `Input` layer (input_layer.cpp), kernel_h / kernel_w / pad_h / pad_w,
+    # ReLUs that write a blob of their own
+    for kw in (dict(input_layer=True), dict(per_axis=True), dict(relu_in_place=False), dict(input_layer=True, per_axis=True, relu_in_place=False)):
+        write_deploy_prototxt(str(ok), **kw)
+        r = run("--check-prototxt", str(ok))
+        assert r.stdout.strip() == "ok", (kw, r.stdout)
+    bad = tmp_path / "nonsquare.prototxt"; write_deploy_prototxt(str(bad), kernel_hw={"conv2_2": (3, 5)})
+    r = run("--check-prototxt", str(bad))
+    assert r.returncode == 1 and "non-square kernel" in r.stdout
     for kw, needle in ((dict(drop="conv3_3"), "unexpected ReLU 'relu3_3'"), (dict(num_output={"conv2_1": 96}), "conv2_1 is num_output 96"),
                        (dict(drop="pool2"), "no 2x2 max pool after conv2_2"), (dict(drop="relu4_2"), "conv4_2 is not followed by a ReLU")):
         bad = tmp_path / "bad.prototxt"; write_deploy_prototxt(str(bad), **kw)
@@ -436,6 +445,39 @@ def test_cli_two_logical_gpus_io_pool_shared_weights(tmp_path, ctx):
     write_deploy_prototxt(str(mdir / "VGG_ILSVRC_19_layers_deploy.prototxt"), num_output={"conv4_1": 256})
     r = subprocess.run([BIN, "-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(tmp_path / "o2")], capture_output=True, text=True, env=env)
     assert r.returncode == 255 and "conv4_1 is num_output 256" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_eight_logical_gpus_four_in_flight(tmp_path):
+    """The full-node host shape in ONE process on one device: `-gpus 8 -inflight 4` with NCT_DEVICE_OVERRIDE=0 = 32 worker contexts (arena, streams,
+    host thread each) + 16 I/O threads, one parse and ONE device copy of the weights. Every pair is processed exactly once, the files are byte-identical to `-gpus 1
+    -inflight 2`, also with the decoded backlog squeezed to a single pair (NCT_IO_READY_MB=0: the byte bound of the ready queue), and duplicate pairs.txt lines (same
+    output name, encoded concurrently) leave no temporary file behind. scripts/cli_8gpu_shape.py measures the throughput of this shape on 700x700 pairs."""
+    from caffemodel_io import synthetic_vgg19, write_caffemodel, write_deploy_prototxt
+    ws, bs = synthetic_vgg19(19)
+    mdir = tmp_path / "model" / "vgg19"; mdir.mkdir(parents=True)
+    write_caffemodel(str(mdir / "VGG_ILSVRC_19_layers.caffemodel"), ws, bs)
+    write_deploy_prototxt(str(mdir / "VGG_ILSVRC_19_layers_deploy.prototxt"), input_layer=True)
+    inp = tmp_path / "in"; inp.mkdir()
+    lines = []
+    for i in range(40):
+        h, w = 64 + 8 * (i % 5), 64 + 8 * (i % 3)
+        Image.fromarray(synth.image(300 + i, h, w)[..., ::-1].copy()).save(inp / f"s{i}.png"); Image.fromarray(synth.image(400 + i, w, h)[..., ::-1].copy()).save(inp / f"r{i}.png")
+        lines.append(f"s{i}.png r{i}.png 2.0\n")
+    lines += lines[:6]                                              # six duplicate lines: two writers of the same output name
+    (inp / "pairs.txt").write_text("".join(lines))
+    blobs = {}
+    for tag, args, extra in (("ref", ["-gpus", "1", "-inflight", "2"], {}), ("node", ["-gpus", "8", "-inflight", "4"], {}), ("squeezed", ["-gpus", "8", "-inflight", "4"], {"NCT_IO_READY_MB": "0"})):
+        out = tmp_path / f"out_{tag}"
+        r = subprocess.run([BIN, "-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(out), *args], capture_output=True, text=True, env=dict(os.environ, NCT_DEVICE_OVERRIDE="0", **extra))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr
+        if tag != "ref":
+            assert "1 device copy of" in r.stdout and "shared by 32 context(s)" in r.stdout and "on 8 GPU(s), 4 in flight each" in r.stdout
+        assert r.stdout.count("Final output file:") == 46
+        names = sorted(os.listdir(out))
+        assert not [n for n in names if ".tmp" in n] and len([n for n in names if n.endswith(".png")]) == 40
+        blobs[tag] = {n: (out / n).read_bytes() for n in names if n.endswith(".png")}
+    assert blobs["node"] == blobs["ref"] and blobs["squeezed"] == blobs["ref"]
 
 
 @pytest.mark.gpu
