@@ -371,6 +371,13 @@ __device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s
             for (int q = 0; q < NQ; ++q) y[q] -= c.w[k] * s_v[q * LN + p + lds_off<LW>(k)];
         }
 }
+// XCD-aware tile order (round 4): consecutive workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2. A 2-D grid puts neighbouring tiles on different
+// XCDs, so every halo pixel was fetched from the fabric again (k_mg_up: 131 MB per launch for 66 MB of compulsory bytes, 84 % L2 misses). The legs run on a 1-D grid and
+// give each XCD a contiguous band of tile rows: neighbouring tiles meet in the same L2. Pure scheduling: which workgroup computes a tile has no influence on its values.
+__device__ __forceinline__ int mg_tile_of_block(int bid, int ntiles) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 constexpr int mg_threads(int TX, int TY) { return ((TX + 2 * MG_NS + 1) * (TY + 2 * MG_NS + 1) + 63) / 64 * 64; }
 // TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below.
 // Sweep k produces its iterate on ring(k) = the thread grid shrunk by k from every side; the residual lives on ring(MG_NS) = the tile + one pixel to the left / top.
@@ -380,7 +387,8 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
     if (st->nactive == 0) return;
     constexpr int HA = MG_NS + 1, HB = MG_NS, LW = TX + HA + HB, LH = TY + HA + HB, LN = LW * LH;
     __shared__ vf s_a[NQ * LN], s_b[NQ * LN];
-    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int tiles_x = (F.W + TX - 1) / TX, tile = mg_tile_of_block(blockIdx.x, gridDim.x);
+    const int x0 = (tile % tiles_x) * TX, y0 = (tile / tiles_x) * TY;
     const int p = threadIdx.x;
     const int ly = p / LW, lx = p - ly * LW;
     const int gy = y0 + ly - HA, gx = x0 + lx - HA;
@@ -448,7 +456,8 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
     constexpr int HA = ODD ? MG_NS + 1 : MG_NS, HB = ODD ? MG_NS : MG_NS + 1, LW = TX + HA + HB, LH = TY + HA + HB, LN = LW * LH;
     constexpr int OL = ODD ? 1 : 0, OR = ODD ? 0 : 1;                          // xe lives on the grid minus its first (odd sweep count) / last (even) row and column
     __shared__ vf s_a[NQ * LN], s_b[NQ * LN];
-    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int tiles_x = (L.W + TX - 1) / TX, tile = mg_tile_of_block(blockIdx.x, gridDim.x);
+    const int x0 = (tile % tiles_x) * TX, y0 = (tile / tiles_x) * TY;
     const int p = threadIdx.x;
     const int ly = p / LW, lx = p - ly * LW;
     const int gy = y0 + ly - HA, gx = x0 + lx - HA;
@@ -865,7 +874,7 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     // dependent load chains short and spreads over more CUs.
     constexpr int TXB = NCT_MG_TXB, TYB = NCT_MG_TYB;
     auto down = [&](int l) {
-        const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
+        const dim3 gb(cdiv(lv[l].W, TXB) * cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16) * cdiv(lv[l].H, 8));      // 1-D: mg_tile_of_block maps block -> tile
         if (l == 0) {
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, double, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
             else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, double, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
@@ -875,7 +884,7 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
         }
     };
     auto up = [&](int l, const vf* ec) {
-        const dim3 gb(cdiv(lv[l].W, TXB), cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16), cdiv(lv[l].H, 8));
+        const dim3 gb(cdiv(lv[l].W, TXB) * cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16) * cdiv(lv[l].H, 8));
         const int Wc = lv[l + 1].W, nc = lv[l + 1].n;
         if (l == 0) {
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, double, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
