@@ -529,7 +529,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
 // P0 = pixels per thread of the first fused level: 2 (<= 2048 pixels: 44x44 at 700x700; no spills) or 4 (63x63 at 1000x1000; the 9-point coefficients of four pixels
 // beside the deeper levels' state exceed the 128 VGPRs of a 1024-thread workgroup: ~60 spilled registers, still faster than the launches it replaces)
 #ifndef NCT_MID_MAXP0
-#define NCT_MID_MAXP0 1      // largest first fused level, in units of 1024 pixels (1, 2 or 4)
+#define NCT_MID_MAXP0 2      // largest first fused level, in units of 1024 pixels (1, 2 or 4): 2 = the 44x44 level of a 700x700 pair rides in k_mg_mid (same time as its two tile launches, 186 launches fewer per pair)
 #endif
 constexpr int MID_T = 1024, MID_P1 = 1, MID_N1 = MID_T * MID_P1, MID_LV = 5;
 // largest level at depth d >= 1 (the first fused level: P0 * 1024); levels shrink ~4x per depth. The levels below the first park their 10 coefficients and 4 prolongation
