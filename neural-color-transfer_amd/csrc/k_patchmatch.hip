@@ -532,6 +532,159 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
     }
 }
 
+// ---- C = 64 / 128, propagation-only steps (jump 8 / 4 / 2: three of the four launches of an iteration) with the candidates of a wave's SIXTEEN (C = 128: eight) queries packed (round 4).
+// k_pm_step lets each query walk its own short candidate list, so a wave spends max-over-its-eight-queries rounds per pass — with 1.5 live candidates per query on
+// average (0.4 in late iterations) half to two thirds of the lane groups idle in every round, and the rounds are a dependent chain (tile rows -> sum -> next). Here every wave
+// first lists the live (query, candidate) pairs of BOTH passes (its 16 queries) in LDS, then its eight lane groups take eight list entries per round whatever query they belong
+// to, and finally each query scans ITS results in candidate order with the reference's accept rule (d < dbest, first wins). A propagation candidate's distance does not depend
+// on the other candidates of its query — only the early-rejection threshold did, and the initial dbest is a valid (weaker) threshold — so NNF and distances are the same bits.
+// Rounds per wave: ceil(live candidates / 8) instead of sum over the passes of the longest list.
+#ifndef NCT_PM_PACK
+#define NCT_PM_PACK 2        // 0: off, 1: C = 64 only, 2: C = 64 and 128
+#endif
+#ifndef NCT_PM_PROP_OCC
+#define NCT_PM_PROP_OCC NCT_PM_OCC8        // workgroups per CU the packed kernel is compiled for, and how it fetches a candidate's rows (pm_dist8 STAGE): one row at a time
+#define NCT_PM_PROP_STAGE 0                // measured 11.41 ms for the finest level of a 700x700 pair vs 12.17 (first row, then two together) / 12.18 (whole tile); five workgroups per CU 11.53, six 13.5
+#endif
+template <int NCH, int MODE, int TQX, int TQY, int LPQ>
+__global__ __launch_bounds__(256, LPQ == 8 ? NCT_PM_PROP_OCC : 1) void k_pm_prop(PMJob j0, PMJob j1, int nblk0, int jump, int tstep, int strip, unsigned long long* __restrict__ counter) {
+    constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2, QW = LPQ == 16 ? 4 : 8, QH = 256 / LPQ / QW, NSX = 4 * TQX / QW, NSUB = NSX * (4 * TQY / QH);
+    constexpr int GPW = 64 / LPQ;                          // lane groups (= queries per pass) of a wave
+    static_assert(NSUB == 2 && (NCH == 1 || NCH == 2), "two passes per workgroup: 16 (C = 64) or 8 (C = 128) queries per wave");
+    constexpr bool EX = MODE == NCT_PM_ROWREJECT;
+    const bool second = (int)blockIdx.x >= nblk0;
+    const PMJob& J = second ? j1 : j0;
+    const float* __restrict__ A = J.A; const float* __restrict__ B = J.B; const uint2* __restrict__ Bh = J.Bh;
+    const uint32_t* __restrict__ nnf_in = J.nnf_in; const float* __restrict__ d_in = J.d_in;
+    uint32_t* __restrict__ nnf_out = J.nnf_out; float* __restrict__ d_out = J.d_out;
+    const PMGeom g = J.g;
+    const int ntiles = g.tiles_x * g.tiles_y;
+    int bid = (int)blockIdx.x - (second ? nblk0 : 0);
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ty = bid / g.tiles_x, tx = bid - ty * g.tiles_x;
+    const int grp = threadIdx.x / LPQ, v = threadIdx.x % LPQ, wv = threadIdx.x >> 6, gw = grp % GPW;
+    const int ox = tx * 4 * TQX, oy = ty * 4 * TQY;
+    __shared__ uint32_t s_list[4][8 * GPW];     // per wave: live (slot, k, candidate) entries
+    __shared__ uint4 s_q[4][2 * GPW];           // per wave and query slot: ax | ay << 16, lx | ly << 8 | amask << 16, dbest, -
+    __shared__ float s_res[4][8 * GPW];         // per wave: distance of candidate k of slot s at [s * 4 + k]
+
+    // ---- the NNF words of both passes first (they fly under the staging loop's barrier)
+    uint32_t vbest[NSUB], vnb[NSUB][4]; float dq[NSUB]; int qi[NSUB]; bool live[NSUB];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int qx = ox + (sub % NSX) * QW + (grp % QW), qy = oy + (sub / NSX) * QH + (grp / QW);
+        live[sub] = qx < g.aw && qy < g.ah;
+        const int ax = live[sub] ? qx : 0, ay = live[sub] ? qy : 0;
+        qi[sub] = ay * g.aw + ax;
+        vbest[sub] = nnf_in[qi[sub]]; dq[sub] = d_in[qi[sub]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int nx = ax + ((k == 0) ? -jump : (k == 1 ? jump : 0)), ny = ay + ((k == 2) ? -jump : (k == 3 ? jump : 0));
+            vnb[sub][k] = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
+        }
+    }
+    extern __shared__ float4 s_a[];
+    {
+        constexpr int c4 = 16 * NCH;
+        for (int e = threadIdx.x; e < RW * RH * c4; e += 256) {
+            const int r = e / c4, j = e - r * c4;
+            const int ry = clampi(oy - 1 + r / RW, 0, g.ah - 1), rx = clampi(ox - 1 + r % RW, 0, g.aw - 1);
+            s_a[e] = reinterpret_cast<const float4*>(A + ((size_t)ry * g.aw + rx) * (64 * NCH))[j];
+        }
+    }
+    // ---- phase A: every query lists its live candidates (the rules of k_pm_step: inside both images, not stale, not the current match)
+    uint32_t cl[NSUB][4]; int ncl[NSUB];
+    int base = 0;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int ax = qi[sub] % g.aw, ay = qi[sub] / g.aw;
+        const int xb0 = nnf_x(vbest[sub]), yb0 = nnf_y(vbest[sub]);
+        ncl[sub] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cl[sub][k] = 0;
+            const int sxx = (k == 0) ? -jump : (k == 1 ? jump : 0), syy = (k == 2) ? -jump : (k == 3 ? jump : 0);
+            const int nx = ax + sxx, ny = ay + syy;
+            const uint32_t vp = vnb[sub][k];
+            const int xp = nnf_x(vp) - sxx, yp = nnf_y(vp) - syy;
+            bool valid = live[sub] && nx >= 0 && nx < g.aw && ny >= 0 && ny < g.ah && yp >= 0 && yp < g.bh && xp >= 0 && xp < g.bw;
+            valid = valid && !(tstep > 4 && (int)(vp >> 24) < tstep - 4);
+            valid = valid && !(xp == xb0 && yp == yb0);
+            if (valid) {
+                const uint32_t c = xy_pack(xp, yp);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (ncl[sub] == i) cl[sub][i] = c;
+                ++ncl[sub];
+            }
+        }
+        const int slot = sub * GPW + gw;
+        if (v == 0) {
+            unsigned amask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = ay + t / 3 - 1, xx = ax + t % 3 - 1;
+                amask |= ((yy >= 0 && yy < g.ah && xx >= 0 && xx < g.aw) ? 1u : 0u) << t;
+            }
+            s_q[wv][slot] = make_uint4((unsigned)ax | ((unsigned)ay << 16), (unsigned)(ax - ox) | ((unsigned)(ay - oy) << 8) | (amask << 16), __float_as_uint(dq[sub]), 0u);
+        }
+        const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(v == 0 && ncl[sub] > i);
+            if (v == 0 && ncl[sub] > i) s_list[wv][base + __builtin_popcountll(m & below)] = ((unsigned)slot << 26) | ((unsigned)i << 24) | cl[sub][i];
+            base += __builtin_popcountll(m);
+        }
+    }
+    __syncthreads();                                     // the staged region, the lists and the query records are complete
+    // ---- phase B: one list entry per lane group and round
+    for (int r = 0; r * GPW < base; ++r) {
+        const int e = r * GPW + gw;
+        if (e < base) {
+            const uint32_t ent = s_list[wv][e];
+            const int slot = ent >> 26, k = (ent >> 24) & 3;
+            const uint4 q = s_q[wv][slot];
+            const int ax = q.x & 0xFFFF, ay = q.x >> 16, lx = q.y & 0xFF, ly = (q.y >> 8) & 0xFF;
+            const unsigned amask = q.y >> 16;
+            const float dbest = __uint_as_float(q.z);
+            float d;
+            if constexpr (LPQ == 8) d = pm_dist8<MODE, RW, NCT_PM_PROP_STAGE>(B, g, ax, ay, amask, nnf_x(ent & 0xFFFFFFu), nnf_y(ent & 0xFFFFFFu), v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+            else d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, nnf_x(ent & 0xFFFFFFu), nnf_y(ent & 0xFFFFFFu), v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+            if (v == 0) s_res[wv][slot * 4 + k] = d;
+        }
+    }
+    __syncthreads();
+    // ---- phase C: every query scans its candidates in order (accept d < dbest: the first of equal distances wins, as in the sequential walk)
+    unsigned nevals = 0, naccept = 0;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        if (!(live[sub] && v == 0)) continue;
+        const int slot = sub * GPW + gw;
+        uint32_t best = vbest[sub] & 0xFFFFFFu; float dbest = dq[sub];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < ncl[sub]) {
+                float d = s_res[wv][slot * 4 + k];
+                if (d >= dbest) d = dbest;
+                if (d < dbest) { best = cl[sub][k]; dbest = d; ++naccept; }
+                ++nevals;
+            }
+        const uint32_t stamp = best != (vbest[sub] & 0xFFFFFFu) ? (uint32_t)tstep : (vbest[sub] >> 24);
+        nnf_out[qi[sub]] = best | (strip ? 0u : stamp << 24);
+        d_out[qi[sub]] = dbest;
+    }
+    if (counter) {
+        __shared__ unsigned s_cnt[2];
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        if (v == 0) { atomicAdd(&s_cnt[0], nevals); atomicAdd(&s_cnt[1], naccept); }
+        __syncthreads();
+        if (threadIdx.x < 2) atomicAdd(counter + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]);
+    }
+}
+
 // query tile of a workgroup per channel count: 8x8 at C = 64 (25 KB of LDS), 8x4 at C = 128 (31 KB), 4x4 above (37 / 74 KB)
 template <int NCH> struct PMTile { static constexpr int TQX = NCH == 1 ? 2 : (NCH == 2 ? 2 : 1), TQY = NCH == 1 ? 2 : 1; };
 // lanes per query: 8 at C = 64 (pm_dist8), else 16. Measured alternatives (two unpacked chains per lane): C = 128 with 8 lanes
@@ -546,6 +699,13 @@ static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob
     if (lds > 32768 && !(ctx->pm_attr_mask & abit)) {
         NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE, TQX, TQY, LPQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->pm_attr_mask |= abit;
+    }
+    if constexpr ((NCH == 1 || (NCH == 2 && NCT_PM_PACK >= 2)) && MODE != NCT_PM_FP16 && NCT_PM_PACK != 0) {
+        if (mode == 1 && jump != 1) {              // propagation-only step: the packed form (its dynamic LDS is the same staged region)
+            hipLaunchKernelGGL((k_pm_prop<NCH, MODE, TQX, TQY, LPQ>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, jump, tstep, strip, counter);
+            NCT_LAUNCH_CHECK();
+            return 0;
+        }
     }
     hipLaunchKernelGGL((k_pm_step<NCH, MODE, TQX, TQY, LPQ>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, mode, jump, iter, tstep, strip, counter);
     NCT_LAUNCH_CHECK();
