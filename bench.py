@@ -16,8 +16,8 @@ Other workloads (parity-test configurations of BASELINE.json, selectable for sca
 with sides 256..1000 per step, dynamic tickets from the rendezvous store = work stealing across ranks without a collective).
 
 Extra objects:
-  roofline     — the dominant kernel AS THE PIPELINE RUNS IT: k_pm_step<1, 1, 2, 2, 8> (C = 64, finest level, both directions per launch, unit-norm
-                 features with the exact row rejection). avg launch time = HIP events recorded on the library's stream around the
+  roofline     — the dominant kernel AS THE PIPELINE RUNS IT: the finest PatchMatch level's 41 launches, k_pm_step<1, 1, 2, 2, 8> / k_pm_prop<1, 1, 2, 2, 8> (C = 64, both directions per
+                 launch, unit-norm features with the exact row rejection). avg launch time = HIP events recorded on the library's stream around the
                  level's 41 launches of a real pair; `traffic` = fabric-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE
                  x2 gfx950 correction + WRITE_SIZE, separate passes) of THIS build — collected live when rocprofv3 is on PATH, else
                  read from profiles/ only if the recorded build id equals this libnct.so's; `achieved` = traffic / launch time,
@@ -354,7 +354,10 @@ def pmc_traffic(device, live):
     return None, why
 
 
-def read_pmc_csv(td, ctr, prefix="void k_pm_step<1, 1,"):
+PM_FINEST = ("void k_pm_step<1, 1,", "void k_pm_prop<1, 1,")      # the finest level's 41 launches: init + 10 x (3 packed propagation launches + 1 propagation/random-search launch)
+
+
+def read_pmc_csv(td, ctr, prefix=PM_FINEST):
     import csv, glob
     f = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
     rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == ctr]
@@ -393,7 +396,7 @@ def finish_pmc(vals, bid, how):
         by_step = {name: {"launches_per_level": len(v) // (len(fs["per_dispatch"]) // 41), "avg_launch_us": sum(u for _, u in v) / len(v), "fabric_bytes_per_launch": sum(b for b, _ in v) / len(v),
                           "fabric_GBs": sum(b for b, _ in v) / sum(u for _, u in v) / 1e3, "frac_of_hbm_peak": sum(b for b, _ in v) / sum(u for _, u in v) / 1e3 / HBM_PEAK_GBS}
                    for name, v in cls.items() if v}
-    return {"build_id": bid, "how": how, "kernel": "k_pm_step<1, 1, 2, 2, 8>", "dispatches": vals["FETCH_SIZE"]["dispatches"], "by_step": by_step,
+    return {"build_id": bid, "how": how, "kernel": "k_pm_step<1, 1, 2, 2, 8> + k_pm_prop<1, 1, 2, 2, 8> (the finest level's 41 launches)", "dispatches": vals["FETCH_SIZE"]["dispatches"], "by_step": by_step,
             "FETCH_SIZE_KB_per_dispatch_raw": vals["FETCH_SIZE"]["mean"], "WRITE_SIZE_KB_per_dispatch_raw": vals["WRITE_SIZE"]["mean"],
             "calibration": cal, "corrected_bytes_per_launch": {"fetch": fetch, "write": write, "total": fetch + write}, "l1": l1}
 
@@ -422,7 +425,8 @@ def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
             traffic = pmc["corrected_bytes_per_launch"]["total"]
     footprint = nq * C * 4 + nq * 16
     achieved = (traffic if traffic is not None else alg / n_launch) / launch_s / 1e9
-    return {"bound": "hbm", "kernel": f"k_pm_step<1, 1, 2, 2, 8> (C=64, 8x8 queries per workgroup, 8 lanes per query, {sshape[1]}x{sshape[0]} <-> {rshape[1]}x{rshape[0]}, both directions per launch, pipeline features)",
+    return {"bound": "hbm", "kernel": f"k_pm_step<1, 1, 2, 2, 8> (init + the 10 propagation/random-search launches) and k_pm_prop<1, 1, 2, 2, 8> (the 30 packed propagation launches) — C=64, 8x8 queries per workgroup, "
+                                      f"8 lanes per query, {sshape[1]}x{sshape[0]} <-> {rshape[1]}x{rshape[0]}, both directions per launch, pipeline features",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "basis": "PMC fabric-side bytes (FETCH_SIZE x2 + WRITE_SIZE) per launch / event-timed launch" if traffic is not None else
                      "ALGORITHMIC bytes (no PMC pass of this build available) — not an HBM fraction, can exceed 1",
@@ -467,7 +471,7 @@ def patchmatch_roofline_1000(device):
         nq = 2 * 1000 * 1000
         foot = nq * 64 * 4 + nq * 16
         gbs = (fetch + write) / us / 1e3
-        return {"bound": "hbm", "kernel": "k_pm_step<1, 1, 2, 2, 8> at 1000x1000 <-> 1000x1000 (BASELINE config 4), counter-pass launch durations", "dispatches": fs["dispatches"],
+        return {"bound": "hbm", "kernel": "k_pm_step<1, 1, 2, 2, 8> + k_pm_prop<1, 1, 2, 2, 8> at 1000x1000 <-> 1000x1000 (BASELINE config 4), counter-pass launch durations", "dispatches": fs["dispatches"],
                 "traffic": fetch + write, "avg_launch_us": us, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "by_step": by,
                 "footprint_bytes": foot, "footprint_over_mall": foot / (256.0 * 1024 * 1024), "restream_factor": (fetch + write) / foot,
                 "fetch_size_factor": 2.0, "fetch_size_factor_basis": "profiles/round4_fetch_calibration.md: FETCH_SIZE x 1024 / known bytes = 0.50 on a streaming read AND on 8-lane x 16-B tile rows at random pixels",

@@ -220,8 +220,11 @@ __global__ void k_mg_weights(Lvl L) {
     double w[8]; coup8(L, r, c, w);
     const double d = L.d[i];
     double pa = 0.0, pb = 0.0;
-    if (!(r & 1) && (c & 1)) { const double den = (d - w[2]) - w[3]; pa = ((w[1] + w[5]) + w[7]) / den; pb = ((w[0] + w[4]) + w[6]) / den; }
-    else if ((r & 1) && !(c & 1)) { const double den = (d - w[0]) - w[1]; pa = ((w[3] + w[6]) + w[7]) / den; pb = ((w[2] + w[4]) + w[5]) / den; }
+    // (den <= 0 cannot happen on level 0 and did not on any Galerkin level seen; such a point would fall back to plain averaging of its existing coarse neighbours)
+    if (!(r & 1) && (c & 1)) { const double den = (d - w[2]) - w[3]; const bool e2 = c + 1 < L.W;
+                               if (den > 0.0) { pa = ((w[1] + w[5]) + w[7]) / den; pb = ((w[0] + w[4]) + w[6]) / den; } else { pa = e2 ? 0.5 : 1.0; pb = e2 ? 0.5 : 0.0; } }
+    else if ((r & 1) && !(c & 1)) { const double den = (d - w[0]) - w[1]; const bool e2 = r + 1 < L.H;
+                                    if (den > 0.0) { pa = ((w[3] + w[6]) + w[7]) / den; pb = ((w[2] + w[4]) + w[5]) / den; } else { pa = e2 ? 0.5 : 1.0; pb = e2 ? 0.5 : 0.0; } }
     else if ((r & 1) && (c & 1)) pa = 1.0 / d;
     L.pa[i] = pa; L.pb[i] = pb;
 }

@@ -204,8 +204,12 @@ static void mg_weights(lvl_t* L) {
         double w[8]; COUP8(double, L, wE, wS, wSE, wSW, r, c, w);
         const double d = L->d[i];
         double pa = 0.0, pb = 0.0;
-        if (!(r & 1) && (c & 1)) { const double den = (d - w[2]) - w[3]; pa = ((w[1] + w[5]) + w[7]) / den; pb = ((w[0] + w[4]) + w[6]) / den; }           /* W: W+SW+NW ; E: E+SE+NE */
-        else if ((r & 1) && !(c & 1)) { const double den = (d - w[0]) - w[1]; pa = ((w[3] + w[6]) + w[7]) / den; pb = ((w[2] + w[4]) + w[5]) / den; }      /* N: N+NE+NW ; S: S+SE+SW */
+        /* den <= 0 cannot happen on level 0 (den = r + the two weights along the line) and did not on any Galerkin level seen; should a stencil with couplings of the
+         * wrong sign produce it, the point falls back to plain averaging of its existing coarse neighbours instead of dividing by it */
+        if (!(r & 1) && (c & 1)) { const double den = (d - w[2]) - w[3]; const int e2 = c + 1 < W;
+                                   if (den > 0.0) { pa = ((w[1] + w[5]) + w[7]) / den; pb = ((w[0] + w[4]) + w[6]) / den; } else { pa = e2 ? 0.5 : 1.0; pb = e2 ? 0.5 : 0.0; } }     /* W: W+SW+NW ; E: E+SE+NE */
+        else if ((r & 1) && !(c & 1)) { const double den = (d - w[0]) - w[1]; const int e2 = r + 1 < L->H;
+                                        if (den > 0.0) { pa = ((w[3] + w[6]) + w[7]) / den; pb = ((w[2] + w[4]) + w[5]) / den; } else { pa = e2 ? 0.5 : 1.0; pb = e2 ? 0.5 : 0.0; } } /* N: N+NE+NW ; S: S+SE+SW */
         else if ((r & 1) && (c & 1)) pa = 1.0 / d;
         L->pa[i] = pa; L->pb[i] = pb;
     }
@@ -292,9 +296,8 @@ static void mg_finish(lvl_t* L) {
 static int g_wls_log[64], g_wls_log_n = 0;
 int orc_wls_log(int* out, int reset) { const int n = g_wls_log_n; if (out) memcpy(out, g_wls_log, sizeof(int) * (size_t)n); if (reset) g_wls_log_n = 0; return n; }
 
-/* a,b: full-res [N][3] in (x0) / out. iters_out[6] nullable. Returns max iterations, or -1 if not converged. */
-int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double rtol, int* iters_out) {
-    lvl_t lv[16]; int nl = 0;
+static int mg_build(lvl_t* lv, const double* lab, int H, int W, double lamda, double alpha, const double* roughness) {
+    int nl = 0;
     { int h = H, w = W;
       for (;;) {
           lvl_t* L = &lv[nl]; memset(L, 0, sizeof *L); L->H = h; L->W = w; L->n = h * w; L->nine = nl > 0;
@@ -315,6 +318,54 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
         if (l + 1 < nl) mg_weights(&lv[l]);
         mg_finish(&lv[l]);
     }
+    return nl;
+}
+static void mg_free(lvl_t* lv, int nl) {
+    for (int l = 0; l < nl; ++l) { lvl_t* L = &lv[l]; free(L->d); free(L->wE); free(L->wS); free(L->wSE); free(L->wSW); free(L->pa); free(L->pb); free(L->fd); free(L->fdinv); free(L->fE); free(L->fS);
+                                   free(L->fSE); free(L->fSW); free(L->fpst); free(L->b); free(L->x); free(L->x2); }
+}
+
+/* Property-test hooks (tests/test_oracle_color.py): z = Vcycle(r) for nv vectors of [n][6] doubles on the hierarchy of this system, and the level operators' statistics.
+ * The cycle must be a SYMMETRIC positive definite linear map (R = P^T, the post-smoother the adjoint of the pre-smoother) for PCG to be a valid solver. */
+int orc_wls_vcycle_apply(const double* lab, int H, int W, double lamda, double alpha, const double* roughness, const double* r_in, double* z_out, int nv) {
+    lvl_t lv[16];
+    const int nl = mg_build(lv, lab, H, W, lamda, alpha, roughness);
+    const int n = lv[0].n;
+    float* scr1 = (float*)malloc(sizeof(float) * (size_t)n * NQ);
+    for (int v = 0; v < nv; ++v) {
+        vcycle(lv, nl, r_in + (size_t)v * n * NQ, scr1);
+        for (size_t j = 0; j < (size_t)n * NQ; ++j) z_out[(size_t)v * n * NQ + j] = (double)lv[0].x[j];
+    }
+    free(scr1); mg_free(lv, nl);
+    return nl;
+}
+/* per level (up to 16): [n, min d, min over rows of (d - sum of couplings) = the coarse "data term", number of couplings of the wrong sign (w < 0), max dt / d] */
+int orc_wls_hierarchy_stats(const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double* out /*[16][5]*/) {
+    lvl_t lv[16];
+    const int nl = mg_build(lv, lab, H, W, lamda, alpha, roughness);
+    for (int l = 0; l < nl; ++l) {
+        const lvl_t* L = &lv[l];
+        double dmin = 1e300, rmin = 1e300, ratio = 1.0; double neg = 0;
+        for (int i = 0; i < L->n; ++i) {
+            const int r = i / L->W, c = i - r * L->W;
+            double w[8]; COUP8(double, L, wE, wS, wSE, wSW, r, c, w);
+            double s = 0, sa = fabs(L->d[i]);
+            for (int k = 0; k < 8; ++k) { s += w[k]; sa += fabs(w[k]); if (w[k] < 0) neg += 1; }
+            if (L->d[i] < dmin) dmin = L->d[i];
+            if (L->d[i] - s < rmin) rmin = L->d[i] - s;
+            const double dt = 0.5 * sa > L->d[i] ? 0.5 * sa : L->d[i];
+            if (dt / L->d[i] > ratio) ratio = dt / L->d[i];
+        }
+        out[l * 5] = L->n; out[l * 5 + 1] = dmin; out[l * 5 + 2] = rmin; out[l * 5 + 3] = neg; out[l * 5 + 4] = ratio;
+    }
+    mg_free(lv, nl);
+    return nl;
+}
+
+/* a,b: full-res [N][3] in (x0) / out. iters_out[6] nullable. Returns max iterations, or -1 if not converged. */
+int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, double lamda, double alpha, const double* roughness, double rtol, int* iters_out) {
+    lvl_t lv[16];
+    const int nl = mg_build(lv, lab, H, W, lamda, alpha, roughness);
     lvl_t* F = &lv[0];
     const int n = F->n;
     float* scr1 = (float*)malloc(sizeof(float) * (size_t)n * NQ);
@@ -383,8 +434,7 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
     if (iters_out) memcpy(iters_out, iters, sizeof iters);
     int mx = 0; for (int q = 0; q < 6; ++q) if (iters[q] > mx) mx = iters[q];
     if (g_wls_log_n < 64) g_wls_log[g_wls_log_n++] = mx;
-    for (int l = 0; l < nl; ++l) { lvl_t* L = &lv[l]; free(L->d); free(L->wE); free(L->wS); free(L->wSE); free(L->wSW); free(L->pa); free(L->pb); free(L->fd); free(L->fdinv); free(L->fE); free(L->fS);
-                                   free(L->fSE); free(L->fSW); free(L->fpst); free(L->b); free(L->x); free(L->x2); }
+    mg_free(lv, nl);
     free(scr1); free(x6); free(r); free(p); free(sv); free(w); free(acc);
     return any ? -1 : mx;
 }

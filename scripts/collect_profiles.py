@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
-"""Turns the output of scripts/final_measure.sh (gpurun_out/<tag>/) into the tracked summaries under profiles/ (round 3 names):
-round3_bench.json, round3_pmc_patchmatch.json, round3_e2e_kernels.md, round3_workloads.md, round3_pmc_patchmatch_levels.md, round3_pmc_vgg_mfma.md,
-round3_wls_rtol_sweep.json, round3_pytest_gpu.txt.
-usage: python scripts/collect_profiles.py <tag>"""
+"""Turns the output of scripts/final_measure.sh (gpurun_out/<tag>/) into the tracked summaries under profiles/:
+<round>_bench.json, <round>_pmc_patchmatch.json, <round>_e2e_kernels.md, <round>_workloads.md, <round>_pmc_patchmatch_levels.md, <round>_pmc_color.md, <round>_pmc_vgg_mfma.md,
+<round>_wls_rtol_sweep.json, <round>_pytest_gpu.txt.
+usage: python scripts/collect_profiles.py <tag> [round4]"""
 import csv, json, os, re, sys, collections
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(REPO, "gpurun_out", tag)
 dst = os.path.join(REPO, "profiles")
-R = "round3"
+R = sys.argv[2] if len(sys.argv) > 2 else "round4"
+RN = R.replace("round", "round ")
 
 
 def jline(name):
@@ -35,15 +36,16 @@ if os.path.exists(sweep) and os.path.getsize(sweep) > 10:
 # ---- per-kernel table of the one-pair-in-flight profiled run
 prof = jline("prof_bench.json")
 rows = list(csv.DictReader(open(os.path.join(src, "prof", "b_kernel_stats.csv"))))
-pairs = 3 * 4 + 2      # context warm-up + (1 warm-up + 2 timed) steps + host-to-host + the single-pair latency (warm run + best of three) / latency-flag / stage / roofline pairs,
-                       # one in flight: see bench.py
+pairs = sum(int(r["Calls"]) for r in rows if r["Name"].startswith("k_km_init("))      # one k-means seeding per pair: warm-ups, timed steps, host-to-host region, latency / stage / roofline pairs
 calls = sum(int(r["Calls"]) for r in rows)
 total = sum(int(r["TotalDurationNs"]) for r in rows)
 pm = [r for r in rows if r["Name"].startswith("void k_pm_step<1, 1,")][0]
-L = [f"# round 3 — `rocprofv3 --kernel-trace --stats` of `python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-latency-flag` (one pair in flight), MI355X", "",
-     f"Build id {prof['build_id']} (the build of profiles/{R}_bench.json: {bench['build_id']}). The run processes {pairs} pairs (context warm-up, 1 warm-up + 2 timed steps, the host-to-host",
-     f"region, the latency / stage / roofline pairs): divide calls and totals by {pairs} for one 700x700 pair. Bench line of this profiled run: {prof['value']:.2f} pairs/s, single pair {prof['single_pair_ms']:.1f} ms (tracing on);",
-     f"its event-timed average launch of `{prof['roofline']['kernel'].split(' (')[0]}` is {prof['roofline']['avg_launch_ms'] * 1e3:.1f} us, the trace's own average below {float(pm['AverageNs']) / 1e3:.1f} us (the un-traced bench: {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us).",
+pmp = [r for r in rows if r["Name"].startswith("void k_pm_prop<1, 1,")]
+pm_avg = (int(pm["TotalDurationNs"]) + sum(int(r["TotalDurationNs"]) for r in pmp)) / (int(pm["Calls"]) + sum(int(r["Calls"]) for r in pmp)) / 1e3
+L = [f"# {RN} — `rocprofv3 --kernel-trace --stats` of `python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-latency-flag` (one pair in flight), MI355X", "",
+     f"Build id {prof['build_id']} (the build of profiles/{R}_bench.json: {bench['build_id']}). The run processes {pairs} pairs (warm-ups of both resident sets, 1 warm-up + 2 timed steps, the host-to-host",
+     f"region, the latency / stage / roofline / kernel-clock pairs; counted by `k_km_init`, one per pair): divide calls and totals by {pairs} for one 700x700 pair. Bench line of this profiled run: {prof['value']:.2f} pairs/s, single pair {prof['single_pair_ms']:.1f} ms (tracing on);",
+     f"its event-timed average launch of the finest PatchMatch level (`k_pm_step<1, 1, 2, 2, 8>` + `k_pm_prop<1, 1, 2, 2, 8>`, 41 launches per level) is {prof['roofline']['avg_launch_ms'] * 1e3:.1f} us, the trace's own average over both rows below {pm_avg:.1f} us (the un-traced bench: {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us).",
      f"Total: {calls} kernel launches = {calls // pairs} per pair, {total / 1e6:.1f} ms of kernel time = {total / 1e6 / pairs:.1f} ms per pair.", "",
      "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
 for r in rows:
@@ -59,7 +61,7 @@ if os.path.exists(p):
     for line in open(p):
         if line.startswith("{"):
             cli = json.loads(line)
-W = [f"# round 3 — the other bench workloads (BASELINE configs 1, 3, 4, 5) on one MI355X, build {bench['build_id']}", "",
+W = [f"# {RN} — the other bench workloads (BASELINE configs 1, 3, 4, 5) on one MI355X, build {bench['build_id']}", "",
      "`python bench.py --workload <name>` (4 pairs in flight per GPU unless noted; `value` = pairs/s; batch workloads are host buffer in -> host buffer out):", "",
      "| workload | BASELINE config | what a step is | pairs/s | ms per step | single pair |", "|---|---|---|---|---|---|"]
 desc = {"pair700": ("2", "4 resident 700x700 pairs"), "pair1000": ("4", "4 resident 1000x1000 pairs"), "pair256l5": ("1", "4 resident 256x256 pairs, L=5 only"),
@@ -68,7 +70,7 @@ for name, b in wl.items():
     if b:
         W.append(f"| {name} | {desc[name][0]} | {desc[name][1]} | {b['value']:.2f} | {b['ms_per_step']:.1f} | {b['single_pair_ms']:.1f} ms |")
 W += ["", f"Host buffer in -> host buffer out over the same 4-in-flight 700x700 batches (`host_to_host_pairs_per_s`): {bench['host_to_host_pairs_per_s']:.2f} pairs/s vs {bench['value']:.2f} resident.",
-      f"Single 700x700 pair: {bench['single_pair_ms']:.1f} ms; with `NCT_FLAG_LATENCY` (the CLI's `-inflight 1`): {bench['single_pair_latency_flag_ms']:.1f} ms, output identical: {bench['latency_flag_output_identical']}."]
+      f"Single 700x700 pair: {bench['single_pair_ms']:.1f} ms (median of {bench.get('single_pair_ms_samples', 1)}, min {bench.get('single_pair_ms_min', bench['single_pair_ms']):.1f}); with `NCT_FLAG_LATENCY` (the CLI's `-inflight 1`): {bench['single_pair_latency_flag_ms']:.1f} ms, output identical: {bench['latency_flag_output_identical']}."]
 if two:
     W.append(f"Two ranks (gloo) sharing GPU 0 through `bench.py --gpus 2 --dist-backend gloo --device-override 0 --inflight 2`: n_gpus 2, {two['value']:.2f} pairs/s in total.")
 if cli and wl["mixed256"]:
@@ -76,6 +78,21 @@ if cli and wl["mixed256"]:
           f"`scripts/mixed_batch_cli.py 32 4`: the first 32 pairs of the mixed256 workload as PNG files through `neural_color_transfer -inflight 4` (decode + shrink + encode included):",
           f"**{cli['cli_pairs_per_s_io_pool']:.2f} pairs/s with the I/O pool** (`-io 2`, the default for one GPU) vs {cli['cli_pairs_per_s_io0']:.2f} with `-io 0` (every worker does its own zlib, the round-2 behaviour)",
           f"vs {wl['mixed256']['value']:.2f} pairs/s for `bench.py --workload mixed256 --batch 32` (host buffers, no files): the pool runs at {100 * cli['cli_pairs_per_s_io_pool'] / wl['mixed256']['value']:.0f} % of the library rate."]
+shape = None
+p8 = os.path.join(src, "cli_8gpu_shape.txt")
+if os.path.exists(p8):
+    for line in open(p8):
+        if line.startswith("{"):
+            shape = json.loads(line)
+if shape:
+    a, b8, c8 = shape["gpus1_inflight4"], shape["gpus8_inflight4_on_one_device"], shape["gpus8_inflight1_on_one_device"]
+    W += ["", "## The CLI's full-node host shape on one device (VERDICT r3 item 6; `scripts/cli_8gpu_shape.py 64 700`, NCT_DEVICE_OVERRIDE=0: every logical GPU on device 0, one process)", "",
+          "| shape | worker contexts | pairs/s (64 pairs of 700x700 as PNG files, decode + encode included) | host CPUs busy | kernel launches / s | files identical to `-gpus 1` |", "|---|---|---|---|---|---|",
+          f"| `-gpus 1 -inflight 4` | {a['contexts']} | {a['cli_pairs_per_s']:.2f} | {a['host_cpus_busy']} | {a['kernel_launches_per_s']} | — |",
+          f"| `-gpus 8 -inflight 4` | {b8['contexts']} | **{b8['cli_pairs_per_s']:.2f}** ({100 * shape['ratio_8x4_over_1x4']:.0f} %) | {b8['host_cpus_busy']} | {b8['kernel_launches_per_s']} | {b8['outputs_identical_to_gpus1']} |",
+          f"| `-gpus 8 -inflight 1` | {c8['contexts']} | {c8['cli_pairs_per_s']:.2f} | {c8['host_cpus_busy']} | {c8['kernel_launches_per_s']} | {c8['outputs_identical_to_gpus1']} |", "",
+          f"{shape['host_threads']} host threads on the box. With 32 contexts every context runs only two of the 64 pairs, so its first-pair costs (arena growth, module loads) weigh 50 %; the rate stays within",
+          "10 % of the saturated 1-GPU rate: the HIP runtime does not collapse under the thread and launch count of a full node's worth of contexts on one device."]
 cb = bench.get("cpu_baseline")
 if cb:
     W += ["", "## CPU baseline", f"{cb['sample']}: **{cb['value']:.5f} pairs/s on {cb['cores']} threads** (1 thread, scaled from a 64x64 pair: {cb['value_1thread']:.5f})."]
@@ -86,16 +103,18 @@ pm_all = os.path.join(src, "pmc_pm_all.txt")
 if os.path.exists(pm_all):
     d = collections.defaultdict(dict)
     for l in open(pm_all):
-        m = re.match(r"(\S+) void (k_pm_step<[^>]+>) (\S+): ([\d,]+) per launch over (\d+)", l)
+        m = re.match(r"(\S+) void (k_pm_(?:step|prop)<[^>]+>) (\S+): ([\d,]+) per launch over (\d+)", l)
         if m:
             d[m.group(2)][m.group(3)] = float(m.group(4).replace(",", "")); d[m.group(2)]["n"] = int(m.group(5))
     names = sorted(d)
-    T = [f"# round 3 — counters of every PatchMatch instantiation the pipeline launches (one real 700x700 pair, `scripts/final_measure.sh`: six counter-only passes), build {bench['build_id']}", "",
+    T = [f"# {RN} — counters of every PatchMatch instantiation the pipeline launches (one real 700x700 pair, `scripts/final_measure.sh`: six counter-only passes), build {bench['build_id']}", "",
          "Per launch (mean over the level's 41 launches; C = 512 runs two levels = 82). cycles = GRBM_GUI_ACTIVE / 8 XCDs. FETCH_SIZE x 2 (gfx950 tallies 128-B requests as 64 B) counts",
          "L2 misses INCLUDING Infinity-Cache hits: the feature maps of every level fit the 256 MiB MALL, so the HBM share of `fabric GB/s` is unknown and <= it.", "",
          "| | " + " | ".join(f"`{n}`" for n in names) + " |", "|---|" + "---|" * len(names)]
-    lvl = {"k_pm_step<1, 1, 2, 2, 8>": "C = 64, 700^2 (finest), ROWREJECT, 8 lanes/query", "k_pm_step<2, 1, 2, 1, 16>": "C = 128, 350^2, ROWREJECT", "k_pm_step<4, 0, 1, 1, 16>": "C = 256, 175^2, PLAIN", "k_pm_step<8, 0, 1, 1, 16>": "C = 512, 88^2 + 44^2, PLAIN"}
+    lvl = {"k_pm_step<1, 1, 2, 2, 8>": "C = 64, 700^2 (finest), ROWREJECT, 8 lanes/query: init + jump-1 launches", "k_pm_prop<1, 1, 2, 2, 8>": "C = 64, 700^2: the 30 packed propagation launches",
+           "k_pm_step<2, 1, 2, 1, 16>": "C = 128, 350^2, ROWREJECT: init + jump-1 launches", "k_pm_prop<2, 1, 2, 1, 16>": "C = 128, 350^2: packed propagation", "k_pm_step<4, 0, 1, 1, 16>": "C = 256, 175^2, PLAIN", "k_pm_step<8, 0, 1, 1, 16>": "C = 512, 88^2 + 44^2, PLAIN"}
     T.append("| level | " + " | ".join(lvl.get(n, "") for n in names) + " |")
+    T.append("| launches per pair | " + " | ".join(str(d[n]["n"]) for n in names) + " |")
     def row(label, f):
         T.append(f"| {label} | " + " | ".join(f(d[n]) for n in names) + " |")
     cyc = lambda v: v["GRBM_GUI_ACTIVE"] / 8.0
@@ -113,14 +132,53 @@ if os.path.exists(pm_all):
     per = os.path.join(src, "pmc_pm_finest_per_dispatch.txt")
     if os.path.exists(per):
         T += ["", "## The 41 launches of the finest level one by one (`scripts/pmc_per_dispatch.py`)", "",
-              "launch 0 = initial distances; 1-40 = 10 iterations x jumps 8, 4, 2, 1; every fourth (4, 8, ..., 40) adds the random search (6 candidates per query, up to +-32 px from the match):",
+              "launch 0 = initial distances; 1-40 = 10 iterations x jumps 8, 4, 2, 1 (jumps 8, 4, 2: `k_pm_prop`, packed propagation); every fourth (4, 8, ..., 40; `k_pm_step`) adds the random search (6 candidates per query, up to +-32 px from the match):",
               "those ten launches move most of the level's fabric bytes, at the rate the fabric sustains; the propagation-only launches mostly hit L1/L2 and — with the candidates that cannot win",
               "skipped — are short.", ""] + [l.rstrip("\n") for l in open(per)]
     open(os.path.join(dst, f"{R}_pmc_patchmatch_levels.md"), "w").write("\n".join(T) + "\n")
 
+# ---- colour-solver kernels (round 4): per-launch counter means of the same passes
+pc = os.path.join(src, "pmc_color_all.txt")
+if os.path.exists(pc):
+    d = collections.OrderedDict(); cur = None
+    for l in open(pc):
+        if l.startswith("== "):
+            cur = l[3:].strip().replace("void ", "").replace("(anonymous namespace)::", ""); d[cur] = {}
+            continue
+        m = re.match(r"(\S+) .*? (\S+): ([\d,]+) per launch over (\d+)", l)
+        if m and cur:
+            d[cur][m.group(2)] = float(m.group(3).replace(",", "")); d[cur]["n"] = int(m.group(4))
+    names = [n for n in d if d[n].get("GRBM_GUI_ACTIVE")]
+    rc = bench.get("roofline_color", {}).get("kernels", {})
+    Tc = [f"# {RN} — counters of the colour-solver kernels (one real 700x700 pair, `scripts/final_measure.sh`: counter-only passes over scripts/pair_only.py), build {bench['build_id']}", "",
+          "Per launch, MEAN OVER ALL LAUNCHES OF THE ROW IN THE PAIR: the WLS rows include the ~20 % of launches enqueued past convergence (they exit on a flag in ~1 us), `k_s1_apply<true>` runs 50 launches",
+          "at 700^2 and 100 at 350^2 (a finest launch moves ~2x the row's mean). cycles = GRBM_GUI_ACTIVE / 8 XCDs. Fabric bytes = FETCH_SIZE x 2 (profiles/round4_fetch_calibration.md) + WRITE_SIZE, incl.",
+          "Infinity-Cache hits. Event-timed single launches and compulsory bytes per kernel: `roofline_color` of profiles/" + R + "_bench.json.", "",
+          "| | " + " | ".join(f"`{n}`" for n in names) + " |", "|---|" + "---|" * len(names)]
+    def rowc(label, f):
+        Tc.append(f"| {label} | " + " | ".join(f(d[n]) for n in names) + " |")
+    cyc = lambda v: v["GRBM_GUI_ACTIVE"] / 8.0
+    rowc("launches in the pair", lambda v: str(v["n"]))
+    rowc("launch, cycles / us at 2.4 GHz", lambda v: f"{cyc(v):,.0f} / {cyc(v) / 2400:.1f}")
+    rowc("waves", lambda v: f"{v['SQ_WAVES']:,.0f}")
+    rowc("wave cycles parked (s_waitcnt, barrier) / issue-stalled / issuing", lambda v: f"{100 * v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % / {100 * v['SQ_WAIT_INST_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % / {100 * v['SQ_ACTIVE_INST_ANY'] / v['SQ_WAVE_CYCLES']:.0f} %")
+    rowc("VALU / LDS / vector-memory read instructions", lambda v: f"{v['SQ_INSTS_VALU'] / 1e6:.2f} M / {v['SQ_INSTS_LDS'] / 1e6:.2f} M / {v['SQ_INSTS_VMEM_RD'] / 1e6:.2f} M")
+    rowc("L1 hit rate", lambda v: f"{100 * (1 - v['TCP_TCC_READ_REQ_sum'] / v['TCP_TOTAL_CACHE_ACCESSES_sum']):.0f} %")
+    rowc("L2 hit rate (requests)", lambda v: f"{100 * v['TCC_HIT_sum'] / v['TCC_REQ_sum']:.0f} % ({v['TCC_REQ_sum'] / 1e6:.2f} M)")
+    rowc("fabric bytes read / written", lambda v: f"{v['FETCH_SIZE'] * 2048 / 1e6:.1f} MB / {v['WRITE_SIZE'] * 1024 / 1e6:.1f} MB")
+    rowc("fabric GB/s over the launch's cycles = share of 8 TB/s", lambda v: f"{(v['FETCH_SIZE'] * 2048 + v['WRITE_SIZE'] * 1024) / (cyc(v) / 2.4e9) / 1e9:,.0f} = {(v['FETCH_SIZE'] * 2048 + v['WRITE_SIZE'] * 1024) / (cyc(v) / 2.4e9) / 8e12:.2f}")
+    if rc:
+        Tc += ["", "## Event-timed single launches at 700x700 against compulsory bytes (`roofline_color` of the bench line)", "", "| kernel | avg launch us | samples | bytes per pixel (what) | GB/s | of 8 TB/s |", "|---|---|---|---|---|---|"]
+        for k, e in rc.items():
+            if "bytes_per_pixel" in e:
+                Tc.append(f"| {k} | {e['avg_launch_us']:.1f} | {e['samples']} | {e['bytes_per_pixel']} ({e['bytes']}) | {e['achieved']:,.0f} | {e['frac']:.2f} |")
+            else:
+                Tc.append(f"| {k} | {e['avg_us']:.1f} | {e['samples']} | {e['what']} | | |")
+    open(os.path.join(dst, f"{R}_pmc_color.md"), "w").write("\n".join(Tc) + "\n")
+
 vg = os.path.join(src, "vgg_mfma_by_grid.txt")
 if os.path.exists(vg):
-    V = [f"# round 3 — MFMA counters of the shipped conv kernel `k_conv3x3_mfma2b<WCO, CT, POOL>` (VGG19 forward 700x700 -> conv5_1, three forwards; two counter-only passes), build {bench['build_id']}", "",
+    V = [f"# {RN} — MFMA counters of the shipped conv kernel `k_conv3x3_mfma2b<WCO, CT, POOL>` (VGG19 forward 700x700 -> conv5_1, three forwards; two counter-only passes), build {bench['build_id']}", "",
          "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (launch cycles x 1024 SIMDs), launch cycles = GRBM_GUI_ACTIVE / 8 XCDs (`scripts/pmc_by_grid.py`; the grid size tells the layers apart:",
          "491520 = conv1_1 at 700^2, 493568 = conv1_2 + pool, 245760 = conv2_1, 247808 = conv2_2 + pool, 122880 = conv3_x, 65536 = conv4_x, 32768 = conv5_1). The cycle base is the GRBM counter's, so the",
          "shares compare layers and builds, not an absolute peak fraction (conv5_1's 124 workgroups could not exceed 0.48). bench.py repeats the two passes live (`vgg_mfma.mfma_util`:",

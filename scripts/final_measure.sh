@@ -15,22 +15,28 @@ timeout 300 python bench.py --workload pair256l5 --steps 10 --warmup 2 --no-cpu-
 timeout 300 python bench.py --workload batch64 --batch 16 --steps 1 --warmup 1 --no-cpu-baseline --no-pmc > $out/bench_batch.json 2>/dev/null
 timeout 300 python bench.py --workload mixed256 --batch 32 --steps 1 --warmup 1 --no-cpu-baseline --no-pmc > $out/bench_mixed.json 2>/dev/null
 timeout 300 python scripts/mixed_batch_cli.py 32 4 > $out/cli_mixed.txt 2>&1; tail -1 $out/cli_mixed.txt
+timeout 600 python scripts/cli_8gpu_shape.py 64 700 > $out/cli_8gpu_shape.txt 2>&1; tail -1 $out/cli_8gpu_shape.txt | cut -c1-300
 timeout 300 python bench.py --gpus 2 --dist-backend gloo --device-override 0 --inflight 2 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc > $out/bench_2rank_gloo.json 2>/dev/null
-timeout 900 python scripts/wls_rtol_sweep.py > $out/wls_rtol_sweep.json 2> $out/wls_rtol_sweep.err
+SWEEP_RTOLS=1e-7,1e-6,1e-8 timeout 900 python scripts/wls_rtol_sweep.py > $out/wls_rtol_sweep.json 2> $out/wls_rtol_sweep.err
 # counters: PatchMatch instantiations of one real pair (SQ / TA / TCP / TCC, fabric bytes), conv MFMA utilisation
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" \
            "TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TD_TD_BUSY_sum" \
-           "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+           "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
     i=$((i+1))
     timeout 300 rocprofv3 --pmc $set --kernel-trace -d $out/pmc/p$i -o c --output-format csv -- python scripts/pair_only.py 700 1 > $out/pmc_p$i.log 2>&1
 done
-for pre in "void k_pm_step<1, 1," "void k_pm_step<2, 1," "void k_pm_step<4, 0," "void k_pm_step<8, 0,"; do echo "== $pre"; python scripts/pmc_summary.py $out/pmc "$pre"; done > $out/pmc_pm_all.txt 2>&1
+for pre in "void k_pm_step<1, 1," "void k_pm_prop<1, 1," "void k_pm_step<2, 1," "void k_pm_prop<2, 1," "void k_pm_step<4, 0," "void k_pm_step<8, 0,"; do echo "== $pre"; python scripts/pmc_summary.py $out/pmc "$pre"; done > $out/pmc_pm_all.txt 2>&1
+# colour-solver kernels out of the same six passes (round 4)
+for pre in "void (anonymous namespace)::k_mg_down<6, 32, 16, double" "void (anonymous namespace)::k_mg_up<6, 32, 16, double" "void (anonymous namespace)::k_mg_down<6, 32, 16, float" "void (anonymous namespace)::k_mg_up<6, 32, 16, float" \
+           "void (anonymous namespace)::k_cg_apply" "void (anonymous namespace)::k_cg_update" "void k_s1_apply<true>" "k_s1_update(" "k_s1_dir("; do
+    echo "== $pre"; python scripts/pmc_summary.py $out/pmc "$pre"
+done > $out/pmc_color_all.txt 2>&1
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $out/vgg/p1 -o c --output-format csv -- python scripts/vgg_only.py > $out/vgg_p1.log 2>&1
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CU_CYCLES --kernel-trace -d $out/vgg/p2 -o c --output-format csv -- python scripts/vgg_only.py > $out/vgg_p2.log 2>&1
 python scripts/pmc_by_grid.py $out/vgg "void k_conv3x3_mfma" > $out/vgg_mfma_by_grid.txt 2>&1
-python scripts/pmc_per_dispatch.py $out/pmc "void k_pm_step<1, 1," > $out/pmc_pm_finest_per_dispatch.txt 2>&1
+python scripts/pmc_per_dispatch.py $out/pmc "void k_pm_step<1, 1,|void k_pm_prop<1, 1," > $out/pmc_pm_finest_per_dispatch.txt 2>&1
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "c_counter_collection.csv" -size +30M -delete
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1; tail -1 $out/smoke.txt
 ls -la $out

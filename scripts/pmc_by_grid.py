@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch counter means grouped by (kernel name prefix, grid size): the conv kernel runs every VGG layer, the grid tells the layers apart.
-usage: pmc_by_grid.py <dir with p*/…_counter_collection.csv> <kernel name prefix>"""
+usage: pmc_by_grid.py <dir with p*/…_counter_collection.csv> <kernel name prefix[|prefix...]>"""
 import csv, glob, os, sys
 from collections import defaultdict
 root, prefix = sys.argv[1], sys.argv[2]
@@ -8,7 +8,7 @@ tab = defaultdict(lambda: defaultdict(lambda: [0.0, set()]))
 for p in sorted(glob.glob(os.path.join(root, "p*"))):
     for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith(prefix):
+            if r["Kernel_Name"].startswith(tuple(prefix.split("|"))):
                 key = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))
                 e = tab[key][r["Counter_Name"]]; e[0] += float(r["Counter_Value"]); e[1].add(r["Dispatch_Id"])
 for key in sorted(tab):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-dispatch table of the counters collected by scripts/final_measure.sh for one kernel (one row per launch, in launch order): duration, L1 / L2 hit rates,
 fabric bytes and rate — shows how unlike the 41 launches of a PatchMatch level are (init / propagation / propagation + random search).
-usage: pmc_per_dispatch.py <dir with p*/…_counter_collection.csv> <kernel name prefix>"""
+usage: pmc_per_dispatch.py <dir with p*/…_counter_collection.csv> <kernel name prefix[|prefix...]>"""
 import csv, glob, os, sys, collections
 root, prefix = sys.argv[1], sys.argv[2]
 tabs = []
@@ -9,7 +9,7 @@ for p in sorted(glob.glob(os.path.join(root, "p*"))):
     for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
         rows = collections.OrderedDict()
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith(prefix):
+            if r["Kernel_Name"].startswith(tuple(prefix.split("|"))):
                 d = rows.setdefault(int(r["Dispatch_Id"]), {"us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3})
                 d[r["Counter_Name"]] = float(r["Counter_Value"])
         tabs.append(list(rows.values()))

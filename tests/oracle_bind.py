@@ -111,6 +111,10 @@ class Oracle:
         l.orc_wls_solve.argtypes = [_f64p, _f64p, _f64p, I, I, C.c_double, C.c_double, _f64p, I]
         l.orc_wls_solve.restype = I
         l.orc_wls_system.argtypes = [_f64p, I, I, C.c_double, C.c_double, _f64p, _f64p, _f64p, _f64p]
+        l.orc_wls_vcycle_apply.argtypes = [_f64p, I, I, C.c_double, C.c_double, _f64p, _f64p, _f64p, I]
+        l.orc_wls_vcycle_apply.restype = I
+        l.orc_wls_hierarchy_stats.argtypes = [_f64p, I, I, C.c_double, C.c_double, _f64p, _f64p]
+        l.orc_wls_hierarchy_stats.restype = I
         self._color_declared = True
 
     def bgr2lab(self, bgr):
@@ -129,6 +133,22 @@ class Oracle:
             self.l.orc_lab2bgr_u8_form.argtypes = [_u8p, C.c_size_t, _u8p, I]
             self.l.orc_lab2bgr_u8_form(a.reshape(-1, 3), a.size // 3, out.reshape(-1, 3), form)
         return out
+
+    def wls_vcycle(self, lab, lamda, alpha, rough, r):
+        """z = V-cycle(r) of the S2 preconditioner for the WLS system of (lab [H][W][3] in [0,1], roughness [H*W]); r: [nv][H*W][6]. Returns (z, number of levels)."""
+        self._decl_color()
+        lab = np.ascontiguousarray(lab, np.float64); H, W = lab.shape[:2]
+        r = np.ascontiguousarray(r, np.float64); z = np.empty_like(r)
+        nl = self.l.orc_wls_vcycle_apply(lab.reshape(-1), H, W, lamda, alpha, np.ascontiguousarray(rough, np.float64).reshape(-1), r.reshape(-1), z.reshape(-1), r.shape[0])
+        return z, nl
+
+    def wls_hierarchy_stats(self, lab, lamda, alpha, rough):
+        """per level: [n, min diagonal, min row sum (d - sum of couplings), number of couplings of the wrong sign, max safe-diagonal / diagonal]"""
+        self._decl_color()
+        lab = np.ascontiguousarray(lab, np.float64); H, W = lab.shape[:2]
+        out = np.zeros((16, 5))
+        nl = self.l.orc_wls_hierarchy_stats(lab.reshape(-1), H, W, lamda, alpha, np.ascontiguousarray(rough, np.float64).reshape(-1), out.reshape(-1))
+        return out[:nl]
 
     def resize_u8c3(self, img, dh, dw):
         self._decl_color()

@@ -47,7 +47,7 @@ def test_bench_emits_contract_json():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_GBs"):
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert "k_pm_step<1, 1, 2, 2, 8>" in rf["kernel"] and rf["launches"] == 41 and rf["traffic"] is None       # PMC passes exist for 700x700 only
+    assert "k_pm_step<1, 1, 2, 2, 8>" in rf["kernel"] and "k_pm_prop<1, 1, 2, 2, 8>" in rf["kernel"] and rf["launches"] == 41 and rf["traffic"] is None       # PMC passes exist for 700x700 only
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "value_1thread"):
         assert k in cb, k

@@ -331,6 +331,61 @@ def test_knn_matches_reference_nanoflann(oracle):
         assert exact_ids == checked and checked > (n if name == "smooth" else 100), (name, exact_ids, checked)
 
 
+def _wls_case(oracle, H, W, lam_factor, seed=3, rough_frac=0.1):
+    lab = oracle.bgr2lab(synth.image(seed, H, W)).astype(np.float64) / 255.0
+    rough = np.where(np.random.default_rng(1).random(H * W) < rough_frac, 1e-6, 1.0)
+    return lab, rough, 0.024 * lam_factor
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 253.0), (45, 71, 16.0), (97, 33, 4.0)])
+def test_mg_preconditioner_is_symmetric_positive_definite(oracle, dims):
+    """S2 (round 4): PCG needs the preconditioner to be ONE symmetric positive definite linear map. The V-cycle of oracle/orc_wls_mg.c (= k_wls_mg.hip) is built so — restriction
+    = transpose of the operator-dependent prolongation (the same fp32 P columns on both sides), post-smoother = adjoint of the pre-smoother (Chebyshev-weighted Jacobi sweeps of one
+    operator commute), symmetric Galerkin stencils (forward couplings stored once), a symmetric coarsest solve — and this checks it from the outside on random vectors, independently
+    of any mirror: <M^-1 a, b> = <a, M^-1 b> to fp32 accuracy, <M^-1 a, a> > 0, linearity; odd sizes included (the last row / column has no coarse partner)."""
+    H, W, lf = dims
+    lab, rough, lam = _wls_case(oracle, H, W, lf)
+    rng = np.random.default_rng(7)
+    n = H * W
+    a = rng.standard_normal((n, 6)); b = rng.standard_normal((n, 6))
+    smooth = np.add.outer(np.sin(np.arange(H) / 9.0), np.cos(np.arange(W) / 7.0)).reshape(n, 1) * np.ones((1, 6))     # a smooth vector exercises the coarse levels
+    z, nl = oracle.wls_vcycle(lab, lam, 1.2, rough, np.stack([a, b, smooth, a + 2.0 * b]))
+    assert nl >= 4
+    za, zb, zs, zab = z
+    for q in range(6):
+        lhs, rhs = float(za[:, q] @ b[:, q]), float(a[:, q] @ zb[:, q])
+        assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), np.linalg.norm(za[:, q]) * np.linalg.norm(b[:, q]) * 1e-2), (q, lhs, rhs)
+        assert float(za[:, q] @ a[:, q]) > 0 and float(zs[:, q] @ smooth[:, q]) > 0
+        lin = np.abs(zab[:, q] - (za[:, q] + 2.0 * zb[:, q])).max()
+        assert lin <= 2e-5 * np.abs(zab[:, q]).max(), (q, lin)
+    # the six right-hand sides share the operator and nothing else: a column of zeros stays zero
+    a0 = a.copy(); a0[:, 2] = 0.0
+    z0, _ = oracle.wls_vcycle(lab, lam, 1.2, rough, a0[None])
+    assert np.all(z0[0][:, 2] == 0.0) and np.array_equal(z0[0][:, 0], za[:, 0])
+
+
+def test_mg_galerkin_levels_are_diagonally_sane(oracle):
+    """The Galerkin coarse operators P^T A P of the vertex-centred hierarchy: level sizes halve (rounding up) down to <= 64 unknowns; every diagonal is positive; level 0 is an
+    M-matrix whose smallest row sum is the smallest data term; couplings of the wrong sign may appear on coarse levels (the operator-dependent P does not sum to one where the data
+    term matters, so Galerkin rows need not be diagonally dominant), and the safe smoother diagonal max(d, (|d| + sum |w|) / 2) then exceeds d by less than 2x (positive
+    definiteness itself is what test_mg_preconditioner_is_symmetric_positive_definite checks)."""
+    H, W = 83, 120
+    lab, rough, lam = _wls_case(oracle, H, W, 63.0)
+    st = oracle.wls_hierarchy_stats(lab, lam, 1.2, rough)
+    sizes = [int(v) for v in st[:, 0]]
+    h, w, exp = H, W, []
+    while True:
+        exp.append(h * w)
+        if h * w <= 64 or (h <= 8 and w <= 8):
+            break
+        h, w = (h + 1) // 2, (w + 1) // 2
+    assert sizes == exp
+    assert (st[:, 1] > 0).all()                                    # diagonals
+    assert abs(st[0, 2] - rough.min()) <= 1e-9 * st[0, 1]           # level 0: row sum = data term
+    assert st[0, 3] == 0 and st[0, 4] == 1.0                        # level 0: M-matrix, safe diagonal = diagonal
+    assert (st[:, 4] >= 1.0).all() and (st[:, 4] < 2.0).all()
+
+
 def test_mg_smoother_degree_changes_iterations_not_the_solution(oracle):
     """S2 preconditioner: the V-cycle's Chebyshev-weighted Jacobi smoother runs MG_NS sweeps per leg (k_wls_mg.hip / orc_wls_mg.c; the product's default is 3). The degree
     only changes how fast PCG converges — at the solver's tolerance the solutions of the 2-, 3- and 4-sweep cycles agree far below an 8-bit step and the 8-bit results are equal;
