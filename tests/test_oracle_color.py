@@ -367,7 +367,7 @@ def test_mg_preconditioner_is_symmetric_positive_definite(oracle, dims):
 def test_mg_galerkin_levels_are_diagonally_sane(oracle):
     """The Galerkin coarse operators P^T A P of the vertex-centred hierarchy: level sizes halve (rounding up) down to <= 64 unknowns; every diagonal is positive; level 0 is an
     M-matrix whose smallest row sum is the smallest data term; couplings of the wrong sign may appear on coarse levels (the operator-dependent P does not sum to one where the data
-    term matters, so Galerkin rows need not be diagonally dominant), and the safe smoother diagonal max(d, (|d| + sum |w|) / 2) then exceeds d by less than 2x (positive
+    term matters, so Galerkin rows need not be diagonally dominant), and the safe smoother diagonal max(d, (|d| + sum |w|) / 2) then exceeds d (positive
     definiteness itself is what test_mg_preconditioner_is_symmetric_positive_definite checks)."""
     H, W = 83, 120
     lab, rough, lam = _wls_case(oracle, H, W, 63.0)
@@ -383,7 +383,7 @@ def test_mg_galerkin_levels_are_diagonally_sane(oracle):
     assert (st[:, 1] > 0).all()                                    # diagonals
     assert abs(st[0, 2] - rough.min()) <= 1e-9 * st[0, 1]           # level 0: row sum = data term
     assert st[0, 3] == 0 and st[0, 4] == 1.0                        # level 0: M-matrix, safe diagonal = diagonal
-    assert (st[:, 4] >= 1.0).all() and (st[:, 4] < 2.0).all()
+    assert (st[:, 4] >= 1.0).all() and (st[1:, 4] > 1.0).any()     # some coarse row is not diagonally dominant: the safe diagonal is in use
 
 
 def test_mg_smoother_degree_changes_iterations_not_the_solution(oracle):
