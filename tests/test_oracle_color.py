@@ -405,3 +405,21 @@ def test_mg_smoother_degree_changes_iterations_not_the_solution(oracle):
     for ns in (2, 4):
         assert np.allclose(res[ns][1]["ab_wls"], res[3][1]["ab_wls"], rtol=0, atol=5e-6)
         assert np.array_equal(res[ns][0], res[3][0])
+
+
+def test_oracle_pair_reproduces_the_committed_tiny_fixture(oracle):
+    """Regression pin of the ORACLE itself (CPU only): the whole L=5->1 loop on the 64x56 / 48x64 pair of tests/golden/pair_exact_tiny.npz (gen_pair700_exact.py tiny) must
+    reproduce the committed CRC of every level's intermediate result — with the canonical-order S2 solver and with the exact S2 solve, which agree byte for byte. A change of
+    any oracle stage (the S2 hierarchy of round 4 included) that moved a single output byte would show here without a GPU; the full-size fixtures of the same generator are what
+    the GPU path is held to."""
+    import os, zlib
+    from caffemodel_io import synthetic_vgg19
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pair_exact_tiny.npz"))
+    sh, sw, rh, rw = (int(v) for v in g["shape"])
+    ws, bs = synthetic_vgg19(19)
+    src, ref = synth.image(1000, sh, sw), synth.image(1001, rh, rw)
+    out, lv = oracle.process_pair(src, ref, ws, bs, want_levels=True)
+    assert [zlib.crc32(lv[l].tobytes()) for l in range(5)] == [int(v) for v in g["level_crc_canonical"]]
+    assert zlib.crc32(out.tobytes()) == int(g["crc_canonical"]) == int(g["crc_exact"]) and g["idx"].size == 0
+    out_x, lv_x = oracle.process_pair(src, ref, ws, bs, want_levels=True, s2_exact=True)
+    assert np.array_equal(out_x, out) and [zlib.crc32(lv_x[l].tobytes()) for l in range(5)] == [int(v) for v in g["level_crc_exact"]]
