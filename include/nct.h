@@ -244,6 +244,9 @@ int nct_dev_download(nct_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 int nct_chw_to_hwc_dev(nct_ctx* ctx, const float* src_chw, float* dst_hwc, int C, int H, int W);
 int nct_hwc_to_chw_dev(nct_ctx* ctx, const float* src_hwc, float* dst_chw, int C, int H, int W);
 int nct_vgg19_features_dev(nct_ctx* ctx, const uint8_t* d_bgr, int h, int w, int stride, int deepest_tap, float* const* d_taps_chw, int* dims);   /* main.cu:94,102,426 */
+/* the same forward with the taps ALSO / INSTEAD channel-last (d_taps_hwc[t], nullable like d_taps_chw[t], which may itself be NULL): the tap layer's own epilogue writes the HWC map
+ * the correspondence seams below read, so an integrator who does not need Caffe's planar blobs skips nct_chw_to_hwc_dev altogether */
+int nct_vgg19_features_hwc_dev(nct_ctx* ctx, const uint8_t* d_bgr, int h, int w, int stride, int deepest_tap, float* const* d_taps_chw, float* const* d_taps_hwc, int* dims);
 int nct_feat_normalize_dev(nct_ctx* ctx, const float* src_hwc, float* dst_hwc, float* resp, int C, int H, int W);                                    /* main.cu:265,274,313 */
 int nct_nnf_init_dev(nct_ctx* ctx, uint32_t* nnf, int ah, int aw, int bh, int bw);                                                                    /* main.cu:232-233 */
 int nct_nnf_upsample_dev(nct_ctx* ctx, const uint32_t* nnf_half, uint32_t* nnf, int ah, int aw, int bh, int bw, int ah_half, int aw_half);           /* main.cu:240-250 */

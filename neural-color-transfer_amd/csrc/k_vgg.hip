@@ -61,7 +61,7 @@ typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 // map is written. The K loop does not change: every lane fetches the rows of its own pixel.
 template <int WCO, int CT, bool POOL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_conv3x3_mfma2b(const float* __restrict__ in, const float* __restrict__ wp /*packed, see k_pack_weights*/,
-                                                        const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int relu) {
+                                                        const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int relu, float* __restrict__ out_hwc) {
     constexpr int WPX = 4 / WCO;             // waves along pixels
     constexpr int BLK_PX = WPX * 64;
     constexpr int BLK_CO = WCO * 32 * CT;
@@ -233,6 +233,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     } else {
         const int pw = pt * BLK_PX + wpx * 64;
+        // tap layers (conv*_1) can write the map channel-last as well / instead: PatchMatch, votes and normalisation read HWC, and a lane holds four consecutive couts of its
+        // pixel in registers 4 g .. 4 g + 3 (rows 8 g + 4 half + 0..3), i.e. one 16-byte store per group — the separate CHW -> HWC transpose pass of a tap (read + write) becomes
+        // one more write here. Same values: bias add and ReLU are the same operations as in the planar stores below.
+        if (out_hwc) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int pp = pw + 32 * b + l31;
+                if (pp < HW) {
+                    float* dst = out_hwc + (size_t)pp * g.Cout + m0 + 4 * half;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float4 v0, v1;
+                        float* e0 = &v0.x; float* e1 = &v1.x;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int row = j + 8 * gq + 4 * half;
+                            float t0 = acc0[16 * b + 4 * gq + j] + bias[m0 + row];
+                            if (relu) t0 = fmaxf(t0, 0.f);
+                            e0[j] = t0;
+                            if constexpr (CT == 2) { float t1 = acc1[16 * b + 4 * gq + j] + bias[m0 + 32 + row]; if (relu) t1 = fmaxf(t1, 0.f); e1[j] = t1; }
+                        }
+                        *reinterpret_cast<float4*>(dst + 8 * gq) = v0;
+                        if constexpr (CT == 2) *reinterpret_cast<float4*>(dst + 32 + 8 * gq) = v1;
+                    }
+                }
+            }
+        }
+        if (out)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int pp = pw + 32 * b + l31;
@@ -261,8 +289,11 @@ bool nctk_conv3x3_pool_fits(int H, int W) {
 }
 
 // pool = 1: `out` receives only the 2x2/2 max-pooled map [Cout][(H-1)/2+1][(W-1)/2+1] (what nctk_maxpool2x2 would make of the conv output)
+// out_hwc (nullable, pool == 0 only): the same map channel-last [H*W][Cout]; `out` may then be null
 int nctk_conv3x3(nct_ctx* ctx, hipStream_t s, const float* in, const float* wp, const float* bias, float* out,
-                 int Cin, int Cout, int H, int W, int relu, int pool) {
+                 int Cin, int Cout, int H, int W, int relu, int pool, float* out_hwc) {
+    NCT_REQUIRE(out || out_hwc, "conv3x3: no output");
+    NCT_REQUIRE(!(pool && out_hwc), "conv3x3: the channel-last output exists for un-pooled layers only");
     NCT_REQUIRE((Cin & 1) == 0 && (Cout & 63) == 0, "conv3x3: Cin=%d must be even (pad) and Cout=%d a multiple of 64", Cin, Cout);
     NCT_REQUIRE((size_t)Cin * H * W * 4 < ((size_t)1 << 32), "conv3x3: input of %d x %d x %d floats exceeds the 4 GB a buffer descriptor addresses", Cin, H, W);
     const int WCO = (Cout % 128 == 0) ? 2 : 1;
@@ -274,8 +305,8 @@ int nctk_conv3x3(nct_ctx* ctx, hipStream_t s, const float* in, const float* wp, 
     do {                                                                                                                                          \
         ConvGeom g{Cin, Cout, H, W, cdiv(ntiles, wpx), nblk_n_, tiles_x, Ho, Wo};                                                                  \
         const int nblocks = cdiv(g.npx_blocks, 8) * 8 * g.nblk_n;                                                                                 \
-        if (pool) hipLaunchKernelGGL((k_conv3x3_mfma2b<wco, ct, true>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);             \
-        else      hipLaunchKernelGGL((k_conv3x3_mfma2b<wco, ct, false>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu);            \
+        if (pool) hipLaunchKernelGGL((k_conv3x3_mfma2b<wco, ct, true>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu, (float*)nullptr);             \
+        else      hipLaunchKernelGGL((k_conv3x3_mfma2b<wco, ct, false>), dim3(nblocks), dim3(256), 0, s, in, wp, bias, out, g, relu, out_hwc);            \
     } while (0)
     if (full_blocks >= NCT_CONV_PT1_BELOW) {
         if (WCO == 2) NCT_CONV_LAUNCH(2, 2, 2, Cout / 128);

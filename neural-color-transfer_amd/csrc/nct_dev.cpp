@@ -57,6 +57,12 @@ int nct_vgg19_features_dev(nct_ctx* ctx, const uint8_t* d_bgr, int h, int w, int
     return nctk_vgg19_forward(ctx, ctx->stream, d_bgr, h, w, stride, deepest_tap, d_taps_chw, dims);
 }
 
+int nct_vgg19_features_hwc_dev(nct_ctx* ctx, const uint8_t* d_bgr, int h, int w, int stride, int deepest_tap, float* const* d_taps_chw, float* const* d_taps_hwc, int* dims) {
+    CTX_ENTER();
+    NCT_REQUIRE(d_bgr && h > 0 && w > 0 && stride >= 3 * w, "vgg19_features_hwc_dev: bad image arguments");
+    return nctk_vgg19_forward(ctx, ctx->stream, d_bgr, h, w, stride, deepest_tap, d_taps_chw, dims, d_taps_hwc);
+}
+
 // N1: norm (main.cu:265,274,313)
 int nct_feat_normalize_dev(nct_ctx* ctx, const float* src_hwc, float* dst_hwc, float* resp, int C, int H, int W) {
     CTX_ENTER();

@@ -95,7 +95,8 @@ int nctk_nnf_upsample(nct_ctx* ctx, hipStream_t s, const uint32_t* nnf_half, uin
 int nctk_patchmatch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
                     int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist, unsigned long long* eval_counter /*nullable*/);
 // k_vgg.hip / nct_vgg.cpp
-int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps_chw, int* dims);
+int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps_chw, int* dims,
+                       float* const* d_taps_hwc = nullptr /* the same taps channel-last, written by the tap layers' epilogues */);
 void nct_vgg_free(nct_ctx* ctx);
 // k_cvt.hip
 int nctk_bgr2lab(nct_ctx* ctx, hipStream_t s, const uint8_t* src, uint8_t* dst, size_t npix);

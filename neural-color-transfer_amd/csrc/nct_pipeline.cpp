@@ -108,22 +108,20 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     std::vector<DevBuf<float>*> rfeat(5, nullptr);     // R features, un-normalised, HWC, indexed by level
     struct Cleanup2 { std::vector<DevBuf<float>*>& a; ~Cleanup2() { for (auto* p : a) delete p; } } cleanup2{rfeat};
     {
-        float* taps[5]; std::vector<DevBuf<float>*> chw(5, nullptr);
-        Cleanup2 c3{chw};
-        for (int t = 0; t < 5; ++t) { const int l = 4 - t; chw[t] = new DevBuf<float>(ctx, (size_t)kTapC[t] * bh[l] * bw[l]); if (!chw[t]->ok()) return NCT_ERR_HIP; taps[t] = *chw[t]; }
-        rc = nctk_vgg19_forward(ctx, s, P->ref, RH, RW, RW * 3, 5, taps, nullptr); if (rc) return rc;
+        // the five taps of R arrive channel-last straight from their conv layers' epilogues (round 4: no CHW -> HWC transpose pass)
+        float* taps_hwc[5];
         for (int t = 0; t < 5; ++t) {
             const int l = 4 - t;
             rfeat[l] = new DevBuf<float>(ctx, (size_t)kTapC[t] * bh[l] * bw[l]); if (!rfeat[l]->ok()) return NCT_ERR_HIP;
-            rc = nctk_chw_to_hwc(ctx, s, taps[t], *rfeat[l], kTapC[t], bh[l] * bw[l]); if (rc) return rc;
+            taps_hwc[t] = *rfeat[l];
         }
+        rc = nctk_vgg19_forward(ctx, s, P->ref, RH, RW, RW * 3, 5, nullptr, nullptr, taps_hwc); if (rc) return rc;
     }
-    DevBuf<float> sfeat_chw(ctx, (size_t)64 * N), sfeat(ctx, (size_t)64 * N);   // S features of the current level (largest: 64 x H x W)
-    if (!sfeat_chw.ok() || !sfeat.ok()) return NCT_ERR_HIP;
+    DevBuf<float> sfeat(ctx, (size_t)64 * N);   // S features of the current level, channel-last (largest: H x W x 64)
+    if (!sfeat.ok()) return NCT_ERR_HIP;
     {
-        float* taps[5] = {nullptr, nullptr, nullptr, nullptr, sfeat_chw};
-        rc = nctk_vgg19_forward(ctx, s, P->src, H, W, W * 3, 5, taps, nullptr); if (rc) return rc;
-        rc = nctk_chw_to_hwc(ctx, s, sfeat_chw, sfeat, 512, ah[0] * aw[0]); if (rc) return rc;
+        float* taps_hwc[5] = {nullptr, nullptr, nullptr, nullptr, sfeat};
+        rc = nctk_vgg19_forward(ctx, s, P->src, H, W, W * 3, 5, nullptr, nullptr, taps_hwc); if (rc) return rc;
     }
     MARK(ST_VGG, 0);
 
@@ -252,10 +250,9 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         // re-predict: S features of the next level from the intermediate result (main.cu:424-427)
         if (l < nlevels - 1) {
             const int tap = 4 - l;                         // next level uses tap (5 - (l+1))
-            float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-            taps[tap - 1] = sfeat_chw;
-            rc = nctk_vgg19_forward(ctx, s, P->out, H, W, W * 3, tap, taps, nullptr); if (rc) return rc;
-            rc = nctk_chw_to_hwc(ctx, s, sfeat_chw, sfeat, kTapC[tap - 1], ah[l + 1] * aw[l + 1]); if (rc) return rc;
+            float* taps_hwc[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+            taps_hwc[tap - 1] = sfeat;
+            rc = nctk_vgg19_forward(ctx, s, P->out, H, W, W * 3, tap, nullptr, nullptr, taps_hwc); if (rc) return rc;
             MARK(ST_VGG, l);
         }
     }

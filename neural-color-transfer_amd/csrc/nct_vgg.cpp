@@ -16,7 +16,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 
-int nctk_conv3x3(nct_ctx*, hipStream_t, const float* in, const float* wp, const float* bias, float* out, int Cin, int Cout, int H, int W, int relu, int pool);
+int nctk_conv3x3(nct_ctx*, hipStream_t, const float* in, const float* wp, const float* bias, float* out, int Cin, int Cout, int H, int W, int relu, int pool, float* out_hwc = nullptr);
 bool nctk_conv3x3_pool_fits(int H, int W);
 int nctk_maxpool2x2(nct_ctx*, hipStream_t, const float* in, float* out, int C, int H, int W);
 int nctk_vgg_preprocess(nct_ctx*, hipStream_t, const uint8_t* bgr, int stride, float* out, int H, int W);
@@ -368,7 +368,9 @@ void nct_vgg_free(nct_ctx* ctx) {
 // ---------------------------------------------------------------- forward (device): taps in CHW
 // d_bgr: device u8 BGR HWC. d_taps[t] (nullable, caller-owned device buffers of C*h*w floats) receive tap t+1.
 // dims[t] = {C,h,w} is filled for every tap <= deepest_tap.
-int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps, int* dims) {
+// d_taps: Caffe's planar CHW maps of the taps (entries nullable); d_taps_hwc (nullable array, entries nullable): the same taps channel-last, written by the tap layer's own
+// epilogue (no transpose pass). A tap asked for only channel-last is still written planar into the ping-pong buffer when a further layer reads it; the deepest tap is then not.
+int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps, int* dims, float* const* d_taps_hwc) {
     vgg_weights* v = ctx->vgg ? ((vgg_holder*)ctx->vgg)->w.get() : nullptr;
     if (!v || !v->loaded) return ctx->fail(NCT_ERR_STATE, "vgg19: weights not loaded (nct_vgg19_load_caffemodel / _load_raw)");
     NCT_REQUIRE(deepest_tap >= 1 && deepest_tap <= 5, "vgg19: deepest_tap must be 1..5");
@@ -386,12 +388,14 @@ int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H,
         int tap = -1;
         for (int t = 0; t < 5; ++t) if (kTapConv[t] == i) tap = t;
         float* dst;
+        float* dst_hwc = (tap >= 0 && d_taps_hwc) ? d_taps_hwc[tap] : nullptr;
         if (tap >= 0 && d_taps && d_taps[tap]) dst = d_taps[tap];
+        else if (i == last && dst_hwc) dst = nullptr;                        // the forward ends here and nobody asked for the planar map
         else dst = (cur == pp[0]) ? pp[1] : pp[0];
         // a pooled layer is never a tap (taps are conv*_1): where the tile shape fits, the pool rides in the conv epilogue and the unpooled map is never written
         const bool pooled = kPoolAfter[i] && i < last;
         const bool fuse = pooled && tap < 0 && (ctx->conv_pool_fuse == 1 || (ctx->conv_pool_fuse < 0 && nctk_conv3x3_pool_fits(h, w)));
-        rc = nctk_conv3x3(ctx, s, cur, v->wp[i], v->bias[i], dst, (kCin[i] + 1) & ~1, kCout[i], h, w, 1, fuse ? 1 : 0);
+        rc = nctk_conv3x3(ctx, s, cur, v->wp[i], v->bias[i], dst, (kCin[i] + 1) & ~1, kCout[i], h, w, 1, fuse ? 1 : 0, dst_hwc);
         if (rc) return rc;
         cur = dst;
         if (tap >= 0 && dims) { dims[tap * 3 + 0] = kCout[i]; dims[tap * 3 + 1] = h; dims[tap * 3 + 2] = w; }

@@ -91,6 +91,7 @@ SIGNATURES = {
     "nct_chw_to_hwc_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "nct_hwc_to_chw_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "nct_vgg19_features_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    "nct_vgg19_features_hwc_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
     "nct_feat_normalize_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "nct_nnf_init_dev": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4),
     "nct_nnf_upsample_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6),
