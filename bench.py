@@ -326,7 +326,7 @@ def pmc_traffic(device, live):
     gfx950 -> x2; the k_normalize dispatch of the same pass, a pure 125.44 MB streaming read, is kept as the calibration check).
     Returns (dict, how) or (None, why)."""
     exe = shutil.which("rocprofv3")
-    rec = os.path.join(REPO, "profiles", "round2_pmc_patchmatch.json")
+    rec = os.path.join(REPO, "profiles", "round4_pmc_patchmatch.json")
     bid = lib_build_id()
     why = "live PMC disabled"
     if live and exe:
@@ -340,6 +340,8 @@ def pmc_traffic(device, live):
                                    cwd=REPO, env=env, check=True, capture_output=True, timeout=300)
                     for ctr in ctrs:
                         vals[ctr] = read_pmc_csv(td, ctr)
+                        if ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                            COLOR_PMC[ctr] = read_color_pmc(td, ctr)
             out = finish_pmc(vals, bid, "live rocprofv3 passes inside bench.py")
             return out, "live"
         except Exception as e:      # noqa: BLE001 — fall back to the recorded passes
@@ -349,9 +351,34 @@ def pmc_traffic(device, live):
     if os.path.exists(rec):
         d = json.load(open(rec))
         if d.get("build_id") == bid:
-            return d, "recorded (profiles/round2_pmc_patchmatch.json, same build id)"
+            return d, "recorded (profiles/round4_pmc_patchmatch.json, same build id)"
         why += "; the recorded PMC passes belong to another build"
     return None, why
+
+
+# the colour-solver kernels of roofline_color in the same counter passes (the pair of scripts/pair_only.py runs them all): name prefix in the trace per roofline_color key
+COLOR_KERNELS = {"s1_apply": "void k_s1_apply<true>", "s1_dir": "k_s1_dir(", "s1_update": "k_s1_update(", "wls_down": "void (anonymous namespace)::k_mg_down<6, 32, 16, double",
+                 "wls_up": "void (anonymous namespace)::k_mg_up<6, 32, 16, double", "wls_apply": "void (anonymous namespace)::k_cg_apply<6>", "wls_update": "void (anonymous namespace)::k_cg_update<6>"}
+COLOR_PMC = {}
+
+
+def read_color_pmc(td, ctr):
+    """mean counter value per FULL-RESOLUTION, WORKING launch of each colour kernel: the largest grid of the name (k_s1_apply<true> also runs at 350x350) and, for the WLS kernels,
+    without the launches enqueued past convergence (they exit on a flag and count next to nothing: below a quarter of the median)"""
+    import csv, glob
+    f = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+    rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == ctr]
+    out = {}
+    for key, pre in COLOR_KERNELS.items():
+        rr = [r for r in rows if r["Kernel_Name"].startswith(pre)]
+        if not rr:
+            continue
+        gmax = max(int(r["Grid_Size"]) for r in rr)
+        v = sorted(float(r["Counter_Value"]) for r in rr if int(r["Grid_Size"]) == gmax)
+        med = v[len(v) // 2]
+        w = [x for x in v if x >= 0.25 * med] if med > 0 else v
+        out[key] = {"launches": len(w), "mean": sum(w) / len(w)}
+    return out
 
 
 PM_FINEST = ("void k_pm_step<1, 1,", "void k_pm_prop<1, 1,")      # the finest level's 41 launches: init + 10 x (3 packed propagation launches + 1 propagation/random-search launch)
@@ -503,11 +530,20 @@ def color_roofline(nct, ctx, prm, sshape):
         "wls_apply": (24 + 48 + 24 + 48, "z (fp32 x 6), r, fp64 coefficients in; w out"),
         "wls_update": (48 * 4 + 24 + 48 + 48 * 4, "p, s, x, r, z, w in; p, s, x, r out"),
     }
-    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "pixels": N, "kernels": {}}
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "pixels": N, "kernels": {},
+           "traffic_note": "traffic = fabric-side bytes per full-resolution launch from the live FETCH_SIZE (x2, profiles/round4_fetch_calibration.md) and WRITE_SIZE passes of the roofline object "
+                           "(same pair, scripts/pair_only.py), Infinity-Cache hits included; null without those passes; traffic_frac = traffic / event-timed launch / 8 TB/s"}
     for k, (bpp, what) in model.items():
         if ns.get(k):
             gbs = bpp * N / us[k] / 1e3
-            out["kernels"][k] = {"avg_launch_us": us[k], "samples": ns[k], "bytes_per_pixel": bpp, "bytes_per_launch": bpp * N, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes": what}
+            e = {"avg_launch_us": us[k], "samples": ns[k], "bytes_per_pixel": bpp, "bytes_per_launch": bpp * N, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes": what, "traffic": None}
+            fs, wsz = COLOR_PMC.get("FETCH_SIZE", {}).get(k), COLOR_PMC.get("WRITE_SIZE", {}).get(k)
+            if fs and wsz and N == 700 * 700:
+                e["traffic"] = fs["mean"] * 2048.0 + wsz["mean"] * 1024.0
+                e["traffic_over_compulsory"] = e["traffic"] / (bpp * N)
+                e["traffic_frac"] = e["traffic"] / us[k] / 1e3 / HBM_PEAK_GBS
+                e["traffic_launches"] = fs["launches"]
+            out["kernels"][k] = e
     if ns.get("wls_coarse"):
         out["kernels"]["wls_coarse"] = {"avg_us": us["wls_coarse"], "samples": ns["wls_coarse"], "what": "everything below the finest level of one V-cycle (latency bound: 7 launches)"}
     it_s1 = sum(us[k] for k in ("s1_apply", "s1_dir", "s1_update") if ns.get(k))

@@ -529,11 +529,11 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
 // prolongation over the parents NW, NE, SW, SE), so the cycle is bit-identical to the tile-fused launches it replaces. lv[0] is the first fused
 // level: its rhs lv[0].b was written by the restriction above it, its correction goes to lv[0].x2. The coarsest grid (n <= 64) is solved by
 // `sweeps` damped-Jacobi sweeps from zero by one wave (one lane per unknown, the iterate in a register, neighbours through ds_bpermute).
-// P0 = pixels per thread of the first fused level: 2 (<= 2048 pixels: 44x44 at 700x700; no spills) or 4 (63x63 at 1000x1000; the 9-point coefficients of four pixels
-// beside the deeper levels' state exceed the 128 VGPRs of a 1024-thread workgroup: ~60 spilled registers, still faster than the launches it replaces)
+// P0 = pixels per thread of the first fused level: 1 or 2 (<= 2048 pixels: 44x44 at 700x700; 63x63 at 1000x1000 stays on tile launches — four pixels per thread measured slower)
 #ifndef NCT_MID_MAXP0
-#define NCT_MID_MAXP0 2      // largest first fused level, in units of 1024 pixels (1, 2 or 4): 2 = the 44x44 level of a 700x700 pair rides in k_mg_mid (same time as its two tile launches, 186 launches fewer per pair)
+#define NCT_MID_MAXP0 2      // largest first fused level, in units of 1024 pixels (1 or 2): 2 = the 44x44 level of a 700x700 pair rides in k_mg_mid (same time as its two tile launches, 186 launches fewer per pair)
 #endif
+static_assert(NCT_MID_MAXP0 == 1 || NCT_MID_MAXP0 == 2, "k_mg_mid is instantiated for one or two pixels per thread at its first level (four measured slower: DESIGN.md 9)");
 constexpr int MID_T = 1024, MID_P1 = 1, MID_N1 = MID_T * MID_P1, MID_LV = 5;
 // largest level at depth d >= 1 (the first fused level: P0 * 1024); levels shrink ~4x per depth. The levels below the first park their 10 coefficients and 4 prolongation
 // weights per pixel in LDS for the way back up (a workgroup has the CU to itself: 79 KB of the 160 KB), so only right-hand side and iterate stay in registers across the recursion
@@ -916,9 +916,8 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
             int rc = kt_b(NCT_KT_WLS_DOWN); if (rc) return rc; down(0); LCHK(); rc = kt_e(); if (rc) return rc;
             rc = kt_b(NCT_KT_WLS_COARSE); if (rc) return rc;
             for (int l = 1; l < tail0; ++l) { down(l); LCHK(); }
-            if (lv[tail0].n <= MID_T)          hipLaunchKernelGGL(k_mg_mid<1>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
-            else if (lv[tail0].n <= 2 * MID_T) hipLaunchKernelGGL(k_mg_mid<2>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
-            else                               hipLaunchKernelGGL(k_mg_mid<4>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+            if (lv[tail0].n <= MID_T) hipLaunchKernelGGL(k_mg_mid<1>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+            else                      hipLaunchKernelGGL(k_mg_mid<2>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
             LCHK();
             for (int l = tail0 - 1; l >= 1; --l) { up(l, lv[l + 1].x2); LCHK(); }
             rc = kt_e(); if (rc) return rc;
@@ -926,9 +925,8 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
             return 0;
         }
         for (int l = 0; l < tail0; ++l) { down(l); LCHK(); }
-        if (lv[tail0].n <= MID_T)          hipLaunchKernelGGL(k_mg_mid<1>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
-        else if (lv[tail0].n <= 2 * MID_T) hipLaunchKernelGGL(k_mg_mid<2>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
-        else                               hipLaunchKernelGGL(k_mg_mid<4>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+        if (lv[tail0].n <= MID_T) hipLaunchKernelGGL(k_mg_mid<1>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
+        else                      hipLaunchKernelGGL(k_mg_mid<2>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
         LCHK();
         for (int l = tail0 - 1; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
         return 0;

@@ -168,12 +168,15 @@ if os.path.exists(pc):
     rowc("fabric bytes read / written", lambda v: f"{v['FETCH_SIZE'] * 2048 / 1e6:.1f} MB / {v['WRITE_SIZE'] * 1024 / 1e6:.1f} MB")
     rowc("fabric GB/s over the launch's cycles = share of 8 TB/s", lambda v: f"{(v['FETCH_SIZE'] * 2048 + v['WRITE_SIZE'] * 1024) / (cyc(v) / 2.4e9) / 1e9:,.0f} = {(v['FETCH_SIZE'] * 2048 + v['WRITE_SIZE'] * 1024) / (cyc(v) / 2.4e9) / 8e12:.2f}")
     if rc:
-        Tc += ["", "## Event-timed single launches at 700x700 against compulsory bytes (`roofline_color` of the bench line)", "", "| kernel | avg launch us | samples | bytes per pixel (what) | GB/s | of 8 TB/s |", "|---|---|---|---|---|---|"]
+        Tc += ["", "## Event-timed single launches at 700x700 against compulsory bytes, and their fabric-side traffic (`roofline_color` of the bench line)", "",
+               "| kernel | avg launch us | samples | compulsory bytes per pixel (what) | GB/s | of 8 TB/s | fabric MB per full-resolution launch (live PMC) | x compulsory | fabric share of 8 TB/s |", "|---|---|---|---|---|---|---|---|---|"]
         for k, e in rc.items():
             if "bytes_per_pixel" in e:
-                Tc.append(f"| {k} | {e['avg_launch_us']:.1f} | {e['samples']} | {e['bytes_per_pixel']} ({e['bytes']}) | {e['achieved']:,.0f} | {e['frac']:.2f} |")
+                t = e.get("traffic")
+                Tc.append(f"| {k} | {e['avg_launch_us']:.1f} | {e['samples']} | {e['bytes_per_pixel']} ({e['bytes']}) | {e['achieved']:,.0f} | {e['frac']:.2f} | "
+                          + (f"{t / 1e6:.0f} | {e['traffic_over_compulsory']:.2f} | {e['traffic_frac']:.2f} |" if t else "— | — | — |"))
             else:
-                Tc.append(f"| {k} | {e['avg_us']:.1f} | {e['samples']} | {e['what']} | | |")
+                Tc.append(f"| {k} | {e['avg_us']:.1f} | {e['samples']} | {e['what']} | | | | | |")
     open(os.path.join(dst, f"{R}_pmc_color.md"), "w").write("\n".join(Tc) + "\n")
 
 vg = os.path.join(src, "vgg_mfma_by_grid.txt")
