@@ -81,7 +81,7 @@ struct PState { double gam[6], alp[6], bb[6]; int active[6]; int iters[6]; int n
 // cross-wave steps go through LDS, the six steps inside the first wave are lane shifts (a lane t < off adds the value lane t + off held BEFORE
 // the step, exactly as the array form does; what lanes >= off compute is never used).
 template <int NV>
-__device__ __forceinline__ void mg_block_reduce(double (&v)[NV], double* __restrict__ partial) {
+__device__ __forceinline__ void mg_block_reduce(double (&v)[NV], double* __restrict__ partial, int lb = -1 /* logical block whose slot receives the sums (default: blockIdx.x) */) {
     __shared__ double s_red[128 * NV];
     const int t = threadIdx.x;
     if (t >= 128) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ void mg_block_reduce(double (&v)[NV], double* __restr
             double x = v[q] + s_red[q * 128 + t];                          // off = 64
             x += __shfl_down(x, 32); x += __shfl_down(x, 16); x += __shfl_down(x, 8);
             x += __shfl_down(x, 4); x += __shfl_down(x, 2); x += __shfl_down(x, 1);
-            if (t == 0) partial[(size_t)blockIdx.x * NV + q] = x;
+            if (t == 0) partial[(size_t)(lb < 0 ? (int)blockIdx.x : lb) * NV + q] = x;
         }
     }
 }
@@ -767,7 +767,10 @@ template <int NQ>
 __global__ __launch_bounds__(256) void k_cg_apply(const PState* __restrict__ st, Lvl L, const vf* __restrict__ z, const double* __restrict__ r,
                                                   double* __restrict__ w, double* __restrict__ partial) {
     if (st->nactive == 0) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware block order (as the V-cycle legs): each XCD takes a contiguous eighth of the image, so the rows above and below a block's pixels are in its own L2
+    // (109 MB of fabric traffic per launch for 70 MB of compulsory bytes before). The partial sums keep their LOGICAL block slot: the reduction order is unchanged.
+    const int lb = mg_tile_of_block(blockIdx.x, gridDim.x);
+    const int i = lb * 256 + threadIdx.x;
     double acc[3 * NQ];
 #pragma unroll
     for (int q = 0; q < 3 * NQ; ++q) acc[q] = 0.0;
@@ -781,7 +784,7 @@ __global__ __launch_bounds__(256) void k_cg_apply(const PState* __restrict__ st,
             acc[q] = rv * u; acc[NQ + q] = y[q] * u; acc[2 * NQ + q] = rv * rv;
         }
     }
-    mg_block_reduce<3 * NQ>(acc, partial);
+    mg_block_reduce<3 * NQ>(acc, partial, lb);
 }
 // three workgroups: workgroup j reduces gamma (0), delta (1), rho (2) of all 6 systems in the fixed order
 template <int NQ>
