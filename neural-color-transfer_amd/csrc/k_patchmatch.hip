@@ -540,17 +540,17 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
 // on the other candidates of its query — only the early-rejection threshold did, and the initial dbest is a valid (weaker) threshold — so NNF and distances are the same bits.
 // Rounds per wave: ceil(live candidates / 8) instead of sum over the passes of the longest list.
 #ifndef NCT_PM_PACK
-#define NCT_PM_PACK 2        // 0: off, 1: C = 64 only, 2: C = 64 and 128
+#define NCT_PM_PACK 3        // 0: off, 1: C = 64 only, 2: C = 64 and 128, 3: every level (C >= 256: one pass, the four queries of a wave share its lane groups)
 #endif
 #ifndef NCT_PM_PROP_OCC
 #define NCT_PM_PROP_OCC NCT_PM_OCC8        // workgroups per CU the packed kernel is compiled for, and how it fetches a candidate's rows (pm_dist8 STAGE): one row at a time
 #define NCT_PM_PROP_STAGE 0                // measured 11.41 ms for the finest level of a 700x700 pair vs 12.17 (first row, then two together) / 12.18 (whole tile); five workgroups per CU 11.53, six 13.5
 #endif
 template <int NCH, int MODE, int TQX, int TQY, int LPQ>
-__global__ __launch_bounds__(256, LPQ == 8 ? NCT_PM_PROP_OCC : 1) void k_pm_prop(PMJob j0, PMJob j1, int nblk0, int jump, int tstep, int strip, unsigned long long* __restrict__ counter) {
+__global__ __launch_bounds__(256, LPQ == 8 ? NCT_PM_PROP_OCC : (NCH == 8 ? 2 : 1)) void k_pm_prop(PMJob j0, PMJob j1, int nblk0, int jump, int tstep, int strip, unsigned long long* __restrict__ counter) {
     constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2, QW = LPQ == 16 ? 4 : 8, QH = 256 / LPQ / QW, NSX = 4 * TQX / QW, NSUB = NSX * (4 * TQY / QH);
     constexpr int GPW = 64 / LPQ;                          // lane groups (= queries per pass) of a wave
-    static_assert(NSUB == 2 && (NCH == 1 || NCH == 2), "two passes per workgroup: 16 (C = 64) or 8 (C = 128) queries per wave");
+    static_assert(NSUB == 1 || NSUB == 2, "one or two passes per workgroup: 16 (C = 64), 8 (C = 128) or 4 (C >= 256) queries per wave");
     constexpr bool EX = MODE == NCT_PM_ROWREJECT;
     const bool second = (int)blockIdx.x >= nblk0;
     const PMJob& J = second ? j1 : j0;
@@ -567,9 +567,9 @@ __global__ __launch_bounds__(256, LPQ == 8 ? NCT_PM_PROP_OCC : 1) void k_pm_prop
     const int ty = bid / g.tiles_x, tx = bid - ty * g.tiles_x;
     const int grp = threadIdx.x / LPQ, v = threadIdx.x % LPQ, wv = threadIdx.x >> 6, gw = grp % GPW;
     const int ox = tx * 4 * TQX, oy = ty * 4 * TQY;
-    __shared__ uint32_t s_list[4][8 * GPW];     // per wave: live (slot, k, candidate) entries
-    __shared__ uint4 s_q[4][2 * GPW];           // per wave and query slot: ax | ay << 16, lx | ly << 8 | amask << 16, dbest, -
-    __shared__ float s_res[4][8 * GPW];         // per wave: distance of candidate k of slot s at [s * 4 + k]
+    __shared__ uint32_t s_list[4][4 * NSUB * GPW];     // per wave: live (slot, k, candidate) entries
+    __shared__ uint4 s_q[4][NSUB * GPW];               // per wave and query slot: ax | ay << 16, lx | ly << 8 | amask << 16, dbest, -
+    __shared__ float s_res[4][4 * NSUB * GPW];         // per wave: distance of candidate k of slot s at [s * 4 + k]
 
     // ---- the NNF words of both passes first (they fly under the staging loop's barrier)
     uint32_t vbest[NSUB], vnb[NSUB][4]; float dq[NSUB]; int qi[NSUB]; bool live[NSUB];
@@ -700,8 +700,15 @@ static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob
         NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE, TQX, TQY, LPQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->pm_attr_mask |= abit;
     }
-    if constexpr ((NCH == 1 || (NCH == 2 && NCT_PM_PACK >= 2)) && MODE != NCT_PM_FP16 && NCT_PM_PACK != 0) {
+    if constexpr ((NCH == 1 || (NCH == 2 && NCT_PM_PACK >= 2) || (NCH >= 4 && NCT_PM_PACK >= 3)) && MODE != NCT_PM_FP16 && NCT_PM_PACK != 0) {
         if (mode == 1 && jump != 1) {              // propagation-only step: the packed form (its dynamic LDS is the same staged region)
+            if constexpr (NCH >= 4) {                  // > 32 KB of dynamic LDS: the same opt-in as k_pm_step, once per context and instantiation (bits 27..30 of the mask)
+                constexpr unsigned pbit = 1u << (27 + (NCH == 8 ? 2 : 0) + (MODE == NCT_PM_ROWREJECT ? 1 : 0));
+                if (!(ctx->pm_attr_mask & pbit)) {
+                    NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_prop<NCH, MODE, TQX, TQY, LPQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    ctx->pm_attr_mask |= pbit;
+                }
+            }
             hipLaunchKernelGGL((k_pm_prop<NCH, MODE, TQX, TQY, LPQ>), dim3(nblk0 + nblk1), dim3(256), lds, s, j0, j1, nblk0, jump, tstep, strip, counter);
             NCT_LAUNCH_CHECK();
             return 0;
