@@ -21,6 +21,7 @@
 #include "nct_device.h"
 #include "nct_detmath.h"
 #include <cstring>
+#include <cstdio>
 #include <rocprim/device/device_radix_sort.hpp>   // rocPRIM directly (no CUB-compatibility layer)
 
 #define LAB_D(u) ((double)(u) * (1.0 / 255.0))      // Mat::convertTo(CV_64F, 1/255)
@@ -417,6 +418,247 @@ __global__ __launch_bounds__(256) void k_s1_update_f(int n, int nb, const double
     }
     block_reduce_store<3>(acc, partial_rr);
 }
+// ---- persistent variant for the levels whose whole grid is resident with one workgroup per CU (nb <= S1_PERSIST_NB: 44^2 .. 175^2 of a 700^2 pair): the
+// maxit iterations of the recurrence above in ONE launch instead of 3 x maxit. Same block decomposition (256 consecutive pixels per workgroup), same
+// per-pixel operation order, same two-stage reductions in the same order => the same bits as the three-kernel form. What changes is where things live:
+//   * a thread owns its pixel for the whole solve: x, r, p and Op(p) of the pixel stay in registers, and so does everything the operator needs that does
+//     not change between iterations (data block, the four local weights 2 g^2, the eight out-edge ids and weights, its in-edge range);
+//   * the workgroup's in-edge range (one contiguous piece of the target-sorted edge arrays) is parked in LDS once (S1_PERSIST_EDGES entries; what does not
+//     fit is read from the arrays);
+//   * per iteration only p crosses workgroups: 48 B stored per pixel, ~20 gathers of 48 B, and the two partial-sum vectors.
+// Three grid-wide barriers per iteration (p published -> Op; p.Op(p) partials -> alpha; r.r partials -> beta), each the placement-independent protocol:
+// every thread's stores are complete at the workgroup barrier, thread 0 issues an agent-scope release fence, arrives on ONE monotonic counter, polls it
+// with relaxed agent-scope loads (s_sleep between polls), and issues an agent-scope acquire fence before the workgroup barrier that lets the others go.
+// The spin is bounded by the constant-rate clock (S1_PERSIST_TIMEOUT_TICKS at 100 MHz): a grid that cannot become resident (a GPU oversubscribed by many
+// processes) raises *fail, leaves x untouched and returns; the host then repeats the solve with the three-kernel form (nctk_local_color_transfer).
+constexpr int S1_PERSIST_NB = 32;          // 44^2 (8 workgroups) and 88^2 (31); at 175^2 (120) the three-kernel form is faster (2.6 against 3.7 ms per level)
+constexpr int S1_PERSIST_EDGES = 4096;
+#ifndef NCT_S1_PERSIST_TIMEOUT_TICKS
+#define NCT_S1_PERSIST_TIMEOUT_TICKS 25000000ull     // 0.25 s
+#endif
+struct S1Bar { unsigned count; int fail; };
+#ifndef NCT_S1P_SC1
+#define NCT_S1P_SC1 0        // 1: p and the partial sums cross workgroups through agent-scope (sc1: write-through / cache-bypassing) 8-byte accesses instead of plain ones
+                             //    (measured, §9: 4.2 / 3.4 / 5.1 ms per level against 2.4 / 2.2 / 3.7 — 120 eight-byte loads per pixel that all go to memory)
+#endif
+#ifndef NCT_S1P_FENCE
+#define NCT_S1P_FENCE 1      // 1: release / acquire fences at agent scope around the counter (L2 write-back + invalidate); 0: s_waitcnt vmcnt(0) only (needs NCT_S1P_SC1)
+#endif
+__device__ __forceinline__ double s1p_ld(const double* q) {
+#if NCT_S1P_SC1
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *q;
+#endif
+}
+__device__ __forceinline__ void s1p_st(double* q, double v) {
+#if NCT_S1P_SC1
+    __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *q = v;
+#endif
+}
+__device__ __forceinline__ bool s1_grid_barrier(S1Bar* bar, unsigned target) {
+    __shared__ int s_fail;
+#if !NCT_S1P_FENCE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every thread's write-through stores have been acknowledged
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#if NCT_S1P_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+        __hip_atomic_fetch_add(&bar->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int fail = 0;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&bar->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__hip_atomic_load(&bar->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > NCT_S1_PERSIST_TIMEOUT_TICKS) { fail = 1; break; }
+        }
+        if (fail) __hip_atomic_store(&bar->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if NCT_S1P_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        s_fail = fail;
+    }
+    __syncthreads();
+    return s_fail == 0;
+}
+// the fixed-order reductions of block_reduce_store / final_reduce on memory that other workgroups write during the launch (no __restrict__, no const)
+__device__ __forceinline__ void s1p_block_store(double (&v)[3], double* partial, double* s_red) {
+    tree256<3>(v, s_red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s1p_st(partial + (size_t)blockIdx.x * 3 + q, v[q]);
+    }
+}
+__device__ __forceinline__ void s1p_final(double* partial, int nb, double (&out)[3], double* s_red, double* s_out) {
+    const int t = threadIdx.x;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int b = t; b < nb; b += 256)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc[q] += s1p_ld(partial + (size_t)b * 3 + q);
+    tree256<3>(acc, s_red);
+    if (t == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s_out[q] = acc[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q] = s_out[q];
+    __syncthreads();
+}
+__global__ __launch_bounds__(256, 1) void k_s1_cg_persist(S1Sys S, int maxit, double tol2, double* __restrict__ x /*[2][n][3]*/, const double* __restrict__ r_in,
+                                                          double* p /*[n][6]: in = the packed first guess, rewritten every iteration*/,
+                                                          double* partA, double* partB, const CGState* __restrict__ st_in, CGState* __restrict__ st_out, S1Bar* bar) {
+    __shared__ double s_red[128 * 3];
+    __shared__ double s_out[3];
+    __shared__ int s_esrc[S1_PERSIST_EDGES];
+    __shared__ double s_ew[S1_PERSIST_EDGES];
+    const int n = S.n, w = S.w, h = S.h, nb = gridDim.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    // ---- loop invariants of the pixel
+    double daa[3], dab[3], dbb[3], lw[4], ow[8];
+    int lj[4], oj[8], e0 = 0, e1 = 0;
+    double xv[6], rv[6], pv[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { daa[c] = dab[c] = dbb[c] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lw[k] = 0.0; lj[k] = -1; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ow[k] = 0.0; oj[k] = 0; }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { xv[c] = rv[c] = pv[c] = 0.0; }
+    if (live) {
+        const int y = i / w, xx = i - y * w;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { daa[c] = S.daa[(size_t)i * 3 + c]; dab[c] = S.dab[(size_t)i * 3 + c]; dbb[c] = S.dbb[(size_t)i * 3 + c]; }
+        if (xx + 1 < w) { const double g = S.gx[i]; lw[0] = 2.0 * (g * g); lj[0] = i + 1; }
+        if (xx > 0) { const double g = S.gx[i - 1]; lw[1] = 2.0 * (g * g); lj[1] = i - 1; }
+        if (y + 1 < h) { const double g = S.gy[i]; lw[2] = 2.0 * (g * g); lj[2] = i + w; }
+        if (y > 0) { const double g = S.gy[i - w]; lw[3] = 2.0 * (g * g); lj[3] = i - w; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { oj[k] = S.knn_id[(size_t)i * 8 + k]; ow[k] = S.iw2[(size_t)i * 8 + k]; }
+        e0 = S.rev_start[i]; e1 = S.rev_start[i + 1];
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t j = ((size_t)part * n + i) * 3 + c;
+                xv[part * 3 + c] = x[j]; rv[part * 3 + c] = r_in[j]; pv[part * 3 + c] = p[(size_t)i * 6 + part * 3 + c];
+            }
+    }
+    const int i0 = blockIdx.x * 256, i1 = min(i0 + 256, n);
+    const int E0 = S.rev_start[i0], E1 = S.rev_start[i1];
+    for (int t = threadIdx.x; t < min(E1 - E0, S1_PERSIST_EDGES); t += 256) { s_esrc[t] = S.rev_src[E0 + t]; s_ew[t] = S.rev_w[E0 + t]; }
+    // ---- CG scalars (every workgroup carries the same copy: same partials, same order)
+    double r0[3], r1[3], vb[3]; int act[3], iters[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r0[c] = st_in->r0[c]; r1[c] = st_in->r1[c]; vb[c] = st_in->vb[c]; act[c] = st_in->active[c]; iters[c] = st_in->iters[c]; }
+    const double va_in[3] = {st_in->va[0], st_in->va[1], st_in->va[2]};
+    unsigned gen = 0;
+    bool ok = true;
+    __syncthreads();
+    for (int k = 1; k <= maxit; ++k) {
+        // -- beta step + direction (k_s1_dir_f)
+        if (k > 1) {
+            double sm[3]; s1p_final(partB, nb, sm, s_red, s_out);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bool a = act[c] != 0;
+                const double vbn = a ? sm[c] / r1[c] : vb[c];
+                const int an = a ? (sm[c] > tol2 ? 1 : 0) : 0;
+                r0[c] = a ? r1[c] : r0[c]; r1[c] = a ? sm[c] : r1[c]; vb[c] = vbn; iters[c] += a ? 1 : 0; act[c] = an;
+            }
+        }
+        if (!(act[0] | act[1] | act[2])) break;                 // nothing iterates any more (every workgroup takes this exit together)
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (!act[c]) continue;
+                pv[part * 3 + c] = k == 1 ? rv[part * 3 + c] : vb[c] * pv[part * 3 + c] + rv[part * 3 + c];
+            }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s1p_st(p + (size_t)i * 6 + c, pv[c]);
+        }
+        ok = s1_grid_barrier(bar, (unsigned)nb * ++gen); if (!ok) break;
+        // -- Op(p) (s1_op<false>), p.Op(p)
+        double ya[3] = {0.0, 0.0, 0.0}, yb[3] = {0.0, 0.0, 0.0}, acc[3] = {0.0, 0.0, 0.0};
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                ya[c] = daa[c] * pv[c] + dab[c] * pv[3 + c];
+                yb[c] = dab[c] * pv[c] + dbb[c] * pv[3 + c];
+            }
+            auto edge = [&](int j, double wt) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { ya[c] += wt * (pv[c] - s1p_ld(p + (size_t)j * 6 + c)); yb[c] += wt * (pv[3 + c] - s1p_ld(p + (size_t)j * 6 + 3 + c)); }
+            };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (lj[q] >= 0) edge(lj[q], lw[q]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) edge(oj[q], ow[q]);
+            int e = e0;
+            for (; e + 4 <= e1; e += 4) {
+                int j[4]; double wt[4], gv[4][6];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = e + u - E0;
+                    if (t < S1_PERSIST_EDGES) { j[u] = s_esrc[t]; wt[u] = s_ew[t]; } else { j[u] = S.rev_src[e + u]; wt[u] = S.rev_w[e + u]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) gv[u][c] = s1p_ld(p + (size_t)j[u] * 6 + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { ya[c] += wt[u] * (pv[c] - gv[u][c]); yb[c] += wt[u] * (pv[3 + c] - gv[u][3 + c]); }
+            }
+            for (; e < e1; ++e) {
+                const int t = e - E0;
+                int j; double wt;
+                if (t < S1_PERSIST_EDGES) { j = s_esrc[t]; wt = s_ew[t]; } else { j = S.rev_src[e]; wt = S.rev_w[e]; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { ya[c] += wt * (pv[c] - s1p_ld(p + (size_t)j * 6 + c)); yb[c] += wt * (pv[3 + c] - s1p_ld(p + (size_t)j * 6 + 3 + c)); }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = pv[c] * ya[c] + pv[3 + c] * yb[c];
+        }
+        s1p_block_store(acc, partA, s_red);
+        ok = s1_grid_barrier(bar, (unsigned)nb * ++gen); if (!ok) break;
+        // -- alpha step, x += va p, r -= va Op(p), r.r (k_s1_update_f)
+        double sm[3]; s1p_final(partA, nb, sm, s_red, s_out);
+        double acc2[3] = {0.0, 0.0, 0.0};
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (!act[c]) continue;
+                const double va = r1[c] / sm[c];
+                xv[c] = xv[c] + va * pv[c];
+                { const double rn = rv[c] - va * ya[c]; rv[c] = rn; acc2[c] += rn * rn; }
+                xv[3 + c] = xv[3 + c] + va * pv[3 + c];
+                { const double rn = rv[3 + c] - va * yb[c]; rv[3 + c] = rn; acc2[c] += rn * rn; }
+            }
+        }
+        s1p_block_store(acc2, partB, s_red);
+        ok = s1_grid_barrier(bar, (unsigned)nb * ++gen); if (!ok) break;
+    }
+    if (!ok) return;                                            // x untouched: the host repeats the solve
+    if (live) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[((size_t)part * n + i) * 3 + c] = xv[part * 3 + c];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        st_out->r0[c] = r0[c]; st_out->r1[c] = r1[c]; st_out->va[c] = va_in[c]; st_out->vb[c] = vb[c]; st_out->iters[c] = iters[c]; st_out->active[c] = act[c];
+    }
+}
 // [part][n][3] -> [n][6]
 __global__ void k_pack6(int n, const double* __restrict__ x, double* __restrict__ x6) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -514,9 +756,9 @@ static int dbg_copy(nct_ctx* ctx, hipStream_t s, double* host, const double* dev
     return 0;
 }
 
-int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, const uint8_t* s_lab_level, const uint8_t* g_lab_level,
+static int local_color_transfer_once(nct_ctx* ctx, hipStream_t s, const float* err, const uint8_t* s_lab_level, const uint8_t* g_lab_level,
                               const uint8_t* s_lab_full, const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W,
-                              const nct_color_params& prm, uint8_t* out_lab_full, const nct_color_debug* dbg) {
+                              const nct_color_params& prm, uint8_t* out_lab_full, const nct_color_debug* dbg, bool* s1_stalled) {
     const int n = h * w, N = H * W;
     const int nbl = cdiv(n, 256), nbL = cdiv(N, 256);
     // ---------------- T1 + T2
@@ -533,6 +775,7 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
     { int rcm = ctx->mark(s, nct_stage_tag_color()); if (rcm) return rcm; }
     // ---------------- S1
     const double normFactor = (double)(W * H) / (double)(w * h);
+    bool persist_used = false;
     {
         DevBuf<double> gx(ctx, n), gy(ctx, n), daa(ctx, (size_t)3 * n), dab(ctx, (size_t)3 * n), dbb(ctx, (size_t)3 * n), rhs(ctx, (size_t)6 * n), iw2(ctx, (size_t)8 * n);
         DevBuf<double> r(ctx, (size_t)6 * n), p(ctx, (size_t)6 * n), Ap(ctx, (size_t)6 * n), partial(ctx, (size_t)nbl * 3);
@@ -569,7 +812,26 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         else      hipLaunchKernelGGL(k_s1_residual<false>, dim3(nbl), dim3(256), 0, s, S, (const double*)p, (const double*)rhs, (double*)r, (double*)partial);
         LCHK();
         CGState* st_final = (CGState*)st;
-        if (nbl <= S1_FUSE_NB) {
+        bool persist_done = false;
+        if (nbl <= S1_PERSIST_NB && ctx->s1_persist) {
+            // one launch for the whole recurrence (k_s1_cg_persist); S[1] -> S[0], then the last beta step as below
+            DevBuf<S1Bar> bar(ctx, 1);
+            if (!bar.ok()) return NCT_ERR_HIP;
+            CGState* S2[2] = {(CGState*)st, (CGState*)st + 1};
+            NCT_HIP(hipMemsetAsync((S1Bar*)bar, 0, sizeof(S1Bar), s));
+            if (ctx->s1_persist == 2) NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)&((S1Bar*)bar)->fail, 1, 1, s));   // test hook (NCT_S1_PERSIST=2): the launch finds the stall flag raised
+            hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, S2[1], tol2, 3); LCHK();
+            hipLaunchKernelGGL(k_s1_cg_persist, dim3(nbl), dim3(256), 0, s, S, maxit, tol2, (double*)x, (const double*)r, (double*)p, (double*)partial, (double*)partial2,
+                               (const CGState*)S2[1], S2[0], (S1Bar*)bar); LCHK();
+            st_final = S2[0];
+            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, s, (const double*)partial2, nbl, st_final, tol2); LCHK();
+            // the stall flag travels to page-locked memory behind the kernel; it is looked at after the WLS solve of this level, whose convergence polls have
+            // taken the host past this point of the stream anyway (no extra synchronisation)
+            NCT_HIP(hipMemcpyAsync(ctx->s1_stall_flag(), &((S1Bar*)bar)->fail, sizeof(int), hipMemcpyDeviceToHost, s));
+            persist_done = true; persist_used = true;
+        }
+        if (persist_done) {
+        } else if (nbl <= S1_FUSE_NB) {
             // 3 launches per iteration; state ping-pongs between S[0] and S[1] (iteration k reads S[k&1], writes S[(k+1)&1])
             CGState* S2[2] = {(CGState*)st, (CGState*)st + 1};
             hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, S2[1], tol2, 3); LCHK();
@@ -632,10 +894,24 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
         { int rcm = ctx->mark(s, nct_stage_tag_color()); if (rcm) return rcm; }
         int rc = nctk_wls_solve_mg(ctx, s, X, rough, wx, wy, H, W, ctx->wls_rtol, wit); if (rc) return rc;
         { int rcm = ctx->mark(s, nct_stage_tag_wls()); if (rcm) return rcm; }
+        if (persist_used && *(volatile int*)ctx->s1_stall_flag() != 0) { *s1_stalled = true; return 0; }
         if (dbg && dbg->wls_iters) for (int q = 0; q < 6; ++q) dbg->wls_iters[q] = wit[q];
     }
     if (dbg) { int rc = dbg_copy(ctx, s, dbg->ab_wls, X, (size_t)6 * N); if (rc) return rc; }
     // ---------------- A1
     hipLaunchKernelGGL(k_apply, dim3(cdiv(3 * N, 256)), dim3(256), 0, s, (const double*)Xa, (const double*)Xb, s_lab_full, N, out_lab_full); LCHK();
     return 0;
+}
+int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, const uint8_t* s_lab_level, const uint8_t* g_lab_level,
+                              const uint8_t* s_lab_full, const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W,
+                              const nct_color_params& prm, uint8_t* out_lab_full, const nct_color_debug* dbg) {
+    bool stalled = false;
+    *ctx->s1_stall_flag() = 0;
+    int rc = local_color_transfer_once(ctx, s, err, s_lab_level, g_lab_level, s_lab_full, knn_id, knn_w, layer, h, w, H, W, prm, out_lab_full, dbg, &stalled);
+    if (rc || !stalled) return rc;
+    // k_s1_cg_persist gave up at a grid barrier (its workgroups did not all become resident within the time limit: a GPU shared with many other processes). It left
+    // the first guess untouched; everything after it in this level ran on that guess and is overwritten now. This context uses the three-kernel form from here on.
+    ctx->s1_persist = 0; ctx->s1_stalls++;
+    fprintf(stderr, "nct: S1 persistent launch stalled at level %d (%d x %d); repeating the level with per-iteration launches, which this context keeps from now on\n", layer, w, h);
+    return local_color_transfer_once(ctx, s, err, s_lab_level, g_lab_level, s_lab_full, knn_id, knn_w, layer, h, w, H, W, prm, out_lab_full, dbg, &stalled);
 }

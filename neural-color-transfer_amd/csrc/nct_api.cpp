@@ -95,10 +95,11 @@ int nct_create(int device, nct_ctx** out) {
         if ((e = hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     for (int l = 0; l < 4; ++l)
         if ((e = hipEventCreateWithFlags(&c->ev_poll[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
-    if ((e = hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault)) != hipSuccess) { g_create_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
+    if ((e = hipHostMalloc(&c->pinned, 4096 + 64, hipHostMallocDefault)) != hipSuccess) { g_create_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     if (const char* g = getenv("NCT_WLS_GRAPH")) c->wls_graph = atoi(g);
     if (const char* r = getenv("NCT_WLS_RTOL")) { const double v = atof(r); if (v > 0 && v < 1) c->wls_rtol = v; }
     if (const char* f = getenv("NCT_CONV_POOL_FUSE")) { const int v = atoi(f); if (v == 0 || v == 1) c->conv_pool_fuse = v; }
+    if (const char* q = getenv("NCT_S1_PERSIST")) { const int v = atoi(q); if (v >= 0 && v <= 2) c->s1_persist = v; }   // 2: test hook, the first persistent launch reports a stall
     if (const char* m = getenv("NCT_WLS_MAXIT")) { const int v = atoi(m); if (v > 0) c->wls_maxit = v; }
     *out = c;
     return NCT_OK;

@@ -19,7 +19,7 @@ struct nct_ctx {
     hipEvent_t ev_poll[4] = {nullptr, nullptr, nullptr, nullptr};   // completion of the in-flight solver-state read-backs (k_wls_mg.hip: two per half-solve)
     hipStream_t stream_wls = nullptr;  // helper stream of the split WLS solve (NCT_FLAG_LATENCY)
     hipEvent_t ev_wls_fork = nullptr, ev_wls_join = nullptr;
-    void* pinned = nullptr;                        // 4 KB of page-locked host memory for those read-backs
+    void* pinned = nullptr;                        // 4 KB of page-locked host memory for those read-backs (+ 64 B: s1_stall_flag)
     std::string err;
     std::vector<nct_block> blocks;    // cached device allocations, reused across calls and pairs
     size_t bytes_allocated = 0;
@@ -45,6 +45,9 @@ struct nct_ctx {
     std::vector<int> tm_tags;                   // tag of mark i = the stage that ENDS at event i
     int mark(hipStream_t s, int tag);           // nct_api.cpp; no-op unless tm_on
     // kernel clock (NCT_FLAG_TIME_KERNELS): event pairs around single launches of the full-resolution colour-solver kernels; sample i = events 2i, 2i+1, id kt_ids[i]
+    int s1_persist = 1;                         // S1 at the small levels as one persistent launch (k_colorsolve.hip: k_s1_cg_persist); NCT_S1_PERSIST=0: the three-kernel form
+    int s1_stalls = 0;                          // times the persistent launch gave up at a grid barrier (the level was then repeated with per-iteration launches)
+    int* s1_stall_flag() { return (int*)((char*)pinned + 4096); }   // its read-back word, behind the WLS solver's 4 KB
     bool kt_on = false;
     std::vector<hipEvent_t> kt_events; std::vector<int> kt_ids;
     int kt_begin(hipStream_t s, int id);        // nct_api.cpp; no-ops unless kt_on
