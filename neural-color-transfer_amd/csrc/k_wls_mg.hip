@@ -19,6 +19,11 @@
 // Jacobi-PCG needed 2633/1391/701/359/357 iterations (rtol 1e-10) on the five levels of a 700x700 pair (profiles/r1b); this needs
 // 63/47/34/27/27 (rtol 1e-6) at ~150 us each. Roofline: Infinity-Cache/HBM streaming at 700^2 and 350^2, launch latency below.
 #include "nct_internal.h"
+#include <chrono>
+#include <atomic>
+#include <cstdlib>
+#include <cstdio>
+#include <cmath>
 #include "nct_device.h"
 #include <vector>
 #include <cstring>
@@ -75,7 +80,7 @@ struct Lvl { int H, W, n, nine;                                  // nine: 9-poin
 // State of the 6 right-hand sides of the single-reduction (Chronopoulos-Gear) PCG, double buffered: the update kernel of iteration k
 // reads st[k & 1] and (workgroup 0) writes st[(k + 1) & 1]. nactive = number of systems still iterating: the host polls it only every
 // few iterations, and every kernel of an iteration enqueued past convergence returns at once when it is 0.
-struct PState { double gam[6], alp[6], bb[6]; int active[6]; int iters[6]; int nactive; };
+struct PState { double gam[6], alp[6], bb[6]; int active[6]; int iters[6]; int nactive; int seq; double rho[6]; };   // rho: r.r the last iteration saw (host-side convergence forecast only); seq: publication number of a host-visible copy (pcg_publish)
 
 // Fixed 256-wide tree s[t] += s[t + off], off = 128 … 1 (the order the oracle mirrors), evaluated with two barriers instead of nine: the two
 // cross-wave steps go through LDS, the six steps inside the first wave are lane shifts (a lane t < off adds the value lane t + off held BEFORE
@@ -213,9 +218,7 @@ __global__ void k_mg_diag(Lvl L, const double* __restrict__ rough) {
     L.fd[i] = (vf)a00; L.fdinv[i] = (vf)(OMEGA / a00); L.fE[i] = (vf)L.wE[i]; L.fS[i] = (vf)L.wS[i];
 }
 // interpolation weights towards the next coarser level: the stencil collapsed across the coarse grid line
-__global__ void k_mg_weights(Lvl L) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.n) return;
+__device__ __forceinline__ void mg_weights_at(const Lvl& L, int i) {
     const int r = i / L.W, c = i - r * L.W;
     double w[8]; coup8(L, r, c, w);
     const double d = L.d[i];
@@ -228,10 +231,13 @@ __global__ void k_mg_weights(Lvl L) {
     else if ((r & 1) && (c & 1)) pa = 1.0 / d;
     L.pa[i] = pa; L.pb[i] = pb;
 }
+__global__ void k_mg_weights(Lvl L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    mg_weights_at(L, i);
+}
 // column I of P as a 3x3 block around fine point (2Y, 2X): pst[I*9 + (dy+1)*3 + dx+1]
-__global__ void k_mg_pstencil(Lvl L, Lvl C, double* __restrict__ pst_out) {      // also L.fpst = (float) of it: THE transfer weights of the cycle
-    const int I = blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= C.n) return;
+__device__ __forceinline__ void mg_pstencil_at(const Lvl& L, const Lvl& C, double* pst_out, int I) {      // also L.fpst = (float) of it: THE transfer weights of the cycle
     const int Y = I / C.W, X = I - Y * C.W;
     const int W = L.W, H = L.H, r = 2 * Y, c = 2 * X, f = r * W + c;
     double pst[9];
@@ -257,10 +263,13 @@ __global__ void k_mg_pstencil(Lvl L, Lvl C, double* __restrict__ pst_out) {     
 #pragma unroll
     for (int k = 0; k < 9; ++k) { pst_out[(size_t)I * 9 + k] = pst[k]; L.fpst[(size_t)I * 9 + k] = (vf)pst[k]; }
 }
+__global__ void k_mg_pstencil(Lvl L, Lvl C, double* __restrict__ pst_out) {
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= C.n) return;
+    mg_pstencil_at(L, C, pst_out, I);
+}
 // the same weights per fine point: plane s = parent s of the point in the order NW, NE, SW, SE (cell centre) / W, E / N, S (line points); 0 for absent parents and coarse points
-__global__ void k_mg_pweights(Lvl L, Lvl C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.n) return;
+__device__ __forceinline__ void mg_pweights_at(const Lvl& L, const Lvl& C, int i) {
     const int r = i / L.W, c = i - r * L.W;
     const int Y0 = r >> 1, X0 = c >> 1, ny = (r & 1) ? 2 : 1, nx = (c & 1) ? 2 : 1;
     vf pw[4] = {0.f, 0.f, 0.f, 0.f};
@@ -275,10 +284,13 @@ __global__ void k_mg_pweights(Lvl L, Lvl C) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) L.fpw[(size_t)k * L.n + i] = pw[k];
 }
+__global__ void k_mg_pweights(Lvl L, Lvl C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    mg_pweights_at(L, C, i);
+}
 // Galerkin product: A_c(I, J) = sum over the fine points i of block(I), row-major, of pst_I(i) * (A pst_J)(i) for J = I and its four forward neighbours
-__global__ void k_mg_galerkin(Lvl L, Lvl C, const double* __restrict__ pst) {
-    const int I = blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= C.n) return;
+__device__ __forceinline__ void mg_galerkin_at(const Lvl& L, const Lvl& C, const double* pst, int I) {
     const int Wc = C.W, Hc = C.H, Y = I / Wc, X = I - Y * Wc;
     const int W = L.W, H = L.H;
     // J = (Y + JY[j], X + JX[j]): self, E, S, SE, SW
@@ -317,11 +329,14 @@ __global__ void k_mg_galerkin(Lvl L, Lvl C, const double* __restrict__ pst) {
     C.wSE[I] = jok[3] ? -acc[3] : 0.0;
     C.wSW[I] = jok[4] ? -acc[4] : 0.0;
 }
+__global__ void k_mg_galerkin(Lvl L, Lvl C, const double* __restrict__ pst) {
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= C.n) return;
+    mg_galerkin_at(L, C, pst, I);
+}
 // 9-point levels: fp32 copies and the safe smoother diagonal dt = max(d, (|d| + sum |w|) / 2) — Gershgorin keeps lambda_max(dt^-1 A) <= 2 where a Galerkin
 // stencil has couplings of the wrong sign; dt = d on M-matrix rows
-__global__ void k_mg_finish(Lvl L) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.n) return;
+__device__ __forceinline__ void mg_finish_at(const Lvl& L, int i) {
     const int r = i / L.W, c = i - r * L.W;
     const double d = L.d[i];
     double w[8]; coup8(L, r, c, w);
@@ -330,6 +345,37 @@ __global__ void k_mg_finish(Lvl L) {
     for (int k = 0; k < 8; ++k) s += fabs(w[k]);
     const double h = 0.5 * s, dt = h > d ? h : d;
     L.fd[i] = (vf)d; L.fdinv[i] = (vf)(OMEGA / dt); L.fE[i] = (vf)L.wE[i]; L.fS[i] = (vf)L.wS[i]; L.fSE[i] = (vf)L.wSE[i]; L.fSW[i] = (vf)L.wSW[i];
+}
+__global__ void k_mg_finish(Lvl L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    mg_finish_at(L, i);
+}
+
+// The small levels of the hierarchy in ONE launch: one 1024-thread workgroup walks levels l0 .. nl-1 (coarse level of at most MG_TAIL_N points each) through
+// the same five stages with the same per-point functions; a stage boundary is a workgroup barrier instead of a kernel boundary (5 launches of ~5 us of dependent
+// latency each per level before: 24 launches and ~0.12 ms per solve at 700x700). Needs pa / pb of level l0 - 1 (k_mg_weights) done.
+#ifndef NCT_MG_TAIL_N
+#define NCT_MG_TAIL_N 512
+#endif
+constexpr int MG_TAIL_N = NCT_MG_TAIL_N;
+constexpr int MG_MAXL = 12;
+struct LvlPack { Lvl lv[MG_MAXL]; };
+__global__ __launch_bounds__(1024) void k_mg_setup_tail(LvlPack P, int l0, int nl, double* pst) {
+    const int t = threadIdx.x;
+    for (int l = l0; l < nl; ++l) {
+        const Lvl& L = P.lv[l - 1]; const Lvl& C = P.lv[l];
+        for (int I = t; I < C.n; I += 1024) mg_pstencil_at(L, C, pst, I);
+        __syncthreads();
+        for (int i = t; i < L.n; i += 1024) mg_pweights_at(L, C, i);
+        for (int I = t; I < C.n; I += 1024) mg_galerkin_at(L, C, pst, I);
+        __syncthreads();
+        for (int i = t; i < C.n; i += 1024) mg_finish_at(C, i);
+        if (l + 1 < nl) {
+            for (int i = t; i < C.n; i += 1024) mg_weights_at(C, i);     // reads d and the couplings (k_mg_galerkin's output), not what mg_finish_at writes
+        }
+        __syncthreads();
+    }
 }
 
 // ---- V-cycle (fp32, vectors planar [6][n])
@@ -729,6 +775,15 @@ __global__ __launch_bounds__(MID_T) void k_mg_mid(const PState* __restrict__ st,
 // ---- PCG pieces at the fine level
 
 // x6 = interleave(X); r = rough*x0 - M x0 ; partial: rr, bb (12)
+// The solver state the host polls is written by the kernel that produces it, straight into page-locked host memory (fine-grained, device-visible): fields, a
+// system-scope fence, then the publication number the host spins on. No copy command and no event sit in the stream between two iterations (an in-order
+// stream would hold the next kernel back until the copy engine has finished: a bubble per poll).
+__device__ __forceinline__ void pcg_publish(PState* __restrict__ host_out, const PState& v, int seq) {
+    PState o = v; o.seq = 0;
+    *host_out = o;
+    __threadfence_system();
+    __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <int NQ>
 __global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restrict__ rough, const double* __restrict__ X /*[2][n][3]*/, double* __restrict__ x6, double* __restrict__ r, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -751,12 +806,12 @@ __global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restri
     mg_block_reduce<2 * NQ>(acc, partial);
 }
 template <int NQ>
-__global__ void k_pcg_start_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, double rtol2) {
+__global__ void k_pcg_start_fin(const double* __restrict__ partial, int nb, PState* __restrict__ st, double rtol2, PState* __restrict__ host_out, int seq) {
     double s[2 * NQ]; mg_final_reduce<2 * NQ>(partial, nb, s);
-    if (threadIdx.x < NQ) { const int q = threadIdx.x; st->bb[q] = s[NQ + q]; st->gam[q] = 0; st->alp[q] = 0; st->iters[q] = 0;
+    if (threadIdx.x < NQ) { const int q = threadIdx.x; st->bb[q] = s[NQ + q]; st->gam[q] = 0; st->alp[q] = 0; st->iters[q] = 0; st->rho[q] = s[q];
                             st->active[q] = (s[q] > rtol2 * s[NQ + q]) ? 1 : 0; }
     __syncthreads();
-    if (threadIdx.x == 0) { int na = 0; for (int q = 0; q < NQ; ++q) na += st->active[q]; st->nactive = na; }
+    if (threadIdx.x == 0) { int na = 0; for (int q = 0; q < NQ; ++q) na += st->active[q]; st->nactive = na; if (host_out) pcg_publish(host_out, *st, seq); }
 }
 // Single-reduction PCG (Chronopoulos & Gear): per iteration  u = M^-1 r (the V-cycle, fp32) ; w = A u ; gamma = r.u, delta = w.u,
 // rho = r.r in ONE reduction ; beta = gamma/gamma_old, alpha = gamma / (delta - beta*gamma/alpha_old) ; p = u + beta p ; s = w + beta s
@@ -797,8 +852,8 @@ __global__ void k_cg_fin(const PState* __restrict__ st, const double* __restrict
 template <int NQ>
 __global__ __launch_bounds__(256) void k_cg_update(int n, const PState* __restrict__ sc, PState* __restrict__ sn, const double* __restrict__ sums, double rtol2, int first,
                                                    const vf* __restrict__ z, const double* __restrict__ w, double* __restrict__ p, double* __restrict__ s,
-                                                   double* __restrict__ x, double* __restrict__ r) {
-    if (sc->nactive == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) *sn = *sc; return; }
+                                                   double* __restrict__ x, double* __restrict__ r, PState* __restrict__ host_out, int seq) {
+    if (sc->nactive == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) { *sn = *sc; if (host_out) pcg_publish(host_out, *sc, seq); } return; }
     double al[NQ], be[NQ]; bool act[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -814,8 +869,10 @@ __global__ __launch_bounds__(256) void k_cg_update(int n, const PState* __restri
             sn->bb[q] = sc->bb[q];
             sn->gam[q] = act[q] ? sums[q] : sc->gam[q]; sn->alp[q] = act[q] ? al[q] : sc->alp[q];
             sn->iters[q] = sc->iters[q] + (act[q] ? 1 : 0); sn->active[q] = act[q] ? 1 : 0; na += act[q] ? 1 : 0;
+            sn->rho[q] = sc->active[q] != 0 ? sums[2 * NQ + q] : sc->rho[q];
         }
         sn->nactive = na;
+        if (host_out) pcg_publish(host_out, *sn, seq);
     }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -852,6 +909,7 @@ struct ErrSink {
     std::string err;
     int fail(int code, const char* fmt, ...) { char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); err = buf; return code; }
 };
+static std::atomic<int> g_seq{0};                         // publication numbers of the host-visible solver states: unique per process, so a slot never shows a stale match
 struct PartBufs {
     double *x6, *r, *p, *sv, *w, *partial, *sums; PState* st;      // Krylov vectors [NQ][N], reduction scratch, double-buffered state
     std::vector<Lvl> lv;                                            // the shared operator hierarchy with THIS part's V-cycle vectors (b, x, x2)
@@ -859,6 +917,8 @@ struct PartBufs {
     const double* rough;                                            // the data term (right-hand side = rough * x0)
     nct_ctx* kt;                                                    // kernel clock (NCT_FLAG_TIME_KERNELS, unsplit solves only), else null
     int maxit, graph;
+    bool trace;
+    bool forecast;                                                  // size the batches by the convergence forecast (pcg_part)
     int iters[NQMAX];
 };
 template <int NQ>
@@ -872,7 +932,10 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     const PState* cur = st;
     const double rtol2 = rtol * rtol;
     hipLaunchKernelGGL(k_pcg_start<NQ>, dim3(nb), dim3(256), 0, s, F, B.rough, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
-    hipLaunchKernelGGL(k_pcg_start_fin<NQ>, dim3(1), dim3(256), 0, s, (const double*)partial, nb, st, rtol2); LCHK();
+    const bool zero_copy = !B.graph;                       // the graph hook replays fixed kernel arguments: it keeps the copy + event form
+    int seq_of_slot[2] = {0, 0};
+    seq_of_slot[0] = ++g_seq;
+    hipLaunchKernelGGL(k_pcg_start_fin<NQ>, dim3(1), dim3(256), 0, s, (const double*)partial, nb, st, rtol2, zero_copy ? &B.hst[0] : (PState*)nullptr, seq_of_slot[0]); LCHK();
 
     // z = Vcycle(r). Levels 0..nl-2 run the tile-fused down/up legs (2 launches per level), the coarsest grid one wave per right-hand side.
     // lv[l].x2 = where level l's correction ends up (the up leg cannot write in place: neighbouring tiles still read lv[l].x).
@@ -940,6 +1003,7 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     // the GPU always has a batch queued. The batch enqueued past convergence costs only empty launches (nactive == 0).
     const int maxit = B.maxit, batch = NCT_WLS_BATCH;
     PState* hst = B.hst;                                  // two slots of page-locked memory
+    PState* pub_to = nullptr; int pub_seq = 0;           // set for the LAST iteration of a batch: its update kernel publishes the state
     auto iteration = [&](int it) -> int {
         cur = st + (it & 1);
         PState* nxt = st + ((it + 1) & 1);
@@ -951,26 +1015,62 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
         hipLaunchKernelGGL(k_cg_fin<NQ>, dim3(3), dim3(256), 0, s, cur, (const double*)partial, nb, (double*)sums); LCHK();
         rc = kt_b(NCT_KT_WLS_UPDATE); if (rc) return rc;
         hipLaunchKernelGGL(k_cg_update<NQ>, dim3(nb), dim3(256), 0, s, N, cur, nxt, (const double*)sums, rtol2, it == 0 ? 1 : 0, z, (const double*)w,
-                           (double*)p, (double*)sv, (double*)x6, (double*)r); LCHK();
+                           (double*)p, (double*)sv, (double*)x6, (double*)r, pub_to, pub_seq); LCHK();
         rc = kt_e(); if (rc) return rc;
         cur = nxt;
         return 0;
     };
-    auto snapshot = [&](int slot) -> int {
+    auto snapshot = [&](int slot) -> int {               // copy + event form (graph hook only)
         NCT_HIP(hipMemcpyAsync(&hst[slot], cur, sizeof(PState), hipMemcpyDeviceToHost, s));
         NCT_HIP(hipEventRecord(B.ev[slot], s));
         return 0;
     };
-    int it = 0, slot = 0; bool done = false;
-    { int rc = snapshot(slot); if (rc) return rc; }        // state after the start kernel (x0 may already solve the system)
+    auto wait_published = [&](int slot) -> int {           // spin on the publication number (the kernels of at least one batch are queued behind it)
+        const int want_seq = seq_of_slot[slot];
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 1; __atomic_load_n(&hst[slot].seq, __ATOMIC_ACQUIRE) != want_seq; ++spins) {
+            if (spins > 4096) std::this_thread::yield();
+            if ((spins & 0xFFFFu) == 0) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipSuccess && q != hipErrorNotReady) return ctx->fail(NCT_ERR_HIP, "WLS MG-PCG: stream error while polling the solver state: %s", hipGetErrorString(q));
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) return ctx->fail(NCT_ERR_HIP, "WLS MG-PCG: the solver state was not published within 60 s");
+            }
+        }
+        return 0;
+    };
+    // Snapshot k is taken behind the k-th enqueue (k = 0: behind the start kernel), into slot k & 1; the host reads them in order, one per turn, after it
+    // has enqueued the next batch. How MANY iterations that batch gets is a forecast: from the last two snapshots it has read, the host knows r.r of every
+    // system still iterating and its decay per iteration, hence the iterations still needed (the one that finds r.r below the threshold included); what is
+    // already in flight is subtracted. A forecast of 0 enqueues nothing and just waits for the in-flight snapshot — if the solve is not done then (the decay
+    // slowed down), the GPU idles for one host round trip (~20 us), about what ONE needless iteration costs; without the forecast every solve ran 2-4 of
+    // those (22-44 empty launches: 19 iterations of 110 per 700x700 pair). The forecast never changes what an iteration computes.
+    int it = 0; bool done = false;
+    int issued = 0, seen = -1;                             // snapshot numbers
+    int its_at_snapshot[2] = {0, 0};                       // iterations enqueued when snapshot (k & 1) was taken
+    if (!zero_copy) { int rc = snapshot(0); if (rc) return rc; }   // state after the start kernel (x0 may already solve the system); zero-copy: k_pcg_start_fin published it
     PState fin; memset(&fin, 0, sizeof fin);
+    double prev_rho[6]; int prev_its = -1;
+    int remaining_after_seen = -1;                         // forecast; -1 = none yet
+    int its_seen = 0;
     // Experiment hook (NCT_WLS_GRAPH=1): from the second batch on, the iteration batch (its kernels, arguments and the
     // state double-buffering repeat exactly) is captured once and replayed as a HIP graph instead of being enqueued kernel by kernel.
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     struct GraphCleanup { hipGraph_t& g; hipGraphExec_t& e; ~GraphCleanup() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } gcleanup{graph, gexec};
+    const bool forecast = B.forecast && !B.graph;
+    bool forecast_on = forecast;
     while (true) {
-        const bool enqueued = it < maxit;
-        if (enqueued && B.graph && it >= batch) {
+        int want = batch;
+        if (forecast_on && remaining_after_seen >= 0) {
+            const int inflight = it - its_seen;
+            want = remaining_after_seen - inflight;
+            if (want > batch) want = batch;
+            if (want < 0) want = 0;
+            if (want == 0 && issued == seen) { want = batch; forecast_on = false; }   // nothing in flight and not converged: the forecast was short (the decay
+                                                                                       // flattened) — the GPU just idled for a round trip; fixed batches for the rest of this solve
+        }
+        if (it + want > maxit) want = maxit - it;
+        const bool enqueued = want > 0;
+        if (enqueued && B.graph && it >= batch && want == batch) {
             if (!gexec) {
                 NCT_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 int rc = 0;
@@ -984,18 +1084,51 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
             it += batch;
             cur = st + (it & 1);
         } else
-        if (enqueued) { for (int k = 0; k < batch; ++k, ++it) { int rc = iteration(it); if (rc) return rc; } }
-        { int rc = snapshot(slot ^ 1); if (rc) return rc; }
-        NCT_HIP(hipEventSynchronize(B.ev[slot]));  // the snapshot taken BEFORE the batch just enqueued
-        fin = hst[slot];
+        if (enqueued) {
+            for (int k = 0; k < want; ++k, ++it) {
+                if (zero_copy && k == want - 1) { seq_of_slot[(issued + 1) & 1] = ++g_seq; pub_to = &hst[(issued + 1) & 1]; pub_seq = seq_of_slot[(issued + 1) & 1]; }
+                int rc = iteration(it); pub_to = nullptr; if (rc) return rc;
+            }
+        }
+        if (enqueued) { ++issued; its_at_snapshot[issued & 1] = it; if (!zero_copy) { int rc = snapshot(issued & 1); if (rc) return rc; } }
+        if (seen == issued) break;                         // nothing left to read: the iteration budget is spent
+        ++seen;
+        if (zero_copy) { int rc = wait_published(seen & 1); if (rc) return rc; } else NCT_HIP(hipEventSynchronize(B.ev[seen & 1]));
+        fin = hst[seen & 1];
+        its_seen = its_at_snapshot[seen & 1];
         if (fin.nactive == 0) { done = true; break; }
-        if (!enqueued) break;                              // that was the snapshot behind the last batch: the iteration budget is spent
-        slot ^= 1;
+        if (it >= maxit && seen == issued) break;
+        if (forecast) {
+            // iterations still needed after this snapshot: the slowest system's m = ceil(log(threshold / rho) / log(decay per iteration)), decay from the
+            // previous snapshot read; no forecast (full batches) while there is no history or the residual does not decay
+            const int ridx = its_seen > 0 ? its_seen - 1 : 0;   // fin.rho = r_ridx . r_ridx (the start kernel and iteration 0 both see r_0)
+            int need = -1; bool ok = prev_its >= 0 && ridx > prev_its;
+            if (ok) {
+                need = 1;
+                for (int q = 0; q < NQ; ++q) {
+                    if (!fin.active[q]) continue;
+                    const double thr = rtol2 * fin.bb[q], rho = fin.rho[q];
+                    if (!(rho > 0.0) || !(prev_rho[q] > 0.0) || !(thr > 0.0)) { ok = false; break; }
+                    const double decay = pow(rho / prev_rho[q], 1.0 / (double)(ridx - prev_its));
+                    if (!(decay < 0.95)) { ok = false; break; }
+                    // fin.rho = r.r the LAST iteration saw, i.e. one update older than the residual now: the next iteration sees rho * decay
+                    const double m = rho * decay <= thr ? 1.0 : 1.0 + ceil(log(thr / (rho * decay)) / log(decay));
+                    if (m > need) need = (int)(m < 1e6 ? m : 1e6);
+                }
+            }
+            remaining_after_seen = ok ? need : -1;
+            for (int q = 0; q < NQ; ++q) prev_rho[q] = fin.rho[q];
+            prev_its = ridx;
+        }
     }
     // iterations enqueued after `fin` was taken leave the state untouched (nactive == 0), so fin is final
     if (!done) return ctx->fail(NCT_ERR_HIP, "WLS MG-PCG did not converge in %d iterations", maxit);
     hipLaunchKernelGGL(k_pcg_finish<NQ>, dim3(cdiv(N * NQ, 256)), dim3(256), 0, s, N, (const double*)x6, X); LCHK();
     for (int q = 0; q < NQ; ++q) B.iters[q] = fin.iters[q];
+    if (B.trace) {                                          // NCT_WLS_TRACE=1: iterations enqueued against iterations that did something, snapshots read
+        int mx = 0; for (int q = 0; q < NQ; ++q) mx = fin.iters[q] > mx ? fin.iters[q] : mx;
+        fprintf(stderr, "nct wls: %d x %d, %d iterations enqueued, %d needed (+1 that finds every system converged), %d snapshots read\n", F.W, F.H, it, mx, seen + 1);
+    }
     return 0;
 }
 }  // namespace
@@ -1039,7 +1172,10 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
         double* pst = newd((size_t)lv[1].n * 9);                  // columns of P as 3x3 blocks, reused level by level
         if (!pst) return NCT_ERR_HIP;
         hipLaunchKernelGGL(k_mg_diag, dim3(cdiv(lv[0].n, 256)), dim3(256), 0, s, lv[0], rough); LCHK();
-        for (int l = 0; l < nl; ++l) {
+        int l_tail = nl;                                        // first level built by k_mg_setup_tail
+        for (int l = 1; l < nl; ++l) if (lv[l].n <= MG_TAIL_N) { l_tail = l; break; }
+        if (nl > MG_MAXL) l_tail = nl;
+        for (int l = 0; l < l_tail; ++l) {
             const dim3 g(cdiv(lv[l].n, 256));
             if (l > 0) {
                 const dim3 gc(cdiv(lv[l].n, 128));
@@ -1049,6 +1185,11 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
                 hipLaunchKernelGGL(k_mg_finish, g, dim3(256), 0, s, lv[l]); LCHK();
             }
             if (l + 1 < nl) { hipLaunchKernelGGL(k_mg_weights, g, dim3(256), 0, s, lv[l]); LCHK(); }
+        }
+        if (l_tail < nl) {
+            LvlPack P;
+            for (int l = 0; l < nl; ++l) P.lv[l] = lv[l];
+            hipLaunchKernelGGL(k_mg_setup_tail, dim3(1), dim3(1024), 0, s, P, l_tail, nl, pst); LCHK();
         }
     }
     const int N = lv[0].n, nb = cdiv(N, 256);
@@ -1069,7 +1210,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             if ((l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
         }
         B.hst = (PState*)ctx->pinned + 2 * h; B.ev[0] = ctx->ev_poll[2 * h]; B.ev[1] = ctx->ev_poll[2 * h + 1];
-        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph; B.rough = rough; B.kt = (ctx->kt_on && !split) ? ctx : nullptr;
+        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph; B.forecast = ctx->wls_forecast != 0; B.trace = getenv("NCT_WLS_TRACE") != nullptr; B.rough = rough; B.kt = (ctx->kt_on && !split) ? ctx : nullptr;
         memset(B.iters, 0, sizeof B.iters);
     }
     if (!split) {

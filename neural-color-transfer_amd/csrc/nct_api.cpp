@@ -1,6 +1,7 @@
 // nct_api.cpp — C-ABI entry points (host-pointer variants) + context / arena management.
 // Every function here is a thin marshalling layer: upload, call the device launcher (nctk_*), download.
 #include "nct_internal.h"
+#include <chrono>
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
@@ -38,6 +39,7 @@ int nct_ctx::mark(hipStream_t s, int tag) {
     }
     if (hipEventRecord(tm_events[i], s) != hipSuccess) return fail(NCT_ERR_HIP, "hipEventRecord failed");
     tm_tags.push_back(tag);
+    tm_host.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count());
     return 0;
 }
 int nct_ctx::kt_begin(hipStream_t s, int id) {
@@ -97,6 +99,7 @@ int nct_create(int device, nct_ctx** out) {
         if ((e = hipEventCreateWithFlags(&c->ev_poll[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     if ((e = hipHostMalloc(&c->pinned, 4096 + 64, hipHostMallocDefault)) != hipSuccess) { g_create_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     if (const char* g = getenv("NCT_WLS_GRAPH")) c->wls_graph = atoi(g);
+    if (const char* f = getenv("NCT_WLS_FORECAST")) { const int v = atoi(f); if (v == 0 || v == 1) c->wls_forecast = v; }
     if (const char* r = getenv("NCT_WLS_RTOL")) { const double v = atof(r); if (v > 0 && v < 1) c->wls_rtol = v; }
     if (const char* f = getenv("NCT_CONV_POOL_FUSE")) { const int v = atoi(f); if (v == 0 || v == 1) c->conv_pool_fuse = v; }
     if (const char* q = getenv("NCT_S1_PERSIST")) { const int v = atoi(q); if (v >= 0 && v <= 2) c->s1_persist = v; }   // 2: test hook, the first persistent launch reports a stall

@@ -35,6 +35,7 @@ struct nct_ctx {
     // stage clock: events recorded on the main stream at stage boundaries, read once after the pair's final synchronise
     // (no host syncs in between: see nct_pair_timing in nct.h)
     int wls_split = 0;                          // NCT_FLAG_LATENCY of the running pair: a- and b-half of the WLS solve on two streams
+    int wls_forecast = 1;                       // size the PCG iteration batches by the host's convergence forecast (k_wls_mg.hip: pcg_part); NCT_WLS_FORECAST=0: fixed batches
     int wls_graph = 0;                          // experiment hook (env NCT_WLS_GRAPH=1): replay the PCG iteration batch as a HIP graph
     int conv_pool_fuse = -1;                    // VGG: 2x2 max-pool inside the conv epilogue: -1 = where the tile shape fits the map (nctk_conv3x3_pool_fits), 0 never, 1 always (NCT_CONV_POOL_FUSE; tests)
     double wls_rtol = 1e-7;                     // relative residual at which the WLS solve stops. 1e-7: the 8-bit result of every level equals the EXACT solve's on the
@@ -42,6 +43,7 @@ struct nct_ctx {
     int wls_maxit = 5000;                       // iteration budget of the WLS solve (test hook: env NCT_WLS_MAXIT)
     bool tm_on = false;
     std::vector<hipEvent_t> tm_events;          // pool, reused across pairs
+    std::vector<double> tm_host;                // host clock (us) at mark i: NCT_HOST_TRACE=1 prints it beside the GPU clock (how far the host runs ahead)
     std::vector<int> tm_tags;                   // tag of mark i = the stage that ENDS at event i
     int mark(hipStream_t s, int tag);           // nct_api.cpp; no-op unless tm_on
     // kernel clock (NCT_FLAG_TIME_KERNELS): event pairs around single launches of the full-resolution colour-solver kernels; sample i = events 2i, 2i+1, id kt_ids[i]

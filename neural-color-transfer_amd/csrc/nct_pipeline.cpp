@@ -4,6 +4,8 @@
 // no CSR ping-pong for the solvers. S features are recomputed from the intermediate result only up to the tap the
 // next level needs (1115 instead of 2297 GFLOP per 700x700 pair, identical values).
 #include "nct_internal.h"
+#include <cstdlib>
+#include <cstdio>
 #include <chrono>
 #include <cstring>
 #include <algorithm>
@@ -51,6 +53,13 @@ static int read_marks(nct_ctx* ctx, nct_pair_timing* t) {
             else if (stage == ST_WLS) t->wls_level_ms[level] += ms;
         }
     }
+    if (getenv("NCT_HOST_TRACE") && ctx->tm_host.size() == ctx->tm_tags.size()) {
+        static const char* names[9] = {"other", "vgg", "cluster", "pm", "vote", "knn", "color", "nonlocal", "wls"};
+        for (size_t i = 1; i < ctx->tm_tags.size(); ++i) {
+            float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->tm_events[0], ctx->tm_events[i]);
+            fprintf(stderr, "nct mark %-8s L%d  host %8.3f ms  gpu %8.3f ms\n", names[(ctx->tm_tags[i] >> 3) % 9], ctx->tm_tags[i] & 7, (ctx->tm_host[i] - ctx->tm_host[0]) / 1000.0, ms);
+        }
+    }
     t->color_ms += t->nonlocal_ms + t->wls_ms;       // color_ms is the whole stage; the two solves are also reported on their own
     return 0;
 }
@@ -66,7 +75,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     NCT_REQUIRE(prm->levels >= 1 && prm->levels <= 5, "process: levels must be in [1, 5] (got %d)", prm->levels);
     if (timing) memset(timing, 0, sizeof *timing);
     auto wall0 = std::chrono::steady_clock::now();
-    ctx->tm_on = timing != nullptr; ctx->tm_tags.clear();
+    ctx->tm_on = timing != nullptr; ctx->tm_tags.clear(); ctx->tm_host.clear();
     ctx->kt_on = timing != nullptr && (prm->flags & NCT_FLAG_TIME_KERNELS) != 0; ctx->kt_ids.clear();
     struct TmOff { nct_ctx* c; ~TmOff() { c->tm_on = false; c->kt_on = false; } } tm_off{ctx};
     const int nlevels = prm->levels;
