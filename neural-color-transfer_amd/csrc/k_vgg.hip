@@ -60,15 +60,15 @@ typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 // block 1 = row 2 ty + 1), so a pooling window is two registers of one lane (vertical) and two neighbouring lanes (horizontal, one DPP quad_perm); only the pooled
 // map is written. The K loop does not change: every lane fetches the rows of its own pixel.
 template <int WCO, int CT, bool POOL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_conv3x3_mfma2b(const float* __restrict__ in, const float* __restrict__ wp /*packed, see k_pack_weights*/,
-                                                        const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int relu, float* __restrict__ out_hwc) {
+__device__ __forceinline__ void conv3x3_mfma2b_body(const float* __restrict__ in, const float* __restrict__ wp /*packed, see k_pack_weights*/,
+                                                    const float* __restrict__ bias, float* __restrict__ out, const ConvGeom& g, int relu, float* __restrict__ out_hwc, int bid) {
     constexpr int WPX = 4 / WCO;             // waves along pixels
     constexpr int BLK_PX = WPX * 64;
     constexpr int BLK_CO = WCO * 32 * CT;
     const int HW = g.H * g.W;
     int pt, nb;
     {
-        const int bid = blockIdx.x, grp = bid / (8 * g.nblk_n), rem = bid - grp * 8 * g.nblk_n;
+        const int grp = bid / (8 * g.nblk_n), rem = bid - grp * 8 * g.nblk_n;
         nb = rem >> 3; pt = grp * 8 + (rem & 7);
     }
     if (pt >= g.npx_blocks) return;
@@ -289,6 +289,20 @@ bool nctk_conv3x3_pool_fits(int H, int W) {
 }
 
 // pool = 1: `out` receives only the 2x2/2 max-pooled map [Cout][(H-1)/2+1][(W-1)/2+1] (what nctk_maxpool2x2 would make of the conv output)
+template <int WCO, int CT, bool POOL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_conv3x3_mfma2b(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                        float* __restrict__ out, ConvGeom g, int relu, float* __restrict__ out_hwc) {
+    conv3x3_mfma2b_body<WCO, CT, POOL>(in, wp, bias, out, g, relu, out_hwc, (int)blockIdx.x);
+}
+// Two images through the SAME layer in one launch (own geometry each, shared weights): the first nblocks1 workgroups take image 1, the rest image 2. For conv5_1 of
+// the source and the reference (44 x 44 pixels at 700 x 700: 124 workgroups per image, half the chip idle for 190 us, twice per pair).
+template <int WCO, int CT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_conv3x3_mfma2b_pair(const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ wp,
+                                                        const float* __restrict__ bias, float* __restrict__ out1, float* __restrict__ out2, ConvGeom g1, ConvGeom g2, int nblocks1, int relu,
+                                                        float* __restrict__ hwc1, float* __restrict__ hwc2) {
+    const bool second = (int)blockIdx.x >= nblocks1;
+    conv3x3_mfma2b_body<WCO, CT, false>(second ? in2 : in1, wp, bias, second ? out2 : out1, second ? g2 : g1, relu, second ? hwc2 : hwc1, second ? (int)blockIdx.x - nblocks1 : (int)blockIdx.x);
+}
 // out_hwc (nullable, pool == 0 only): the same map channel-last [H*W][Cout]; `out` may then be null
 int nctk_conv3x3(nct_ctx* ctx, hipStream_t s, const float* in, const float* wp, const float* bias, float* out,
                  int Cin, int Cout, int H, int W, int relu, int pool, float* out_hwc) {
@@ -314,6 +328,33 @@ int nctk_conv3x3(nct_ctx* ctx, hipStream_t s, const float* in, const float* wp, 
     } else if (Cout % 128 == 0) NCT_CONV_LAUNCH(4, 1, 1, Cout / 128);
     else                        NCT_CONV_LAUNCH(2, 1, 2, Cout / 64);
 #undef NCT_CONV_LAUNCH
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same layer for two images in ONE launch where both would run on grids too small to fill the chip (k_conv3x3_mfma2b_pair); otherwise two launches. No pooling.
+int nctk_conv3x3_pair(nct_ctx* ctx, hipStream_t s, const float* in1, int H1, int W1, const float* in2, int H2, int W2, const float* wp, const float* bias,
+                      float* out1, float* out2, int Cin, int Cout, int relu, float* hwc1, float* hwc2) {
+    auto small = [&](int H, int W) {
+        const int WCO = (Cout % 128 == 0) ? 2 : 1;
+        return cdiv(cdiv(H * W, 64), 4 / WCO) * (Cout / (64 * WCO)) < NCT_CONV_PT1_BELOW;
+    };
+    const bool ok = (Cin & 1) == 0 && (Cout & 63) == 0 && small(H1, W1) && small(H2, W2) && (size_t)Cin * H1 * W1 * 4 < ((size_t)1 << 32) && (size_t)Cin * H2 * W2 * 4 < ((size_t)1 << 32) &&
+                    (out1 || hwc1) && (out2 || hwc2) && ctx->conv_pair != 0;
+    if (!ok) {
+        int rc = nctk_conv3x3(ctx, s, in1, wp, bias, out1, Cin, Cout, H1, W1, relu, 0, hwc1); if (rc) return rc;
+        return nctk_conv3x3(ctx, s, in2, wp, bias, out2, Cin, Cout, H2, W2, relu, 0, hwc2);
+    }
+    const int nt1 = cdiv(H1 * W1, 64), nt2 = cdiv(H2 * W2, 64);
+#define NCT_CONV_PAIR(wco, ct, wpx, nblk_n_)                                                                                                      \
+    do {                                                                                                                                          \
+        ConvGeom g1{Cin, Cout, H1, W1, cdiv(nt1, wpx), nblk_n_, 0, 0, 0}, g2{Cin, Cout, H2, W2, cdiv(nt2, wpx), nblk_n_, 0, 0, 0};                 \
+        const int nb1 = cdiv(g1.npx_blocks, 8) * 8 * g1.nblk_n, nb2 = cdiv(g2.npx_blocks, 8) * 8 * g2.nblk_n;                                     \
+        hipLaunchKernelGGL((k_conv3x3_mfma2b_pair<wco, ct>), dim3(nb1 + nb2), dim3(256), 0, s, in1, in2, wp, bias, out1, out2, g1, g2, nb1, relu, hwc1, hwc2); \
+    } while (0)
+    if (Cout % 128 == 0) NCT_CONV_PAIR(4, 1, 1, Cout / 128);
+    else                 NCT_CONV_PAIR(2, 1, 2, Cout / 64);
+#undef NCT_CONV_PAIR
     NCT_LAUNCH_CHECK();
     return 0;
 }

@@ -47,6 +47,7 @@ struct nct_ctx {
     std::vector<int> tm_tags;                   // tag of mark i = the stage that ENDS at event i
     int mark(hipStream_t s, int tag);           // nct_api.cpp; no-op unless tm_on
     // kernel clock (NCT_FLAG_TIME_KERNELS): event pairs around single launches of the full-resolution colour-solver kernels; sample i = events 2i, 2i+1, id kt_ids[i]
+    int conv_pair = 1;                          // conv5_1 of the source and the reference in one launch (k_vgg.hip: nctk_conv3x3_pair); NCT_CONV_PAIR=0: two launches
     int s1_persist = 1;                         // S1 at the small levels as one persistent launch (k_colorsolve.hip: k_s1_cg_persist); NCT_S1_PERSIST=0: the three-kernel form
     int s1_stalls = 0;                          // times the persistent launch gave up at a grid barrier (the level was then repeated with per-iteration launches)
     int* s1_stall_flag() { return (int*)((char*)pinned + 4096); }   // its read-back word, behind the WLS solver's 4 KB
@@ -100,6 +101,11 @@ int nctk_nnf_upsample(nct_ctx* ctx, hipStream_t s, const uint32_t* nnf_half, uin
 int nctk_patchmatch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, int C, int ah, int aw, int bh, int bw,
                     int iters, int rs_max, uint32_t seed, uint32_t* nnf, float* dist, unsigned long long* eval_counter /*nullable*/);
 // k_vgg.hip / nct_vgg.cpp
+int nctk_conv3x3_pair(nct_ctx* ctx, hipStream_t s, const float* in1, int H1, int W1, const float* in2, int H2, int W2, const float* wp, const float* bias,
+                      float* out1, float* out2, int Cin, int Cout, int relu, float* hwc1, float* hwc2);
+// both images to conv5_1 (channel-last taps only), the last layer for both in one launch
+int nctk_vgg19_forward_pair(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr1, int H1, int W1, int stride1, float* const* taps_hwc1,
+                            const uint8_t* d_bgr2, int H2, int W2, int stride2, float* const* taps_hwc2);
 int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps_chw, int* dims,
                        float* const* d_taps_hwc = nullptr /* the same taps channel-last, written by the tap layers' epilogues */);
 void nct_vgg_free(nct_ctx* ctx);

@@ -114,6 +114,8 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     MARK(ST_OTHER, 0);
 
     // ---- VGG19: R once (all five taps kept, HWC), S to conv5_1 (main.cu:94,102)
+    DevBuf<float> sfeat(ctx, (size_t)64 * N);   // S features of the current level, channel-last (largest: H x W x 64)
+    if (!sfeat.ok()) return NCT_ERR_HIP;
     std::vector<DevBuf<float>*> rfeat(5, nullptr);     // R features, un-normalised, HWC, indexed by level
     struct Cleanup2 { std::vector<DevBuf<float>*>& a; ~Cleanup2() { for (auto* p : a) delete p; } } cleanup2{rfeat};
     {
@@ -124,13 +126,9 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
             rfeat[l] = new DevBuf<float>(ctx, (size_t)kTapC[t] * bh[l] * bw[l]); if (!rfeat[l]->ok()) return NCT_ERR_HIP;
             taps_hwc[t] = *rfeat[l];
         }
-        rc = nctk_vgg19_forward(ctx, s, P->ref, RH, RW, RW * 3, 5, nullptr, nullptr, taps_hwc); if (rc) return rc;
-    }
-    DevBuf<float> sfeat(ctx, (size_t)64 * N);   // S features of the current level, channel-last (largest: H x W x 64)
-    if (!sfeat.ok()) return NCT_ERR_HIP;
-    {
-        float* taps_hwc[5] = {nullptr, nullptr, nullptr, nullptr, sfeat};
-        rc = nctk_vgg19_forward(ctx, s, P->src, H, W, W * 3, 5, nullptr, nullptr, taps_hwc); if (rc) return rc;
+        // R and S together: conv5_1 of both images is one launch (two grids of 124 workgroups at 700 x 700 would each leave half the chip idle)
+        float* staps_hwc[5] = {nullptr, nullptr, nullptr, nullptr, sfeat};
+        rc = nctk_vgg19_forward_pair(ctx, s, P->ref, RH, RW, RW * 3, taps_hwc, P->src, H, W, W * 3, staps_hwc); if (rc) return rc;
     }
     MARK(ST_VGG, 0);
 

@@ -370,7 +370,9 @@ void nct_vgg_free(nct_ctx* ctx) {
 // dims[t] = {C,h,w} is filled for every tap <= deepest_tap.
 // d_taps: Caffe's planar CHW maps of the taps (entries nullable); d_taps_hwc (nullable array, entries nullable): the same taps channel-last, written by the tap layer's own
 // epilogue (no transpose pass). A tap asked for only channel-last is still written planar into the ping-pong buffer when a further layer reads it; the deepest tap is then not.
-int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps, int* dims, float* const* d_taps_hwc) {
+// stop_into (nullable): the forward stops in FRONT of its last conv layer and leaves that layer's input (the pooled map of the layer before) there; *stop_h / *stop_w = its size
+static int vgg19_forward_impl(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps, int* dims, float* const* d_taps_hwc,
+                              float* stop_into, int* stop_h, int* stop_w) {
     vgg_weights* v = ctx->vgg ? ((vgg_holder*)ctx->vgg)->w.get() : nullptr;
     if (!v || !v->loaded) return ctx->fail(NCT_ERR_STATE, "vgg19: weights not loaded (nct_vgg19_load_caffemodel / _load_raw)");
     NCT_REQUIRE(deepest_tap >= 1 && deepest_tap <= 5, "vgg19: deepest_tap must be 1..5");
@@ -385,6 +387,7 @@ int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H,
     const float* cur = pp[0];
     const int last = kTapConv[deepest_tap - 1];
     for (int i = 0; i <= last; ++i) {
+        if (stop_into && i == last) { *stop_h = h; *stop_w = w; break; }
         int tap = -1;
         for (int t = 0; t < 5; ++t) if (kTapConv[t] == i) tap = t;
         float* dst;
@@ -392,22 +395,40 @@ int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H,
         if (tap >= 0 && d_taps && d_taps[tap]) dst = d_taps[tap];
         else if (i == last && dst_hwc) dst = nullptr;                        // the forward ends here and nobody asked for the planar map
         else dst = (cur == pp[0]) ? pp[1] : pp[0];
+        const bool into_stop = stop_into && i == last - 1;                   // this layer's (pooled) output is what the caller keeps
         // a pooled layer is never a tap (taps are conv*_1): where the tile shape fits, the pool rides in the conv epilogue and the unpooled map is never written
         const bool pooled = kPoolAfter[i] && i < last;
         const bool fuse = pooled && tap < 0 && (ctx->conv_pool_fuse == 1 || (ctx->conv_pool_fuse < 0 && nctk_conv3x3_pool_fits(h, w)));
+        if (into_stop && (fuse || !pooled)) dst = stop_into;
         rc = nctk_conv3x3(ctx, s, cur, v->wp[i], v->bias[i], dst, (kCin[i] + 1) & ~1, kCout[i], h, w, 1, fuse ? 1 : 0, dst_hwc);
         if (rc) return rc;
         cur = dst;
         if (tap >= 0 && dims) { dims[tap * 3 + 0] = kCout[i]; dims[tap * 3 + 1] = h; dims[tap * 3 + 2] = w; }
         if (fuse) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
         else if (pooled) {
-            float* pd = (cur == pp[0]) ? pp[1] : pp[0];
+            float* pd = into_stop ? stop_into : ((cur == pp[0]) ? pp[1] : pp[0]);
             rc = nctk_maxpool2x2(ctx, s, cur, pd, kCout[i], h, w);
             if (rc) return rc;
             cur = pd; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
         }
     }
     return 0;
+}
+int nctk_vgg19_forward(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr, int H, int W, int stride, int deepest_tap, float* const* d_taps, int* dims, float* const* d_taps_hwc) {
+    return vgg19_forward_impl(ctx, s, d_bgr, H, W, stride, deepest_tap, d_taps, dims, d_taps_hwc, nullptr, nullptr, nullptr);
+}
+int nctk_vgg19_forward_pair(nct_ctx* ctx, hipStream_t s, const uint8_t* d_bgr1, int H1, int W1, int stride1, float* const* taps_hwc1,
+                            const uint8_t* d_bgr2, int H2, int W2, int stride2, float* const* taps_hwc2) {
+    NCT_REQUIRE(taps_hwc1 && taps_hwc2 && taps_hwc1[4] && taps_hwc2[4], "vgg19 pair: both conv5_1 maps are needed");
+    auto pooled4 = [](int n) { for (int k = 0; k < 4; ++k) n = (n - 1) / 2 + 1; return n; };
+    DevBuf<float> p1(ctx, (size_t)512 * pooled4(H1) * pooled4(W1)), p2(ctx, (size_t)512 * pooled4(H2) * pooled4(W2));
+    if (!p1.ok() || !p2.ok()) return NCT_ERR_HIP;
+    int h1 = 0, w1 = 0, h2 = 0, w2 = 0;
+    int rc = vgg19_forward_impl(ctx, s, d_bgr1, H1, W1, stride1, 5, nullptr, nullptr, taps_hwc1, p1, &h1, &w1); if (rc) return rc;
+    rc = vgg19_forward_impl(ctx, s, d_bgr2, H2, W2, stride2, 5, nullptr, nullptr, taps_hwc2, p2, &h2, &w2); if (rc) return rc;
+    vgg_weights* v = ((vgg_holder*)ctx->vgg)->w.get();
+    const int i = kTapConv[4];
+    return nctk_conv3x3_pair(ctx, s, p1, h1, w1, p2, h2, w2, v->wp[i], v->bias[i], nullptr, nullptr, (kCin[i] + 1) & ~1, kCout[i], 1, taps_hwc1[4], taps_hwc2[4]);
 }
 
 extern "C" {
