@@ -93,18 +93,13 @@ __device__ __forceinline__ void for_each_source(const uint32_t* __restrict__ val
 // b_img / out_img (nullable): the IMAGE-domain vote of the same pixel (B1, reconstruct_bds) rides along — it walks exactly the same coherence taps and the same merged
 // source list, so lanes 0..2 of the pixel's row accumulate the three colour channels (integer sums: order-free) and write the guidance pixel. One traversal of the inverse
 // map per level instead of two (k_vote_image alone: 0.75 ms at 700x700).
-#ifndef NCT_VOTE_SORTED
-#define NCT_VOTE_SORTED 1
-#endif
-constexpr int VOTE_MAXS = 32;
+constexpr int VOTE_MAXS = 36;          // entries of one round: at most four per tap list
 template <int NCH>   // float4 chunks per lane (C = 64*NCH), 0 = generic (loops, re-reads pout from memory)
 __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restrict__ ann, const uint32_t* __restrict__ inv_vals, const int* __restrict__ inv_start,
                                                        const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pw_out,
                                                        int C, int ah, int aw, int bh, int bw, double wa, double wb,
                                                        const uint8_t* __restrict__ b_img, uint8_t* __restrict__ out_img) {
-#if NCT_VOTE_SORTED
     __shared__ uint32_t s_keys[16][VOTE_MAXS], s_sorted[16][VOTE_MAXS];
-#endif
     const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int v = threadIdx.x & 15;
     const bool live = pix < ah * aw;
@@ -144,29 +139,42 @@ __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restric
         }
     // completeness (avg_vote_bds_b): atomicAdd(float*, (float)(wb*pin)) in ascending source order
     const float wbf = (float)wb;
-#if NCT_VOTE_SORTED
-    // The source order is fixed (ascending source pixel), the way it is produced is not: instead of a 9-way merge whose every step waits for the advanced list's
-    // next head and then for that source's feature row (one dependent chain of ~9 x 2 loads per pixel, repeated by all 16 lanes), lane t < 9 fetches ITS tap's list
-    // (all entries in flight), the <= VOTE_MAXS (source, tap) words of the pixel are rank-sorted through LDS (sources are unique: a source pixel has one
-    // correspondence), and the rows are then requested four at a time and accumulated in that order. A pixel with more sources than VOTE_MAXS takes the merge.
-    int mylen = 0, mypos = 0;
+    // The source order is fixed (ascending source pixel), the way it is produced is not. A 9-way merge waits at every step for the advanced list's next head and then
+    // for that source's feature row: one dependent chain per SOURCE — and the in-degree of the inverse map is skewed (700x700 bench pair: median 2, mean 9, p99 94,
+    // max 816 sources per pixel; scripts/vote_sources_hist.py): the launch lasted as long as its worst pixel's chain (0.96 of 1.36 ms at 700x700). Now in rounds:
+    // lane t < 9 of the pixel fetches the next five entries of ITS tap's list; pivot = the smallest fifth entry over the nine lists; every entry below the pivot (at
+    // most four per list, all four of the list that set it) is smaller than everything that stays behind, so the round's <= 36 (source, tap) words are rank-sorted
+    // through LDS (sources are unique: a source pixel has one correspondence) and their rows are requested four at a time and accumulated in that order.
+    int lpos = 0, lend = 0;
     if (live && v < 9) {
         const int dx = v / 3 - 1, dy = v % 3 - 1;
         const int sx = ax - dx, sy = ay - dy;
-        if (sx >= 0 && sx < aw && sy >= 0 && sy < ah) { const int sidx = sy * aw + sx; mypos = inv_start[sidx]; mylen = inv_start[sidx + 1] - mypos; }
+        if (sx >= 0 && sx < aw && sy >= 0 && sy < ah) { const int sidx = sy * aw + sx; lpos = inv_start[sidx]; lend = inv_start[sidx + 1]; }
     }
-    int incl = mylen;                                     // inclusive scan over the 16 lanes of the pixel
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) { const int up = __shfl_up(incl, off, 16); if (v >= off) incl += up; }
-    const int total = __shfl(incl, 15, 16), excl = incl - mylen;
-    const bool fast = total <= VOTE_MAXS;
     uint32_t* keys = s_keys[threadIdx.x >> 4];
     uint32_t* sorted = s_sorted[threadIdx.x >> 4];
-    if (fast) for (int k = 0; k < mylen; ++k) keys[excl + k] = (inv_vals[mypos + k] << 4) | (uint32_t)v;
-    __syncthreads();
-    if (fast) {
-        for (int e = v; e < total; e += 16) {
-            const uint32_t key = keys[e];
+    int more = 1;
+    while (more) {
+        uint32_t e[5];
+        const int rem = lend - lpos;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) e[k] = k < rem ? inv_vals[lpos + k] : 0xFFFFFFFFu;
+        uint32_t pivot = e[4];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const uint32_t o = __shfl_xor(pivot, off, 16); pivot = o < pivot ? o : pivot; }
+        int take = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) take += e[k] < pivot ? 1 : 0;          // e is ascending; the padding 0xFFFFFFFF is never below a pivot
+        int incl = take;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const int up = __shfl_up(incl, off, 16); if (v >= off) incl += up; }
+        const int total = __shfl(incl, 15, 16), excl = incl - take;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < take) keys[excl + k] = (e[k] << 4) | (uint32_t)v;
+        lpos += take;
+        __syncthreads();
+        for (int el = v; el < total; el += 16) {
+            const uint32_t key = keys[el];
             int rank = 0;
             for (int o = 0; o < total; ++o) rank += keys[o] < key ? 1 : 0;
             const int t = (int)(key & 15u), q = (int)(key >> 4);
@@ -175,9 +183,7 @@ __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restric
             const int xb = qx + dx, yb = qy + dy;
             sorted[rank] = (xb < bw && xb >= 0 && yb < bh && yb >= 0) ? (uint32_t)(yb * bw + xb) : 0xFFFFFFFFu;
         }
-    }
-    __syncthreads();
-    if (live && fast) {
+        __syncthreads();
         for (int e0 = 0; e0 < total; e0 += 4) {
             uint32_t bid[4]; float4 row[4][NR];
 #pragma unroll
@@ -206,26 +212,8 @@ __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restric
                     }
             }
         }
+        more = __syncthreads_or(lpos < lend ? 1 : 0);                   // also: nobody still reads keys / sorted when the next round overwrites them
     }
-    if (live && !fast)
-#else
-    if (live)
-#endif
-    for_each_source(inv_vals, inv_start, ax, ay, ah, aw, bh, bw, [&](int bid) {
-        pw = pw + wbf;
-        if (img) ib += b_img[(size_t)bid * 3 + v];
-        ++bcnt;
-        const float4* src = reinterpret_cast<const float4*>(pin + (size_t)bid * C);
-#pragma unroll
-        for (int k = 0; k < NR; ++k)
-            if (k < nch) {
-                const float4 x = src[v + 16 * k];
-                acc[k].x = acc[k].x + (float)(wb * (double)x.x);
-                acc[k].y = acc[k].y + (float)(wb * (double)x.y);
-                acc[k].z = acc[k].z + (float)(wb * (double)x.z);
-                acc[k].w = acc[k].w + (float)(wb * (double)x.w);
-            }
-    });
     if (!live) return;
     // avg_vote_bds
     float4* dst = reinterpret_cast<float4*>(pout + (size_t)pix * C);

@@ -1,0 +1,10 @@
+import sys, statistics
+sys.path.insert(0, "tests"); sys.path.insert(0, "neural-color-transfer_amd/python")
+import nct, synth
+from caffemodel_io import synthetic_vgg19
+ws, bs = synthetic_vgg19(19)
+c = nct.Context(0); c.vgg19_load_raw(ws, bs)
+c.pair_upload(synth.image(1000, 700, 700), synth.image(1001, 700, 700))
+prm = nct.Params.default(); c.pair_run(prm); c.pair_run(prm)
+lv = [list(c.pair_run(prm, want_timing=True)["vote_level_ms"]) for _ in range(5)]
+print("vote_level_ms", [round(statistics.median(x[k] for x in lv), 3) for k in range(5)], flush=True)
