@@ -93,7 +93,8 @@ __device__ __forceinline__ void for_each_source(const uint32_t* __restrict__ val
 // b_img / out_img (nullable): the IMAGE-domain vote of the same pixel (B1, reconstruct_bds) rides along — it walks exactly the same coherence taps and the same merged
 // source list, so lanes 0..2 of the pixel's row accumulate the three colour channels (integer sums: order-free) and write the guidance pixel. One traversal of the inverse
 // map per level instead of two (k_vote_image alone: 0.75 ms at 700x700).
-constexpr int VOTE_MAXS = 36;          // entries of one round: at most four per tap list
+constexpr int VK = 8;                   // entries one tap list can contribute to a round (2 / 4 / 6 / 8: votes 2.32 / 2.09 / 2.03 / 2.01 ms per pair)
+constexpr int VOTE_MAXS = 9 * VK;
 template <int NCH>   // float4 chunks per lane (C = 64*NCH), 0 = generic (loops, re-reads pout from memory)
 __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restrict__ ann, const uint32_t* __restrict__ inv_vals, const int* __restrict__ inv_start,
                                                        const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pw_out,
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restric
     // The source order is fixed (ascending source pixel), the way it is produced is not. A 9-way merge waits at every step for the advanced list's next head and then
     // for that source's feature row: one dependent chain per SOURCE — and the in-degree of the inverse map is skewed (700x700 bench pair: median 2, mean 9, p99 94,
     // max 816 sources per pixel; scripts/vote_sources_hist.py): the launch lasted as long as its worst pixel's chain (0.96 of 1.36 ms at 700x700). Now in rounds:
-    // lane t < 9 of the pixel fetches the next five entries of ITS tap's list; pivot = the smallest fifth entry over the nine lists; every entry below the pivot (at
-    // most four per list, all four of the list that set it) is smaller than everything that stays behind, so the round's <= 36 (source, tap) words are rank-sorted
+    // lane t < 9 of the pixel fetches the next VK + 1 entries of ITS tap's list; pivot = the smallest (VK + 1)-th entry over the nine lists; every entry below the pivot (at
+    // most VK per list, all VK of the list that set it) is smaller than everything that stays behind, so the round's <= 9 VK (source, tap) words are rank-sorted
     // through LDS (sources are unique: a source pixel has one correspondence) and their rows are requested four at a time and accumulated in that order.
     int lpos = 0, lend = 0;
     if (live && v < 9) {
@@ -155,22 +156,22 @@ __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restric
     uint32_t* sorted = s_sorted[threadIdx.x >> 4];
     int more = 1;
     while (more) {
-        uint32_t e[5];
+        uint32_t e[VK + 1];
         const int rem = lend - lpos;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) e[k] = k < rem ? inv_vals[lpos + k] : 0xFFFFFFFFu;
-        uint32_t pivot = e[4];
+        for (int k = 0; k <= VK; ++k) e[k] = k < rem ? inv_vals[lpos + k] : 0xFFFFFFFFu;
+        uint32_t pivot = e[VK];
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) { const uint32_t o = __shfl_xor(pivot, off, 16); pivot = o < pivot ? o : pivot; }
         int take = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) take += e[k] < pivot ? 1 : 0;          // e is ascending; the padding 0xFFFFFFFF is never below a pivot
+        for (int k = 0; k < VK; ++k) take += e[k] < pivot ? 1 : 0;          // e is ascending; the padding 0xFFFFFFFF is never below a pivot
         int incl = take;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) { const int up = __shfl_up(incl, off, 16); if (v >= off) incl += up; }
         const int total = __shfl(incl, 15, 16), excl = incl - take;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (k < take) keys[excl + k] = (e[k] << 4) | (uint32_t)v;
+        for (int k = 0; k < VK; ++k) if (k < take) keys[excl + k] = (e[k] << 4) | (uint32_t)v;
         lpos += take;
         __syncthreads();
         for (int el = v; el < total; el += 16) {
