@@ -234,6 +234,9 @@ int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat, int n, in
 #ifndef NCT_KNN_MAX_BLOCKS
 #define NCT_KNN_MAX_BLOCKS 1024
 #endif
+#ifndef NCT_KNN_LANES16_BELOW
+#define NCT_KNN_LANES16_BELOW 31000     // pixels: 44^2 .. 175^2 of a 700^2 pair search with sixteen lanes per entry (k_knn_grid16)
+#endif
 constexpr int KNN_K = 8;          // Config.h:68 m_kNum
 constexpr int KNN_SLOTS = 5;      // a pixel belongs to its own cluster + at most 4 neighbouring ones
 
@@ -389,6 +392,108 @@ __device__ __forceinline__ void knn_grid_entry(int e, const unsigned* __restrict
         if (bi[t] != id && bi[t] != 0x7fffffff && ni < KNN_K) { od[ni] = bd[t]; oi[ni] = bi[t]; ++ni; }
     for (; ni < KNN_K; ++ni) { od[ni] = 1e300; oi[ni] = -1; }
 }
+// The same search by SIXTEEN lanes per entry, for the coarse levels (a few thousand queries: one thread per entry leaves the chip to a few hundred waves that each
+// walk hundreds of points one after the other — 430 us for the 1936 pixels of 44 x 44, and the first nonlocal solve waits for exactly that graph). Lane v scans the
+// points whose index in the sorted array is v modulo 16 into its OWN (k+1)-list (ownership by absolute index: lanes prune on different thresholds, so they do not scan the same ranges); a list only ever holds points that were the best seen by its lane, so its (k+1)-th entry
+// bounds the true one from above and every pruning decision a lane takes on it is valid; at the end of a ring the sixteen lists are merged (nine rounds of a 16-lane
+// butterfly minimum under (dist, id); entries the lanes share since the last merge pop together) and every lane continues from the merged list. The result is the set
+// of the k+1 smallest under the total order: the same ids as the one-thread form and the brute-force oracle.
+__device__ __forceinline__ void knn_grid_entry16(int e, int v, const unsigned* __restrict__ cols, const unsigned* __restrict__ keys,
+                                                 const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
+                                                 int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
+    const int cb = 8 - cs, CELLS = 1 << cb; const unsigned cmask = (unsigned)CELLS - 1u;
+    const unsigned key = keys[e] >> (3 * cs);
+    const int id = (int)vals[e];
+    const int l = (int)(key >> (3 * cb));
+    const int cz = (int)((key >> (2 * cb)) & cmask), cy = (int)((key >> cb) & cmask), cx = (int)(key & cmask);
+    const unsigned pc = cols[e];
+    double bd[KNN_K + 1]; int bi[KNN_K + 1]; int bq[KNN_K + 1];
+#pragma unroll
+    for (int t = 0; t <= KNN_K; ++t) { bd[t] = 1e300; bi[t] = 0x7fffffff; bq[t] = 0x7fffffff; }
+    auto scan = [&](int b0, int b1) {
+        for (int t = b0 + ((v - b0) & 15); t < b1; t += 16) {     // lane v owns the points with index = v (mod 16), whatever range ITS thresholds make it scan
+            const unsigned qc = cols[t];
+            const int e0 = (int)(pc & 255u) - (int)(qc & 255u), e1 = (int)((pc >> 8) & 255u) - (int)((qc >> 8) & 255u), e2 = (int)((pc >> 16) & 255u) - (int)((qc >> 16) & 255u);
+            const int q2 = e0 * e0 + e1 * e1 + e2 * e2;
+            if (q2 > bq[KNN_K]) continue;
+            const int jd = (int)vals[t];
+            const double d = lab_dist(pc, qc);
+            if (!ent_less(d, jd, bd[KNN_K], bi[KNN_K])) continue;
+            bd[KNN_K] = d; bi[KNN_K] = jd; bq[KNN_K] = q2;
+#pragma unroll
+            for (int u = KNN_K; u > 0; --u)
+                if (ent_less(bd[u], bi[u], bd[u - 1], bi[u - 1])) {
+                    const double td = bd[u]; bd[u] = bd[u - 1]; bd[u - 1] = td;
+                    const int ti = bi[u]; bi[u] = bi[u - 1]; bi[u - 1] = ti;
+                    const int tq = bq[u]; bq[u] = bq[u - 1]; bq[u - 1] = tq;
+                }
+        }
+    };
+    auto merge16 = [&]() {
+        double od[KNN_K + 1]; int oi[KNN_K + 1], oq[KNN_K + 1];
+#pragma unroll
+        for (int s = 0; s <= KNN_K; ++s) {
+            double md = bd[0]; int mi = bi[0], mq = bq[0];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const double xd = __shfl_xor(md, off, 16); const int xi = __shfl_xor(mi, off, 16), xq = __shfl_xor(mq, off, 16);
+                if (ent_less(xd, xi, md, mi)) { md = xd; mi = xi; mq = xq; }
+            }
+            od[s] = md; oi[s] = mi; oq[s] = mq;
+            if (bi[0] == mi) {                                        // this lane's head is the winner (or every list is exhausted): pop
+#pragma unroll
+                for (int u = 0; u < KNN_K; ++u) { bd[u] = bd[u + 1]; bi[u] = bi[u + 1]; bq[u] = bq[u + 1]; }
+                bd[KNN_K] = 1e300; bi[KNN_K] = 0x7fffffff; bq[KNN_K] = 0x7fffffff;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s <= KNN_K; ++s) { bd[s] = od[s]; bi[s] = oi[s]; bq[s] = oq[s]; }
+    };
+    const int base = l << (3 * cb);
+    const int qz = (int)((pc >> 16) & 255u), qy = (int)((pc >> 8) & 255u), qx = (int)(pc & 255u);
+    auto gap = [&](int q, int c) { const int lo = c << cs, hi = lo + (1 << cs) - 1; return q < lo ? lo - q : (q > hi ? q - hi : 0); };
+    for (int r = 0; r < CELLS; ++r) {
+        if (r > 0) { const int bound = (r - 1) * (1 << cs) + 1; if (bq[KNN_K] < bound * bound) break; }   // merged list: the same value in all sixteen lanes
+        for (int dz = -r; dz <= r; ++dz) {
+            const int z = cz + dz; if (z < 0 || z >= CELLS) continue;
+            const int gz = gap(qz, z);
+            for (int dy = -r; dy <= r; ++dy) {
+                const int yy = cy + dy; if (yy < 0 || yy >= CELLS) continue;
+                const int gy = gap(qy, yy), gzy = gz * gz + gy * gy;
+                if (gzy > bq[KNN_K]) continue;
+                const int row = base | (z << (2 * cb)) | (yy << cb);
+                if (max(abs(dz), abs(dy)) == r) {
+                    int x0 = max(cx - r, 0), x1 = min(cx + r, CELLS - 1);
+                    while (x0 < x1 && gzy + gap(qx, x0) * gap(qx, x0) > bq[KNN_K]) ++x0;
+                    while (x1 > x0 && gzy + gap(qx, x1) * gap(qx, x1) > bq[KNN_K]) --x1;
+                    if (gzy + gap(qx, x0) * gap(qx, x0) > bq[KNN_K]) continue;
+                    scan(start[row | x0], start[(row | x1) + 1]);
+                } else {
+                    if (cx - r >= 0 && gzy + gap(qx, cx - r) * gap(qx, cx - r) <= bq[KNN_K]) scan(start[row | (cx - r)], start[(row | (cx - r)) + 1]);
+                    if (cx + r < CELLS && gzy + gap(qx, cx + r) * gap(qx, cx + r) <= bq[KNN_K]) scan(start[row | (cx + r)], start[(row | (cx + r)) + 1]);
+                }
+            }
+        }
+        merge16();
+    }
+    if (v != 0) return;
+    const int slot = atomicAdd(&nslot[id], 1);
+    double* od = cand_d + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
+    int* oi = cand_id + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
+    int ni = 0;
+#pragma unroll
+    for (int t = 0; t <= KNN_K; ++t)
+        if (bi[t] != id && bi[t] != 0x7fffffff && ni < KNN_K) { od[ni] = bd[t]; oi[ni] = bi[t]; ++ni; }
+    for (; ni < KNN_K; ++ni) { od[ni] = 1e300; oi[ni] = -1; }
+}
+__global__ __launch_bounds__(256) void k_knn_grid16(const unsigned* __restrict__ cols, const int* __restrict__ count, const unsigned* __restrict__ keys,
+                                                    const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
+                                                    int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
+    const int m = *count;
+    const int v = threadIdx.x & 15;
+    for (int e = blockIdx.x * 16 + (threadIdx.x >> 4); e < m; e += gridDim.x * 16)
+        knn_grid_entry16(e, v, cols, keys, vals, start, cs, nslot, cand_d, cand_id);
+}
 // Grid-stride over the entries with a BOUNDED grid: the searches are long-running and this kernel lives on the side stream; a grid
 // that fills every CU slot makes the short main-stream kernels wait until all of its workgroups have been dispatched.
 __global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ cols, const int* __restrict__ count, const unsigned* __restrict__ keys,
@@ -471,6 +576,10 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_entry_colours, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, (const int*)count, (const unsigned*)vals_s, (unsigned*)cols);
     NCT_LAUNCH_CHECK();
+    if (n <= NCT_KNN_LANES16_BELOW)
+        hipLaunchKernelGGL(k_knn_grid16, dim3(std::min(cdiv(cap, 16), 4 * NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
+                           (const int*)start, cs, (int*)nslot, (double*)cand_d, (int*)cand_id);
+    else
     hipLaunchKernelGGL(k_knn_grid, dim3(std::min(cdiv(cap, 256), NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
                        (const int*)start, cs, (int*)nslot, (double*)cand_d, (int*)cand_id);
     NCT_LAUNCH_CHECK();
