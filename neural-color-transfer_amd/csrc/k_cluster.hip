@@ -275,17 +275,23 @@ __global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* 
     const unsigned m = mask[cy * lw + cx];
     const unsigned col = (unsigned)lab[(size_t)i * 3] | ((unsigned)lab[(size_t)i * 3 + 1] << 8) | ((unsigned)lab[(size_t)i * 3 + 2] << 16);
     const int nlabels = nlabels_dev ? *nlabels_dev : nlabels_host;   // the pipeline passes the k-means result without a host round trip
-    // one atomic per wave and label instead of one per entry (the order of the entries is irrelevant: they are sorted afterwards and the
-    // search result does not depend on the order inside a cell)
+    // ONE atomic per wave instead of one per entry (round 4: instead of one per wave and label — up to 122 k atomics on the one counter at 700x700, 389 us): the wave
+    // counts its entries over all labels first and reserves them together. The order of the entries is irrelevant: they are sorted afterwards and the search result
+    // does not depend on the order inside a cell.
+    const int lane = threadIdx.x & 63;
+    const unsigned long long active = __ballot(1);
+    const int leader = __ffsll((long long)active) - 1;
+    int tot = 0;
+    for (int l = 0; l < nlabels; ++l) tot += __popcll(__ballot((m >> l) & 1u));
+    if (tot == 0) return;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, tot);
+    base = __shfl(base, leader);
     for (int l = 0; l < nlabels; ++l) {
         const bool in = (m >> l) & 1u;
         const unsigned long long bal = __ballot(in);
-        if (bal == 0ull) continue;
-        const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(count, __popcll(bal));
-        base = __shfl(base, leader);
         if (in) { const int pos = base + __popcll(bal & ((1ull << lane) - 1ull)); keys[pos] = entry_key(l, col, cs); vals[pos] = (unsigned)i; }
+        base += __popcll(bal);
     }
 }
 // start[k] = first sorted entry with key >= k, k in [0, nkeys]
