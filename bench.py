@@ -42,6 +42,7 @@ import sys
 import tempfile
 import threading
 import time
+import zlib
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "neural-color-transfer_amd", "python"))
@@ -50,6 +51,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+MALL_BYTES = 256.0 * 1024 * 1024     # Infinity Cache
 WORKLOADS = ("pair700", "pair1000", "pair256l5", "batch64", "mixed256")
 
 
@@ -65,6 +67,14 @@ def lib_build_id():
     for f in sorted(glob.glob(os.path.join(REPO, "neural-color-transfer_amd", "csrc", "*")) + [os.path.join(REPO, "include", "nct.h"), os.path.join(REPO, "neural-color-transfer_amd", "Makefile")]):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def lib_so_id(nct):
+    """sha256[:16] of the shared object as loaded by this process (ctypes handle's path)."""
+    try:
+        return hashlib.sha256(open(nct.lib()._name, "rb").read()).hexdigest()[:16]
+    except Exception as e:      # noqa: BLE001
+        return f"unavailable: {type(e).__name__}"
 
 
 def free_port():
@@ -83,6 +93,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="[test hook] pairs per step for batch64 / mixed256 (0 = 64 / 256)")
     ap.add_argument("--dist-backend", default="nccl", help="[test hook] torch.distributed backend (gloo exercises the N>1 path on a 1-GPU box)")
     ap.add_argument("--device-override", type=int, default=-1, help="[test hook] run every rank on this device instead of LOCAL_RANK")
+    ap.add_argument("--dist-single", default="auto", choices=("auto", "on", "off"),
+                    help="N = 1: run the barrier / MAX-reduce through a ONE-rank RCCL process group as well, so that the code the 8-GPU run depends on executes in every "
+                         "1-GPU run (auto: try, fall back to no group and say why in rccl_error; on: fail if RCCL cannot start; off: no group, rounds 1-4)")
+    ap.add_argument("--force-dist", action="store_true", help="alias of --dist-single on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the oracle on the full SxS pair even on a small host (the default from 32 host threads on: ~2 min)")
     ap.add_argument("--cpu-baseline-sample", action="store_true", help="time the oracle on the bounded 350x350 sample only (seconds) and scale by pixel count")
@@ -112,6 +126,7 @@ def main():
     import torch
     dist = None
     rccl_ranks = None
+    rccl_error = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -120,6 +135,27 @@ def main():
             rccl_ranks = dist.get_world_size()
         else:
             dist.init_process_group(args.dist_backend)
+    elif (args.force_dist or args.dist_single != "off") and args.dist_backend == "nccl":
+        # one rank: the SAME branch the N > 1 run takes (communicator on the device, device-side barrier, MAX all-reduce of a cuda tensor in timed_region) — VERDICT r4 item 6
+        import datetime
+        import torch.distributed as dist
+        try:
+            torch.cuda.set_device(local_rank)
+            if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
+                os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(free_port())
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=120))
+            dist.barrier()
+            rccl_ranks = dist.get_world_size()
+        except Exception as e:      # noqa: BLE001
+            if args.force_dist or args.dist_single == "on":
+                raise
+            rccl_error = f"{type(e).__name__}: {str(e)[:200]}"
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:       # noqa: BLE001
+                pass
+            dist = None
 
     import nct
     import synth
@@ -292,7 +328,7 @@ def main():
         "config": {"workload": desc + "; synthetic He-init VGG19 loaded from a V1 caffemodel", "name": wl,
                    "pairs_per_gpu_per_step": K if scaling == "weak" else pairs_per_step / world,
                    "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
-        "rccl_ranks": rccl_ranks,
+        "rccl_ranks": rccl_ranks, "rccl_error": rccl_error,
         "host_to_host_pairs_per_s": host_to_host,
         "value_basis": "inputs resident in HBM when the timed region starts (nct_pair_run; the task contract's definition of `value`). SURVEY 8(d)'s host-in -> host-out "
                        "wall over the same batches (nct_process_pair: + 2.9 MB of PCIe per pair) = host_to_host_pairs_per_s",
@@ -301,8 +337,17 @@ def main():
         "stages_ms": stages,
         "output_checksum": int(out.astype(np.uint64).sum()),
         "latency_flag_output_identical": None if latency_checksum is None else latency_checksum == int(out.astype(np.uint64).sum()),
-        "build_id": lib_build_id(),
+        "build_id": lib_build_id(), "build_id_basis": "sha256[:16] over csrc/*, include/nct.h, Makefile (the sources)",
+        "build_id_so": lib_so_id(nct), "build_id_so_basis": "sha256[:16] of the libnct.so file this process loaded",
     }
+    if wl == "pair700" and S == 700 and rank == 0:
+        # the resident pair of slot 0 is the bench pair of tests/golden/pair700_oracle.json (seeds 1000 / 1001): its byte sum pins the timed code path to the oracle's result
+        try:
+            gold = json.load(open(os.path.join(REPO, "tests", "golden", "pair700_oracle.json")))["700"]
+            res["parity_check"] = {"golden": "tests/golden/pair700_oracle.json[700] (CPU oracle, canonical order)", "golden_sum": gold["sum"], "golden_crc32": gold["crc32"],
+                                   "output_crc32": zlib.crc32(out.tobytes()), "match": bool(gold["sum"] == res["output_checksum"] and gold["crc32"] == zlib.crc32(out.tobytes()))}
+        except Exception as e:      # noqa: BLE001
+            res["parity_check"] = {"match": None, "why": f"{type(e).__name__}: {e}"}
     res["vgg_mfma"] = vgg_mfma(src.shape[0], src.shape[1], ref.shape[0], ref.shape[1], prm.levels, stages["vgg_ms"])
     if rank == 0 and not args.no_roofline and not args.no_pmc and world == 1 and wl == "pair700" and S == 700:
         res["vgg_mfma"].update(vgg_mfma_util(local_rank))
@@ -455,8 +500,10 @@ def patchmatch_roofline(nct, ctx, prm, sshape, rshape, device, live_pmc):
     return {"bound": "hbm", "kernel": f"k_pm_step<1, 1, 2, 2, 8> (init + the 10 propagation/random-search launches) and k_pm_prop<1, 1, 2, 2, 8> (the 30 packed propagation launches) — C=64, 8x8 queries per workgroup, "
                                       f"8 lanes per query, {sshape[1]}x{sshape[0]} <-> {rshape[1]}x{rshape[0]}, both directions per launch, pipeline features",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "basis": "PMC fabric-side bytes (FETCH_SIZE x2 + WRITE_SIZE) per launch / event-timed launch" if traffic is not None else
+            "basis": "fabric incl. Infinity Cache: PMC fabric-side bytes (FETCH_SIZE x2 + WRITE_SIZE, L2 misses; MALL hits are counted) per launch / event-timed launch" if traffic is not None else
                      "ALGORITHMIC bytes (no PMC pass of this build available) — not an HBM fraction, can exceed 1",
+            # HBM share of frac: a launch sweeps its whole footprint, so at most MALL / footprint of the fabric-side bytes can be Infinity-Cache hits
+            "hbm_frac_bounds": None if traffic is None else [achieved / HBM_PEAK_GBS * max(0.0, 1.0 - MALL_BYTES / footprint), achieved / HBM_PEAK_GBS],
             "traffic_source": how, "pmc": pmc, "launches": n_launch, "avg_launch_ms": 1e3 * launch_s, "evals": evals,
             "algorithmic_bytes_per_launch": alg / n_launch, "algorithmic_GBs": alg_gbs,
             "traffic_over_algorithmic": None if traffic is None else traffic / (alg / n_launch),
@@ -501,6 +548,7 @@ def patchmatch_roofline_1000(device):
         return {"bound": "hbm", "kernel": "k_pm_step<1, 1, 2, 2, 8> + k_pm_prop<1, 1, 2, 2, 8> at 1000x1000 <-> 1000x1000 (BASELINE config 4), counter-pass launch durations", "dispatches": fs["dispatches"],
                 "traffic": fetch + write, "avg_launch_us": us, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "by_step": by,
                 "footprint_bytes": foot, "footprint_over_mall": foot / (256.0 * 1024 * 1024), "restream_factor": (fetch + write) / foot,
+                "basis": "fabric incl. Infinity Cache (footprint 2x the MALL: at least half of it is HBM)", "hbm_frac_bounds": [gbs / HBM_PEAK_GBS * max(0.0, 1.0 - MALL_BYTES / foot), gbs / HBM_PEAK_GBS],
                 "fetch_size_factor": 2.0, "fetch_size_factor_basis": "profiles/round4_fetch_calibration.md: FETCH_SIZE x 1024 / known bytes = 0.50 on a streaming read AND on 8-lane x 16-B tile rows at random pixels",
                 "note": "footprint 2.0x the Infinity Cache: at most half of these bytes can be MALL hits, so HBM demand >= frac / 2 and <= frac; the 700x700 figure (roofline.frac) is fabric-side incl. MALL"}
     except Exception as e:      # noqa: BLE001

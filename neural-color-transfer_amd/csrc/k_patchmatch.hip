@@ -700,7 +700,15 @@ static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob
         NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pm_step<NCH, MODE, TQX, TQY, LPQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->pm_attr_mask |= abit;
     }
-    if constexpr ((NCH == 1 || (NCH == 2 && NCT_PM_PACK >= 2) || (NCH >= 4 && NCT_PM_PACK >= 3)) && MODE != NCT_PM_FP16 && NCT_PM_PACK != 0) {
+    // k_pm_prop hard-codes the two exact skip rules (stale candidates, candidates equal to the current match); the checking builds that evaluate them anyway
+    // (-DNCT_PM_EVAL_STALE / -DNCT_PM_EVAL_SAME) therefore take k_pm_step for every step, which honours the macros. Its eval counters also differ in meaning:
+    // k_pm_prop filters against the query's INITIAL match of the step, so a candidate proposed by two neighbours is evaluated and counted twice (+0.08 % evaluations).
+#if defined(NCT_PM_EVAL_STALE) || defined(NCT_PM_EVAL_SAME)
+    constexpr bool packed_ok = false;
+#else
+    constexpr bool packed_ok = true;
+#endif
+    if constexpr (packed_ok && (NCH == 1 || (NCH == 2 && NCT_PM_PACK >= 2) || (NCH >= 4 && NCT_PM_PACK >= 3)) && MODE != NCT_PM_FP16 && NCT_PM_PACK != 0) {
         if (mode == 1 && jump != 1) {              // propagation-only step: the packed form (its dynamic LDS is the same staged region)
             if constexpr (NCH >= 4) {                  // > 32 KB of dynamic LDS: the same opt-in as k_pm_step, once per context and instantiation (bits 27..30 of the mask)
                 constexpr unsigned pbit = 1u << (27 + (NCH == 8 ? 2 : 0) + (MODE == NCT_PM_ROWREJECT ? 1 : 0));

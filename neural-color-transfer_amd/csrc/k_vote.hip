@@ -4,14 +4,15 @@
 //
 // MI355X design: the completeness vote is a *gather*, not an atomic scatter. The R->S NNF is inverted once per
 // level (stable radix sort of (matched S pixel, R pixel) pairs + per-S-pixel segment starts), then every S pixel
-// merges the <=9 per-tap source lists in ascending source order. That (a) removes 9*C float atomics per R pixel,
-// (b) makes the fp32 sum order deterministic (ascending source pixel, taps dx-outer/dy-inner) == oracle/orc_vote.c,
+// walks the <=9 per-tap source lists, tap after tap, each in ascending source order. That (a) removes 9*C float atomics per R pixel,
+// (b) makes the fp32 sum order deterministic (taps dx-outer/dy-inner, ascending source pixel inside a tap, long lists in blocks of 64) == oracle/orc_vote.c,
 // (c) lets the coherence vote, the completeness vote and the final division fuse into ONE kernel per domain.
 // Roofline: HBM/L2 gather, ~18 feature vectors read + 1 written per S pixel.
 #include "nct_internal.h"
 #include "nct_device.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>   // rocPRIM directly (no CUB-compatibility layer)
+#include <rocprim/device/device_scan.hpp>
 
 // ---------------------------------------------------------------- inverse map of the R->S NNF
 __global__ void k_inv_keys(const uint32_t* __restrict__ bnn, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int nb, int aw) {
@@ -90,17 +91,115 @@ __device__ __forceinline__ void for_each_source(const uint32_t* __restrict__ val
 }
 
 // ---------------------------------------------------------------- B2 feature vote (one 16-lane row per S pixel)
-// b_img / out_img (nullable): the IMAGE-domain vote of the same pixel (B1, reconstruct_bds) rides along — it walks exactly the same coherence taps and the same merged
-// source list, so lanes 0..2 of the pixel's row accumulate the three colour channels (integer sums: order-free) and write the guidance pixel. One traversal of the inverse
-// map per level instead of two (k_vote_image alone: 0.75 ms at 700x700).
-constexpr int VK = 8;                   // entries one tap list can contribute to a round (2 / 4 / 6 / 8: votes 2.32 / 2.09 / 2.03 / 2.01 ms per pair)
-constexpr int VOTE_MAXS = 9 * VK;
-template <int NCH>   // float4 chunks per lane (C = 64*NCH), 0 = generic (loops, re-reads pout from memory)
+// Canonical order v2 (round 5; = oracle/orc_vote.c): after the coherence part, TAP-MAJOR — for the nine taps (dx outer, dy inner) the sources whose match is the tapped
+// neighbour s = target - tap, ascending source pixel: that is simply the contiguous range start[s] .. start[s + 1] of the sorted inverse map, no merge across lists.
+// Rounds 1-4 added in ascending source pixel across all nine lists (a rank sort through LDS per round); the order is this project's own choice (the reference's float
+// atomics have none) and tap-major is what makes LONG lists tractable: natural photographs collapse 10^4 R pixels of a flat region onto one match (in4/tar4: 47 535
+// sources on one target — 24 ms for the finest vote where the synthetic pair takes 1.2). A list is added in blocks of VT = 64: the first block source by source into the
+// target's sums; every further block summed from zero in the same way by k_vote_hub — one 16-lane row per (block, tap), all blocks of a level in parallel — and then
+// added as ONE addend, in block order. Lists of <= 64 sources (all but a few hundred on the synthetic pairs) never leave this kernel.
+// b_img / out_img (nullable): the IMAGE-domain vote of the same pixel (B1, reconstruct_bds) rides along — it walks exactly the same taps and sources, so lanes 0..2 of the
+// pixel's row accumulate the three colour channels (integer sums: order-free) and write the guidance pixel.
+constexpr int VT = 64;
+struct VoteHub {
+    const int* hstart;       // [na + 1] index of the first further block of S pixel s (exclusive scan of (cnt - 1) / VT for cnt > VT); hstart[na] = number of blocks
+    const int* blk_s;        // [blocks] the S pixel whose list the block belongs to
+    const int* blk_pos;      // [blocks] position of the block's first entry in the sorted inverse map
+    float* P;                // [blocks * 9][C] block sums per tap
+    float* PW;               // [blocks * 9]    their weight sums
+    int* CNT;                // [blocks * 9]    in-bounds sources (image vote)
+    int* IB;                 // [blocks * 9][3] their colour sums (image vote)
+};
+// entry code: bit 31 = block partial (index = (block * 9 + tap)), else source row (index = tapped R pixel); 0xFFFFFFFF = nothing (out of bounds / beyond the end)
+constexpr uint32_t V_NONE = 0xFFFFFFFFu, V_PART = 0x80000000u;
+
+template <int NCH, int NR>
+__device__ __forceinline__ void vote_accumulate(uint32_t mycode, int count, int v, int nch, int C, const float* __restrict__ pin, const VoteHub& H, double wb, float wbf,
+                                                bool img, const uint8_t* __restrict__ b_img, float4 (&acc)[NR], float& pw, int& ib, int& bcnt) {
+    // `count` entries of the row's 16 lanes (lane u holds entry u), consumed in lane order, four rows in flight
+    for (int e0 = 0; e0 < count; e0 += 4) {
+        uint32_t code[4]; float4 row[4][NR];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            code[u] = __shfl(mycode, e0 + u, 16);
+            if (e0 + u >= count) code[u] = V_NONE;
+            if (code[u] != V_NONE) {
+                const bool part = (code[u] & V_PART) != 0;
+                const float4* src = reinterpret_cast<const float4*>((part ? H.P : pin) + (size_t)(code[u] & ~V_PART) * C);
+#pragma unroll
+                for (int k = 0; k < NR; ++k) if (k < nch) row[u][k] = src[v + 16 * k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (code[u] == V_NONE) continue;
+            if (code[u] & V_PART) {
+                const uint32_t idx = code[u] & ~V_PART;
+                pw = pw + H.PW[idx];
+                bcnt += H.CNT[idx];
+                if (img) ib += H.IB[(size_t)idx * 3 + v];
+#pragma unroll
+                for (int k = 0; k < NR; ++k)
+                    if (k < nch) { acc[k].x = acc[k].x + row[u][k].x; acc[k].y = acc[k].y + row[u][k].y; acc[k].z = acc[k].z + row[u][k].z; acc[k].w = acc[k].w + row[u][k].w; }
+            } else {
+                pw = pw + wbf;
+                ++bcnt;
+                if (img) ib += b_img[(size_t)code[u] * 3 + v];
+#pragma unroll
+                for (int k = 0; k < NR; ++k)
+                    if (k < nch) {
+                        const float4 x = row[u][k];
+                        acc[k].x = acc[k].x + (float)(wb * (double)x.x);
+                        acc[k].y = acc[k].y + (float)(wb * (double)x.y);
+                        acc[k].z = acc[k].z + (float)(wb * (double)x.z);
+                        acc[k].w = acc[k].w + (float)(wb * (double)x.w);
+                    }
+            }
+        }
+    }
+}
+
+// one 16-lane row per (further block, tap): the block's <= VT sources in ascending order, summed from zero exactly like a first block
+template <int NCH>
+__global__ __launch_bounds__(256) void k_vote_hub(const uint32_t* __restrict__ inv_vals, const int* __restrict__ inv_start, const float* __restrict__ pin, VoteHub H,
+                                                  int C, int na, int bh, int bw, double wb, const uint8_t* __restrict__ b_img) {
+    const int nunits = H.hstart[na] * 9;
+    const int v = threadIdx.x & 15;
+    constexpr int NR = NCH > 0 ? NCH : 8;
+    const int nch = NCH > 0 ? NCH : ((C >> 2) + 15 - v) / 16;
+    const float wbf = (float)wb;
+    const bool img = b_img != nullptr && v < 3;
+    for (int unit = blockIdx.x * 16 + (threadIdx.x >> 4); unit < nunits; unit += gridDim.x * 16) {
+        const int blk = unit / 9, t = unit - blk * 9;
+        const int dx = t / 3 - 1, dy = t % 3 - 1;
+        const int pos = H.blk_pos[blk], end = min(pos + VT, inv_start[H.blk_s[blk] + 1]);
+        float4 acc[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float pw = 0.f; int ib = 0, bcnt = 0;
+        for (int j0 = pos; j0 < end; j0 += 16) {
+            uint32_t code = V_NONE;
+            if (j0 + v < end) {
+                const int q = (int)inv_vals[j0 + v];
+                const int qy = q / bw, qx = q - qy * bw;
+                const int xb = qx + dx, yb = qy + dy;
+                if (xb < bw && xb >= 0 && yb < bh && yb >= 0) code = (uint32_t)(yb * bw + xb);
+            }
+            vote_accumulate<NCH, NR>(code, min(16, end - j0), v, nch, C, pin, H, wb, wbf, img, b_img, acc, pw, ib, bcnt);
+        }
+        float4* dst = reinterpret_cast<float4*>(H.P + (size_t)unit * C);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) if (k < nch) dst[v + 16 * k] = acc[k];
+        if (v == 0) { H.PW[unit] = pw; H.CNT[unit] = bcnt; }
+        if (b_img != nullptr && v < 3) H.IB[(size_t)unit * 3 + v] = ib;
+    }
+}
+
+template <int NCH>   // float4 chunks per lane (C = 64*NCH), 0 = generic (C <= 512, any multiple of 4)
 __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restrict__ ann, const uint32_t* __restrict__ inv_vals, const int* __restrict__ inv_start,
-                                                       const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pw_out,
+                                                       const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pw_out, VoteHub H,
                                                        int C, int ah, int aw, int bh, int bw, double wa, double wb,
                                                        const uint8_t* __restrict__ b_img, uint8_t* __restrict__ out_img) {
-    __shared__ uint32_t s_keys[16][VOTE_MAXS], s_sorted[16][VOTE_MAXS];
     const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int v = threadIdx.x & 15;
     const bool live = pix < ah * aw;
@@ -138,82 +237,50 @@ __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restric
                 }
             }
         }
-    // completeness (avg_vote_bds_b): atomicAdd(float*, (float)(wb*pin)) in ascending source order
+    // completeness (avg_vote_bds_b): atomicAdd(float*, (float)(wb*pin)) in the canonical order of the header comment. The nine lists' first blocks and the block sums
+    // of their further blocks form ONE sequence per target (list 0's sources, list 0's block sums, list 1's sources, …); lane u of the row decodes entry j0 + u of it —
+    // sixteen inverse-map words requested at once — and the row then consumes the sixteen entries in order, four feature rows in flight.
     const float wbf = (float)wb;
-    // The source order is fixed (ascending source pixel), the way it is produced is not. A 9-way merge waits at every step for the advanced list's next head and then
-    // for that source's feature row: one dependent chain per SOURCE — and the in-degree of the inverse map is skewed (700x700 bench pair: median 2, mean 9, p99 94,
-    // max 816 sources per pixel; scripts/vote_sources_hist.py): the launch lasted as long as its worst pixel's chain (0.96 of 1.36 ms at 700x700). Now in rounds:
-    // lane t < 9 of the pixel fetches the next VK + 1 entries of ITS tap's list; pivot = the smallest (VK + 1)-th entry over the nine lists; every entry below the pivot (at
-    // most VK per list, all VK of the list that set it) is smaller than everything that stays behind, so the round's <= 9 VK (source, tap) words are rank-sorted
-    // through LDS (sources are unique: a source pixel has one correspondence) and their rows are requested four at a time and accumulated in that order.
-    int lpos = 0, lend = 0;
+    int lpos = 0, nfirst = 0, nblk = 0, hb = 0;
     if (live && v < 9) {
         const int dx = v / 3 - 1, dy = v % 3 - 1;
         const int sx = ax - dx, sy = ay - dy;
-        if (sx >= 0 && sx < aw && sy >= 0 && sy < ah) { const int sidx = sy * aw + sx; lpos = inv_start[sidx]; lend = inv_start[sidx + 1]; }
+        if (sx >= 0 && sx < aw && sy >= 0 && sy < ah) {
+            const int sidx = sy * aw + sx;
+            lpos = inv_start[sidx];
+            const int cnt = inv_start[sidx + 1] - lpos;
+            nfirst = min(cnt, VT);
+            hb = H.hstart[sidx]; nblk = H.hstart[sidx + 1] - hb;
+        }
     }
-    uint32_t* keys = s_keys[threadIdx.x >> 4];
-    uint32_t* sorted = s_sorted[threadIdx.x >> 4];
-    int more = 1;
-    while (more) {
-        uint32_t e[VK + 1];
-        const int rem = lend - lpos;
+    int incl = nfirst + nblk;
 #pragma unroll
-        for (int k = 0; k <= VK; ++k) e[k] = k < rem ? inv_vals[lpos + k] : 0xFFFFFFFFu;
-        uint32_t pivot = e[VK];
+    for (int off = 1; off < 16; off <<= 1) { const int up = __shfl_up(incl, off, 16); if (v >= off) incl += up; }
+    const int total = __shfl(incl, 15, 16);
+    int offs[9];                                          // exclusive start of tap t's entries in the target's sequence
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { const uint32_t o = __shfl_xor(pivot, off, 16); pivot = o < pivot ? o : pivot; }
-        int take = 0;
+    for (int t = 0; t < 9; ++t) offs[t] = t == 0 ? 0 : __shfl(incl, t - 1, 16);
+    for (int j0 = 0; j0 < total; j0 += 16) {
+        const int j = j0 + v;
+        int t = 0;
 #pragma unroll
-        for (int k = 0; k < VK; ++k) take += e[k] < pivot ? 1 : 0;          // e is ascending; the padding 0xFFFFFFFF is never below a pivot
-        int incl = take;
+        for (int u = 1; u < 9; ++u) t += offs[u] <= j ? 1 : 0;
+        int ot = 0;
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { const int up = __shfl_up(incl, off, 16); if (v >= off) incl += up; }
-        const int total = __shfl(incl, 15, 16), excl = incl - take;
-#pragma unroll
-        for (int k = 0; k < VK; ++k) if (k < take) keys[excl + k] = (e[k] << 4) | (uint32_t)v;
-        lpos += take;
-        __syncthreads();
-        for (int el = v; el < total; el += 16) {
-            const uint32_t key = keys[el];
-            int rank = 0;
-            for (int o = 0; o < total; ++o) rank += keys[o] < key ? 1 : 0;
-            const int t = (int)(key & 15u), q = (int)(key >> 4);
-            const int dx = t / 3 - 1, dy = t % 3 - 1;
-            const int qy = q / bw, qx = q - qy * bw;
-            const int xb = qx + dx, yb = qy + dy;
-            sorted[rank] = (xb < bw && xb >= 0 && yb < bh && yb >= 0) ? (uint32_t)(yb * bw + xb) : 0xFFFFFFFFu;
+        for (int u = 0; u < 9; ++u) ot = u == t ? offs[u] : ot;
+        const int r = j - ot;
+        const int lp = __shfl(lpos, t, 16), nf = __shfl(nfirst, t, 16), hbt = __shfl(hb, t, 16);
+        uint32_t code = V_NONE;
+        if (j < total) {
+            if (r < nf) {
+                const int dx = t / 3 - 1, dy = t % 3 - 1;
+                const int q = (int)inv_vals[lp + r];
+                const int qy = q / bw, qx = q - qy * bw;
+                const int xb = qx + dx, yb = qy + dy;
+                if (xb < bw && xb >= 0 && yb < bh && yb >= 0) code = (uint32_t)(yb * bw + xb);
+            } else code = V_PART | (uint32_t)((hbt + (r - nf)) * 9 + t);
         }
-        __syncthreads();
-        for (int e0 = 0; e0 < total; e0 += 4) {
-            uint32_t bid[4]; float4 row[4][NR];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                bid[u] = e0 + u < total ? sorted[e0 + u] : 0xFFFFFFFFu;
-                if (bid[u] != 0xFFFFFFFFu) {
-                    const float4* src = reinterpret_cast<const float4*>(pin + (size_t)bid[u] * C);
-#pragma unroll
-                    for (int k = 0; k < NR; ++k) if (k < nch) row[u][k] = src[v + 16 * k];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (bid[u] == 0xFFFFFFFFu) continue;
-                pw = pw + wbf;
-                if (img) ib += b_img[(size_t)bid[u] * 3 + v];
-                ++bcnt;
-#pragma unroll
-                for (int k = 0; k < NR; ++k)
-                    if (k < nch) {
-                        const float4 x = row[u][k];
-                        acc[k].x = acc[k].x + (float)(wb * (double)x.x);
-                        acc[k].y = acc[k].y + (float)(wb * (double)x.y);
-                        acc[k].z = acc[k].z + (float)(wb * (double)x.z);
-                        acc[k].w = acc[k].w + (float)(wb * (double)x.w);
-                    }
-            }
-        }
-        more = __syncthreads_or(lpos < lend ? 1 : 0);                   // also: nobody still reads keys / sorted when the next round overwrites them
+        vote_accumulate<NCH, NR>(code, min(16, total - j0), v, nch, C, pin, H, wb, wbf, img, b_img, acc, pw, ib, bcnt);
     }
     if (!live) return;
     // avg_vote_bds
@@ -233,13 +300,49 @@ __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restric
     }
 }
 
+// block table of the long lists: per S pixel the number of further blocks, scanned; one thread per S pixel fills its blocks' entries
+__global__ void k_vote_blk_counts(const int* __restrict__ inv_start, int na, int* __restrict__ cnt) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > na) return;
+    int c = 0;
+    if (s < na) { const int n = inv_start[s + 1] - inv_start[s]; c = n > VT ? (n - 1) / VT : 0; }
+    cnt[s] = c;
+}
+__global__ void k_vote_blk_fill(const int* __restrict__ inv_start, const int* __restrict__ hstart, int na, int* __restrict__ blk_s, int* __restrict__ blk_pos) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= na) return;
+    const int b0 = hstart[s], nb = hstart[s + 1] - b0, p0 = inv_start[s];
+    for (int k = 0; k < nb; ++k) { blk_s[b0 + k] = s; blk_pos[b0 + k] = p0 + (k + 1) * VT; }
+}
+struct VoteHubBufs {
+    DevBuf<int> cnt, hstart, blk_s, blk_pos, CNT, IB; DevBuf<float> P, PW;
+    VoteHubBufs(nct_ctx* c, int nb, int na, int C) : cnt(c, (size_t)na + 1), hstart(c, (size_t)na + 1), blk_s(c, (size_t)nb / VT + 1), blk_pos(c, (size_t)nb / VT + 1),
+        CNT(c, ((size_t)nb / VT + 1) * 9), IB(c, ((size_t)nb / VT + 1) * 27), P(c, ((size_t)nb / VT + 1) * 9 * C), PW(c, ((size_t)nb / VT + 1) * 9) {}
+    bool ok() const { return cnt.ok() && hstart.ok() && blk_s.ok() && blk_pos.ok() && CNT.ok() && IB.ok() && P.ok() && PW.ok(); }
+    VoteHub view() const { return VoteHub{hstart, blk_s, blk_pos, P, PW, CNT, IB}; }
+};
+
 static int launch_vote_features(nct_ctx* ctx, hipStream_t s, const InvMap& inv, const uint32_t* ann, const float* pin_hwc, float* pout_hwc, float* pw,
                                 int C, int ah, int aw, int bh, int bw, float w_coh, float w_comp, const uint8_t* b_img = nullptr, uint8_t* out_img = nullptr) {
     const double wa = w_coh / (double)(aw * ah);
     const double wb = w_comp / (double)(bw * bh);
-    dim3 grid(cdiv(ah * aw, 16)), block(256);
-#define NCT_VOTE_LAUNCH(N) hipLaunchKernelGGL(k_vote_features<N>, grid, block, 0, s, ann, (const uint32_t*)inv.vals_s, (const int*)inv.start, \
-                                              pin_hwc, pout_hwc, pw, C, ah, aw, bh, bw, wa, wb, b_img, out_img)
+    const int na = ah * aw, nb = bh * bw;
+    VoteHubBufs hb(ctx, nb, na, C);
+    if (!hb.ok()) return NCT_ERR_HIP;
+    hipLaunchKernelGGL(k_vote_blk_counts, dim3(cdiv(na + 1, 256)), dim3(256), 0, s, (const int*)inv.start, na, (int*)hb.cnt); NCT_LAUNCH_CHECK();
+    size_t scan_bytes = 0;
+    NCT_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (const int*)hb.cnt, (int*)hb.hstart, 0, (size_t)na + 1, rocprim::plus<int>(), s));
+    DevBuf<char> tmp(ctx, scan_bytes + 16);
+    if (!tmp.ok()) return NCT_ERR_HIP;
+    NCT_HIP(rocprim::exclusive_scan((void*)(char*)tmp, scan_bytes, (const int*)hb.cnt, (int*)hb.hstart, 0, (size_t)na + 1, rocprim::plus<int>(), s));
+    hipLaunchKernelGGL(k_vote_blk_fill, dim3(cdiv(na, 256)), dim3(256), 0, s, (const int*)inv.start, (const int*)hb.hstart, na, (int*)hb.blk_s, (int*)hb.blk_pos); NCT_LAUNCH_CHECK();
+    const VoteHub H = hb.view();
+    // the hub pass: the number of further blocks is known on the device only; a fixed grid walks them with a stride and exits at once where there are none
+    int hub_grid = cdiv((nb / VT + 1) * 9, 16); if (hub_grid > 2048) hub_grid = 2048;
+    dim3 grid(cdiv(na, 16)), block(256);
+#define NCT_VOTE_LAUNCH(N) do { \
+        hipLaunchKernelGGL(k_vote_hub<N>, dim3(hub_grid), block, 0, s, (const uint32_t*)inv.vals_s, (const int*)inv.start, pin_hwc, H, C, na, bh, bw, wb, b_img); \
+        hipLaunchKernelGGL(k_vote_features<N>, grid, block, 0, s, ann, (const uint32_t*)inv.vals_s, (const int*)inv.start, pin_hwc, pout_hwc, pw, H, C, ah, aw, bh, bw, wa, wb, b_img, out_img); } while (0)
     switch (C) {
         case 64: NCT_VOTE_LAUNCH(1); break;
         case 128: NCT_VOTE_LAUNCH(2); break;

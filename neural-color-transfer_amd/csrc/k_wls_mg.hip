@@ -1210,7 +1210,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             if ((l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
         }
         B.hst = (PState*)ctx->pinned + 2 * h; B.ev[0] = ctx->ev_poll[2 * h]; B.ev[1] = ctx->ev_poll[2 * h + 1];
-        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph; B.forecast = ctx->wls_forecast != 0; B.trace = getenv("NCT_WLS_TRACE") != nullptr; B.rough = rough; B.kt = (ctx->kt_on && !split) ? ctx : nullptr;
+        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph; B.forecast = ctx->wls_forecast != 0; B.trace = getenv("NCT_WLS_TRACE") != nullptr; B.rough = rough; B.kt = (ctx->kt_on && !split && !ctx->wls_graph) ? ctx : nullptr;   /* events recorded inside a stream capture cannot be read back: no kernel clock under NCT_WLS_GRAPH */
         memset(B.iters, 0, sizeof B.iters);
     }
     if (!split) {

@@ -103,10 +103,20 @@ int nct_create(int device, nct_ctx** out) {
     if (const char* r = getenv("NCT_WLS_RTOL")) { const double v = atof(r); if (v > 0 && v < 1) c->wls_rtol = v; }
     if (const char* f = getenv("NCT_CONV_POOL_FUSE")) { const int v = atoi(f); if (v == 0 || v == 1) c->conv_pool_fuse = v; }
     if (const char* q = getenv("NCT_CONV_PAIR")) { const int v = atoi(q); if (v == 0 || v == 1) c->conv_pair = v; }
-    if (const char* q = getenv("NCT_S1_PERSIST")) { const int v = atoi(q); if (v >= 0 && v <= 2) c->s1_persist = v; }   // 2: test hook, the first persistent launch reports a stall
+    if (const char* q = getenv("NCT_S1_HUB_HINT")) { const int v = atoi(q); if (v == 0 || v == 1) c->s1_hub_hint = v; }
     if (const char* m = getenv("NCT_WLS_MAXIT")) { const int v = atoi(m); if (v > 0) c->wls_maxit = v; }
     *out = c;
     return NCT_OK;
+}
+
+int nct_ctx_counter(nct_ctx* ctx, int which, int64_t* out) {
+    if (!ctx || !out) return NCT_ERR_INVALID;
+    switch (which) {
+        case NCT_CTR_ARENA_BYTES: *out = (int64_t)ctx->bytes_allocated; return NCT_OK;
+        case NCT_CTR_S1_HUB_BLOCKS_L0: case NCT_CTR_S1_HUB_BLOCKS_L0 + 1: case NCT_CTR_S1_HUB_BLOCKS_L0 + 2: case NCT_CTR_S1_HUB_BLOCKS_L0 + 3: case NCT_CTR_S1_HUB_BLOCKS_L0 + 4:
+            *out = ctx->s1_hub_blocks_last[which - NCT_CTR_S1_HUB_BLOCKS_L0]; return NCT_OK;
+    }
+    return ctx->fail(NCT_ERR_INVALID, "nct_ctx_counter: unknown counter %d", which);
 }
 
 int nct_device_count(int* count) {

@@ -19,7 +19,7 @@ struct nct_ctx {
     hipEvent_t ev_poll[4] = {nullptr, nullptr, nullptr, nullptr};   // completion of the in-flight solver-state read-backs (k_wls_mg.hip: two per half-solve)
     hipStream_t stream_wls = nullptr;  // helper stream of the split WLS solve (NCT_FLAG_LATENCY)
     hipEvent_t ev_wls_fork = nullptr, ev_wls_join = nullptr;
-    void* pinned = nullptr;                        // 4 KB of page-locked host memory for those read-backs (+ 64 B: s1_stall_flag)
+    void* pinned = nullptr;                        // 4 KB of page-locked host memory for those read-backs (+ 64 B: s1_hub_blocks)
     std::string err;
     std::vector<nct_block> blocks;    // cached device allocations, reused across calls and pairs
     size_t bytes_allocated = 0;
@@ -48,9 +48,9 @@ struct nct_ctx {
     int mark(hipStream_t s, int tag);           // nct_api.cpp; no-op unless tm_on
     // kernel clock (NCT_FLAG_TIME_KERNELS): event pairs around single launches of the full-resolution colour-solver kernels; sample i = events 2i, 2i+1, id kt_ids[i]
     int conv_pair = 1;                          // conv5_1 of the source and the reference in one launch (k_vgg.hip: nctk_conv3x3_pair); NCT_CONV_PAIR=0: two launches
-    int s1_persist = 1;                         // S1 at the small levels as one persistent launch (k_colorsolve.hip: k_s1_cg_persist); NCT_S1_PERSIST=0: the three-kernel form
-    int s1_stalls = 0;                          // times the persistent launch gave up at a grid barrier (the level was then repeated with per-iteration launches)
-    int* s1_stall_flag() { return (int*)((char*)pinned + 4096); }   // its read-back word, behind the WLS solver's 4 KB
+    int* s1_hub_blocks() { return (int*)((char*)pinned + 4096); }   // [5] hub block count of each pyramid level's kNN graph (k_s1.hip), written by the side stream behind the WLS solver's 4 KB
+    long long s1_hub_blocks_last[5] = {0, 0, 0, 0, 0};            // the counts the last pair's solves were launched with (-1: not known when the solve was enqueued); nct_ctx_counter
+    int s1_hub_hint = 1;                        // use the host-side hub block counts (NCT_S1_HUB_HINT=0: always launch the hub pass — the conservative path, for tests)
     bool kt_on = false;
     std::vector<hipEvent_t> kt_events; std::vector<int> kt_ids;
     int kt_begin(hipStream_t s, int id);        // nct_api.cpp; no-ops unless kt_on
@@ -121,12 +121,38 @@ int nct_stage_tag_nonlocal(); int nct_stage_tag_wls(); int nct_stage_tag_color()
 int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat_hwc_norm, int n, int C, int K, int iters, uint64_t seed, int* labels, int* nlabels_dev);
 int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, int w, const int* labels, int lh, int lw, int nlabels, const int* nlabels_dev /*nullable: overrides nlabels*/, int samples,
                    int* knn_id, double* knn_w);
+// k_s1.hip — S1, the nonlocal truncated CG. The graph-only part of its system depends on the level's kNN graph alone and is built once per level (in the pipeline: on the
+// side stream, right behind the graph); nseg_hint is what the HOST knows about the number of hub blocks when it enqueues the solve (-1: nothing, the hub pass is launched anyway)
+#define NCT_S1_SEG 64                        // in-edges of a pixel summed one by one; every further block of this many is summed by a tree in the hub pass
+struct nct_s1_graph {
+    int n;
+    double* iw2;                             // [n][8] squared nonlocal weight of every out-edge
+    unsigned long long* starts;              // [n + 1] low half: start of the pixel's first block (<= 64 in-edges) in c_src / c_w; high half: index of its first hub block
+    int* c_src; double* c_w;                 // compact arrays of the first blocks
+    int* rev_start;                          // [n + 1] start of the pixel's in-edges in the target-sorted edge list
+    int* rev_src; double* rev_w;             // that list by position (only entries behind a first block are written and read)
+    int* seg_tgt; int* seg_e0;               // hub block table: target pixel, position of the block's first edge
+    double* hub_part;                        // [blocks][6] block sums of the current operator pass
+    int nseg_hint;
+};
+struct nct_s1_graph_bufs {
+    int n;
+    DevBuf<double> iw2, c_w, rev_w, hub_part; DevBuf<unsigned long long> starts; DevBuf<int> c_src, rev_start, rev_src, seg_tgt, seg_e0;
+    nct_s1_graph_bufs(nct_ctx* c, int n_) : n(n_), iw2(c, (size_t)8 * n_), c_w(c, (size_t)8 * n_), rev_w(c, (size_t)8 * n_), hub_part(c, ((size_t)n_ / 8 + 1) * 6), starts(c, (size_t)n_ + 1),
+                                            c_src(c, (size_t)8 * n_), rev_start(c, (size_t)n_ + 1), rev_src(c, (size_t)8 * n_), seg_tgt(c, (size_t)n_ / 8 + 1), seg_e0(c, (size_t)n_ / 8 + 1) {}
+    bool ok() const { return iw2.ok() && c_w.ok() && rev_w.ok() && hub_part.ok() && starts.ok() && c_src.ok() && rev_start.ok() && rev_src.ok() && seg_tgt.ok() && seg_e0.ok(); }
+    nct_s1_graph view(int hint) const { return nct_s1_graph{n, iw2, starts, c_src, c_w, rev_start, rev_src, rev_w, seg_tgt, seg_e0, hub_part, hint}; }
+};
+int nctk_s1_graph_build(nct_ctx* ctx, hipStream_t s, const int* knn_id, const double* knn_w, double nonlocalWeight, const nct_s1_graph& g, int* nseg_pinned /*nullable*/);
+int nctk_s1_solve(nct_ctx* ctx, hipStream_t s, const nct_s1_graph& g, const int* knn_id, const double* weight, float dWeight, const uint8_t* s_lab_level,
+                  const uint8_t* g_lab_level, const double* gx, const double* gy, int layer, int h, int w, double* x, int* cg_iters_host);
 // k_colorsolve.hip
 struct nct_color_params { double eps, nonlocal_weight, local_weight, wls_lambda_init, wls_alpha, k_num; };
 struct nct_color_debug { double *ab_local, *ab_nonlocal, *ab_up, *rough, *ab_wls; int* cg_iters; int* wls_iters; };   // host pointers, all nullable
 int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, const uint8_t* s_lab_level, const uint8_t* g_lab_level,
                               const uint8_t* s_lab_full, const int* knn_id, const double* knn_w, int layer, int h, int w, int H, int W,
-                              const nct_color_params& prm, uint8_t* out_lab_full, const nct_color_debug* dbg);
+                              const nct_color_params& prm, uint8_t* out_lab_full, const nct_color_debug* dbg,
+                              const nct_s1_graph* graph = nullptr /* the level's prebuilt graph part of S1; null: built inside, on s */);
 // k_wls_mg.hip
 int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* rough, const double* wx, const double* wy, int H, int W,
                       double rtol, int* iters_out);

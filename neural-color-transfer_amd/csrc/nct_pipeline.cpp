@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstring>
 #include <algorithm>
+#include <cmath>
 
 struct pair_state {
     uint8_t *src = nullptr, *ref = nullptr, *out = nullptr;    // device BGR images
@@ -150,9 +151,10 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     std::vector<DevBuf<uint8_t>*> slab(5, nullptr);
     std::vector<DevBuf<int>*> knn_ids(5, nullptr);
     std::vector<DevBuf<double>*> knn_ws(5, nullptr);
-    struct Cleanup3 { std::vector<DevBuf<uint8_t>*>& a; std::vector<DevBuf<int>*>& b; std::vector<DevBuf<double>*>& c; nct_ctx* ctx;
+    std::vector<nct_s1_graph_bufs*> s1g(5, nullptr);       // the graph-only part of S1's system (reverse adjacency, hub block table: k_s1.hip), built behind each graph
+    struct Cleanup3 { std::vector<DevBuf<uint8_t>*>& a; std::vector<DevBuf<int>*>& b; std::vector<DevBuf<double>*>& c; std::vector<nct_s1_graph_bufs*>& d; nct_ctx* ctx;
                       ~Cleanup3() { (void)hipStreamSynchronize(ctx->stream2); ctx->defer_release = false; ctx->flush_deferred();
-                                    for (auto* p : a) delete p; for (auto* p : b) delete p; for (auto* p : c) delete p; } } cleanup3{slab, knn_ids, knn_ws, ctx};
+                                    for (auto* p : a) delete p; for (auto* p : b) delete p; for (auto* p : c) delete p; for (auto* p : d) delete p; } } cleanup3{slab, knn_ids, knn_ws, s1g, ctx};
     // enqueued from inside the level loop, AFTER the coarsest level's correspondence work has been submitted: the side stream's ~200
     // small packets would otherwise sit in front of the main stream's and the main stream starts the level loop ~2.6 ms late
     auto enqueue_knn = [&]() -> int {
@@ -164,13 +166,17 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         for (int l = 0; l < nlevels; ++l) {
             const size_t npx = (size_t)ah[l] * aw[l];
             slab[l] = new DevBuf<uint8_t>(ctx, npx * 3); knn_ids[l] = new DevBuf<int>(ctx, npx * 8); knn_ws[l] = new DevBuf<double>(ctx, npx * 8);
-            if (!slab[l]->ok() || !knn_ids[l]->ok() || !knn_ws[l]->ok()) return NCT_ERR_HIP;
+            s1g[l] = new nct_s1_graph_bufs(ctx, (int)npx);
+            if (!slab[l]->ok() || !knn_ids[l]->ok() || !knn_ws[l]->ok() || !s1g[l]->ok()) return NCT_ERR_HIP;
         }
         int rc2 = 0;
         ctx->defer_release = true;
         for (int l = 0; l < nlevels && rc2 == 0; ++l) {      // only the levels that run (nct_params.levels)
             rc2 = nctk_bgr2lab(ctx, s2, simg[l], *slab[l], (size_t)ah[l] * aw[l]);
             if (rc2 == 0) rc2 = nctk_knn_graph(ctx, s2, *slab[l], ah[l], aw[l], labels, ah[0], aw[0], 0, nlab_dev, 1 << l, *knn_ids[l], *knn_ws[l]);
+            // S1's reverse adjacency and hub block table depend on the graph alone: built here, off the main stream; the block count lands in page-locked memory
+            // before ev_level[l] completes, so the host can size (or skip) the level's hub passes without a synchronisation
+            if (rc2 == 0) rc2 = nctk_s1_graph_build(ctx, s2, *knn_ids[l], *knn_ws[l], sqrt(prm->nonlocal_weight / (double)prm->k_num), s1g[l]->view(-1), ctx->s1_hub_blocks() + l);
             if (rc2 == 0 && hipEventRecord(ctx->ev_level[l], s2) != hipSuccess) rc2 = ctx->fail(NCT_ERR_HIP, "hipEventRecord failed");
         }
         ctx->defer_release = false;
@@ -248,7 +254,14 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         dbg.wls_iters = wls_it;
         const nct_color_stages* cs = lv ? lv->color[l] : nullptr;
         if (cs) { dbg.ab_local = cs->ab_local; dbg.ab_nonlocal = cs->ab_nonlocal; dbg.ab_up = cs->ab_up; dbg.rough = cs->roughness; dbg.ab_wls = cs->ab_wls; dbg.cg_iters = cs->cg_iters; }
-        rc = nctk_local_color_transfer(ctx, s, err, s_lab_l, g_lab_l, s_lab_full, knn_id, knn_w, l, ah[l], aw[l], H, W, cp, out_lab, (timing || cs) ? &dbg : nullptr); if (rc) return rc;
+        // what the host knows about level l's hub blocks right now: the count, if the side stream has passed ev_level[l] (always, from the second level on: the host
+        // has just waited for the previous level's WLS solve); else -1 and the hub pass is launched on the device-side count. The result does not depend on it.
+        int hub_hint = -1;
+        if (ctx->s1_hub_hint && hipEventQuery(ctx->ev_level[l]) == hipSuccess) hub_hint = *(volatile int*)(ctx->s1_hub_blocks() + l);
+        (void)hipGetLastError();                                     // hipEventQuery's hipErrorNotReady is not an error
+        ctx->s1_hub_blocks_last[l] = hub_hint;
+        const nct_s1_graph s1graph = s1g[l]->view(hub_hint);
+        rc = nctk_local_color_transfer(ctx, s, err, s_lab_l, g_lab_l, s_lab_full, knn_id, knn_w, l, ah[l], aw[l], H, W, cp, out_lab, (timing || cs) ? &dbg : nullptr, &s1graph); if (rc) return rc;
         if (cs && cs->wls_iters) for (int q = 0; q < 6; ++q) cs->wls_iters[q] = wls_it[q];
         rc = nctk_lab2bgr(ctx, s, out_lab, P->out, N, (prm->flags & NCT_FLAG_LAB2BGR_CUBE) ? 1 : 0); if (rc) return rc;
         if (timing) { timing->wls_iters[l] = *std::max_element(wls_it, wls_it + 6); }

@@ -327,19 +327,21 @@ struct Pipeline {
     size_t cap = 4, total = 0, next_load = 0, loading = 0, finished = 0;
     // decoded pixels waiting for a GPU worker: images are queued BEFORE the GPU-side shrink to MAX_SIZE and a decoder accepts up to 64 MP (192 MB), so the queue is
     // bounded by bytes as well as by count — a new load starts only while the decoded backlog is below byte_cap (or nothing at all is queued or loading)
-    size_t ready_bytes = 0, byte_cap = (size_t)1 << 30;
-    bool may_load() const { return next_load < total && ready.size() + loading < cap && (ready_bytes < byte_cap || ready.size() + loading == 0); }
+    // Loads in flight are charged too: a load reserves `load_estimate` bytes when it starts — the largest decoded pair seen so far, at least two 1000 x 1000
+    // images — and is corrected to its real size when it lands in `ready`, so several I/O threads cannot all pass the test while the backlog is still being decoded.
+    size_t ready_bytes = 0, byte_cap = (size_t)1 << 30, loading_bytes = 0, load_estimate = (size_t)6 << 20;
+    bool may_load() const { return next_load < total && ready.size() + loading < cap && (ready_bytes + loading_bytes < byte_cap || ready.size() + loading == 0); }
     bool loads_done() const { return next_load >= total && loading == 0; }
 };
 
 void io_thread(Pipeline& P, const Config& cfg, const std::vector<Pair>& pairs) {
     for (;;) {
-        std::unique_ptr<Job> j; bool store = false; size_t idx = 0;
+        std::unique_ptr<Job> j; bool store = false; size_t idx = 0, reserved = 0;
         {
             std::unique_lock<std::mutex> lk(P.m);
             P.cv.wait(lk, [&] { return !P.results.empty() || P.may_load() || P.finished == P.total; });
             if (!P.results.empty()) { j = std::move(P.results.front()); P.results.pop_front(); store = true; }       // encoding first: it frees memory and unblocks workers
-            else if (P.may_load()) { idx = P.next_load++; ++P.loading; }
+            else if (P.may_load()) { idx = P.next_load++; ++P.loading; reserved = P.load_estimate; P.loading_bytes += reserved; }
             else return;                                                                                                 // finished == total
         }
         P.cv.notify_all();
@@ -352,8 +354,12 @@ void io_thread(Pipeline& P, const Config& cfg, const std::vector<Pair>& pairs) {
             const bool go = j->state == Job::LOADED;
             if (!go) finish(cfg, *j);
             std::lock_guard<std::mutex> lk(P.m);
-            --P.loading;
-            if (go) { P.ready_bytes += j->cnt.px.size() + j->stl.px.size(); P.ready.push_back(std::move(j)); } else ++P.finished;
+            --P.loading; P.loading_bytes -= reserved;
+            if (go) {
+                const size_t b = j->cnt.px.size() + j->stl.px.size();
+                P.ready_bytes += b; P.load_estimate = std::max(P.load_estimate, b);
+                P.ready.push_back(std::move(j));
+            } else ++P.finished;
         }
         P.cv.notify_all();
     }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "nct_destroy": (None, [C.c_void_p]),
     "nct_last_error": (C.c_char_p, [C.c_void_p]),
     "nct_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "nct_ctx_counter": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "nct_synchronize": (C.c_int, [C.c_void_p]),
     "nct_feat_normalize": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "nct_nnf_init": (C.c_int, [C.c_void_p, _u32p, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -148,6 +149,7 @@ class PairTiming(C.Structure):
         return d
 
 
+CTR_ARENA_BYTES, CTR_S1_HUB_BLOCKS_L0 = 0, 1
 FLAG_FEAT16 = 1
 FLAG_COUNT_EVALS = 2
 FLAG_LATENCY = 4
@@ -230,6 +232,12 @@ class Context:
         buf = C.create_string_buffer(256)
         self._chk(self._l.nct_device_name(self._h, buf, 256))
         return buf.value.decode()
+
+    def counter(self, which):
+        """nct_ctx_counter: CTR_ARENA_BYTES, CTR_S1_HUB_BLOCKS_L0 + level"""
+        v = C.c_int64(0)
+        self._chk(self._l.nct_ctx_counter(self._h, which, C.byref(v)))
+        return v.value
 
     def synchronize(self):
         self._chk(self._l.nct_synchronize(self._h))

@@ -44,7 +44,19 @@ static void canon_sum(const double* v, int n, int nq, double* out) {
     free(partial);
 }
 
-/* ================================================================= S1 */
+/* ================================================================= S1 (canonical order v2, round 5)
+ * Two things changed against rounds 1-4, both in the part of the arithmetic that is this project's own specification (cuSPARSE / cuBLAS hide the reference's
+ * summation orders):
+ *  (1) the recurrence is the SINGLE-REDUCTION form of the same CG (Chronopoulos & Gear 1989): w = Op(r) and both dot products gamma = r.r, delta = w.r in one
+ *      pass, then p = r + beta p, s = w + beta s (= Op(p) by linearity), x += alpha p, r -= alpha s in one pass — the same iterates as SparseSolver_GPU.cu:132-159
+ *      in exact arithmetic (alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1})), the same caps (ColorTransfer.cpp:916-921), the same start;
+ *  (2) LONG in-edge lists. Natural photographs hold groups of 10^4 pixels of ONE colour; findSubKNNs breaks the distance ties by id, so the group's lowest ids
+ *      become kNN hubs with in-degrees up to the group size (demo/example/in/in1.png: 33 335; tests/synth.py: 37). A sequential sum over such a list is a
+ *      33 335-step dependent chain per operator application. The order is therefore: the FIRST ORC_S1_SEG (64) in-edges of a pixel are added one by one in
+ *      ascending edge id, as before; every further block of 64 in-edges (ascending edge id, relative to the list's start) is first summed by a 64-leaf halving
+ *      tree (missing leaves = +0) and the block sums are added in ascending block order. Lists of <= 64 entries — every pixel of the synthetic pairs — are summed
+ *      exactly as in rounds 1-4. */
+#define ORC_S1_SEG 64
 typedef struct {
     int n, h, w;
     double *daa, *dab, *dbb, *gx, *gy, *iw2;
@@ -69,8 +81,22 @@ static void s1_op(const s1sys_t* S, const double* p, int i, double* ya, double* 
     if (y + 1 < h) { const double g = S->gy[i]; EDGE(i + w, 2.0 * (g * g)); }
     if (y > 0) { const double g = S->gy[i - w]; EDGE(i - w, 2.0 * (g * g)); }
     for (int k = 0; k < 8; ++k) EDGE(S->knn_id[(size_t)i * 8 + k], S->iw2[(size_t)i * 8 + k]);
-    for (int e = S->rev_start[i]; e < S->rev_start[i + 1]; ++e) { const unsigned ed = S->rev_edge[e]; EDGE((int)(ed >> 3), S->iw2[ed]); }
+    const int e0 = S->rev_start[i], e1 = S->rev_start[i + 1];
+    for (int e = e0; e < e1 && e < e0 + ORC_S1_SEG; ++e) { const unsigned ed = S->rev_edge[e]; EDGE((int)(ed >> 3), S->iw2[ed]); }
 #undef EDGE
+    for (int b0 = e0 + ORC_S1_SEG; b0 < e1; b0 += ORC_S1_SEG) {          /* further blocks of 64: tree sum, then one addition per block */
+        double leaf[6][ORC_S1_SEG];
+        for (int t = 0; t < ORC_S1_SEG; ++t) {
+            const int e = b0 + t;
+            if (e < e1) {
+                const unsigned ed = S->rev_edge[e]; const int j = (int)(ed >> 3); const double wt = S->iw2[ed];
+                for (int c = 0; c < 3; ++c) { leaf[c][t] = wt * (a[c] - pa[(size_t)j * 3 + c]); leaf[3 + c][t] = wt * (b[c] - pb[(size_t)j * 3 + c]); }
+            } else for (int c = 0; c < 6; ++c) leaf[c][t] = 0.0;
+        }
+        for (int c = 0; c < 6; ++c)
+            for (int off = ORC_S1_SEG / 2; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) leaf[c][t] += leaf[c][t + off];
+        for (int c = 0; c < 3; ++c) { ya[c] += leaf[c][0]; yb[c] += leaf[3 + c][0]; }
+    }
 }
 
 /* a,b: [n][3] in/out; src/ref: level Lab/255 [n][3]; k must be 8. */
@@ -104,15 +130,15 @@ void orc_nonlocal_solve(double* a, double* b, const double* src, const double* r
       free(cur); }
 
     double* x = (double*)malloc(sizeof(double) * 6 * n); double* r = (double*)malloc(sizeof(double) * 6 * n);
-    double* p = (double*)calloc(6 * (size_t)n, sizeof(double)); double* Ap = (double*)malloc(sizeof(double) * 6 * n);
-    double* acc = (double*)malloc(sizeof(double) * 3 * n);
+    double* p = (double*)calloc(6 * (size_t)n, sizeof(double)); double* sv = (double*)calloc(6 * (size_t)n, sizeof(double)); double* wv = (double*)malloc(sizeof(double) * 6 * n);
+    double* acc = (double*)malloc(sizeof(double) * 6 * n);
     memcpy(x, a, sizeof(double) * 3 * n); memcpy(x + (size_t)3 * n, b, sizeof(double) * 3 * n);
     const double tol2 = 1e-6 * 1e-6;
     const int maxit = maxit_override > 0 ? maxit_override : (layer == 4 ? 50 : 100);
-    double r0[3] = {0, 0, 0}, r1[3], va[3] = {0, 0, 0}, vb[3] = {0, 0, 0}, s[3];
+    double gm[3], al[3] = {0, 0, 0}, be[3] = {0, 0, 0}, s[6];
     int active[3], iters[3] = {0, 0, 0};
-    /* r = rhs - Op(x0) */
-#pragma omp parallel for schedule(static)
+    /* r = rhs - Op(x0); gamma = r.r */
+#pragma omp parallel for schedule(dynamic, 64)
     for (int i = 0; i < n; ++i) {
         double ya[3], yb[3]; s1_op(&S, x, i, ya, yb);
         for (int c = 0; c < 3; ++c) {
@@ -121,38 +147,49 @@ void orc_nonlocal_solve(double* a, double* b, const double* src, const double* r
         }
     }
     canon_sum(acc, n, 3, s);
-    for (int c = 0; c < 3; ++c) { r1[c] = s[c]; active[c] = s[c] > tol2; }
-    for (int kk = 1; kk <= maxit; ++kk) {
-        for (size_t j = 0; j < (size_t)6 * n; ++j) { const int c = (int)(j % 3); if (active[c]) p[j] = (kk == 1) ? r[j] : vb[c] * p[j] + r[j]; }
-#pragma omp parallel for schedule(static)
+    for (int c = 0; c < 3; ++c) { gm[c] = s[c]; active[c] = s[c] > tol2; }
+    for (int kk = 0; kk <= maxit; ++kk) {
+        /* vector pass of iteration kk (none before the first operator pass): p = r + beta p, s = w + beta s, x += alpha p, r -= alpha s */
+        if (kk >= 1) {
+            for (size_t j = 0; j < (size_t)6 * n; ++j) {
+                const int c = (int)(j % 3);
+                if (!active[c]) continue;
+                const double pn = (kk == 1) ? r[j] : be[c] * p[j] + r[j];
+                const double sn = (kk == 1) ? wv[j] : be[c] * sv[j] + wv[j];
+                p[j] = pn; sv[j] = sn;
+                x[j] = x[j] + al[c] * pn;
+                r[j] = r[j] - al[c] * sn;
+            }
+            for (int c = 0; c < 3; ++c) if (active[c]) iters[c]++;
+            if (kk == maxit) break;
+        }
+        /* operator pass: w = Op(r), gamma' = r.r, delta' = w.r */
+#pragma omp parallel for schedule(dynamic, 64)
         for (int i = 0; i < n; ++i) {
-            double ya[3], yb[3]; s1_op(&S, p, i, ya, yb);
+            double ya[3], yb[3]; s1_op(&S, r, i, ya, yb);
             for (int c = 0; c < 3; ++c) {
-                Ap[(size_t)i * 3 + c] = ya[c]; Ap[(size_t)(n + i) * 3 + c] = yb[c];
-                acc[(size_t)i * 3 + c] = p[(size_t)i * 3 + c] * ya[c] + p[(size_t)(n + i) * 3 + c] * yb[c];
+                const double ra = r[(size_t)i * 3 + c], rb = r[(size_t)(n + i) * 3 + c];
+                wv[(size_t)i * 3 + c] = ya[c]; wv[(size_t)(n + i) * 3 + c] = yb[c];
+                acc[(size_t)i * 6 + c] = ra * ra + rb * rb;
+                acc[(size_t)i * 6 + 3 + c] = ra * ya[c] + rb * yb[c];
             }
         }
-        canon_sum(acc, n, 3, s);
-        for (int c = 0; c < 3; ++c) if (active[c]) va[c] = r1[c] / s[c];
-        for (int i = 0; i < n; ++i)
-            for (int c = 0; c < 3; ++c) {
-                double t = 0.0;
-                if (active[c])
-                    for (int part = 0; part < 2; ++part) {
-                        const size_t j = ((size_t)part * n + i) * 3 + c;
-                        x[j] += va[c] * p[j];
-                        const double rn = r[j] - va[c] * Ap[j];
-                        r[j] = rn; t += rn * rn;
-                    }
-                acc[(size_t)i * 3 + c] = t;
+        canon_sum(acc, n, 6, s);
+        for (int c = 0; c < 3; ++c) {
+            if (!active[c]) continue;
+            if (kk == 0) { be[c] = 0.0; al[c] = gm[c] / s[3 + c]; }             /* gamma_0 from the residual pass (the same sum: s[c] == gm[c]) */
+            else {
+                const double g1 = s[c];
+                be[c] = g1 / gm[c];
+                al[c] = g1 / (s[3 + c] - (be[c] * g1) / al[c]);
+                gm[c] = g1;
+                active[c] = g1 > tol2;
             }
-        canon_sum(acc, n, 3, s);
-        for (int c = 0; c < 3; ++c)
-            if (active[c]) { r0[c] = r1[c]; r1[c] = s[c]; vb[c] = s[c] / r0[c]; iters[c]++; active[c] = s[c] > tol2; }
+        }
     }
     if (iters_out) memcpy(iters_out, iters, sizeof iters);
     memcpy(a, x, sizeof(double) * 3 * n); memcpy(b, x + (size_t)3 * n, sizeof(double) * 3 * n);
-    free(x); free(r); free(p); free(Ap); free(acc); free(rhs);
+    free(x); free(r); free(p); free(sv); free(wv); free(acc); free(rhs);
     free(S.gx); free(S.gy); free(S.daa); free(S.dab); free(S.dbb); free(S.iw2); free(S.rev_start); free(S.rev_edge);
 }
 

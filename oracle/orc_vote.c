@@ -8,13 +8,17 @@
  *
  * Divergences:
  *  - vote_weight is zeroed first (the reference does `pw[aid] += wa` on an uninitialised cudaMalloc, main.cu:299).
- *  - the completeness scatter's atomic order is nondeterministic in the reference; here contributions are added
- *    in ascending source-pixel order (by*bw+bx), taps in the kernel's own loop order (dx outer, dy inner),
- *    AFTER all coherence contributions (kernel a completes before kernel b starts).
+ *  - the completeness scatter's atomic order is nondeterministic in the reference; any fixed order is one of its legal realisations. Canonical order v2 (round 5; rounds
+ *    1-4 added in ascending source pixel across all taps): AFTER all coherence contributions (kernel a completes before kernel b starts), TAP-MAJOR: for the nine
+ *    taps in the kernel's own loop order (dx outer, dy inner), the sources whose match is the tapped neighbour s = target - tap, in ascending source pixel. A list of
+ *    more than ORC_VOTE_SEG (64) sources — natural photographs collapse 10^4 pixels of a flat region onto one match (demo/example/in/in4.png: 47 535 sources on one
+ *    target), a 47 535-step chain of float adds — is added in blocks: its first 64 sources one by one into the target's sums, every further block of 64 (ascending,
+ *    relative to the list's start) summed from zero in the same way and then added as ONE addend, in block order. pw follows the same order.
  * Mixed precision is kept literally: `pw += wa` and `pout += pin*wa` are float += double (evaluated in double,
  * rounded to float); atomicAdd(float*, double-expression) rounds the addend to float first, then adds in float.
  */
 #include "orc_common.h"
+#define ORC_VOTE_SEG 64
 
 /* B2 — features are CHW fp32; pin = UN-normalised R features (C,bh,bw); pout = voted features (C,ah,aw). */
 void orc_bds_vote_features(const uint32_t* ann, const uint32_t* bnn, const float* pin, float* pout, float* pw_out /*nullable*/,
@@ -44,28 +48,49 @@ void orc_bds_vote_features(const uint32_t* ann, const uint32_t* bnn, const float
                     }
                 }
         }
-    /* kernel b — serial, ascending source index = the canonical atomic order */
+    /* kernel b — canonical order v2: gather form over the inverse of the R->S field (lists of sources per matched S pixel, ascending source pixel) */
     float wbf = (float)wb;
-    for (int by = 0; by < bh; ++by)
-        for (int bx = 0; bx < bw; ++bx) {
-            uint32_t vp = bnn[by * bw + bx];
-            int xp = orc_int_to_x(vp), yp = orc_int_to_y(vp);
-            for (int dx = -r; dx <= r; ++dx)
-                for (int dy = -r; dy <= r; ++dy) {
-                    int xb = bx + dx, yb = by + dy;
-                    if (xb < bw && xb >= 0 && yb < bh && yb >= 0) {
-                        int xa = xp + dx, ya = yp + dy;
-                        if (xa < aw && xa >= 0 && ya < ah && ya >= 0) {
-                            int aid = ya * aw + xa, bid = yb * bw + xb;
-                            pw[aid] = pw[aid] + wbf;
+    int* start = (int*)calloc((size_t)slice_a + 1, sizeof(int));
+    int* list = (int*)malloc(sizeof(int) * (size_t)slice_b);
+    for (int q = 0; q < slice_b; ++q) { uint32_t vp = bnn[q]; start[orc_int_to_y(vp) * aw + orc_int_to_x(vp) + 1]++; }
+    for (int s = 0; s < slice_a; ++s) start[s + 1] += start[s];
+    { int* cur = (int*)malloc(sizeof(int) * (size_t)slice_a); memcpy(cur, start, sizeof(int) * (size_t)slice_a);
+      for (int q = 0; q < slice_b; ++q) { uint32_t vp = bnn[q]; list[cur[orc_int_to_y(vp) * aw + orc_int_to_x(vp)]++] = q; }
+      free(cur); }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int aid = 0; aid < slice_a; ++aid) {
+        const int ay = aid / aw, ax = aid - ay * aw;
+        float* blk = (float*)malloc(sizeof(float) * (size_t)C);
+        for (int dx = -r; dx <= r; ++dx)
+            for (int dy = -r; dy <= r; ++dy) {
+                const int sx = ax - dx, sy = ay - dy;                   /* the matched pixel whose sources reach this target through tap (dx, dy) */
+                if (sx < 0 || sx >= aw || sy < 0 || sy >= ah) continue;
+                const int e0 = start[sy * aw + sx], e1 = start[sy * aw + sx + 1];
+                for (int b0 = e0; b0 < e1; b0 += ORC_VOTE_SEG) {
+                    const int first = b0 == e0, b1 = b0 + ORC_VOTE_SEG < e1 ? b0 + ORC_VOTE_SEG : e1;
+                    float bw_acc = 0.f;
+                    if (!first) for (int c = 0; c < C; ++c) blk[c] = 0.f;
+                    for (int e = b0; e < b1; ++e) {
+                        const int q = list[e], by = q / bw, bx = q - by * bw;
+                        const int xb = bx + dx, yb = by + dy;
+                        if (xb < bw && xb >= 0 && yb < bh && yb >= 0) {
+                            const int bid = yb * bw + xb;
+                            if (first) pw[aid] = pw[aid] + wbf; else bw_acc = bw_acc + wbf;
                             for (int c = 0; c < C; ++c) {
                                 float t = (float)(wb * (double)pin[(size_t)c * slice_b + bid]);
-                                pout[(size_t)c * slice_a + aid] = pout[(size_t)c * slice_a + aid] + t;
+                                if (first) pout[(size_t)c * slice_a + aid] = pout[(size_t)c * slice_a + aid] + t; else blk[c] = blk[c] + t;
                             }
                         }
                     }
+                    if (!first) {
+                        pw[aid] = pw[aid] + bw_acc;
+                        for (int c = 0; c < C; ++c) pout[(size_t)c * slice_a + aid] = pout[(size_t)c * slice_a + aid] + blk[c];
+                    }
                 }
-        }
+            }
+        free(blk);
+    }
+    free(start); free(list);
     /* avg_vote_bds */
 #pragma omp parallel for schedule(static)
     for (int aid = 0; aid < slice_a; ++aid)

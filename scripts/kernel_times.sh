@@ -1,6 +1,6 @@
-# per-kernel totals of ONE 700x700 pair (kernel trace, no counters), filtered by a name pattern.  usage: bash scripts/kernel_times.sh <tag> <grep pattern>
+# per-kernel totals of ONE 700x700 pair (kernel trace, no counters), filtered by a name pattern.  usage: bash scripts/kernel_times.sh <tag> <grep pattern> [size | natural case]
 out=gpurun_out/$1; mkdir -p $out; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o k -- python scripts/pair_only.py 700 2 > $out/kt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o k -- python scripts/pair_only.py ${3:-700} 2 > $out/kt.log 2>&1
 python - $out/kt/k_kernel_stats.csv "$2" <<'PY'
 import csv, sys, re
 for r in csv.DictReader(open(sys.argv[1])):

@@ -46,6 +46,19 @@ def image(seed, H, W):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def image_flat(seed, H, W):
+    """image() plus what natural photographs have and cosines + noise do not: regions of ONE colour — a flat rectangle over a quarter of the image and a posterised
+    band along the bottom (the reference's demo inputs hold groups of 10^4 identical pixels). Such groups make kNN hubs (the tie rule (distance, id) gives the group's
+    lowest ids an in-degree of the group size), many-source targets of the BDS completeness vote, and stiff WLS systems."""
+    img = image(seed, H, W).copy()
+    rng = np.random.default_rng(seed + 77)
+    y0, x0 = H // 8, W // 6
+    img[y0:y0 + H // 2, x0:x0 + W // 2] = rng.integers(30, 220, 3)
+    band = img[H - H // 4:, :]
+    band[:] = (band // 64) * 64 + 20
+    return img
+
+
 def random_nnf(seed, ah, aw, bh, bw):
     rng = np.random.default_rng(seed)
     x = rng.integers(0, bw, size=(ah, aw)).astype(np.uint32)

@@ -54,12 +54,30 @@ def test_bench_emits_contract_json():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     assert d["single_pair_ms"] > 0 and d["single_pair_ms_min"] <= d["single_pair_ms"] and d["stages_ms"]["total_ms"] > 0 and d["stages_ms"]["nonlocal_ms"] > 0
     assert "resident" in d["value_basis"]
+    assert d["rccl_ranks"] in (1, None) and (d["rccl_ranks"] == 1 or d["rccl_error"])                # default --dist-single auto: the RCCL branch ran, or the line says why not
+    import hashlib
+    so = os.path.join(REPO, "neural-color-transfer_amd", "lib", "libnct.so")
+    assert d["build_id_so"] == hashlib.sha256(open(so, "rb").read()).hexdigest()[:16] and len(d["build_id"]) == 16
     rc = d["roofline_color"]                     # colour-solver kernels: event-timed single launches vs their compulsory bytes (the WLS kernels exist at every size)
     assert rc["bound"] == "hbm" and rc["pixels"] == 128 * 128
     for k in ("wls_down", "wls_up", "wls_apply", "wls_update"):
         e = rc["kernels"][k]
         assert e["samples"] == 20 and e["avg_launch_us"] > 0 and abs(e["frac"] - e["achieved"] / rc["peak"]) < 1e-9 and e["bytes_per_launch"] == e["bytes_per_pixel"] * 128 * 128
     assert rc["wls_iteration"]["us"] > 0 and rc["wls_iteration"]["survey_8d_bytes"] == 11 * 8 * 128 * 128 * 6
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_runs_the_rccl_branch():
+    """every N > 1 test uses gloo, so the RCCL branch (init_process_group("nccl") with a device id, the device-side barrier, the MAX all-reduce of a
+    cuda tensor in nct.shard.timed_region) would first execute on the driver's 8-GPU node. `--dist-single on` runs that very branch with ONE rank (and the default
+    `auto` does the same on every 1-GPU bench run, with a fallback): rccl_ranks must be 1 and the line otherwise unchanged."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = _run("--dist-single", "on", "--size", "96", "--steps", "2", "--warmup", "1", "--inflight", "2", "--no-cpu-baseline", "--no-roofline", env=env)
+    assert d["rccl_ranks"] == 1 and d["rccl_error"] is None and d["n_gpus"] == 1
+    assert d["value"] > 0 and abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    off = _run("--dist-single", "off", "--size", "96", "--steps", "2", "--warmup", "1", "--inflight", "2", "--no-cpu-baseline", "--no-roofline", env=env)
+    assert off["rccl_ranks"] is None and off["output_checksum"] == d["output_checksum"]
+    assert 0.5 * off["value"] < d["value"] < 2.0 * off["value"]                  # a one-rank barrier costs microseconds: the rate is the same within run-to-run noise
 
 
 @pytest.mark.gpu

@@ -77,10 +77,11 @@ def test_knn_graph(ctx, oracle, case):
     assert np.allclose(gw, ow, rtol=1e-14, atol=0)
 
 
-def _level_case(seed, H, W, h, w, nlab_grid, samples, oracle):
-    s_full = synth.image(seed, H, W)
+def _level_case(seed, H, W, h, w, nlab_grid, samples, oracle, flat=False):
+    mk = synth.image_flat if flat else synth.image
+    s_full = mk(seed, H, W)
     s_lvl = oracle.resize_u8c3(s_full, h, w) if (h, w) != (H, W) else s_full
-    g_lvl = oracle.resize_u8c3(synth.image(seed + 1, H, W), h, w)
+    g_lvl = oracle.resize_u8c3(mk(seed + 1, H, W), h, w)
     lh, lw = nlab_grid
     labels = (np.arange(lh * lw).reshape(lh, lw) % 3).astype(np.int32)
     ids, ws = oracle.knn_graph(oracle.bgr2lab(s_lvl), labels, 3, samples)
@@ -90,10 +91,17 @@ def _level_case(seed, H, W, h, w, nlab_grid, samples, oracle):
 
 # the last case (136 896 pixels at the level) runs the forms the bandwidth-bound levels use: workgroup-shared in-edge gathers and unfused scalar steps in S1, 48x8 V-cycle tiles in S2,
 # 2-unit kNN cells
-@pytest.mark.parametrize("case", [(48, 48, 12, 12, (3, 3), 4, 2), (40, 56, 20, 28, (5, 7), 4, 3), (32, 32, 32, 32, (2, 2), 16, 4), (372, 368, 372, 368, (23, 23), 16, 4)])
+# "flat" cases (round 5): images with regions of one colour (synth.image_flat) — kNN hubs with in-degrees of hundreds to ten thousands, i.e. the in-edge blocks beyond a pixel's first
+# 64 that k_s1_hub sums (3 / 40 / 400 / 14 000 pixels of one colour at the level), in the fused (<= 512 workgroups) and unfused, thread-walk and shared-gather forms of the operator
+@pytest.mark.parametrize("case", [(48, 48, 12, 12, (3, 3), 4, 2), (40, 56, 20, 28, (5, 7), 4, 3), (32, 32, 32, 32, (2, 2), 16, 4), (372, 368, 372, 368, (23, 23), 16, 4),
+                                  (96, 96, 48, 48, (3, 3), 16, 3, "flat"), (160, 160, 80, 80, (5, 5), 16, 2, "flat"), (64, 64, 64, 64, (4, 4), 16, 4, "flat"), (372, 368, 372, 368, (23, 23), 16, 4, "flat")])
 def test_local_color_transfer_stages(ctx, oracle, case):
-    H, W, h, w, grid, samples, layer = case
-    err, s_lvl, g_lvl, s_full, ids, ws = _level_case(20 + layer, H, W, h, w, grid, samples, oracle)
+    H, W, h, w, grid, samples, layer = case[:7]
+    flat = len(case) > 7
+    err, s_lvl, g_lvl, s_full, ids, ws = _level_case(20 + layer, H, W, h, w, grid, samples, oracle, flat)
+    if flat:
+        deg = np.bincount(ids.reshape(-1), minlength=ids.shape[0])
+        assert deg.max() > 3 * 64, f"the flat case is meant to have in-edge lists of several blocks (max in-degree {deg.max()})"
     go, gs = ctx.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
     oo, os_ = oracle.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
     # T1: closed-form statistics — same fp64 expression order => bit exact
