@@ -116,6 +116,11 @@ def main():
             print(json.dumps(cmd)); sys.exit(0)
         sys.exit(subprocess.call(cmd))
 
+    # stdout carries ONE line, the JSON record: everything else any library writes to file descriptor 1 (RCCL prints a version banner through C stdio at exit, the
+    # ROCm runtime may print warnings) is sent to stderr for the whole run; the record goes to the saved descriptor at the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -359,10 +364,12 @@ def main():
         res["roofline_1000"] = patchmatch_roofline_1000(local_rank)
     if rank == 0 and not args.no_cpu_baseline and world == 1:               # the CPU port is timed on rank 0 of the 1-GPU run only
         res["cpu_baseline"] = cpu_baseline(synth, ws, bs, src.shape[0], full=(args.cpu_baseline_full or (os.cpu_count() or 1) >= 32) and not args.cpu_baseline_sample)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    os.close(real_stdout)
 
 
 def pmc_traffic(device, live):

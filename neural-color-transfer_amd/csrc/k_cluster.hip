@@ -18,7 +18,8 @@
 #include "nct_device.h"
 #include "nct_detmath.h"
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>   // rocPRIM directly (no CUB-compatibility layer)
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>   // rocPRIM directly (no CUB-compatibility layer)
 #include <algorithm>
 
 // ================================================================= C1: k-means
@@ -237,6 +238,10 @@ int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat, int n, in
 #ifndef NCT_KNN_LANES16_BELOW
 #define NCT_KNN_LANES16_BELOW 31000     // pixels: 44^2 .. 175^2 of a 700^2 pair search with sixteen lanes per entry (k_knn_grid16)
 #endif
+#ifndef NCT_KNN_RING_UNITS
+#define NCT_KNN_RING_UNITS 16
+#endif
+constexpr int KNN_RING_UNITS = NCT_KNN_RING_UNITS;   // Lab units of Chebyshev rings after which a search scans the rest of its cluster in one pass
 constexpr int KNN_K = 8;          // Config.h:68 m_kNum
 constexpr int KNN_SLOTS = 5;      // a pixel belongs to its own cluster + at most 4 neighbouring ones
 
@@ -266,33 +271,33 @@ __device__ __forceinline__ unsigned entry_key(int l, unsigned col, int cs) {
     const unsigned m = (1u << cs) - 1u;
     return (cell_key(l, col, cs) << (3 * cs)) | (((col >> 16) & m) << (2 * cs)) | (((col >> 8) & m) << cs) | (col & m);
 }
+// entries per pixel = clusters it belongs to; an exclusive scan gives every pixel its place, so the entries are generated in ascending pixel id and the STABLE radix sort
+// leaves the ids ascending inside every run of equal (cluster, colour) keys (rounds 1-4 reserved places with one atomic per wave: any order) — the ring search relies on
+// that order to take at most k+1 entries of a run (below)
+__global__ void k_knn_entry_counts(const unsigned* __restrict__ mask, int lw, int lh, int h, int w, int samples, int nlabels_host, const int* __restrict__ nlabels_dev, int* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > h * w) return;
+    int c = 0;
+    if (i < h * w) {
+        const int y = i / w, x = i - y * w;
+        const int cx = min(x / samples, lw - 1), cy = min(y / samples, lh - 1);
+        const int nlabels = nlabels_dev ? *nlabels_dev : nlabels_host;   // the pipeline passes the k-means result without a host round trip
+        c = __popc(mask[cy * lw + cx] & ((nlabels >= 32) ? 0xFFFFFFFFu : ((1u << nlabels) - 1u)));
+    }
+    cnt[i] = c;
+}
 __global__ void k_knn_entries(const unsigned* __restrict__ mask, const uint8_t* __restrict__ lab, int lw, int lh, int h, int w, int samples, int nlabels_host, const int* __restrict__ nlabels_dev, int cs,
-                              int* __restrict__ count, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+                              const int* __restrict__ off, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= h * w) return;
     const int y = i / w, x = i - y * w;
     const int cx = min(x / samples, lw - 1), cy = min(y / samples, lh - 1);
     const unsigned m = mask[cy * lw + cx];
     const unsigned col = (unsigned)lab[(size_t)i * 3] | ((unsigned)lab[(size_t)i * 3 + 1] << 8) | ((unsigned)lab[(size_t)i * 3 + 2] << 16);
-    const int nlabels = nlabels_dev ? *nlabels_dev : nlabels_host;   // the pipeline passes the k-means result without a host round trip
-    // ONE atomic per wave instead of one per entry (round 4: instead of one per wave and label — up to 122 k atomics on the one counter at 700x700, 389 us): the wave
-    // counts its entries over all labels first and reserves them together. The order of the entries is irrelevant: they are sorted afterwards and the search result
-    // does not depend on the order inside a cell.
-    const int lane = threadIdx.x & 63;
-    const unsigned long long active = __ballot(1);
-    const int leader = __ffsll((long long)active) - 1;
-    int tot = 0;
-    for (int l = 0; l < nlabels; ++l) tot += __popcll(__ballot((m >> l) & 1u));
-    if (tot == 0) return;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(count, tot);
-    base = __shfl(base, leader);
-    for (int l = 0; l < nlabels; ++l) {
-        const bool in = (m >> l) & 1u;
-        const unsigned long long bal = __ballot(in);
-        if (in) { const int pos = base + __popcll(bal & ((1ull << lane) - 1ull)); keys[pos] = entry_key(l, col, cs); vals[pos] = (unsigned)i; }
-        base += __popcll(bal);
-    }
+    const int nlabels = nlabels_dev ? *nlabels_dev : nlabels_host;
+    int pos = off[i];
+    for (int l = 0; l < nlabels; ++l)
+        if ((m >> l) & 1u) { keys[pos] = entry_key(l, col, cs); vals[pos] = (unsigned)i; ++pos; }
 }
 // start[k] = first sorted entry with key >= k, k in [0, nkeys]
 // lo/hi (nullable): start table of the 64x coarser cells (keys >> 6) — the search for cell k then stays inside its coarse cell's few entries. With 2-unit cells the
@@ -321,41 +326,67 @@ __device__ __forceinline__ double lab_dist(unsigned p, unsigned q) {
 // so the search stops as soon as the current (k+1)-th best squared distance is < (r*8+1)^2 (strict: ties cannot hide outside).
 // packed Lab colour of every sorted entry: the ring search then streams colours in entry order instead of gathering three bytes per
 // scanned point through the pixel id (that gather was ~3/4 of the search time: 14.1 -> 8.7 ms at 700x700)
-__global__ void k_knn_entry_colours(const uint8_t* __restrict__ lab, const int* __restrict__ count, const unsigned* __restrict__ vals, unsigned* __restrict__ cols) {
+// + in the top byte: how many entries of the entry's run start at it (capped at 255; ids ascend inside a run): the one-thread search takes at most k+1 of them and jumps
+// to the next run — a run of 9 747 identical pixels (in4.png) costs a neighbouring query 39 steps instead of 9 747
+__global__ void k_knn_entry_colours(const uint8_t* __restrict__ lab, const int* __restrict__ count, const unsigned* __restrict__ vals, const int* __restrict__ incl,
+                                    const int* __restrict__ lead, unsigned* __restrict__ cols) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= *count) return;
+    const int m = *count;
+    if (e >= m) return;
     const size_t id = vals[e];
-    cols[e] = (unsigned)lab[id * 3] | ((unsigned)lab[id * 3 + 1] << 8) | ((unsigned)lab[id * 3 + 2] << 16);
+    const int r = incl[e] - 1, nr = incl[m - 1];
+    const int rend = r + 1 < nr ? lead[r + 1] : m;
+    const int rem = rend - e;
+    cols[e] = (unsigned)lab[id * 3] | ((unsigned)lab[id * 3 + 1] << 8) | ((unsigned)lab[id * 3 + 2] << 16) | ((unsigned)(rem < 255 ? rem : 255) << 24);
 }
-__device__ __forceinline__ void knn_grid_entry(int e, const unsigned* __restrict__ cols, const unsigned* __restrict__ keys,
+// e = the sorted entry that LEADS a run of equal (cluster, colour) keys, r = the run's index: the k+1 nearest under (dist, id) are a function of the query's cluster and
+// colour alone (the query itself is an ordinary candidate; findSubKNNs drops it afterwards), so one search serves the whole run — natural photographs hold runs of 10^4
+// pixels (demo/example/in/in4.png: 17 pixels per colour on average, one colour 9 747 times), which made every member scan every other member: 44 ms for one graph.
+// The winners are stored as (pixel id, packed colour): k_knn_scatter recomputes the distance with the same lab_dist and hands every member its list minus itself.
+__device__ __forceinline__ void knn_grid_entry(int e, int r, const unsigned* __restrict__ cols, const unsigned* __restrict__ keys,
                                                const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
-                                               int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
+                                               int* __restrict__ run_id, unsigned* __restrict__ run_col) {
     const int cb = 8 - cs, CELLS = 1 << cb; const unsigned cmask = (unsigned)CELLS - 1u;
     const unsigned key = keys[e] >> (3 * cs);
     const int id = (int)vals[e];
     const int l = (int)(key >> (3 * cb));
     const int cz = (int)((key >> (2 * cb)) & cmask), cy = (int)((key >> cb) & cmask), cx = (int)(key & cmask);
-    const unsigned pc = cols[e];
-    double bd[KNN_K + 1]; int bi[KNN_K + 1]; int bq[KNN_K + 1];
+    const unsigned pc = cols[e] & 0xFFFFFFu;
+    double bd[KNN_K + 1]; int bi[KNN_K + 1]; int bq[KNN_K + 1]; unsigned bc[KNN_K + 1];
 #pragma unroll
-    for (int t = 0; t <= KNN_K; ++t) { bd[t] = 1e300; bi[t] = 0x7fffffff; bq[t] = 0x7fffffff; }
-    auto scan = [&](int b0, int b1) {
-        for (int t = b0; t < b1; ++t) {
-            const unsigned qc = cols[t];
+    for (int t = 0; t <= KNN_K; ++t) { bd[t] = 1e300; bi[t] = 0x7fffffff; bq[t] = 0x7fffffff; bc[t] = 0u; }
+    // run-wise: the entries of a run share colour and distance and their ids ascend, so the first one that does not enter the list ends the run for this query (an entry
+    // that fails on (dist, id) against the current (k+1)-th fails for every larger id as well; the (k+1)-th only improves), and at most k+1 can enter
+    // skip_r >= 0 (the fallback pass below): entries whose cell lies inside the cube of rings 0..skip_r were scanned already
+    auto scan = [&](int b0, int b1, int skip_r) {
+        for (int t = b0; t < b1;) {
+            const unsigned qw = cols[t];
+            const unsigned qc = qw & 0xFFFFFFu; const int rem = (int)(qw >> 24);
             const int e0 = (int)(pc & 255u) - (int)(qc & 255u), e1 = (int)((pc >> 8) & 255u) - (int)((qc >> 8) & 255u), e2 = (int)((pc >> 16) & 255u) - (int)((qc >> 16) & 255u);
             const int q2 = e0 * e0 + e1 * e1 + e2 * e2;
-            if (q2 > bq[KNN_K]) continue;
-            const int jd = (int)vals[t];
-            const double d = lab_dist(pc, qc);
-            if (!ent_less(d, jd, bd[KNN_K], bi[KNN_K])) continue;
-            bd[KNN_K] = d; bi[KNN_K] = jd; bq[KNN_K] = q2;
+            const int tn = min(t + rem, b1);
+            bool seen = false;
+            if (skip_r >= 0) {
+                const int dzc = abs((int)(((qc >> 16) & 255u) >> cs) - cz), dyc = abs((int)(((qc >> 8) & 255u) >> cs) - cy), dxc = abs((int)((qc & 255u) >> cs) - cx);
+                seen = max(dzc, max(dyc, dxc)) <= skip_r;
+            }
+            if (q2 <= bq[KNN_K] && !seen) {
+                const double d = lab_dist(pc, qc);
+                for (int tt = t; tt < tn; ++tt) {
+                    const int jd = (int)vals[tt];
+                    if (!ent_less(d, jd, bd[KNN_K], bi[KNN_K])) break;
+                    bd[KNN_K] = d; bi[KNN_K] = jd; bq[KNN_K] = q2; bc[KNN_K] = qc;
 #pragma unroll
-            for (int u = KNN_K; u > 0; --u)
-                if (ent_less(bd[u], bi[u], bd[u - 1], bi[u - 1])) {
-                    const double td = bd[u]; bd[u] = bd[u - 1]; bd[u - 1] = td;
-                    const int ti = bi[u]; bi[u] = bi[u - 1]; bi[u - 1] = ti;
-                    const int tq = bq[u]; bq[u] = bq[u - 1]; bq[u - 1] = tq;
+                    for (int u = KNN_K; u > 0; --u)
+                        if (ent_less(bd[u], bi[u], bd[u - 1], bi[u - 1])) {
+                            const double td = bd[u]; bd[u] = bd[u - 1]; bd[u - 1] = td;
+                            const int ti = bi[u]; bi[u] = bi[u - 1]; bi[u - 1] = ti;
+                            const int tq = bq[u]; bq[u] = bq[u - 1]; bq[u - 1] = tq;
+                            const unsigned tc = bc[u]; bc[u] = bc[u - 1]; bc[u - 1] = tc;
+                        }
                 }
+            }
+            t = tn;
         }
     };
     const int base = l << (3 * cb);
@@ -366,8 +397,15 @@ __device__ __forceinline__ void knn_grid_entry(int e, const unsigned* __restrict
     // 89 points at 700x700, the 9th-nearest colour is 1-2 units away) most of the 26 cells of ring 1 drop out: ~2400 -> a few hundred points scanned per query.
     const int qz = (int)((pc >> 16) & 255u), qy = (int)((pc >> 8) & 255u), qx = (int)(pc & 255u);   // key order: (col >> 16) is the most significant axis
     auto gap = [&](int q, int c) { const int lo = c << cs, hi = lo + (1 << cs) - 1; return q < lo ? lo - q : (q > hi ? q - hi : 0); };
-    for (int r = 0; r < CELLS; ++r) {
-        if (r > 0) { const int bound = (r - 1) * (1 << cs) + 1; if (bq[KNN_K] < bound * bound) break; }
+    // An isolated colour (natural photographs have them; the synthetic pairs' colours are dense) finds its k+1 neighbours only after dozens of rings — (2 r + 1)^2 cell
+    // rows each, 45 ms for ONE graph of in4.png while every other lane of the wave waits. After KNN_RING_UNITS Lab units of rings the search therefore falls back to
+    // one run-wise pass over the rest of the cluster (entries inside the scanned cube skipped): the same k+1 smallest under (dist, id), bounded work.
+    const int rmax = max(2, KNN_RING_UNITS >> cs);
+    int rr = 0; bool finished = false;
+    for (; rr < CELLS; ++rr) {
+        const int r = rr;
+        if (r > 0) { const int bound = (r - 1) * (1 << cs) + 1; if (bq[KNN_K] < bound * bound) { finished = true; break; } }
+        if (r > rmax) break;
         for (int dz = -r; dz <= r; ++dz) {
             const int z = cz + dz; if (z < 0 || z >= CELLS) continue;
             const int gz = gap(qz, z);
@@ -381,22 +419,18 @@ __device__ __forceinline__ void knn_grid_entry(int e, const unsigned* __restrict
                     while (x0 < x1 && gzy + gap(qx, x0) * gap(qx, x0) > bq[KNN_K]) ++x0;
                     while (x1 > x0 && gzy + gap(qx, x1) * gap(qx, x1) > bq[KNN_K]) --x1;
                     if (gzy + gap(qx, x0) * gap(qx, x0) > bq[KNN_K]) continue;              // x0 == x1 and that cell is too far as well
-                    scan(start[row | x0], start[(row | x1) + 1]);
+                    scan(start[row | x0], start[(row | x1) + 1], -1);
                 } else {                                                 // only the two end cells
-                    if (cx - r >= 0 && gzy + gap(qx, cx - r) * gap(qx, cx - r) <= bq[KNN_K]) scan(start[row | (cx - r)], start[(row | (cx - r)) + 1]);
-                    if (cx + r < CELLS && gzy + gap(qx, cx + r) * gap(qx, cx + r) <= bq[KNN_K]) scan(start[row | (cx + r)], start[(row | (cx + r)) + 1]);
+                    if (cx - r >= 0 && gzy + gap(qx, cx - r) * gap(qx, cx - r) <= bq[KNN_K]) scan(start[row | (cx - r)], start[(row | (cx - r)) + 1], -1);
+                    if (cx + r < CELLS && gzy + gap(qx, cx + r) * gap(qx, cx + r) <= bq[KNN_K]) scan(start[row | (cx + r)], start[(row | (cx + r)) + 1], -1);
                 }
             }
         }
     }
-    const int slot = atomicAdd(&nslot[id], 1);
-    double* od = cand_d + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
-    int* oi = cand_id + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
-    int ni = 0;                                                  // findSubKNNs: drop self, keep the first k
+    if (!finished && rr < CELLS) scan(start[base], start[base + (1 << (3 * cb))], rr - 1);      // rings 0 .. rr - 1 are done
+    (void)id;
 #pragma unroll
-    for (int t = 0; t <= KNN_K; ++t)
-        if (bi[t] != id && bi[t] != 0x7fffffff && ni < KNN_K) { od[ni] = bd[t]; oi[ni] = bi[t]; ++ni; }
-    for (; ni < KNN_K; ++ni) { od[ni] = 1e300; oi[ni] = -1; }
+    for (int t = 0; t <= KNN_K; ++t) { run_id[(size_t)r * (KNN_K + 1) + t] = bi[t]; run_col[(size_t)r * (KNN_K + 1) + t] = bc[t]; }
 }
 // The same search by SIXTEEN lanes per entry, for the coarse levels (a few thousand queries: one thread per entry leaves the chip to a few hundred waves that each
 // walk hundreds of points one after the other — 430 us for the 1936 pixels of 44 x 44, and the first nonlocal solve waits for exactly that graph). Lane v scans the
@@ -404,62 +438,71 @@ __device__ __forceinline__ void knn_grid_entry(int e, const unsigned* __restrict
 // bounds the true one from above and every pruning decision a lane takes on it is valid; at the end of a ring the sixteen lists are merged (nine rounds of a 16-lane
 // butterfly minimum under (dist, id); entries the lanes share since the last merge pop together) and every lane continues from the merged list. The result is the set
 // of the k+1 smallest under the total order: the same ids as the one-thread form and the brute-force oracle.
-__device__ __forceinline__ void knn_grid_entry16(int e, int v, const unsigned* __restrict__ cols, const unsigned* __restrict__ keys,
+__device__ __forceinline__ void knn_grid_entry16(int e, int r, int v, const unsigned* __restrict__ cols, const unsigned* __restrict__ keys,
                                                  const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
-                                                 int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
+                                                 int* __restrict__ run_id, unsigned* __restrict__ run_col) {
     const int cb = 8 - cs, CELLS = 1 << cb; const unsigned cmask = (unsigned)CELLS - 1u;
     const unsigned key = keys[e] >> (3 * cs);
     const int id = (int)vals[e];
     const int l = (int)(key >> (3 * cb));
     const int cz = (int)((key >> (2 * cb)) & cmask), cy = (int)((key >> cb) & cmask), cx = (int)(key & cmask);
-    const unsigned pc = cols[e];
-    double bd[KNN_K + 1]; int bi[KNN_K + 1]; int bq[KNN_K + 1];
+    const unsigned pc = cols[e] & 0xFFFFFFu;
+    double bd[KNN_K + 1]; int bi[KNN_K + 1]; int bq[KNN_K + 1]; unsigned bc[KNN_K + 1];
 #pragma unroll
-    for (int t = 0; t <= KNN_K; ++t) { bd[t] = 1e300; bi[t] = 0x7fffffff; bq[t] = 0x7fffffff; }
-    auto scan = [&](int b0, int b1) {
+    for (int t = 0; t <= KNN_K; ++t) { bd[t] = 1e300; bi[t] = 0x7fffffff; bq[t] = 0x7fffffff; bc[t] = 0u; }
+    auto scan = [&](int b0, int b1, int skip_r) {
         for (int t = b0 + ((v - b0) & 15); t < b1; t += 16) {     // lane v owns the points with index = v (mod 16), whatever range ITS thresholds make it scan
-            const unsigned qc = cols[t];
+            const unsigned qc = cols[t] & 0xFFFFFFu;
             const int e0 = (int)(pc & 255u) - (int)(qc & 255u), e1 = (int)((pc >> 8) & 255u) - (int)((qc >> 8) & 255u), e2 = (int)((pc >> 16) & 255u) - (int)((qc >> 16) & 255u);
             const int q2 = e0 * e0 + e1 * e1 + e2 * e2;
             if (q2 > bq[KNN_K]) continue;
+            if (skip_r >= 0) {
+                const int dzc = abs((int)(((qc >> 16) & 255u) >> cs) - cz), dyc = abs((int)(((qc >> 8) & 255u) >> cs) - cy), dxc = abs((int)((qc & 255u) >> cs) - cx);
+                if (max(dzc, max(dyc, dxc)) <= skip_r) continue;
+            }
             const int jd = (int)vals[t];
             const double d = lab_dist(pc, qc);
             if (!ent_less(d, jd, bd[KNN_K], bi[KNN_K])) continue;
-            bd[KNN_K] = d; bi[KNN_K] = jd; bq[KNN_K] = q2;
+            bd[KNN_K] = d; bi[KNN_K] = jd; bq[KNN_K] = q2; bc[KNN_K] = qc;
 #pragma unroll
             for (int u = KNN_K; u > 0; --u)
                 if (ent_less(bd[u], bi[u], bd[u - 1], bi[u - 1])) {
                     const double td = bd[u]; bd[u] = bd[u - 1]; bd[u - 1] = td;
                     const int ti = bi[u]; bi[u] = bi[u - 1]; bi[u - 1] = ti;
                     const int tq = bq[u]; bq[u] = bq[u - 1]; bq[u - 1] = tq;
+                    const unsigned tc = bc[u]; bc[u] = bc[u - 1]; bc[u - 1] = tc;
                 }
         }
     };
     auto merge16 = [&]() {
-        double od[KNN_K + 1]; int oi[KNN_K + 1], oq[KNN_K + 1];
+        double od[KNN_K + 1]; int oi[KNN_K + 1], oq[KNN_K + 1]; unsigned oc[KNN_K + 1];
 #pragma unroll
         for (int s = 0; s <= KNN_K; ++s) {
-            double md = bd[0]; int mi = bi[0], mq = bq[0];
+            double md = bd[0]; int mi = bi[0], mq = bq[0]; unsigned mc = bc[0];
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) {
-                const double xd = __shfl_xor(md, off, 16); const int xi = __shfl_xor(mi, off, 16), xq = __shfl_xor(mq, off, 16);
-                if (ent_less(xd, xi, md, mi)) { md = xd; mi = xi; mq = xq; }
+                const double xd = __shfl_xor(md, off, 16); const int xi = __shfl_xor(mi, off, 16), xq = __shfl_xor(mq, off, 16); const unsigned xc = __shfl_xor(mc, off, 16);
+                if (ent_less(xd, xi, md, mi)) { md = xd; mi = xi; mq = xq; mc = xc; }
             }
-            od[s] = md; oi[s] = mi; oq[s] = mq;
+            od[s] = md; oi[s] = mi; oq[s] = mq; oc[s] = mc;
             if (bi[0] == mi) {                                        // this lane's head is the winner (or every list is exhausted): pop
 #pragma unroll
-                for (int u = 0; u < KNN_K; ++u) { bd[u] = bd[u + 1]; bi[u] = bi[u + 1]; bq[u] = bq[u + 1]; }
-                bd[KNN_K] = 1e300; bi[KNN_K] = 0x7fffffff; bq[KNN_K] = 0x7fffffff;
+                for (int u = 0; u < KNN_K; ++u) { bd[u] = bd[u + 1]; bi[u] = bi[u + 1]; bq[u] = bq[u + 1]; bc[u] = bc[u + 1]; }
+                bd[KNN_K] = 1e300; bi[KNN_K] = 0x7fffffff; bq[KNN_K] = 0x7fffffff; bc[KNN_K] = 0u;
             }
         }
 #pragma unroll
-        for (int s = 0; s <= KNN_K; ++s) { bd[s] = od[s]; bi[s] = oi[s]; bq[s] = oq[s]; }
+        for (int s = 0; s <= KNN_K; ++s) { bd[s] = od[s]; bi[s] = oi[s]; bq[s] = oq[s]; bc[s] = oc[s]; }
     };
     const int base = l << (3 * cb);
     const int qz = (int)((pc >> 16) & 255u), qy = (int)((pc >> 8) & 255u), qx = (int)(pc & 255u);
     auto gap = [&](int q, int c) { const int lo = c << cs, hi = lo + (1 << cs) - 1; return q < lo ? lo - q : (q > hi ? q - hi : 0); };
-    for (int r = 0; r < CELLS; ++r) {
-        if (r > 0) { const int bound = (r - 1) * (1 << cs) + 1; if (bq[KNN_K] < bound * bound) break; }   // merged list: the same value in all sixteen lanes
+    const int rmax = max(2, KNN_RING_UNITS >> cs);         // then one pass over the rest of the cluster (see knn_grid_entry)
+    int rr = 0; bool finished = false;
+    for (; rr < CELLS; ++rr) {
+        const int r = rr;
+        if (r > 0) { const int bound = (r - 1) * (1 << cs) + 1; if (bq[KNN_K] < bound * bound) { finished = true; break; } }   // merged list: the same value in all sixteen lanes
+        if (r > rmax) break;
         for (int dz = -r; dz <= r; ++dz) {
             const int z = cz + dz; if (z < 0 || z >= CELLS) continue;
             const int gz = gap(qz, z);
@@ -473,41 +516,68 @@ __device__ __forceinline__ void knn_grid_entry16(int e, int v, const unsigned* _
                     while (x0 < x1 && gzy + gap(qx, x0) * gap(qx, x0) > bq[KNN_K]) ++x0;
                     while (x1 > x0 && gzy + gap(qx, x1) * gap(qx, x1) > bq[KNN_K]) --x1;
                     if (gzy + gap(qx, x0) * gap(qx, x0) > bq[KNN_K]) continue;
-                    scan(start[row | x0], start[(row | x1) + 1]);
+                    scan(start[row | x0], start[(row | x1) + 1], -1);
                 } else {
-                    if (cx - r >= 0 && gzy + gap(qx, cx - r) * gap(qx, cx - r) <= bq[KNN_K]) scan(start[row | (cx - r)], start[(row | (cx - r)) + 1]);
-                    if (cx + r < CELLS && gzy + gap(qx, cx + r) * gap(qx, cx + r) <= bq[KNN_K]) scan(start[row | (cx + r)], start[(row | (cx + r)) + 1]);
+                    if (cx - r >= 0 && gzy + gap(qx, cx - r) * gap(qx, cx - r) <= bq[KNN_K]) scan(start[row | (cx - r)], start[(row | (cx - r)) + 1], -1);
+                    if (cx + r < CELLS && gzy + gap(qx, cx + r) * gap(qx, cx + r) <= bq[KNN_K]) scan(start[row | (cx + r)], start[(row | (cx + r)) + 1], -1);
                 }
             }
         }
         merge16();
     }
+    if (!finished && rr < CELLS) { scan(start[base], start[base + (1 << (3 * cb))], rr - 1); merge16(); }
     if (v != 0) return;
+    (void)id;
+#pragma unroll
+    for (int t = 0; t <= KNN_K; ++t) { run_id[(size_t)r * (KNN_K + 1) + t] = bi[t]; run_col[(size_t)r * (KNN_K + 1) + t] = bc[t]; }
+}
+// runs of equal sorted keys = equal (cluster, colour): flag of the leading entry; an inclusive scan of the flags numbers the runs in entry order (the leaders keep
+// the cell order that lets a wave's 64 searches walk the same cells — an unordered compaction lost exactly that)
+__global__ void k_knn_run_flags(const unsigned* __restrict__ keys, const int* __restrict__ count, int cap, int* __restrict__ flag) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cap) return;
+    flag[e] = (e < *count && (e == 0 || keys[e] != keys[e - 1])) ? 1 : 0;
+}
+__global__ void k_knn_run_leads(const int* __restrict__ flag, const int* __restrict__ incl, const int* __restrict__ count, int* __restrict__ lead) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *count) return;
+    if (flag[e]) lead[incl[e] - 1] = e;
+}
+__global__ __launch_bounds__(256) void k_knn_grid16(const unsigned* __restrict__ cols, const int* __restrict__ count, const int* __restrict__ incl, const int* __restrict__ lead,
+                                                    const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
+                                                    int* __restrict__ run_id, unsigned* __restrict__ run_col) {
+    const int m = *count; const int nr = m > 0 ? incl[m - 1] : 0;
+    const int v = threadIdx.x & 15;
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < nr; r += gridDim.x * 16)
+        knn_grid_entry16(lead[r], r, v, cols, keys, vals, start, cs, run_id, run_col);
+}
+// Grid-stride over the runs with a BOUNDED grid: the searches are long-running and this kernel lives on the side stream; a grid
+// that fills every CU slot makes the short main-stream kernels wait until all of its workgroups have been dispatched.
+__global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ cols, const int* __restrict__ count, const int* __restrict__ incl, const int* __restrict__ lead,
+                                                  const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
+                                                  int* __restrict__ run_id, unsigned* __restrict__ run_col) {
+    const int m = *count; const int nr = m > 0 ? incl[m - 1] : 0;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < nr; r += gridDim.x * 256)
+        knn_grid_entry(lead[r], r, cols, keys, vals, start, cs, run_id, run_col);
+}
+// every entry takes its run's k+1 winners minus itself (findSubKNNs: drop self, keep the first k) into one of its pixel's candidate slots
+__global__ void k_knn_scatter(const int* __restrict__ count, const int* __restrict__ incl, const unsigned* __restrict__ cols, const unsigned* __restrict__ vals,
+                              const int* __restrict__ run_id, const unsigned* __restrict__ run_col, int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *count) return;
+    const int r = incl[e] - 1;
+    const int id = (int)vals[e];
+    const unsigned pc = cols[e] & 0xFFFFFFu;
     const int slot = atomicAdd(&nslot[id], 1);
     double* od = cand_d + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
     int* oi = cand_id + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
     int ni = 0;
 #pragma unroll
-    for (int t = 0; t <= KNN_K; ++t)
-        if (bi[t] != id && bi[t] != 0x7fffffff && ni < KNN_K) { od[ni] = bd[t]; oi[ni] = bi[t]; ++ni; }
+    for (int t = 0; t <= KNN_K; ++t) {
+        const int bi = run_id[(size_t)r * (KNN_K + 1) + t];
+        if (bi != id && bi != 0x7fffffff && ni < KNN_K) { od[ni] = lab_dist(pc, run_col[(size_t)r * (KNN_K + 1) + t]); oi[ni] = bi; ++ni; }
+    }
     for (; ni < KNN_K; ++ni) { od[ni] = 1e300; oi[ni] = -1; }
-}
-__global__ __launch_bounds__(256) void k_knn_grid16(const unsigned* __restrict__ cols, const int* __restrict__ count, const unsigned* __restrict__ keys,
-                                                    const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
-                                                    int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
-    const int m = *count;
-    const int v = threadIdx.x & 15;
-    for (int e = blockIdx.x * 16 + (threadIdx.x >> 4); e < m; e += gridDim.x * 16)
-        knn_grid_entry16(e, v, cols, keys, vals, start, cs, nslot, cand_d, cand_id);
-}
-// Grid-stride over the entries with a BOUNDED grid: the searches are long-running and this kernel lives on the side stream; a grid
-// that fills every CU slot makes the short main-stream kernels wait until all of its workgroups have been dispatched.
-__global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ cols, const int* __restrict__ count, const unsigned* __restrict__ keys,
-                                                  const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
-                                                  int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
-    const int m = *count;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < m; e += gridDim.x * 256)
-        knn_grid_entry(e, cols, keys, vals, start, cs, nslot, cand_d, cand_id);
 }
 
 // sortMergeComputeWeight: sort by (dist,id), dedupe, keep k, w = exp(1 - d/3); pad with zero-weight self edges
@@ -557,16 +627,26 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     const unsigned key_sentinel = 1u << 28;                 // sorts after every real key (16 clusters x cells x in-cell position = 4 + 3 cb + 3 cs = 28 bits)
     DevBuf<unsigned> mask(ctx, (size_t)lh * lw), keys(ctx, cap), vals(ctx, cap), keys_s(ctx, cap), vals_s(ctx, cap);
     DevBuf<unsigned> cols(ctx, cap);
-    DevBuf<int> count(ctx, 1), start(ctx, nkeys + 2), cstart(ctx, (nkeys >> 6) + 4), nslot(ctx, n), cand_id(ctx, (size_t)n * KNN_SLOTS * KNN_K);
+    DevBuf<int> start(ctx, nkeys + 2), cstart(ctx, (nkeys >> 6) + 4), nslot(ctx, n), cand_id(ctx, (size_t)n * KNN_SLOTS * KNN_K);
     DevBuf<double> cand_d(ctx, (size_t)n * KNN_SLOTS * KNN_K);
-    if (!mask.ok() || !keys.ok() || !vals.ok() || !keys_s.ok() || !vals_s.ok() || !cols.ok() || !count.ok() || !start.ok() || !cstart.ok() || !nslot.ok() || !cand_id.ok() || !cand_d.ok()) return NCT_ERR_HIP;
-    NCT_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+    if (!mask.ok() || !keys.ok() || !vals.ok() || !keys_s.ok() || !vals_s.ok() || !cols.ok() || !start.ok() || !cstart.ok() || !nslot.ok() || !cand_id.ok() || !cand_d.ok()) return NCT_ERR_HIP;
     NCT_HIP(hipMemsetAsync(nslot, 0, sizeof(int) * n, s));
     NCT_HIP(hipMemsetD32Async((hipDeviceptr_t)(unsigned*)keys, (int)key_sentinel, cap, s));       // unused slots sort to the end
     hipLaunchKernelGGL(k_cell_masks, dim3(cdiv(lh * lw, 256)), dim3(256), 0, s, labels, lh, lw, (unsigned*)mask);
     NCT_LAUNCH_CHECK();
+    DevBuf<int> ecnt(ctx, (size_t)n + 1), eoff(ctx, (size_t)n + 1);
+    if (!ecnt.ok() || !eoff.ok()) return NCT_ERR_HIP;
+    hipLaunchKernelGGL(k_knn_entry_counts, dim3(cdiv(n + 1, 256)), dim3(256), 0, s, (const unsigned*)mask, lw, lh, h, w, samples, nlabels, nlabels_dev, (int*)ecnt); NCT_LAUNCH_CHECK();
+    {
+        size_t sb = 0;
+        NCT_HIP(rocprim::exclusive_scan(nullptr, sb, (const int*)ecnt, (int*)eoff, 0, (size_t)n + 1, rocprim::plus<int>(), s));
+        DevBuf<char> st(ctx, sb + 16);
+        if (!st.ok()) return NCT_ERR_HIP;
+        NCT_HIP(rocprim::exclusive_scan((void*)(char*)st, sb, (const int*)ecnt, (int*)eoff, 0, (size_t)n + 1, rocprim::plus<int>(), s));
+    }
+    const int* count = (const int*)eoff + n;                // number of entries
     hipLaunchKernelGGL(k_knn_entries, dim3(cdiv(n, 256)), dim3(256), 0, s, (const unsigned*)mask, lab_u8, lw, lh, h, w, samples, nlabels, nlabels_dev, cs,
-                       (int*)count, (unsigned*)keys, (unsigned*)vals);
+                       (const int*)eoff, (unsigned*)keys, (unsigned*)vals);
     NCT_LAUNCH_CHECK();
     size_t tmp_bytes = 0;
     NCT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned*)keys, (unsigned*)keys_s, (const unsigned*)vals, (unsigned*)vals_s, cap, 0, 29, s));
@@ -580,14 +660,28 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     } else
         hipLaunchKernelGGL(k_knn_cell_starts, dim3(cdiv(nkeys + 1, 256)), dim3(256), 0, s, (const unsigned*)keys_s, cap, (int*)start, nkeys, 3 * cs, (const int*)nullptr);
     NCT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_knn_entry_colours, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, (const int*)count, (const unsigned*)vals_s, (unsigned*)cols);
+    // one search per run of equal (cluster, colour) entries
+    DevBuf<int> flag(ctx, cap), incl(ctx, cap), lead(ctx, cap), run_id(ctx, (size_t)cap * (KNN_K + 1));
+    DevBuf<unsigned> run_col(ctx, (size_t)cap * (KNN_K + 1));
+    if (!flag.ok() || !incl.ok() || !lead.ok() || !run_id.ok() || !run_col.ok()) return NCT_ERR_HIP;
+    hipLaunchKernelGGL(k_knn_run_flags, dim3(cdiv(cap, 256)), dim3(256), 0, s, (const unsigned*)keys_s, count, cap, (int*)flag); NCT_LAUNCH_CHECK();
+    size_t scan_bytes = 0;
+    NCT_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, (const int*)flag, (int*)incl, (size_t)cap, rocprim::plus<int>(), s));
+    DevBuf<char> tmp2(ctx, scan_bytes + 16);
+    if (!tmp2.ok()) return NCT_ERR_HIP;
+    NCT_HIP(rocprim::inclusive_scan((void*)(char*)tmp2, scan_bytes, (const int*)flag, (int*)incl, (size_t)cap, rocprim::plus<int>(), s));
+    hipLaunchKernelGGL(k_knn_run_leads, dim3(cdiv(cap, 256)), dim3(256), 0, s, (const int*)flag, (const int*)incl, count, (int*)lead); NCT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_knn_entry_colours, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, count, (const unsigned*)vals_s, (const int*)incl, (const int*)lead, (unsigned*)cols);
     NCT_LAUNCH_CHECK();
     if (n <= NCT_KNN_LANES16_BELOW)
-        hipLaunchKernelGGL(k_knn_grid16, dim3(std::min(cdiv(cap, 16), 4 * NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
-                           (const int*)start, cs, (int*)nslot, (double*)cand_d, (int*)cand_id);
+        hipLaunchKernelGGL(k_knn_grid16, dim3(std::min(cdiv(cap, 16), 4 * NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, count, (const int*)incl, (const int*)lead,
+                           (const unsigned*)keys_s, (const unsigned*)vals_s, (const int*)start, cs, (int*)run_id, (unsigned*)run_col);
     else
-    hipLaunchKernelGGL(k_knn_grid, dim3(std::min(cdiv(cap, 256), NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, (const int*)count, (const unsigned*)keys_s, (const unsigned*)vals_s,
-                       (const int*)start, cs, (int*)nslot, (double*)cand_d, (int*)cand_id);
+        hipLaunchKernelGGL(k_knn_grid, dim3(std::min(cdiv(cap, 256), NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, count, (const int*)incl, (const int*)lead,
+                           (const unsigned*)keys_s, (const unsigned*)vals_s, (const int*)start, cs, (int*)run_id, (unsigned*)run_col);
+    NCT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_knn_scatter, dim3(cdiv(cap, 256)), dim3(256), 0, s, count, (const int*)incl, (const unsigned*)cols, (const unsigned*)vals_s,
+                       (const int*)run_id, (const unsigned*)run_col, (int*)nslot, (double*)cand_d, (int*)cand_id);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_merge, dim3(cdiv(n, 256)), dim3(256), 0, s, n, (const int*)nslot, (const double*)cand_d, (const int*)cand_id, knn_id, knn_w);
     NCT_LAUNCH_CHECK();

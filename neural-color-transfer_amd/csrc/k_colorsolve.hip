@@ -60,7 +60,10 @@ __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uin
 __device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 __global__ void k_minmax_f(const float* __restrict__ v, int n, unsigned* __restrict__ mm) {
     unsigned lo = 0xFFFFFFFFu, hi = 0u;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const unsigned o = f2ord(v[i]); lo = min(lo, o); hi = max(hi, o); }
+    // a NaN (the matching error of a dead feature pixel: `norm` divides by a zero norm, GeneralizedPatchMatch.cu:276-277) takes part in neither extreme, exactly like
+    // the reference's `if (err2 < minDist)` / `if (err2 > maxDist)` comparisons (ColorTransfer.cpp:1311-1320); its weight then becomes 1e-6 in k_err_weight, which is what
+    // the reference's max() — the Windows macro (stdafx.h includes windows.h): ((a) > (b)) ? (a) : (b) — makes of a NaN
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const float f = v[i]; if (f == f) { const unsigned o = f2ord(f); lo = min(lo, o); hi = max(hi, o); } }
     for (int off = 32; off >= 1; off >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, off)); hi = max(hi, (unsigned)__shfl_xor((int)hi, off)); }
     if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
 }

@@ -159,9 +159,11 @@ __device__ __forceinline__ float pm_dist8(const float* __restrict__ B, const PMG
         for (int dx = -1; dx <= 1; ++dx) {
             const float4* pa = a_lds + ((ly + 1 + dy) * RW + (lx + 1 + dx)) * C4 + l;
             n += valid[dx + 1] ? 1 : 0;
-            float4 c0 = b0[dx + 1], c1 = b1[dx + 1];
-            if (!valid[dx + 1]) { c0 = make_float4(0.f, 0.f, 0.f, 0.f); c1 = c0; }     // adding +0 products == skipping the tap
-            acc = pk_dot4_acc(pa[0], pa[8], c0, c1, acc);
+            float4 c0 = b0[dx + 1], c1 = b1[dx + 1], a0 = pa[0], a1 = pa[8];
+            // adding +0 products == skipping the tap — with BOTH factors zeroed: the other side of a skipped tap may hold a NaN vector (a dead feature pixel: `norm` has
+            // no epsilon), and NaN x 0 would poison a distance the reference computes without that tap (dist_compute_single tests the bounds of both pixels first)
+            if (!valid[dx + 1]) { c0 = make_float4(0.f, 0.f, 0.f, 0.f); c1 = c0; a0 = c0; a1 = c0; }
+            acc = pk_dot4_acc(a0, a1, c0, c1, acc);
         }
     }
     const float sum = half8_sum(acc.x, acc.y);
@@ -293,6 +295,7 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 float4 a = pa[v + 16 * k];
+                if (!valid) a = make_float4(0.f, 0.f, 0.f, 0.f);         // both factors: see pm_dist8
                 if constexpr (HALF) {
                     uint2 b = Bh[((size_t)yc * g.bw + xc) * (size_t)nchunk + v + 16 * k];
                     if (!valid) b = make_uint2(0u, 0u);
@@ -307,7 +310,7 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
             for (int j = v; j < nchunk; j += 16) {
                 float4 a = pa[j];
                 float4 b = pb[j];
-                if (!valid) b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!valid) { b = make_float4(0.f, 0.f, 0.f, 0.f); a = b; }
                 acc = dot4_acc(a, b, acc);
             }
         }

@@ -1,5 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out/r5b
-timeout 900 python -m pytest tests/test_gpu_correspondence.py -x -q -k "vote" > gpurun_out/r5b/vote.log 2>&1; echo "vote rc=$?"; tail -12 gpurun_out/r5b/vote.log
-timeout 900 python -m pytest tests/test_gpu_pipeline.py -x -q -k "levels_match or end_to_end or minimum_and or dev_seams" > gpurun_out/r5b/pipe.log 2>&1; echo "pipe rc=$?"; tail -12 gpurun_out/r5b/pipe.log
-python scripts/vote_levels.py 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_correspondence.py tests/test_gpu_color.py tests/test_gpu_pipeline.py -q -k "dead or nan_matching" > gpurun_out/r5b/dead.log 2>&1; echo "dead rc=$?"; tail -30 gpurun_out/r5b/dead.log

@@ -119,3 +119,18 @@ def test_local_color_transfer_stages(ctx, oracle, case):
     assert np.array_equal(gs["ab_wls"].view(np.uint64), os_["ab_wls"].view(np.uint64))
     # A1: 8-bit output
     assert np.array_equal(go, oo)
+
+
+def test_local_color_transfer_with_nan_matching_error(ctx, oracle):
+    """T2 on a matching-error map with NaNs (dead feature pixels: see test_patchmatch_dead_feature_pixels): the extremes ignore them (ColorTransfer.cpp:1311-1320 compares
+    with < and >) and their confidence weight is 1e-6 (the reference's max() is the Windows macro: a NaN first operand yields the second) — on the GPU as in the oracle;
+    everything downstream stays finite and bit-identical."""
+    err, s_lvl, g_lvl, s_full, ids, ws = _level_case(23, 40, 56, 20, 28, (5, 7), 4, oracle)
+    err = err.copy(); err[3:6, 4:9] = np.nan; err[0, 0] = np.nan; err[19, 27] = np.nan
+    go, gs = ctx.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, 3, want_stages=True)
+    oo, os_ = oracle.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, 3, want_stages=True)
+    for k in ("ab_local", "ab_nonlocal", "ab_up", "ab_wls"):
+        assert np.isfinite(os_[k]).all() and np.array_equal(gs[k].view(np.uint64), os_[k].view(np.uint64)), k
+    assert np.array_equal(go, oo)
+    clean = np.where(np.isnan(err), np.float32(-0.5), err)           # a map without NaNs gives another result: the NaN pixels really entered with weight 1e-6
+    assert not np.array_equal(oracle.local_color_transfer(clean, s_lvl, g_lvl, s_full, ids, ws, 3), oo)

@@ -164,6 +164,33 @@ def test_patchmatch_bidir_bit_exact(ctx, oracle, C, ah, aw, bh, bw, rs):
     assert counts[0] == counts[1] and counts[0][0] > 0 and counts[0][1] > 0           # same candidates, same acceptances
 
 
+def _same_or_both_nan(a, b):
+    """bit-identical where finite; NaN where the other is NaN (x86 and gfx950 produce different NaN payloads for 0/0: 0xFFC00000 vs 0x7FC00000)"""
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb])
+
+
+@pytest.mark.parametrize("C,ah,aw,bh,bw,rs", [(64, 37, 41, 33, 45, 8), (128, 30, 26, 28, 31, 16), (256, 21, 24, 23, 20, 8), (512, 14, 13, 12, 15, 4), (64, 120, 90, 100, 110, 32)])
+def test_patchmatch_dead_feature_pixels(ctx, oracle, C, ah, aw, bh, bw, rs):
+    """VERDICT r4 item 5 / SURVEY 9 quirk 3: `norm` has no epsilon (GeneralizedPatchMatch.cu:276-277), so an all-zero feature pixel (post-ReLU conv1_1 of a saturated flat
+    region) becomes a NaN vector. The defined behaviour = IEEE comparisons, as in the reference's `d < dbest`: a distance that involves a NaN tap is NaN and never wins; a
+    query whose OWN patch holds a NaN keeps the match it started with. The pipeline's instantiation with the exact row rejection (pm_mode 1: its Cauchy-Schwarz bound
+    assumes unit vectors) must give the oracle's field on such maps: identical NNFs, distances bit-identical where finite and NaN where the oracle's are NaN."""
+    fa, fb = synth.features(31, C, ah, aw), synth.features(32, C, bh, bw)
+    fa[:, 5:9, 7:12] = 0; fa[:, ah - 1, aw - 1] = 0; fb[:, 3:8, 2:6] = 0; fb[:, 0, 0] = 0; fb[:, bh // 2, bw // 2] = 0
+    a, b = oracle.feat_normalize(fa), oracle.feat_normalize(fb)
+    assert np.isnan(a[:, 6, 8]).all() and np.isnan(b[:, 0, 0]).all()
+    seed = 91
+    o_ann, o_annd = oracle.patchmatch(a, b, oracle.nnf_init(ah, aw, bh, bw), iters=5, rs_max=rs, seed=seed)
+    o_bnn, o_bnnd = oracle.patchmatch(b, a, oracle.nnf_init(bh, bw, ah, aw), iters=5, rs_max=rs, seed=seed ^ 0x5bd1e995)
+    assert np.isnan(o_annd).any() and np.isfinite(o_annd).any()
+    ctx.pm_bench_setup(fa, fb)
+    for mode in (0, 1):
+        ms, cnt, ann, annd, bnn, bnnd = ctx.pm_bench_run_bidir(iters=5, rs_max=rs, seed=seed, pm_mode=mode, count=True, fetch=True, both=True)
+        assert np.array_equal(ann, o_ann) and np.array_equal(bnn, o_bnn), f"mode {mode}: NNF differs from the oracle on maps with dead pixels"
+        assert _same_or_both_nan(annd, o_annd) and _same_or_both_nan(bnnd, o_bnnd), f"mode {mode}: distances differ"
+
+
 def test_patchmatch_fp16_mode_close(ctx):
     """Opt-in reduced-precision mode (NCT_FLAG_FEAT16): fp16 candidate tiles, fp32 accumulate. Not bit-identical by definition; the
     match energies stay within the fp16 rounding bound of the fp32 field's."""
