@@ -357,36 +357,47 @@ __device__ __forceinline__ void knn_grid_entry(int e, int r, const unsigned* __r
     for (int t = 0; t <= KNN_K; ++t) { bd[t] = 1e300; bi[t] = 0x7fffffff; bq[t] = 0x7fffffff; bc[t] = 0u; }
     // run-wise: the entries of a run share colour and distance and their ids ascend, so the first one that does not enter the list ends the run for this query (an entry
     // that fails on (dist, id) against the current (k+1)-th fails for every larger id as well; the (k+1)-th only improves), and at most k+1 can enter
-    // skip_r >= 0 (the fallback pass below): entries whose cell lies inside the cube of rings 0..skip_r were scanned already
+    // skip_r >= 0 (the fallback pass below): entries whose cell lies inside the cube of rings 0..skip_r were scanned already.
+    // Four colour words are requested together (a step that depends on the word just loaded — t += run length — made every entry a full dependent round trip: 1.17 ms
+    // instead of 0.97 for HALF the searches at 700x700); an entry that fails takes the rest of its run with it (`adv`), one that enters lets the next one be tested.
     auto scan = [&](int b0, int b1, int skip_r) {
         for (int t = b0; t < b1;) {
-            const unsigned qw = cols[t];
-            const unsigned qc = qw & 0xFFFFFFu; const int rem = (int)(qw >> 24);
-            const int e0 = (int)(pc & 255u) - (int)(qc & 255u), e1 = (int)((pc >> 8) & 255u) - (int)((qc >> 8) & 255u), e2 = (int)((pc >> 16) & 255u) - (int)((qc >> 16) & 255u);
-            const int q2 = e0 * e0 + e1 * e1 + e2 * e2;
-            const int tn = min(t + rem, b1);
-            bool seen = false;
-            if (skip_r >= 0) {
-                const int dzc = abs((int)(((qc >> 16) & 255u) >> cs) - cz), dyc = abs((int)(((qc >> 8) & 255u) >> cs) - cy), dxc = abs((int)((qc & 255u) >> cs) - cx);
-                seen = max(dzc, max(dyc, dxc)) <= skip_r;
-            }
-            if (q2 <= bq[KNN_K] && !seen) {
-                const double d = lab_dist(pc, qc);
-                for (int tt = t; tt < tn; ++tt) {
-                    const int jd = (int)vals[tt];
-                    if (!ent_less(d, jd, bd[KNN_K], bi[KNN_K])) break;
-                    bd[KNN_K] = d; bi[KNN_K] = jd; bq[KNN_K] = q2; bc[KNN_K] = qc;
+            unsigned qw4[4];
 #pragma unroll
-                    for (int u = KNN_K; u > 0; --u)
-                        if (ent_less(bd[u], bi[u], bd[u - 1], bi[u - 1])) {
-                            const double td = bd[u]; bd[u] = bd[u - 1]; bd[u - 1] = td;
-                            const int ti = bi[u]; bi[u] = bi[u - 1]; bi[u - 1] = ti;
-                            const int tq = bq[u]; bq[u] = bq[u - 1]; bq[u - 1] = tq;
-                            const unsigned tc = bc[u]; bc[u] = bc[u - 1]; bc[u - 1] = tc;
-                        }
+            for (int u = 0; u < 4; ++u) qw4[u] = t + u < b1 ? cols[t + u] : 0u;
+            int adv = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t + u >= b1 || u < adv) continue;
+                const unsigned qc = qw4[u] & 0xFFFFFFu; const int rem = (int)(qw4[u] >> 24);
+                const int e0 = (int)(pc & 255u) - (int)(qc & 255u), e1 = (int)((pc >> 8) & 255u) - (int)((qc >> 8) & 255u), e2 = (int)((pc >> 16) & 255u) - (int)((qc >> 16) & 255u);
+                const int q2 = e0 * e0 + e1 * e1 + e2 * e2;
+                bool seen = false;
+                if (skip_r >= 0) {
+                    const int dzc = abs((int)(((qc >> 16) & 255u) >> cs) - cz), dyc = abs((int)(((qc >> 8) & 255u) >> cs) - cy), dxc = abs((int)((qc & 255u) >> cs) - cx);
+                    seen = max(dzc, max(dyc, dxc)) <= skip_r;
                 }
+                bool entered = false;
+                if (q2 <= bq[KNN_K] && !seen) {
+                    const int jd = (int)vals[t + u];
+                    const double d = lab_dist(pc, qc);
+                    if (ent_less(d, jd, bd[KNN_K], bi[KNN_K])) {
+                        entered = true;
+                        bd[KNN_K] = d; bi[KNN_K] = jd; bq[KNN_K] = q2; bc[KNN_K] = qc;
+#pragma unroll
+                        for (int w = KNN_K; w > 0; --w)
+                            if (ent_less(bd[w], bi[w], bd[w - 1], bi[w - 1])) {
+                                const double td = bd[w]; bd[w] = bd[w - 1]; bd[w - 1] = td;
+                                const int ti = bi[w]; bi[w] = bi[w - 1]; bi[w - 1] = ti;
+                                const int tq = bq[w]; bq[w] = bq[w - 1]; bq[w - 1] = tq;
+                                const unsigned tc = bc[w]; bc[w] = bc[w - 1]; bc[w - 1] = tc;
+                            }
+                    }
+                }
+                // the rest of the run shares this entry's colour and has larger ids: if this one does not enter, none of them does (the (k+1)-th only improves)
+                if (!entered) adv = u + rem;
             }
-            t = tn;
+            t += adv > 4 ? adv : 4;
         }
     };
     const int base = l << (3 * cb);

@@ -1,3 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r5b
-timeout 900 python -m pytest tests/test_gpu_correspondence.py tests/test_gpu_color.py tests/test_gpu_pipeline.py -q -k "dead or nan_matching" > gpurun_out/r5b/dead.log 2>&1; echo "dead rc=$?"; tail -30 gpurun_out/r5b/dead.log
+timeout 900 python -m pytest tests/test_gpu_color.py -x -q -k "knn" > gpurun_out/r5b/knn.log 2>&1; echo "knn rc=$?"; tail -3 gpurun_out/r5b/knn.log
+timeout 900 python -m pytest tests/test_gpu_pipeline.py -x -q -k "levels_match or end_to_end" > gpurun_out/r5b/pipe.log 2>&1; echo "pipe rc=$?"; tail -3 gpurun_out/r5b/pipe.log
+bash scripts/kernel_times.sh r5g "k_knn_grid" in4_tar4_2 2>&1 | tail -3
+bash scripts/kernel_times.sh r5h "k_knn_grid" 700 2>&1 | tail -3
