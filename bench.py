@@ -378,7 +378,7 @@ def pmc_traffic(device, live):
     gfx950 -> x2; the k_normalize dispatch of the same pass, a pure 125.44 MB streaming read, is kept as the calibration check).
     Returns (dict, how) or (None, why)."""
     exe = shutil.which("rocprofv3")
-    rec = os.path.join(REPO, "profiles", "round4_pmc_patchmatch.json")
+    rec = os.path.join(REPO, "profiles", "round5_pmc_patchmatch.json")
     bid = lib_build_id()
     why = "live PMC disabled"
     if live and exe:
@@ -403,13 +403,13 @@ def pmc_traffic(device, live):
     if os.path.exists(rec):
         d = json.load(open(rec))
         if d.get("build_id") == bid:
-            return d, "recorded (profiles/round4_pmc_patchmatch.json, same build id)"
+            return d, "recorded (profiles/round5_pmc_patchmatch.json, same build id)"
         why += "; the recorded PMC passes belong to another build"
     return None, why
 
 
 # the colour-solver kernels of roofline_color in the same counter passes (the pair of scripts/pair_only.py runs them all): name prefix in the trace per roofline_color key
-COLOR_KERNELS = {"s1_apply": "void k_s1_apply<true>", "s1_dir": "k_s1_dir(", "s1_update": "k_s1_update(", "wls_down": "void (anonymous namespace)::k_mg_down<6, 32, 16, double",
+COLOR_KERNELS = {"s1_apply": "void k_s1_apply<true>", "s1_update": "void k_s1_update<false>", "wls_down": "void (anonymous namespace)::k_mg_down<6, 32, 16, double",
                  "wls_up": "void (anonymous namespace)::k_mg_up<6, 32, 16, double", "wls_apply": "void (anonymous namespace)::k_cg_apply<6>", "wls_update": "void (anonymous namespace)::k_cg_update<6>"}
 COLOR_PMC = {}
 
@@ -577,9 +577,8 @@ def color_roofline(nct, ctx, prm, sshape):
     # sources/weights/records (~8 x (4 + 8 + 48)) + 4 raster neighbours (L2 hits, not counted) + coefficients daa/dab/dbb (72) + gx, gy (16) + ids (32) + iw2 (64) + Ap out (48);
     # WLS (6 right-hand sides): see DESIGN.md 3.4
     model = {
-        "s1_apply": (48 + 8 * 48 + 8 * 60 + 72 + 16 + 32 + 64 + 48, "p + 8 out-neighbour records + 8 in-edge (src, w, record) + coefficients + Ap"),
-        "s1_dir": (48 + 48 + 48, "r, p in; p out (fp64 x 6)"),
-        "s1_update": (48 * 4 + 48 * 2, "p, Ap, x, r in; x, r out"),
+        "s1_apply": (48 + 8 * 48 + 8 * 60 + 72 + 16 + 32 + 64 + 48, "r + 8 out-neighbour records + 8 in-edge (src, w, record) + coefficients + w = Op(r)"),
+        "s1_update": (48 * 5 + 48 * 4, "r, w, p, s, x in; p, s, x, r out (fp64 x 6 each: the single-reduction recurrence's one vector pass)"),
         "wls_down": (48 + 16 + 24 + 6 + 9, "r (fp64 x 6) + fp32 coefficients in; x (fp32 x 6) + coarse rhs + P columns"),
         "wls_up": (48 + 24 + 16 + 16 + 6 + 24, "r, x, coefficients, P weights, coarse correction in; z out"),
         "wls_apply": (24 + 48 + 24 + 48, "z (fp32 x 6), r, fp64 coefficients in; w out"),
@@ -599,9 +598,11 @@ def color_roofline(nct, ctx, prm, sshape):
                 e["traffic_frac"] = e["traffic"] / us[k] / 1e3 / HBM_PEAK_GBS
                 e["traffic_launches"] = fs["launches"]
             out["kernels"][k] = e
+    if ns.get("s1_scalars"):
+        out["kernels"]["s1_scalars"] = {"avg_us": us["s1_scalars"], "samples": ns["s1_scalars"], "what": "one-workgroup reduction of the operator pass's 1915 x 6 block partials + CG scalars (latency bound)"}
     if ns.get("wls_coarse"):
         out["kernels"]["wls_coarse"] = {"avg_us": us["wls_coarse"], "samples": ns["wls_coarse"], "what": "everything below the finest level of one V-cycle (latency bound: 7 launches)"}
-    it_s1 = sum(us[k] for k in ("s1_apply", "s1_dir", "s1_update") if ns.get(k))
+    it_s1 = sum(us[k] for k in ("s1_apply", "s1_scalars", "s1_update") if ns.get(k))
     it_wls = sum(us[k] for k in ("wls_down", "wls_up", "wls_apply", "wls_update", "wls_coarse") if ns.get(k))
     # WLS per PCG iteration ~ (5 nnz + 6 vectors) x 8 B x n per right-hand side; nonlocal CG per iteration 2 passes over ~25 n rows x (2 idx + 2 val) + 4 vectors of 2 n fp64, per channel
     if it_wls:
@@ -611,7 +612,7 @@ def color_roofline(nct, ctx, prm, sshape):
     if it_s1:
         b = 3 * (2 * 25 * N * (2 * 4 + 2 * 8) + 4 * 2 * N * 8)
         out["s1_iteration"] = {"us": it_s1, "survey_8d_bytes": b, "survey_8d_GBs": b / it_s1 / 1e3, "survey_8d_frac": b / it_s1 / 1e3 / HBM_PEAK_GBS,
-                               "compulsory_bytes": sum(model[k][0] for k in ("s1_apply", "s1_dir", "s1_update")) * N,
+                               "compulsory_bytes": sum(model[k][0] for k in ("s1_apply", "s1_update")) * N,
                                "note": "the survey's model is the reference's explicit CSR A^T A product; the matrix-free operator moves ~3x fewer bytes, so its survey fraction can exceed 1"}
     out["dominant"] = max(out["kernels"].items(), key=lambda kv: kv[1].get("avg_launch_us", 0))[0] if out["kernels"] else None
     return out

@@ -435,7 +435,7 @@ int nctk_s1_solve(nct_ctx* ctx, hipStream_t s, const nct_s1_graph& g, const int*
             hipLaunchKernelGGL(k_s1_update<true>, dim3(nbl), dim3(256), 0, s, n, nbl, (const double*)partial, (const S1State*)slot[k & 1], slot[(k - 1) & 1], k == 1 ? 1 : 0, tol2,
                                k == 1 ? 1 : 0, (double*)r6, (const double*)w6, (double*)p6, (double*)s6, (double*)x6); LCHK();
         } else {
-            if (kt) { int rk = ctx->kt_begin(s, NCT_KT_S1_DIR); if (rk) return rk; }
+            if (kt) { int rk = ctx->kt_begin(s, NCT_KT_S1_SCALARS); if (rk) return rk; }
             hipLaunchKernelGGL(k_s1_scal, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (const S1State*)slot[k & 1], slot[(k - 1) & 1], k == 1 ? 1 : 0, tol2); LCHK();
             if (kt) { int rk = ctx->kt_end(s); if (rk) return rk; rk = ctx->kt_begin(s, NCT_KT_S1_UPDATE); if (rk) return rk; }
             hipLaunchKernelGGL(k_s1_update<false>, dim3(nbl), dim3(256), 0, s, n, nbl, (const double*)partial, (const S1State*)slot[(k - 1) & 1], slot[(k - 1) & 1], 0, tol2,

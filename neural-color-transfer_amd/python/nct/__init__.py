@@ -155,7 +155,7 @@ FLAG_COUNT_EVALS = 2
 FLAG_LATENCY = 4
 FLAG_LAB2BGR_CUBE = 8
 FLAG_TIME_KERNELS = 16
-KT_NAMES = ("s1_apply", "s1_dir", "s1_update", "wls_down", "wls_up", "wls_apply", "wls_update", "wls_coarse")      # nct.h NCT_KT_*
+KT_NAMES = ("s1_apply", "s1_scalars", "s1_update", "wls_down", "wls_up", "wls_apply", "wls_update", "wls_coarse")      # nct.h NCT_KT_*
 LAB2BGR_PIECEWISE, LAB2BGR_CUBE = 0, 1
 
 

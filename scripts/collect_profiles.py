@@ -9,7 +9,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(REPO, "gpurun_out", tag)
 dst = os.path.join(REPO, "profiles")
-R = sys.argv[2] if len(sys.argv) > 2 else "round4"
+R = sys.argv[2] if len(sys.argv) > 2 else "round5"
 RN = R.replace("round", "round ")
 
 
@@ -187,6 +187,31 @@ if os.path.exists(vg):
          "shares compare layers and builds, not an absolute peak fraction (conv5_1's 124 workgroups could not exceed 0.48). bench.py repeats the two passes live (`vgg_mfma.mfma_util`:",
          f"{bench['vgg_mfma'].get('mfma_util')} over all conv launches).", "", "```"] + [l.rstrip("\n") for l in open(vg)] + ["```"]
     open(os.path.join(dst, f"{R}_pmc_vgg_mfma.md"), "w").write("\n".join(V) + "\n")
+
+# ---- round 5: the reference's demo inputs (natural photographs)
+nat = [f for f in sorted(os.listdir(src)) if f.startswith("natural_") and f.endswith(".md")]
+if nat:
+    N = [f"# {RN} — the reference's own demo inputs (`demo/example/in/*.png`, committed as data under tests/golden/natural/) through the stage clock, build {bench['build_id']}", "",
+         "`scripts/natural_report.py 5 <case>`: the natural pair next to a `tests/synth.py` pair of the SAME sizes (median of 5 runs, one pair in flight; stream events), then per pyramid level the",
+         "kNN in-degree distribution (what S1's in-edge blocks are sized on: `deg_gt64` pixels have blocks beyond their first 64 in-edges -> k_s1_hub) and the completeness sources per vote target",
+         "(`vote_gt72` targets have lists with blocks beyond the first 64 -> k_vote_hub). The same pairs on the round-4 kernels: profiles/round5_natural_before.md (nonlocal 1 235 / 406 / 45 ms,",
+         "votes 11.5 / 36.6 / 11.6 ms, 45 ms for one kNN graph). What is left above 1.3x is the WLS solve: its PCG needs 2-3x the iterations on these images (`wls_iters`; scripts/wls_natural_probe.py:",
+         "no low-roughness regions — the edge-aware weights of photographs, with 12-37 % exactly flat neighbour pairs beside strong edges, are a harder operator for the point-Jacobi V-cycle), and",
+         "S1's operator passes where most pixels' first in-edge block is full (64 dependent gathers per thread instead of ~8).", ""]
+    for f in nat:
+        N += open(os.path.join(src, f)).read().splitlines()[2:] + [""]
+    ks = os.path.join(src, "nat_prof", "n_kernel_stats.csv")
+    if os.path.exists(ks):
+        rr = sorted(csv.DictReader(open(ks)), key=lambda r: -int(r["TotalDurationNs"]))
+        N += ["## Kernel table of in4_tar4_2 (`rocprofv3 --kernel-trace --stats -- python scripts/pair_only.py in4_tar4_2 2`: two pairs; the 30 largest rows)", "",
+              "| kernel | calls | total ms | avg us | max us |", "|---|---|---|---|---|"]
+        for r in rr[:30]:
+            N.append(f"| `{r['Name'][:110]}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {int(r['MaxNs']) / 1e3:.1f} |")
+        N.append("")
+    wp = os.path.join(src, "wls_natural_probe.txt")
+    if os.path.exists(wp):
+        N += ["## WLS iterations per right-hand side and roughness statistics (`scripts/wls_natural_probe.py`)", "", "```"] + [l.rstrip("\n") for l in open(wp)] + ["```"]
+    open(os.path.join(dst, f"{R}_natural.md"), "w").write("\n".join(N) + "\n")
 
 print("bench:", bench["value"], "pairs/s, single pair", bench["single_pair_ms"], "ms, roofline frac", bench["roofline"]["frac"], "launches/pair", calls // pairs, "build", bench["build_id"])
 for name, b in wl.items():

@@ -30,7 +30,7 @@ done
 for pre in "void k_pm_step<1, 1," "void k_pm_prop<1, 1," "void k_pm_step<2, 1," "void k_pm_prop<2, 1," "void k_pm_step<4, 0," "void k_pm_step<8, 0,"; do echo "== $pre"; python scripts/pmc_summary.py $out/pmc "$pre"; done > $out/pmc_pm_all.txt 2>&1
 # colour-solver kernels out of the same six passes (round 4)
 for pre in "void (anonymous namespace)::k_mg_down<6, 32, 16, double" "void (anonymous namespace)::k_mg_up<6, 32, 16, double" "void (anonymous namespace)::k_mg_down<6, 32, 16, float" "void (anonymous namespace)::k_mg_up<6, 32, 16, float" \
-           "void (anonymous namespace)::k_cg_apply" "void (anonymous namespace)::k_cg_update" "void k_s1_apply<true>" "k_s1_update(" "k_s1_dir("; do
+           "void (anonymous namespace)::k_cg_apply" "void (anonymous namespace)::k_cg_update" "void k_s1_apply<true>" "void k_s1_update<false>" "k_s1_scal(" "k_s1_hub("; do
     echo "== $pre"; python scripts/pmc_summary.py $out/pmc "$pre"
 done > $out/pmc_color_all.txt 2>&1
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $out/vgg/p1 -o c --output-format csv -- python scripts/vgg_only.py > $out/vgg_p1.log 2>&1
@@ -38,5 +38,10 @@ timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WA
 python scripts/pmc_by_grid.py $out/vgg "void k_conv3x3_mfma" > $out/vgg_mfma_by_grid.txt 2>&1
 python scripts/pmc_per_dispatch.py $out/pmc "void k_pm_step<1, 1,|void k_pm_prop<1, 1," > $out/pmc_pm_finest_per_dispatch.txt 2>&1
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "c_counter_collection.csv" -size +30M -delete
+# round 5: the reference's own demo inputs (natural photographs) through the stage clock, the kernel trace and the counters
+for c in in1_tar1_2 in4_tar4_2 in0_tar0_2 in4_tar4_0 in4_tar4_8; do timeout 300 python scripts/natural_report.py 5 $c > $out/natural_$c.md 2> $out/natural_$c.err; done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/nat_prof -o n -- python scripts/pair_only.py in4_tar4_2 2 > $out/nat_prof.log 2>&1
+find $out/nat_prof -name "*kernel_trace*" -delete; find $out/nat_prof -name "*.db" -delete
+timeout 300 python scripts/wls_natural_probe.py > $out/wls_natural_probe.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1; tail -1 $out/smoke.txt
 ls -la $out

@@ -12,7 +12,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
     timeout 300 rocprofv3 --pmc $set --kernel-trace -d $out/p$i -o c --output-format csv -- python scripts/pair_only.py 700 1 > $out/p$i.log 2>&1
 done
 for pre in "void (anonymous namespace)::k_mg_down<6, 32, 16, double" "void (anonymous namespace)::k_mg_up<6, 32, 16, double" "void (anonymous namespace)::k_mg_down<6, 32, 16, float" "void (anonymous namespace)::k_mg_up<6, 32, 16, float" \
-           "void (anonymous namespace)::k_cg_apply" "void (anonymous namespace)::k_cg_update" "void k_s1_apply<true>" "k_s1_update(" "k_s1_dir("; do
+           "void (anonymous namespace)::k_cg_apply" "void (anonymous namespace)::k_cg_update" "void k_s1_apply<true>" "void k_s1_update<false>" "k_s1_scal(" "k_s1_hub("; do
     echo "== $pre"; python scripts/pmc_summary.py $out "$pre"
 done > $out/pmc_color_all.txt 2>&1
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "c_counter_collection.csv" -size +30M -delete
