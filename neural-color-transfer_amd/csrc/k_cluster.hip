@@ -343,9 +343,14 @@ __global__ void k_knn_entry_colours(const uint8_t* __restrict__ lab, const int* 
 // colour alone (the query itself is an ordinary candidate; findSubKNNs drops it afterwards), so one search serves the whole run — natural photographs hold runs of 10^4
 // pixels (demo/example/in/in4.png: 17 pixels per colour on average, one colour 9 747 times), which made every member scan every other member: 44 ms for one graph.
 // The winners are stored as (pixel id, packed colour): k_knn_scatter recomputes the distance with the same lab_dist and hands every member its list minus itself.
+// RUNS = false: every entry searches for itself and writes its pixel's candidate slot directly (rounds 1-4; the cheaper form where runs are short: the synthetic pairs
+// hold 1.8 pixels per colour, and the run form's extra scatter pass and less coherent waves cost 0.9 ms per pair there). Which form runs is decided ON THE DEVICE from the
+// entries-per-run ratio (knn_use_runs): both kernels are launched, the one not chosen returns at once.
+struct KnnOut { int* run_id; unsigned* run_col; int* nslot; double* cand_d; int* cand_id; };
+__device__ __forceinline__ bool knn_use_runs(int m, int nr, int force) { return force >= 0 ? force != 0 : 2 * (long long)m > 5 * (long long)nr; }   // > 2.5 entries per run
+template <bool RUNS>
 __device__ __forceinline__ void knn_grid_entry(int e, int r, const unsigned* __restrict__ cols, const unsigned* __restrict__ keys,
-                                               const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
-                                               int* __restrict__ run_id, unsigned* __restrict__ run_col) {
+                                               const unsigned* __restrict__ vals, const int* __restrict__ start, int cs, const KnnOut& o) {
     const int cb = 8 - cs, CELLS = 1 << cb; const unsigned cmask = (unsigned)CELLS - 1u;
     const unsigned key = keys[e] >> (3 * cs);
     const int id = (int)vals[e];
@@ -439,9 +444,19 @@ __device__ __forceinline__ void knn_grid_entry(int e, int r, const unsigned* __r
         }
     }
     if (!finished && rr < CELLS) scan(start[base], start[base + (1 << (3 * cb))], rr - 1);      // rings 0 .. rr - 1 are done
-    (void)id;
+    if constexpr (RUNS) {
 #pragma unroll
-    for (int t = 0; t <= KNN_K; ++t) { run_id[(size_t)r * (KNN_K + 1) + t] = bi[t]; run_col[(size_t)r * (KNN_K + 1) + t] = bc[t]; }
+        for (int t = 0; t <= KNN_K; ++t) { o.run_id[(size_t)r * (KNN_K + 1) + t] = bi[t]; o.run_col[(size_t)r * (KNN_K + 1) + t] = bc[t]; }
+    } else {
+        const int slot = atomicAdd(&o.nslot[id], 1);
+        double* od = o.cand_d + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
+        int* oi = o.cand_id + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
+        int ni = 0;                                                  // findSubKNNs: drop self, keep the first k
+#pragma unroll
+        for (int t = 0; t <= KNN_K; ++t)
+            if (bi[t] != id && bi[t] != 0x7fffffff && ni < KNN_K) { od[ni] = bd[t]; oi[ni] = bi[t]; ++ni; }
+        for (; ni < KNN_K; ++ni) { od[ni] = 1e300; oi[ni] = -1; }
+    }
 }
 // The same search by SIXTEEN lanes per entry, for the coarse levels (a few thousand queries: one thread per entry leaves the chip to a few hundred waves that each
 // walk hundreds of points one after the other — 430 us for the 1936 pixels of 44 x 44, and the first nonlocal solve waits for exactly that graph). Lane v scans the
@@ -449,9 +464,9 @@ __device__ __forceinline__ void knn_grid_entry(int e, int r, const unsigned* __r
 // bounds the true one from above and every pruning decision a lane takes on it is valid; at the end of a ring the sixteen lists are merged (nine rounds of a 16-lane
 // butterfly minimum under (dist, id); entries the lanes share since the last merge pop together) and every lane continues from the merged list. The result is the set
 // of the k+1 smallest under the total order: the same ids as the one-thread form and the brute-force oracle.
+template <bool RUNS>
 __device__ __forceinline__ void knn_grid_entry16(int e, int r, int v, const unsigned* __restrict__ cols, const unsigned* __restrict__ keys,
-                                                 const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
-                                                 int* __restrict__ run_id, unsigned* __restrict__ run_col) {
+                                                 const unsigned* __restrict__ vals, const int* __restrict__ start, int cs, const KnnOut& o) {
     const int cb = 8 - cs, CELLS = 1 << cb; const unsigned cmask = (unsigned)CELLS - 1u;
     const unsigned key = keys[e] >> (3 * cs);
     const int id = (int)vals[e];
@@ -538,9 +553,19 @@ __device__ __forceinline__ void knn_grid_entry16(int e, int r, int v, const unsi
     }
     if (!finished && rr < CELLS) { scan(start[base], start[base + (1 << (3 * cb))], rr - 1); merge16(); }
     if (v != 0) return;
-    (void)id;
+    if constexpr (RUNS) {
 #pragma unroll
-    for (int t = 0; t <= KNN_K; ++t) { run_id[(size_t)r * (KNN_K + 1) + t] = bi[t]; run_col[(size_t)r * (KNN_K + 1) + t] = bc[t]; }
+        for (int t = 0; t <= KNN_K; ++t) { o.run_id[(size_t)r * (KNN_K + 1) + t] = bi[t]; o.run_col[(size_t)r * (KNN_K + 1) + t] = bc[t]; }
+    } else {
+        const int slot = atomicAdd(&o.nslot[id], 1);
+        double* od = o.cand_d + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
+        int* oi = o.cand_id + ((size_t)id * KNN_SLOTS + slot) * KNN_K;
+        int ni = 0;
+#pragma unroll
+        for (int t = 0; t <= KNN_K; ++t)
+            if (bi[t] != id && bi[t] != 0x7fffffff && ni < KNN_K) { od[ni] = bd[t]; oi[ni] = bi[t]; ++ni; }
+        for (; ni < KNN_K; ++ni) { od[ni] = 1e300; oi[ni] = -1; }
+    }
 }
 // runs of equal sorted keys = equal (cluster, colour): flag of the leading entry; an inclusive scan of the flags numbers the runs in entry order (the leaders keep
 // the cell order that lets a wave's 64 searches walk the same cells — an unordered compaction lost exactly that)
@@ -554,28 +579,33 @@ __global__ void k_knn_run_leads(const int* __restrict__ flag, const int* __restr
     if (e >= *count) return;
     if (flag[e]) lead[incl[e] - 1] = e;
 }
+template <bool RUNS>
 __global__ __launch_bounds__(256) void k_knn_grid16(const unsigned* __restrict__ cols, const int* __restrict__ count, const int* __restrict__ incl, const int* __restrict__ lead,
-                                                    const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
-                                                    int* __restrict__ run_id, unsigned* __restrict__ run_col) {
+                                                    const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, const int* __restrict__ start, int cs, int force, KnnOut o) {
     const int m = *count; const int nr = m > 0 ? incl[m - 1] : 0;
+    if (knn_use_runs(m, nr, force) != RUNS) return;
     const int v = threadIdx.x & 15;
-    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < nr; r += gridDim.x * 16)
-        knn_grid_entry16(lead[r], r, v, cols, keys, vals, start, cs, run_id, run_col);
+    const int nq = RUNS ? nr : m;
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < nq; r += gridDim.x * 16)
+        knn_grid_entry16<RUNS>(RUNS ? lead[r] : r, r, v, cols, keys, vals, start, cs, o);
 }
-// Grid-stride over the runs with a BOUNDED grid: the searches are long-running and this kernel lives on the side stream; a grid
+// Grid-stride over the runs (entries) with a BOUNDED grid: the searches are long-running and this kernel lives on the side stream; a grid
 // that fills every CU slot makes the short main-stream kernels wait until all of its workgroups have been dispatched.
+template <bool RUNS>
 __global__ __launch_bounds__(256) void k_knn_grid(const unsigned* __restrict__ cols, const int* __restrict__ count, const int* __restrict__ incl, const int* __restrict__ lead,
-                                                  const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, const int* __restrict__ start, int cs,
-                                                  int* __restrict__ run_id, unsigned* __restrict__ run_col) {
+                                                  const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, const int* __restrict__ start, int cs, int force, KnnOut o) {
     const int m = *count; const int nr = m > 0 ? incl[m - 1] : 0;
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < nr; r += gridDim.x * 256)
-        knn_grid_entry(lead[r], r, cols, keys, vals, start, cs, run_id, run_col);
+    if (knn_use_runs(m, nr, force) != RUNS) return;
+    const int nq = RUNS ? nr : m;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < nq; r += gridDim.x * 256)
+        knn_grid_entry<RUNS>(RUNS ? lead[r] : r, r, cols, keys, vals, start, cs, o);
 }
 // every entry takes its run's k+1 winners minus itself (findSubKNNs: drop self, keep the first k) into one of its pixel's candidate slots
-__global__ void k_knn_scatter(const int* __restrict__ count, const int* __restrict__ incl, const unsigned* __restrict__ cols, const unsigned* __restrict__ vals,
+__global__ void k_knn_scatter(const int* __restrict__ count, const int* __restrict__ incl, const unsigned* __restrict__ cols, const unsigned* __restrict__ vals, int force,
                               const int* __restrict__ run_id, const unsigned* __restrict__ run_col, int* __restrict__ nslot, double* __restrict__ cand_d, int* __restrict__ cand_id) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= *count) return;
+    const int m = *count;
+    if (e >= m || !knn_use_runs(m, incl[m - 1], force)) return;
     const int r = incl[e] - 1;
     const int id = (int)vals[e];
     const unsigned pc = cols[e] & 0xFFFFFFu;
@@ -684,14 +714,20 @@ int nctk_knn_graph(nct_ctx* ctx, hipStream_t s, const uint8_t* lab_u8, int h, in
     hipLaunchKernelGGL(k_knn_run_leads, dim3(cdiv(cap, 256)), dim3(256), 0, s, (const int*)flag, (const int*)incl, count, (int*)lead); NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_entry_colours, dim3(cdiv(cap, 256)), dim3(256), 0, s, lab_u8, count, (const unsigned*)vals_s, (const int*)incl, (const int*)lead, (unsigned*)cols);
     NCT_LAUNCH_CHECK();
-    if (n <= NCT_KNN_LANES16_BELOW)
-        hipLaunchKernelGGL(k_knn_grid16, dim3(std::min(cdiv(cap, 16), 4 * NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, count, (const int*)incl, (const int*)lead,
-                           (const unsigned*)keys_s, (const unsigned*)vals_s, (const int*)start, cs, (int*)run_id, (unsigned*)run_col);
-    else
-        hipLaunchKernelGGL(k_knn_grid, dim3(std::min(cdiv(cap, 256), NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, count, (const int*)incl, (const int*)lead,
-                           (const unsigned*)keys_s, (const unsigned*)vals_s, (const int*)start, cs, (int*)run_id, (unsigned*)run_col);
-    NCT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_knn_scatter, dim3(cdiv(cap, 256)), dim3(256), 0, s, count, (const int*)incl, (const unsigned*)cols, (const unsigned*)vals_s,
+    const KnnOut ko{run_id, run_col, nslot, cand_d, cand_id};
+    const int force = ctx->knn_runs;                        // -1: by the entries-per-run ratio, on the device; 0 / 1: NCT_KNN_RUNS (tests)
+#define NCT_KNN_LAUNCH(RUNS) do { \
+    if (n <= NCT_KNN_LANES16_BELOW) \
+        hipLaunchKernelGGL(k_knn_grid16<RUNS>, dim3(std::min(cdiv(cap, 16), 4 * NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, count, (const int*)incl, (const int*)lead, \
+                           (const unsigned*)keys_s, (const unsigned*)vals_s, (const int*)start, cs, force, ko); \
+    else \
+        hipLaunchKernelGGL(k_knn_grid<RUNS>, dim3(std::min(cdiv(cap, 256), NCT_KNN_MAX_BLOCKS)), dim3(256), 0, s, (const unsigned*)cols, count, (const int*)incl, (const int*)lead, \
+                           (const unsigned*)keys_s, (const unsigned*)vals_s, (const int*)start, cs, force, ko); \
+    NCT_LAUNCH_CHECK(); } while (0)
+    NCT_KNN_LAUNCH(false);
+    NCT_KNN_LAUNCH(true);
+#undef NCT_KNN_LAUNCH
+    hipLaunchKernelGGL(k_knn_scatter, dim3(cdiv(cap, 256)), dim3(256), 0, s, count, (const int*)incl, (const unsigned*)cols, (const unsigned*)vals_s, force,
                        (const int*)run_id, (const unsigned*)run_col, (int*)nslot, (double*)cand_d, (int*)cand_id);
     NCT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_knn_merge, dim3(cdiv(n, 256)), dim3(256), 0, s, n, (const int*)nslot, (const double*)cand_d, (const int*)cand_id, knn_id, knn_w);

@@ -103,6 +103,7 @@ int nct_create(int device, nct_ctx** out) {
     if (const char* r = getenv("NCT_WLS_RTOL")) { const double v = atof(r); if (v > 0 && v < 1) c->wls_rtol = v; }
     if (const char* f = getenv("NCT_CONV_POOL_FUSE")) { const int v = atoi(f); if (v == 0 || v == 1) c->conv_pool_fuse = v; }
     if (const char* q = getenv("NCT_CONV_PAIR")) { const int v = atoi(q); if (v == 0 || v == 1) c->conv_pair = v; }
+    if (const char* q = getenv("NCT_KNN_RUNS")) { const int v = atoi(q); if (v == 0 || v == 1) c->knn_runs = v; }
     if (const char* q = getenv("NCT_S1_HUB_HINT")) { const int v = atoi(q); if (v == 0 || v == 1) c->s1_hub_hint = v; }
     if (const char* m = getenv("NCT_WLS_MAXIT")) { const int v = atoi(m); if (v > 0) c->wls_maxit = v; }
     *out = c;

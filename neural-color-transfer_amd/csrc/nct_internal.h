@@ -50,6 +50,7 @@ struct nct_ctx {
     int conv_pair = 1;                          // conv5_1 of the source and the reference in one launch (k_vgg.hip: nctk_conv3x3_pair); NCT_CONV_PAIR=0: two launches
     int* s1_hub_blocks() { return (int*)((char*)pinned + 4096); }   // [5] hub block count of each pyramid level's kNN graph (k_s1.hip), written by the side stream behind the WLS solver's 4 KB
     long long s1_hub_blocks_last[5] = {0, 0, 0, 0, 0};            // the counts the last pair's solves were launched with (-1: not known when the solve was enqueued); nct_ctx_counter
+    int knn_runs = -1;                          // kNN search form: -1 = one search per (cluster, colour) run where runs average > 2.5 entries, decided on the device; 0 / 1 = NCT_KNN_RUNS (tests)
     int s1_hub_hint = 1;                        // use the host-side hub block counts (NCT_S1_HUB_HINT=0: always launch the hub pass — the conservative path, for tests)
     bool kt_on = false;
     std::vector<hipEvent_t> kt_events; std::vector<int> kt_ids;

@@ -77,6 +77,26 @@ def test_knn_graph(ctx, oracle, case):
     assert np.allclose(gw, ow, rtol=1e-14, atol=0)
 
 
+@pytest.mark.parametrize("runs", ["0", "1"])
+def test_knn_graph_both_search_forms(oracle, runs, monkeypatch):
+    """K1 has two search forms that must give the same graph: every entry for itself (short runs of equal (cluster, colour) keys: the synthetic pairs) or one search per run
+    (natural photographs: 17 pixels per colour in in4.png); the device picks by the entries-per-run ratio, NCT_KNN_RUNS forces one. Both on an image with a third of one
+    colour AND isolated colours (the bounded-ring fallback), at the 16-lane (coarse) and one-thread (fine) sizes."""
+    import nct
+    monkeypatch.setenv("NCT_KNN_RUNS", runs)
+    with nct.Context(0) as c:
+        for (h, w, lh, lw, samples) in ((64, 60, 16, 15, 4), (200, 180, 25, 23, 8), (320, 324, 20, 21, 16)):
+            img = synth.image_flat(9, h, w)
+            img[h // 2:h // 2 + 3, : w // 2] = (255, 0, 255)                # colours far from everything else: the ring search gives way to the cluster pass
+            img[0, 0] = (0, 255, 0)
+            lab = oracle.bgr2lab(img)
+            labels = (np.arange(lh * lw).reshape(lh, lw) % 4).astype(np.int32)
+            gi, gw = c.knn_graph(lab, labels, 4, samples)
+            oi, ow = oracle.knn_graph(lab, labels, 4, samples)
+            assert np.array_equal(gi, oi), (runs, h, w)
+            assert np.allclose(gw, ow, rtol=1e-14, atol=0)
+
+
 def _level_case(seed, H, W, h, w, nlab_grid, samples, oracle, flat=False):
     mk = synth.image_flat if flat else synth.image
     s_full = mk(seed, H, W)
