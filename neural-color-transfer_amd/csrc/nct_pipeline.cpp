@@ -257,6 +257,9 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         // what the host knows about level l's hub blocks right now: the count, if the side stream has passed ev_level[l] (always, from the second level on: the host
         // has just waited for the previous level's WLS solve); else -1 and the hub pass is launched on the device-side count. The result does not depend on it.
         int hub_hint = -1;
+        // the coarsest level's graph is built while the host is still far ahead of the GPU (the VGG forwards are running): it waits for that one event — the GPU has
+        // the level's correspondence work queued meanwhile, and the solve's 200 launches are enqueued faster than they execute — rather than launch 101 hub passes blind
+        if (ctx->s1_hub_hint && l == 0) (void)hipEventSynchronize(ctx->ev_level[0]);
         if (ctx->s1_hub_hint && hipEventQuery(ctx->ev_level[l]) == hipSuccess) hub_hint = *(volatile int*)(ctx->s1_hub_blocks() + l);
         (void)hipGetLastError();                                     // hipEventQuery's hipErrorNotReady is not an error
         ctx->s1_hub_blocks_last[l] = hub_hint;
