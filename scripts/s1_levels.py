@@ -1,5 +1,5 @@
 """S1 stage time per level (stream events, one 700x700 pair in flight, median of N runs) + the CRC of the result, for the library NCT_LIB selects.
-usage: [NCT_LIB=...] [NCT_S1_PERSIST=0] python scripts/s1_levels.py [runs=7]"""
+usage: [NCT_LIB=...] [NCT_S1_HUB_HINT=0] python scripts/s1_levels.py [runs=7]"""
 import sys, zlib, statistics
 sys.path.insert(0, "tests"); sys.path.insert(0, "neural-color-transfer_amd/python")
 import nct, synth
