@@ -261,6 +261,38 @@ def test_cli_batch_matches_library(tmp_path, ctx):
 
 
 @pytest.mark.gpu
+def test_cli_on_the_reference_demo_inputs(tmp_path):
+    """The reference's own demo batch through the console driver: `demo/example/pairs.txt`'s layout (an `in/` sub-directory, RGBA and RGB PNGs of unequal sizes, the bds
+    sweep on one pair) with the committed demo inputs (tests/golden/natural/*.png) and the synthetic VGG19; every output PNG must carry the CRC the CPU oracle produced for that
+    line (tests/golden/natural/pair_<case>.npz) — i.e. host PNG decode, alpha drop, naming, scheduling over two workers and PNG encode add nothing to the library's result."""
+    import zlib, shutil, glob
+    from caffemodel_io import synthetic_vgg19, write_caffemodel
+    nat = os.path.join(os.path.dirname(__file__), "golden", "natural")
+    cases = sorted(os.path.basename(f)[5:-4] for f in glob.glob(os.path.join(nat, "pair_*.npz")))
+    if not cases:
+        pytest.skip("natural fixtures not generated")
+    ws, bs = synthetic_vgg19(19)
+    (tmp_path / "model" / "vgg19").mkdir(parents=True)
+    write_caffemodel(str(tmp_path / "model" / "vgg19" / "VGG_ILSVRC_19_layers.caffemodel"), ws, bs)
+    inp = tmp_path / "example"; (inp / "in").mkdir(parents=True)
+    lines = []
+    for c in cases:
+        a, b, bds = c.split("_")
+        for n in (a, b):
+            shutil.copy(os.path.join(nat, n + ".png"), inp / "in" / (n + ".png"))
+        lines.append(f"in/{a}.png in/{b}.png {float(bds):.1f}")
+    (inp / "pairs.txt").write_text("\n".join(lines) + "\n")
+    out = tmp_path / "res"
+    r = run("-m", str(tmp_path / "model"), "-i", str(inp), "-o", str(out), "-g", "0", "-inflight", "2")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for c in cases:
+        a, b, bds = c.split("_")
+        g = np.load(os.path.join(nat, f"pair_{c}.npz"))
+        got = np.ascontiguousarray(np.asarray(Image.open(out / f"{a}_{b}_{float(bds):.2f}.png").convert("RGB"))[..., ::-1])
+        assert zlib.crc32(got.tobytes()) == int(g["crc_canonical"]), c
+
+
+@pytest.mark.gpu
 def test_cli_inflight_workers_give_identical_files(tmp_path):
     """`-inflight K`: K contexts + host threads per GPU take pairs from a shared counter; the files must not depend on K."""
     from caffemodel_io import synthetic_vgg19, write_caffemodel
