@@ -24,6 +24,7 @@
 #include "nct_internal.h"
 #include "nct_device.h"
 #include "nct_reduce.h"
+#include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>   // rocPRIM directly (no CUB-compatibility layer)
 #include <rocprim/device/device_scan.hpp>
 
@@ -38,7 +39,14 @@ struct S1Sys {
     const double *gx, *gy;                  // [n]
     const int* knn_id;                      // [n][8]
     nct_s1_graph g;                         // iw2, compact in-edge arrays, hub block table
+    int xcd;                                // workgroups of one XCD take a contiguous range of pixel blocks (the shared-gather levels; NCT_S1_XCD=0: plain order)
 };
+// workgroup ids go round-robin over the 8 XCDs: XCD x takes the x-th eighth of the logical blocks
+__device__ __forceinline__ int s1_block_of(int bid, int nblocks, int xcd) {
+    if (!xcd) return bid;
+    const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7, idx = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+}
 struct S1State { double gm[3], al[3], be[3]; int active[3], iters[3]; };
 
 // a [pixel][6] record as three 16-byte loads / stores (records are 48 bytes, arena blocks 256-byte aligned)
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void k_s1_hub(nct_s1_graph G, const double* __
 #endif
 constexpr int S1_CHUNK = NCT_S1_CHUNK;
 template <bool COOP>
-__device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__ p, int i, bool live, double (&a)[3], double (&b)[3], double (&ya)[3], double (&yb)[3]) {
+__device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__ p, int i, bool live, double (&a)[3], double (&b)[3], double (&ya)[3], double (&yb)[3], int lb = -1) {
     const int w = S.w, h = S.h;
     int e0 = 0, e1 = 0, h0 = 0, h1 = 0;
 #pragma unroll
@@ -240,7 +248,7 @@ __device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__
         // first-block in-edges of the workgroup's pixels [i0, i1): compact range [E0, E1)
         __shared__ double s_pv[6 * S1_CHUNK];          // [c][edge]
         __shared__ double s_wt[S1_CHUNK];
-        const int i0 = blockIdx.x * 256, i1 = min(i0 + 256, S.n);
+        const int i0 = (lb >= 0 ? lb : (int)blockIdx.x) * 256, i1 = min(i0 + 256, S.n);
         const int E0 = lo32(S.g.starts[i0]), E1 = lo32(S.g.starts[i1]);
         for (int base = E0; base < E1; base += S1_CHUNK) {
             const int cnt = min(S1_CHUNK, E1 - base);
@@ -284,10 +292,11 @@ __global__ __launch_bounds__(256) void k_s1_residual(S1Sys S, const double* __re
 // w = Op(r); block partials of gamma = r.r (slots 0..2) and delta = r.w (slots 3..5), per Lab channel over both parts
 template <bool COOP>
 __global__ __launch_bounds__(256) void k_s1_apply(S1Sys S, const double* __restrict__ r6, double* __restrict__ w6, double* __restrict__ partial /*[nb][6]*/) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lb = s1_block_of(blockIdx.x, gridDim.x, S.xcd);
+    const int i = lb * 256 + threadIdx.x;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     double a[3], b[3], ya[3], yb[3];
-    s1_op<COOP>(S, r6, i, i < S.n, a, b, ya, yb);
+    s1_op<COOP>(S, r6, i, i < S.n, a, b, ya, yb, lb);
     if (i < S.n) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(256) void k_s1_apply(S1Sys S, const double* __restr
         const double o[6] = {ya[0], ya[1], ya[2], yb[0], yb[1], yb[2]};
         st6(w6, (size_t)i, o);
     }
-    block_reduce_store<6>(acc, partial);
+    block_reduce_store<6>(acc, partial, lb);
 }
 
 // ---------------------------------------------------------------- scalars and vector pass
@@ -402,7 +411,12 @@ int nctk_s1_solve(nct_ctx* ctx, hipStream_t s, const nct_s1_graph& g, const int*
     DevBuf<S1State> st(ctx, 2);
     if (!daa.ok() || !dab.ok() || !dbb.ok() || !rhs.ok() || !x6.ok() || !r6.ok() || !w6.ok() || !p6.ok() || !s6.ok() || !partial.ok() || !st.ok()) return NCT_ERR_HIP;
     hipLaunchKernelGGL(k_s1_setup, dim3(nbl), dim3(256), 0, s, n, weight, dWeight, s_lab_level, g_lab_level, (double*)daa, (double*)dab, (double*)dbb, (double*)rhs); LCHK();
-    S1Sys S{n, h, w, daa, dab, dbb, gx, gy, knn_id, g};
+    // XCD-aware block order for the operator pass of the bandwidth-bound levels: an XCD's workgroups take a contiguous eighth of the image, so the rows above and below a
+    // block's pixels and the block's own records are in ITS L2 (round 4 measured no gain on the two-pass recurrence's operator; on this one: 9.8 -> 9.3-9.5 ms for the
+    // finest level of the bench pair, same bits — the partial sums keep their logical block slot). A cluster-major pixel order on top of it (scripts/s1_cluster_probe.py)
+    // LOSES: only 41 % of the bench pair's kNN edges stay inside the pixel's own k-means cluster.
+    static const int s1_xcd = [] { const char* e = getenv("NCT_S1_XCD"); return e ? atoi(e) : 1; }();
+    S1Sys S{n, h, w, daa, dab, dbb, gx, gy, knn_id, g, (s1_xcd && n >= 100000) ? 1 : 0};
     const double tol2 = 1e-6 * 1e-6;
     const int maxit = layer == 4 ? 50 : 100;                       // ColorTransfer.cpp:916-921
     const bool coop = n >= 100000;                                  // shared in-edge gathers pay off on the bandwidth-bound levels only

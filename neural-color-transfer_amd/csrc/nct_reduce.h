@@ -35,12 +35,13 @@ __device__ __forceinline__ void tree256(double (&v)[NQ], double* __restrict__ s_
     }
 }
 template <int NQ>
-__device__ __forceinline__ void block_reduce_store(double (&v)[NQ], double* __restrict__ partial /*[nblocks][NQ]*/) {
+__device__ __forceinline__ void block_reduce_store(double (&v)[NQ], double* __restrict__ partial /*[nblocks][NQ]*/, int slot = -1 /* logical block (default: blockIdx.x) */) {
     __shared__ double s_red[128 * NQ];
     tree256<NQ>(v, s_red);
     if (threadIdx.x == 0) {
+        const size_t b = slot >= 0 ? (size_t)slot : (size_t)blockIdx.x;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) partial[(size_t)blockIdx.x * NQ + q] = v[q];
+        for (int q = 0; q < NQ; ++q) partial[b * NQ + q] = v[q];
     }
 }
 // sum partial[nb][NQ] in a fixed order (single block of 256 threads): thread t adds its partials b = t, t + 256, … in ascending order, then the same tree
