@@ -160,7 +160,7 @@ int nctk_local_color_transfer(nct_ctx* ctx, hipStream_t s, const float* err, con
             // no prebuilt graph part (the host entry point nct_local_color_transfer): build it here, on this stream; the host does not know the hub block count
             nct_s1_graph_bufs gb(ctx, n);
             if (!gb.ok()) return NCT_ERR_HIP;
-            const nct_s1_graph g = gb.view(-1);
+            const nct_s1_graph g = gb.view(-1, -1);
             rc1 = nctk_s1_graph_build(ctx, s, knn_id, knn_w, sqrt(prm.nonlocal_weight / prm.k_num), g, nullptr);
             if (rc1 == 0) rc1 = nctk_s1_solve(ctx, s, g, knn_id, weight, dWeight_f, s_lab_level, g_lab_level, gx, gy, layer, h, w, x, dbg ? dbg->cg_iters : nullptr);
         }

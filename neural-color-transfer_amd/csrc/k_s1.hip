@@ -92,6 +92,20 @@ __global__ void k_s1_counts(const int* __restrict__ rev_start, int n, unsigned l
     }
     cnt[i] = v;
 }
+// pixels with more than 64 hub blocks: super-blocks of 64 blocks (one exclusive scan of ceil(blocks / 64)); thread per pixel fills its super-blocks' first block indices
+__global__ void k_s1_sup_counts(const unsigned long long* __restrict__ starts, int n, int* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    int c = 0;
+    if (i < n) { const int m = hi32(starts[i + 1]) - hi32(starts[i]); c = m > S1_SEG ? (m + S1_SEG - 1) / S1_SEG : 0; }
+    cnt[i] = c;
+}
+__global__ void k_s1_sup_fill(const unsigned long long* __restrict__ starts, const int* __restrict__ sup_start, int n, int* __restrict__ sup_b0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s0 = sup_start[i], ns = sup_start[i + 1] - s0, b0 = hi32(starts[i]);
+    for (int k = 0; k < ns; ++k) sup_b0[s0 + k] = b0 + k * S1_SEG;
+}
 // position e of the target-sorted edge list (ascending edge id src*8+ki inside a target): rank r inside its target's list. r < 64 -> the compact arrays the
 // operator pass reads; r >= 64 -> the full-position arrays the hub pass reads, and the first edge of every further block fills the block table
 __global__ void k_s1_rev_build(const unsigned* __restrict__ keys_sorted, const unsigned* __restrict__ edge_sorted, const double* __restrict__ iw2, int m,
@@ -116,13 +130,16 @@ int nctk_s1_graph_build(nct_ctx* ctx, hipStream_t s, const int* knn_id, const do
     const int n = g.n, m = 8 * n;
     DevBuf<unsigned> ek(ctx, m), ev(ctx, m), eks(ctx, m), evs(ctx, m);
     DevBuf<unsigned long long> cnt(ctx, (size_t)n + 1);
-    if (!ek.ok() || !ev.ok() || !eks.ok() || !evs.ok() || !cnt.ok()) return NCT_ERR_HIP;
+    DevBuf<int> scnt(ctx, (size_t)n + 1);
+    if (!ek.ok() || !ev.ok() || !eks.ok() || !evs.ok() || !cnt.ok() || !scnt.ok()) return NCT_ERR_HIP;
     hipLaunchKernelGGL(k_s1_iw2, dim3(cdiv(m, 256)), dim3(256), 0, s, knn_w, m, nonlocalWeight, g.iw2); LCHK();
     hipLaunchKernelGGL(k_edge_keys, dim3(cdiv(m, 256)), dim3(256), 0, s, knn_id, m, (unsigned*)ek, (unsigned*)ev); LCHK();
     int end_bit = 1; while ((1u << end_bit) < (unsigned)n && end_bit < 32) ++end_bit;
-    size_t tmp_bytes = 0, scan_bytes = 0;
+    size_t tmp_bytes = 0, scan_bytes = 0, scan2_bytes = 0;
     NCT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned*)ek, (unsigned*)eks, (const unsigned*)ev, (unsigned*)evs, m, 0, end_bit, s));
     NCT_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (const unsigned long long*)cnt, g.starts, 0ull, (size_t)n + 1, rocprim::plus<unsigned long long>(), s));
+    NCT_HIP(rocprim::exclusive_scan(nullptr, scan2_bytes, (const int*)scnt, g.sup_start, 0, (size_t)n + 1, rocprim::plus<int>(), s));
+    if (scan2_bytes > scan_bytes) scan_bytes = scan2_bytes;
     DevBuf<char> tmp(ctx, (tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes) + 16);
     if (!tmp.ok()) return NCT_ERR_HIP;
     NCT_HIP(rocprim::radix_sort_pairs((void*)(char*)tmp, tmp_bytes, (const unsigned*)ek, (unsigned*)eks, (const unsigned*)ev, (unsigned*)evs, m, 0, end_bit, s));
@@ -131,9 +148,15 @@ int nctk_s1_graph_build(nct_ctx* ctx, hipStream_t s, const int* knn_id, const do
     NCT_HIP(rocprim::exclusive_scan((void*)(char*)tmp, scan_bytes, (const unsigned long long*)cnt, g.starts, 0ull, (size_t)n + 1, rocprim::plus<unsigned long long>(), s));
     hipLaunchKernelGGL(k_s1_rev_build, dim3(cdiv(m, 256)), dim3(256), 0, s, (const unsigned*)eks, (const unsigned*)evs, (const double*)g.iw2, m, (const int*)g.rev_start,
                        (const unsigned long long*)g.starts, g.c_src, g.c_w, g.rev_src, g.rev_w, g.seg_tgt, g.seg_e0); LCHK();
-    // the number of hub blocks (high half of the last scan element) travels to the host behind this work; the caller reads it only after an event recorded
-    // behind this call has completed
-    if (nseg_pinned) NCT_HIP(hipMemcpyAsync(nseg_pinned, (const char*)(g.starts + n) + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_s1_sup_counts, dim3(cdiv(n + 1, 256)), dim3(256), 0, s, (const unsigned long long*)g.starts, n, (int*)scnt); LCHK();
+    NCT_HIP(rocprim::exclusive_scan((void*)(char*)tmp, scan2_bytes, (const int*)scnt, g.sup_start, 0, (size_t)n + 1, rocprim::plus<int>(), s));
+    hipLaunchKernelGGL(k_s1_sup_fill, dim3(cdiv(n, 256)), dim3(256), 0, s, (const unsigned long long*)g.starts, (const int*)g.sup_start, n, g.sup_b0); LCHK();
+    // the numbers of hub blocks (high half of the last scan element) and super-blocks travel to the host behind this work; the caller reads them only after an
+    // event recorded behind this call has completed
+    if (nseg_pinned) {
+        NCT_HIP(hipMemcpyAsync(nseg_pinned, (const char*)(g.starts + n) + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+        NCT_HIP(hipMemcpyAsync(nseg_pinned + 1, g.sup_start + n, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
     return 0;
 }
 
@@ -176,6 +199,31 @@ __global__ __launch_bounds__(256) void k_s1_hub(nct_s1_graph G, const double* __
 #pragma unroll
             for (int c = 0; c < 6; ++c) G.hub_part[(size_t)sg * 6 + c] = term[c];
         }
+    }
+}
+
+// second level: one wave per super-block of 64 block sums (contiguous records of hub_part), the same 64-leaf tree. Only pixels with more than 64 hub blocks — in-degree
+// above 4160: a letterboxed frame's black bars, a flat background — have super-blocks; their pixel thread then adds <= a few dozen super-block sums instead of thousands of
+// block sums one after the other (700x700 with 30 % black bars: 2 039 blocks on each of nine hubs, the operator pass 488 instead of 147 us)
+__global__ __launch_bounds__(256) void k_s1_hub2(nct_s1_graph G) {
+    const int nsup = G.sup_start[G.n];
+    const int lane = threadIdx.x & 63;
+    for (int sb = blockIdx.x * 4 + (threadIdx.x >> 6); sb < nsup; sb += gridDim.x * 4) {
+        // the super-block's pixel is not stored: its last block is bounded by the next super-block's first (same pixel) or, for a pixel's last super-block, by that
+        // pixel's block range — found through the block table's target
+        const int b0 = G.sup_b0[sb];
+        const int t = G.seg_tgt[b0];
+        const int bend = min(b0 + S1_SEG, hi32(G.starts[t + 1]));
+        double term[6];
+        const bool in = b0 + lane < bend;
+        if (in) ld6(G.hub_part, (size_t)(b0 + lane), term);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) term[c] = in ? term[c] : 0.0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) term[c] += __shfl_xor(term[c], off);
+        if (lane == 0) st6(G.sup_part, (size_t)sb, term);
     }
 }
 
@@ -269,10 +317,15 @@ __device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__
             __syncthreads();
         }
     }
-    // hub pixels: the sums of their further blocks of 64 in-edges, in block order (h0 == h1 for every pixel of a hub-free level)
+    // hub pixels: the sums of their further blocks of 64 in-edges, in block order (h0 == h1 for every pixel of a hub-free level); with more than 64 blocks, the sums of
+    // their super-blocks of 64 blocks instead (k_s1_hub2)
+    bool sup = false;
+    if (h1 - h0 > S1_SEG) { h0 = S.g.sup_start[i]; h1 = S.g.sup_start[i + 1]; sup = true; }
+    const double* __restrict__ part = sup ? S.g.sup_part : S.g.hub_part;
     for (int sg = h0; sg < h1; ++sg) {
+        double q[6]; ld6(part, (size_t)sg, q);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { ya[c] += S.g.hub_part[(size_t)sg * 6 + c]; yb[c] += S.g.hub_part[(size_t)sg * 6 + 3 + c]; }
+        for (int c = 0; c < 3; ++c) { ya[c] += q[c]; yb[c] += q[3 + c]; }
     }
 }
 
@@ -423,8 +476,11 @@ int nctk_s1_solve(nct_ctx* ctx, hipStream_t s, const nct_s1_graph& g, const int*
     const bool fused = nbl <= S1_FUSE_NB;
     // hub pass: only where the host knows (or cannot exclude) that the level has in-edge lists longer than one block
     const int hub_grid = g.nseg_hint == 0 ? 0 : (g.nseg_hint > 0 ? (cdiv(g.nseg_hint, 4) < 4096 ? cdiv(g.nseg_hint, 4) : 4096) : 256);
+    // the second level only where some pixel has more than 64 hub blocks (in-degree above 4160), by the same rule
+    const int hub2_grid = (g.nseg_hint == 0 || g.nsup_hint == 0) ? 0 : (g.nsup_hint > 0 ? (cdiv(g.nsup_hint, 4) < 1024 ? cdiv(g.nsup_hint, 4) : 1024) : 64);
     auto hub = [&](const double* v) -> int {
         if (hub_grid) { hipLaunchKernelGGL(k_s1_hub, dim3(hub_grid), dim3(256), 0, s, g, v); LCHK(); }
+        if (hub2_grid) { hipLaunchKernelGGL(k_s1_hub2, dim3(hub2_grid), dim3(256), 0, s, g); LCHK(); }
         return 0;
     };
     auto apply = [&](bool kt) -> int {

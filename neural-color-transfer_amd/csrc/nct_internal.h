@@ -48,7 +48,7 @@ struct nct_ctx {
     int mark(hipStream_t s, int tag);           // nct_api.cpp; no-op unless tm_on
     // kernel clock (NCT_FLAG_TIME_KERNELS): event pairs around single launches of the full-resolution colour-solver kernels; sample i = events 2i, 2i+1, id kt_ids[i]
     int conv_pair = 1;                          // conv5_1 of the source and the reference in one launch (k_vgg.hip: nctk_conv3x3_pair); NCT_CONV_PAIR=0: two launches
-    int* s1_hub_blocks() { return (int*)((char*)pinned + 4096); }   // [5] hub block count of each pyramid level's kNN graph (k_s1.hip), written by the side stream behind the WLS solver's 4 KB
+    int* s1_hub_blocks() { return (int*)((char*)pinned + 4096); }   // [5][2] hub block and super-block count of each pyramid level's kNN graph (k_s1.hip), written by the side stream behind the WLS solver's 4 KB
     long long s1_hub_blocks_last[5] = {0, 0, 0, 0, 0};            // the counts the last pair's solves were launched with (-1: not known when the solve was enqueued); nct_ctx_counter
     int knn_runs = -1;                          // kNN search form: -1 = one search per (cluster, colour) run where runs average > 2.5 entries, decided on the device; 0 / 1 = NCT_KNN_RUNS (tests)
     int s1_hub_hint = 1;                        // use the host-side hub block counts (NCT_S1_HUB_HINT=0: always launch the hub pass — the conservative path, for tests)
@@ -134,17 +134,21 @@ struct nct_s1_graph {
     int* rev_src; double* rev_w;             // that list by position (only entries behind a first block are written and read)
     int* seg_tgt; int* seg_e0;               // hub block table: target pixel, position of the block's first edge
     double* hub_part;                        // [blocks][6] block sums of the current operator pass
-    int nseg_hint;
+    int* sup_start;                          // [n + 1] index of the pixel's first SUPER-block (64 hub blocks; only pixels with more than 64 hub blocks have any); sup_start[n] = their number
+    int* sup_b0;                             // [super-blocks] index of the super-block's first hub block (its last: min(b0 + 64, the pixel's last block))
+    double* sup_part;                        // [super-blocks][6] super-block sums of the current operator pass
+    int nseg_hint, nsup_hint;                // what the host knows about the two counts (-1: nothing yet)
 };
 struct nct_s1_graph_bufs {
     int n;
-    DevBuf<double> iw2, c_w, rev_w, hub_part; DevBuf<unsigned long long> starts; DevBuf<int> c_src, rev_start, rev_src, seg_tgt, seg_e0;
-    nct_s1_graph_bufs(nct_ctx* c, int n_) : n(n_), iw2(c, (size_t)8 * n_), c_w(c, (size_t)8 * n_), rev_w(c, (size_t)8 * n_), hub_part(c, ((size_t)n_ / 8 + 1) * 6), starts(c, (size_t)n_ + 1),
-                                            c_src(c, (size_t)8 * n_), rev_start(c, (size_t)n_ + 1), rev_src(c, (size_t)8 * n_), seg_tgt(c, (size_t)n_ / 8 + 1), seg_e0(c, (size_t)n_ / 8 + 1) {}
-    bool ok() const { return iw2.ok() && c_w.ok() && rev_w.ok() && hub_part.ok() && starts.ok() && c_src.ok() && rev_start.ok() && rev_src.ok() && seg_tgt.ok() && seg_e0.ok(); }
-    nct_s1_graph view(int hint) const { return nct_s1_graph{n, iw2, starts, c_src, c_w, rev_start, rev_src, rev_w, seg_tgt, seg_e0, hub_part, hint}; }
+    DevBuf<double> iw2, c_w, rev_w, hub_part, sup_part; DevBuf<unsigned long long> starts; DevBuf<int> c_src, rev_start, rev_src, seg_tgt, seg_e0, sup_start, sup_b0;
+    nct_s1_graph_bufs(nct_ctx* c, int n_) : n(n_), iw2(c, (size_t)8 * n_), c_w(c, (size_t)8 * n_), rev_w(c, (size_t)8 * n_), hub_part(c, ((size_t)n_ / 8 + 1) * 6), sup_part(c, ((size_t)n_ / 256 + 2) * 6),
+                                            starts(c, (size_t)n_ + 1), c_src(c, (size_t)8 * n_), rev_start(c, (size_t)n_ + 1), rev_src(c, (size_t)8 * n_), seg_tgt(c, (size_t)n_ / 8 + 1),
+                                            seg_e0(c, (size_t)n_ / 8 + 1), sup_start(c, (size_t)n_ + 1), sup_b0(c, (size_t)n_ / 256 + 2) {}
+    bool ok() const { return iw2.ok() && c_w.ok() && rev_w.ok() && hub_part.ok() && sup_part.ok() && starts.ok() && c_src.ok() && rev_start.ok() && rev_src.ok() && seg_tgt.ok() && seg_e0.ok() && sup_start.ok() && sup_b0.ok(); }
+    nct_s1_graph view(int hint, int hint2) const { return nct_s1_graph{n, iw2, starts, c_src, c_w, rev_start, rev_src, rev_w, seg_tgt, seg_e0, hub_part, sup_start, sup_b0, sup_part, hint, hint2}; }
 };
-int nctk_s1_graph_build(nct_ctx* ctx, hipStream_t s, const int* knn_id, const double* knn_w, double nonlocalWeight, const nct_s1_graph& g, int* nseg_pinned /*nullable*/);
+int nctk_s1_graph_build(nct_ctx* ctx, hipStream_t s, const int* knn_id, const double* knn_w, double nonlocalWeight, const nct_s1_graph& g, int* nseg_pinned /*nullable: [2] hub blocks, super-blocks*/);
 int nctk_s1_solve(nct_ctx* ctx, hipStream_t s, const nct_s1_graph& g, const int* knn_id, const double* weight, float dWeight, const uint8_t* s_lab_level,
                   const uint8_t* g_lab_level, const double* gx, const double* gy, int layer, int h, int w, double* x, int* cg_iters_host);
 // k_colorsolve.hip

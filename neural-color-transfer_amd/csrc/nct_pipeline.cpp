@@ -176,7 +176,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
             if (rc2 == 0) rc2 = nctk_knn_graph(ctx, s2, *slab[l], ah[l], aw[l], labels, ah[0], aw[0], 0, nlab_dev, 1 << l, *knn_ids[l], *knn_ws[l]);
             // S1's reverse adjacency and hub block table depend on the graph alone: built here, off the main stream; the block count lands in page-locked memory
             // before ev_level[l] completes, so the host can size (or skip) the level's hub passes without a synchronisation
-            if (rc2 == 0) rc2 = nctk_s1_graph_build(ctx, s2, *knn_ids[l], *knn_ws[l], sqrt(prm->nonlocal_weight / (double)prm->k_num), s1g[l]->view(-1), ctx->s1_hub_blocks() + l);
+            if (rc2 == 0) rc2 = nctk_s1_graph_build(ctx, s2, *knn_ids[l], *knn_ws[l], sqrt(prm->nonlocal_weight / (double)prm->k_num), s1g[l]->view(-1, -1), ctx->s1_hub_blocks() + 2 * l);
             if (rc2 == 0 && hipEventRecord(ctx->ev_level[l], s2) != hipSuccess) rc2 = ctx->fail(NCT_ERR_HIP, "hipEventRecord failed");
         }
         ctx->defer_release = false;
@@ -256,14 +256,14 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         if (cs) { dbg.ab_local = cs->ab_local; dbg.ab_nonlocal = cs->ab_nonlocal; dbg.ab_up = cs->ab_up; dbg.rough = cs->roughness; dbg.ab_wls = cs->ab_wls; dbg.cg_iters = cs->cg_iters; }
         // what the host knows about level l's hub blocks right now: the count, if the side stream has passed ev_level[l] (always, from the second level on: the host
         // has just waited for the previous level's WLS solve); else -1 and the hub pass is launched on the device-side count. The result does not depend on it.
-        int hub_hint = -1;
+        int hub_hint = -1, sup_hint = -1;
         // the coarsest level's graph is built while the host is still far ahead of the GPU (the VGG forwards are running): it waits for that one event — the GPU has
         // the level's correspondence work queued meanwhile, and the solve's 200 launches are enqueued faster than they execute — rather than launch 101 hub passes blind
         if (ctx->s1_hub_hint && l == 0) (void)hipEventSynchronize(ctx->ev_level[0]);
-        if (ctx->s1_hub_hint && hipEventQuery(ctx->ev_level[l]) == hipSuccess) hub_hint = *(volatile int*)(ctx->s1_hub_blocks() + l);
+        if (ctx->s1_hub_hint && hipEventQuery(ctx->ev_level[l]) == hipSuccess) { hub_hint = *(volatile int*)(ctx->s1_hub_blocks() + 2 * l); sup_hint = *(volatile int*)(ctx->s1_hub_blocks() + 2 * l + 1); }
         (void)hipGetLastError();                                     // hipEventQuery's hipErrorNotReady is not an error
         ctx->s1_hub_blocks_last[l] = hub_hint;
-        const nct_s1_graph s1graph = s1g[l]->view(hub_hint);
+        const nct_s1_graph s1graph = s1g[l]->view(hub_hint, sup_hint);
         rc = nctk_local_color_transfer(ctx, s, err, s_lab_l, g_lab_l, s_lab_full, knn_id, knn_w, l, ah[l], aw[l], H, W, cp, out_lab, (timing || cs) ? &dbg : nullptr, &s1graph); if (rc) return rc;
         if (cs && cs->wls_iters) for (int q = 0; q < 6; ++q) cs->wls_iters[q] = wls_it[q];
         rc = nctk_lab2bgr(ctx, s, out_lab, P->out, N, (prm->flags & NCT_FLAG_LAB2BGR_CUBE) ? 1 : 0); if (rc) return rc;

@@ -54,8 +54,9 @@ static void canon_sum(const double* v, int n, int nq, double* out) {
  *      become kNN hubs with in-degrees up to the group size (demo/example/in/in1.png: 33 335; tests/synth.py: 37). A sequential sum over such a list is a
  *      33 335-step dependent chain per operator application. The order is therefore: the FIRST ORC_S1_SEG (64) in-edges of a pixel are added one by one in
  *      ascending edge id, as before; every further block of 64 in-edges (ascending edge id, relative to the list's start) is first summed by a 64-leaf halving
- *      tree (missing leaves = +0) and the block sums are added in ascending block order. Lists of <= 64 entries — every pixel of the synthetic pairs — are summed
- *      exactly as in rounds 1-4. */
+ *      tree (missing leaves = +0) and the block sums are added in ascending block order — unless there are more than 64 further blocks, in which case they are first
+ *      summed in super-blocks of 64 by the same tree and the super-block sums are added in order. Lists of <= 64 entries — every pixel of the synthetic pairs — are
+ *      summed exactly as in rounds 1-4. */
 #define ORC_S1_SEG 64
 typedef struct {
     int n, h, w;
@@ -84,7 +85,13 @@ static void s1_op(const s1sys_t* S, const double* p, int i, double* ya, double* 
     const int e0 = S->rev_start[i], e1 = S->rev_start[i + 1];
     for (int e = e0; e < e1 && e < e0 + ORC_S1_SEG; ++e) { const unsigned ed = S->rev_edge[e]; EDGE((int)(ed >> 3), S->iw2[ed]); }
 #undef EDGE
-    for (int b0 = e0 + ORC_S1_SEG; b0 < e1; b0 += ORC_S1_SEG) {          /* further blocks of 64: tree sum, then one addition per block */
+    /* further blocks of 64: tree sum per block. At most 64 of them (in-degree <= 64 + 4096): one addition per block, in block order. More (a letterboxed frame, a flat
+     * background: 10^5 pixels of one colour give their hubs thousands of blocks): the block sums are themselves summed in SUPER-BLOCKS of 64 by the same tree (missing
+     * leaves +0), one addition per super-block, in order. */
+    const int nblk = e1 - e0 > ORC_S1_SEG ? (e1 - e0 - 1) / ORC_S1_SEG : 0;
+    double sup[6][ORC_S1_SEG]; int nsup_fill = 0;
+    for (int k = 0; k < nblk; ++k) {
+        const int b0 = e0 + (k + 1) * ORC_S1_SEG;
         double leaf[6][ORC_S1_SEG];
         for (int t = 0; t < ORC_S1_SEG; ++t) {
             const int e = b0 + t;
@@ -95,7 +102,15 @@ static void s1_op(const s1sys_t* S, const double* p, int i, double* ya, double* 
         }
         for (int c = 0; c < 6; ++c)
             for (int off = ORC_S1_SEG / 2; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) leaf[c][t] += leaf[c][t + off];
-        for (int c = 0; c < 3; ++c) { ya[c] += leaf[c][0]; yb[c] += leaf[3 + c][0]; }
+        if (nblk <= ORC_S1_SEG) { for (int c = 0; c < 3; ++c) { ya[c] += leaf[c][0]; yb[c] += leaf[3 + c][0]; } continue; }
+        for (int c = 0; c < 6; ++c) sup[c][nsup_fill] = leaf[c][0];
+        if (++nsup_fill == ORC_S1_SEG || k == nblk - 1) {
+            for (int t = nsup_fill; t < ORC_S1_SEG; ++t) for (int c = 0; c < 6; ++c) sup[c][t] = 0.0;
+            for (int c = 0; c < 6; ++c)
+                for (int off = ORC_S1_SEG / 2; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) sup[c][t] += sup[c][t + off];
+            for (int c = 0; c < 3; ++c) { ya[c] += sup[c][0]; yb[c] += sup[3 + c][0]; }
+            nsup_fill = 0;
+        }
     }
 }
 

@@ -1,3 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out/r5b
-timeout 900 python -m pytest tests/test_gpu_pipeline.py tests/test_cli.py -x -q -s -k "natural_demo_pair_matches or cli_on_the_reference" > gpurun_out/r5b/natfix.log 2>&1; echo "rc=$?"; grep -v "^$" gpurun_out/r5b/natfix.log | tail -12
+timeout 900 python -m pytest tests/test_gpu_color.py tests/test_gpu_pipeline.py -x -q -k "local_color_transfer_stages or levels_match or degenerate or downscaled or hub_pass or in0_tar0" > gpurun_out/r5b/hub2.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r5b/hub2.log
+python scripts/flat_probe.py 2>&1 | tail -4
