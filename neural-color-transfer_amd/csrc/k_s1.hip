@@ -15,7 +15,8 @@
 //    the operator 100x slower (1.06 s instead of 8 ms for the finest level). The in-edge sum is therefore specified in blocks of S1_SEG = 64 edges: the first block
 //    is added edge by edge inside the operator pass as before (lists of <= 64 entries are summed exactly as in rounds 1-4), every further block is summed by a
 //    64-leaf tree — one wave per block, one gather per lane, k_s1_hub — in a pass of its own in front of the operator pass, whose pixel thread then adds the block
-//    sums in order. Whether a level has such blocks is known to the HOST without a synchronisation: the graph-only part of the system (reverse adjacency, block
+//    sums in order (pixels with MORE than 64 further blocks — in-degree above 4 160: a letterboxed frame, a flat background — add the sums of SUPER-blocks of 64 block sums
+//    instead, k_s1_hub2: the same tree one level up). Whether a level has such blocks is known to the HOST without a synchronisation: the graph-only part of the system (reverse adjacency, block
 //    table) is built on the side stream right behind the level's kNN graph and publishes the block count into page-locked memory; by the time the host enqueues a
 //    level's solve the count has long arrived (checked with hipEventQuery; if not, the hub pass is launched anyway — it exits on the device-side count).
 //    Hub-free levels (every level of the synthetic pairs) launch nothing extra.
