@@ -211,7 +211,17 @@ if nat:
     wp = os.path.join(src, "wls_natural_probe.txt")
     if os.path.exists(wp):
         N += ["## WLS iterations per right-hand side and roughness statistics (`scripts/wls_natural_probe.py`)", "", "```"] + [l.rstrip("\n") for l in open(wp)] + ["```"]
+    fp = os.path.join(src, "flat_probe.txt")
+    if os.path.exists(fp):
+        N += ["", "## Letterboxed and flat 700x700 frames (`scripts/flat_probe.py`: stage ms of one pair in flight, hub blocks per level as the host knew them)", "", "```"] + [l.rstrip("\n") for l in open(fp)] + ["```"]
     open(os.path.join(dst, f"{R}_natural.md"), "w").write("\n".join(N) + "\n")
+    rt = os.path.join(src, "wls_rtol_natural.txt")
+    if os.path.exists(rt):
+        T = [f"# {RN} — S2 stopping tolerance on the natural fixtures (`scripts/wls_rtol_natural.py`), build {bench['build_id']}", "",
+             "The GPU result at `NCT_WLS_RTOL` = r against the CPU oracle's EXACT-S2 image (the reference's direct-solve semantics; rebuilt from tests/golden/natural/pair_<case>.npz). At the shipped 1e-7 the GPU",
+             "equals the canonical-order oracle byte for byte at every level (the fixtures' CRCs); whether that canonical image also equals the exact solve's is a matter of 8-bit rounding luck at one of the",
+             "coarse levels, amplified by the chaotic truncated CG downstream (DESIGN.md 4 items 5, 10).", "", "```"] + [l.rstrip("\n") for l in open(rt)] + ["```"]
+        open(os.path.join(dst, f"{R}_wls_rtol_natural.md"), "w").write("\n".join(T) + "\n")
 
 print("bench:", bench["value"], "pairs/s, single pair", bench["single_pair_ms"], "ms, roofline frac", bench["roofline"]["frac"], "launches/pair", calls // pairs, "build", bench["build_id"])
 for name, b in wl.items():

@@ -43,5 +43,8 @@ for c in in1_tar1_2 in4_tar4_2 in0_tar0_2 in4_tar4_0 in4_tar4_8; do timeout 300 
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/nat_prof -o n -- python scripts/pair_only.py in4_tar4_2 2 > $out/nat_prof.log 2>&1
 find $out/nat_prof -name "*kernel_trace*" -delete; find $out/nat_prof -name "*.db" -delete
 timeout 300 python scripts/wls_natural_probe.py > $out/wls_natural_probe.txt 2>&1
+timeout 600 python scripts/wls_rtol_natural.py > $out/wls_rtol_natural.txt 2>&1
+timeout 300 python scripts/flat_probe.py > $out/flat_probe.txt 2>&1
+timeout 600 python scripts/stress_determinism.py 8 > $out/stress_determinism.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1; tail -1 $out/smoke.txt
 ls -la $out
