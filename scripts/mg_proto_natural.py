@@ -23,12 +23,12 @@ def system_img(img_bgr, lamda):
 class VMGx(M.VMG):
     """variants of the cycle: smoother = 'jac' (shipped), 'jac4' (one more sweep, same weights recycled), 'line' (x-line then y-line Jacobi, one pair per leg), 'gs' (symmetric Gauss-Seidel)"""
     def __init__(s, A, H, W, smoother="jac", **kw):
-        s.tile = kw.pop("tile", 0); s.line_levels = kw.pop("line_levels", 99)
+        s.tile = kw.pop("tile", 0); s.line_levels = kw.pop("line_levels", 99); s.njac = kw.pop("njac", 3)
         super().__init__(A, H, W, **kw); s.sm = smoother; s.fac = {}
 
     def smooth(s, l, x, b, pre):
         A, Dinv, P, H, W = s.lv[l]
-        if s.sm == "jac" or (s.sm.startswith("line") and l >= s.line_levels):
+        if s.sm == "jac" or ((s.sm.startswith("line") or s.sm.startswith("jl")) and l >= s.line_levels):
             if l not in s.fac:                                      # the product's safe diagonal: dt = max(d, (|d| + sum |w|) / 2)
                 d = A.diagonal(); off = np.asarray(abs(A).sum(1)).ravel() - abs(d)
                 s.fac[l] = 1.0 / np.maximum(d, (abs(d) + off) / 2)
@@ -43,6 +43,28 @@ class VMGx(M.VMG):
             x = x + spl.spsolve_triangular(L, b - A @ x, lower=True)
             x = x + spl.spsolve_triangular(U, b - A @ x, lower=False)
             return x
+        if s.sm.startswith("jl") and l < s.line_levels:                # Jacobi sweeps + one tile-cut x/y line pair (symmetric: lines last before the coarse grid, first after)
+            key = ("jl", l)
+            if key not in s.fac:
+                d = A.diagonal(); off = np.asarray(abs(A).sum(1)).ravel() - abs(d)
+                coo = A.tocoo(); same_row = (coo.row // W) == (coo.col // W); same_col = (coo.row % W) == (coo.col % W)
+                if s.tile:
+                    same_row &= (coo.row % W) // s.tile == (coo.col % W) // s.tile
+                    same_col &= (coo.row // W) // s.tile == (coo.col // W) // s.tile
+                Ar = sp.csr_matrix((coo.data[same_row], (coo.row[same_row], coo.col[same_row])), shape=A.shape)
+                Ac = sp.csr_matrix((coo.data[same_col], (coo.row[same_col], coo.col[same_col])), shape=A.shape)
+                s.fac[key] = (1.0 / np.maximum(d, (abs(d) + off) / 2), spl.splu(Ar.tocsc()), spl.splu(Ac.tocsc()))
+            Di, Lr, Lc = s.fac[key]; ws = s.ws[:s.njac] if s.njac < 3 else s.ws
+            def jac(x):
+                w_ = list(ws)
+                if x is None: x = w_[0] * Di * b; w_ = w_[1:]
+                for w in w_: x = x + w * Di * (b - A @ x)
+                return x
+            def lines(x, order):
+                for F in order: x = x + 0.9 * F.solve(b - A @ x)
+                return x
+            if pre: return lines(jac(x), (Lr, Lc))
+            return jac(lines(x, (Lc, Lr)))
         if s.sm.startswith("line"):
             if l not in s.fac:
                 idx = np.arange(H * W).reshape(H, W)
@@ -79,7 +101,8 @@ for lam_f in (253.0, 4.0):
         r, wx, wy = system_img(img, 0.024 * lam_f); A = M.assemble(r, wx, wy)
         rng = np.random.default_rng(5); x0 = rng.random(S * S); b = r.ravel() * x0
         res = []
-        for sm, kw in (("jac", {}), ("line", {}), ("line t32", dict(tile=32)), ("line t16", dict(tile=16)), ("line L0 only", dict(line_levels=1)), ("line L0-1 t32", dict(line_levels=2, tile=32))):
+        W2 = (0.5808, 2.6437)
+        for sm, kw in (("jac", {}), ("line L0 t32", dict(line_levels=1, tile=32)), ("jl3 L0 t32", dict(line_levels=1, tile=32)), ("jl2 L0 t32", dict(line_levels=1, tile=32, njac=2)), ("jl1 L0 t32", dict(line_levels=1, tile=32, njac=1)), ("jl3 L0 t16", dict(line_levels=1, tile=16))):
             t = time.time(); mg = VMGx(A, S, S, sm, mode="opdep", ws=W3, **kw)
             _, it = M.pcg(A, b, x0, lambda v: mg.vcycle(0, v)); res.append("%s %d (%.0fs)" % (sm, it, time.time() - t))
         print("lambda x%-5.0f %-10s | " % (lam_f, name) + " | ".join(res), flush=True)
