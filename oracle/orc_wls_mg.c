@@ -27,7 +27,8 @@ void orc_wls_system(const double* lab, int H, int W, double lamda, double alpha,
  * zero where the neighbour does not exist. Level 0: wSE = wSW = NULL (5-point). pa / pb: interpolation weights of the transfer to the next
  * coarser level — (even y, odd x): to the W / E coarse point; (odd y, even x): to the N / S one; (odd, odd): pa = 1 / d. */
 typedef struct { int H, W, n, nine; double *d, *wE, *wS, *wSE, *wSW, *pa, *pb;
-                 float *fd, *fdinv, *fE, *fS, *fSE, *fSW, *fpst, *b, *x, *x2; } lvl_t;   /* fdinv = (float)(omega_0 / dt); fpst: the columns of P towards the next coarser level as
+                 float *fd, *fdinv, *fE, *fS, *fSE, *fSW, *fpst, *b, *x, *x2;
+                 float *lxm, *lxp, *lym, *lyp; } lvl_t;   /* fdinv = (float)(omega_0 / dt); fpst: the columns of P towards the next coarser level as
                                                                                            3x3 blocks, [n_coarse][9], (float) of mg_pstencil's values: THE transfer weights of the cycle */
 
 static void tree256(double* s) { for (int off = 128; off >= 1; off >>= 1) for (int t = 0; t < off; ++t) s[t] += s[t + off]; }
@@ -149,6 +150,109 @@ static void mg_prolong(const lvl_t* L, const lvl_t* C, const float* ec, float* e
     }
 }
 
+/* ---- EXPERIMENTAL (orc_set_mg_lines(1); off by default, mirrors the product's NCT_S2_LINES=1): a block step on the FINEST level, first thing of the pre-smoother and last
+ * thing of the post-smoother. The grid is cut into fixed blocks of LINE_BX x LINE_BY pixels (aligned at 0); inside a block, for a residual r:
+ *     pre :  e1 = Lx^-1 r,  e2 = Ly^-1 (Sy e1),   x += LINE_OM (e1 + e2)        post (the adjoint):  e1 = Ly^-1 r,  e2 = Lx^-1 (Sx e1),  x += LINE_OM (e1 + e2)
+ * Lx / Ly = the tridiagonal matrices of the level's diagonal and the x / y couplings INSIDE the block, Sy / Sx = the y / x couplings inside the block (Sy e1 = r - A_block e1
+ * in exact arithmetic: an alternating-direction block solve). Point Jacobi cannot smooth along the strong couplings of a photograph's flat runs (12-37 % of the neighbour
+ * pairs carry the largest weight, next to edges 10^4 weaker); line solves can (PCG iterations -25 % on the synthetic pair, -40 ... -50 % on photographs).
+ * The Thomas factors come from mg_lines_setup in fp64 and are rounded once: lm[i] = w(i-1, i) / p(i-1) (0 at the start of a line), lp[i] = 1 / p(i), p(i) = d(i) - w(i-1, i) lm[i];
+ * the solves are fp32:   forward y(0) = r(0), y(i) = r(i) + lm(i) y(i-1);   backward e(last) = y(last) lp(last), e(i) = (y(i) + w(i, i+1) e(i+1)) lp(i). */
+#define LINE_BX 32
+#define LINE_BY 16
+#define LINE_OM 0.9f
+static int MG_LINES = 0;
+void orc_set_mg_lines(int on) { MG_LINES = on ? 1 : 0; }
+int orc_get_mg_lines(void) { return MG_LINES; }
+static void mg_lines_setup(lvl_t* L) {
+    const int W = L->W, H = L->H; const size_t n = (size_t)L->n;
+    L->lxm = (float*)malloc(sizeof(float) * n); L->lxp = (float*)malloc(sizeof(float) * n); L->lym = (float*)malloc(sizeof(float) * n); L->lyp = (float*)malloc(sizeof(float) * n);
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < H; ++r)
+        for (int c0 = 0; c0 < W; c0 += LINE_BX) {
+            double p = 0.0;
+            for (int c = c0; c < W && c < c0 + LINE_BX; ++c) {
+                const int i = r * W + c;
+                if (c == c0) { p = L->d[i]; L->lxm[i] = 0.0f; }
+                else { const double w = L->wE[i - 1], m = w / p; p = L->d[i] - w * m; L->lxm[i] = (float)m; }
+                L->lxp[i] = (float)(1.0 / p);
+            }
+        }
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < W; ++c)
+        for (int r0 = 0; r0 < H; r0 += LINE_BY) {
+            double p = 0.0;
+            for (int r = r0; r < H && r < r0 + LINE_BY; ++r) {
+                const int i = r * W + c;
+                if (r == r0) { p = L->d[i]; L->lym[i] = 0.0f; }
+                else { const double w = L->wS[i - W], m = w / p; p = L->d[i] - w * m; L->lym[i] = (float)m; }
+                L->lyp[i] = (float)(1.0 / p);
+            }
+        }
+}
+/* out = in + LINE_OM * B (rhs - M in)   (in == NULL: from zero, out = LINE_OM * B rhs);  pre: x lines first, else y lines first. out must not alias in. */
+static void mg_block_step(const lvl_t* L, const double* r0, const float* in, float* out, int pre) {
+    const int W = L->W, H = L->H, nbx = (W + LINE_BX - 1) / LINE_BX, nby = (H + LINE_BY - 1) / LINE_BY;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int blk = 0; blk < nbx * nby; ++blk) {
+        const int x0 = (blk % nbx) * LINE_BX, y0 = (blk / nbx) * LINE_BY;
+        const int bw = x0 + LINE_BX <= W ? LINE_BX : W - x0, bh = y0 + LINE_BY <= H ? LINE_BY : H - y0;
+        float res[LINE_BY][LINE_BX], e1[LINE_BY][LINE_BX], e2[LINE_BY][LINE_BX];
+        for (int q = 0; q < NQ; ++q) {
+            for (int y = 0; y < bh; ++y)
+                for (int x = 0; x < bw; ++x) {
+                    const int i = (y0 + y) * W + x0 + x;
+                    const float bq = r0 ? (float)r0[(size_t)i * NQ + q] : L->b[(size_t)i * NQ + q];
+                    if (!in) { res[y][x] = bq; continue; }
+                    /* this right-hand side's fp32 stencil in opf's order (E, W, S, N; level 0 is 5-point) */
+                    float yv = L->fd[i] * in[(size_t)i * NQ + q];
+                    if (x0 + x + 1 < W) yv -= L->fE[i] * in[(size_t)(i + 1) * NQ + q];
+                    if (x0 + x > 0) yv -= L->fE[i - 1] * in[(size_t)(i - 1) * NQ + q];
+                    if (y0 + y + 1 < H) yv -= L->fS[i] * in[(size_t)(i + W) * NQ + q];
+                    if (y0 + y > 0) yv -= L->fS[i - W] * in[(size_t)(i - W) * NQ + q];
+                    res[y][x] = bq - yv;
+                }
+            for (int stage = 0; stage < 2; ++stage) {
+                const int xl = (stage == 0) == (pre != 0);                 /* this stage solves x lines */
+                float (*rr)[LINE_BX] = stage == 0 ? res : e2;              /* stage 1's right-hand side is built in e2 and solved in place */
+                float (*ee)[LINE_BX] = stage == 0 ? e1 : e2;
+                if (stage == 1)
+                    for (int y = 0; y < bh; ++y)
+                        for (int x = 0; x < bw; ++x) {
+                            const int i = (y0 + y) * W + x0 + x;
+                            float acc = 0.0f;                                /* what the first stage's line solves left out, inside the block: forward neighbour, then backward */
+                            if (xl) { if (x + 1 < bw) acc += L->fE[i] * e1[y][x + 1]; if (x > 0) acc += L->fE[i - 1] * e1[y][x - 1]; }     /* x lines now: Sx e1 (the first stage solved y lines) */
+                            else    { if (y + 1 < bh) acc += L->fS[i] * e1[y + 1][x]; if (y > 0) acc += L->fS[i - W] * e1[y - 1][x]; }     /* y lines now: Sy e1 */
+                            e2[y][x] = acc;
+                        }
+                if (xl) {
+                    for (int y = 0; y < bh; ++y) {
+                        const int i0 = (y0 + y) * W + x0;
+                        float t = rr[y][0]; ee[y][0] = t;
+                        for (int x = 1; x < bw; ++x) { t = rr[y][x] + L->lxm[i0 + x] * t; ee[y][x] = t; }
+                        t = ee[y][bw - 1] * L->lxp[i0 + bw - 1]; ee[y][bw - 1] = t;
+                        for (int x = bw - 2; x >= 0; --x) { t = (ee[y][x] + L->fE[i0 + x] * t) * L->lxp[i0 + x]; ee[y][x] = t; }
+                    }
+                } else {
+                    for (int x = 0; x < bw; ++x) {
+                        const int i0 = y0 * W + x0 + x;
+                        float t = rr[0][x]; ee[0][x] = t;
+                        for (int y = 1; y < bh; ++y) { t = rr[y][x] + L->lym[i0 + y * W] * t; ee[y][x] = t; }
+                        t = ee[bh - 1][x] * L->lyp[i0 + (bh - 1) * W]; ee[bh - 1][x] = t;
+                        for (int y = bh - 2; y >= 0; --y) { t = (ee[y][x] + L->fS[i0 + y * W] * t) * L->lyp[i0 + y * W]; ee[y][x] = t; }
+                    }
+                }
+            }
+            for (int y = 0; y < bh; ++y)
+                for (int x = 0; x < bw; ++x) {
+                    const size_t j = (size_t)((y0 + y) * W + x0 + x) * NQ + q;
+                    const float u = (e1[y][x] + e2[y][x]) * LINE_OM;
+                    out[j] = in ? in[j] + u : u;
+                }
+        }
+    }
+}
+
 /* z = lv[0].x (fp32) for the fp64 residual r0 (rounded to fp32 on load). scr1: [n0][NQ] float scratch */
 static void vcycle(lvl_t* lv, int nl, const double* r0, float* scr1) {
     for (int l = 0; l < nl - 1; ++l) {
@@ -156,8 +260,14 @@ static void vcycle(lvl_t* lv, int nl, const double* r0, float* scr1) {
         const double* rr = l == 0 ? r0 : NULL;
         /* pre-smoothing from zero: NS sweeps, the result in L->x */
         float* cur = (MG_NS & 1) ? L->x : L->x2; float* oth = (MG_NS & 1) ? L->x2 : L->x;
+        if (l == 0 && MG_LINES) {                           /* block step from zero, then NS regular sweeps: the result in L->x again */
+            float* t = cur; cur = oth; oth = t;
+            mg_block_step(L, rr, NULL, cur, 1);
+            for (int k = 0; k < MG_NS; ++k) { mg_sweep(L, rr, cur, oth, k == 0 ? 1.0f : mg_rk(k)); t = cur; cur = oth; oth = t; }
+        } else {
         mg_sweep(L, rr, NULL, cur, 1.0f);
         for (int k = 1; k < MG_NS; ++k) { mg_sweep(L, rr, cur, oth, mg_rk(k)); float* t = cur; cur = oth; oth = t; }
+        }
         /* cur == L->x ; residual, then restriction */
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < L->n; ++i) {
@@ -190,6 +300,10 @@ static void vcycle(lvl_t* lv, int nl, const double* r0, float* scr1) {
 #pragma omp parallel for schedule(static)
         for (int j = 0; j < L->n; ++j) for (int q = 0; q < NQ; ++q) cur[(size_t)j * NQ + q] = L->x[(size_t)j * NQ + q] + scr1[(size_t)j * NQ + q];
         for (int k = 0; k < MG_NS; ++k) { mg_sweep(L, rr, cur, oth, k == 0 ? 1.0f : mg_rk(k)); float* t = cur; cur = oth; oth = t; }
+        if (l == 0 && MG_LINES) {                           /* cur == L->x: the mirrored block step, back into L->x through scr1 */
+            mg_block_step(L, rr, L->x, scr1, 0);
+            memcpy(L->x, scr1, sizeof(float) * (size_t)L->n * NQ);
+        }
     }
 }
 #undef BVS
@@ -318,11 +432,12 @@ static int mg_build(lvl_t* lv, const double* lab, int H, int W, double lamda, do
         if (l + 1 < nl) mg_weights(&lv[l]);
         mg_finish(&lv[l]);
     }
+    if (MG_LINES) mg_lines_setup(&lv[0]);
     return nl;
 }
 static void mg_free(lvl_t* lv, int nl) {
     for (int l = 0; l < nl; ++l) { lvl_t* L = &lv[l]; free(L->d); free(L->wE); free(L->wS); free(L->wSE); free(L->wSW); free(L->pa); free(L->pb); free(L->fd); free(L->fdinv); free(L->fE); free(L->fS);
-                                   free(L->fSE); free(L->fSW); free(L->fpst); free(L->b); free(L->x); free(L->x2); }
+                                   free(L->fSE); free(L->fSW); free(L->fpst); free(L->b); free(L->x); free(L->x2); free(L->lxm); free(L->lxp); free(L->lym); free(L->lyp); }
 }
 
 /* Property-test hooks (tests/test_oracle_color.py): z = Vcycle(r) for nv vectors of [n][6] doubles on the hierarchy of this system, and the level operators' statistics.

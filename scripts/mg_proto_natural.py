@@ -23,12 +23,12 @@ def system_img(img_bgr, lamda):
 class VMGx(M.VMG):
     """variants of the cycle: smoother = 'jac' (shipped), 'jac4' (one more sweep, same weights recycled), 'line' (x-line then y-line Jacobi, one pair per leg), 'gs' (symmetric Gauss-Seidel)"""
     def __init__(s, A, H, W, smoother="jac", **kw):
-        s.tile = kw.pop("tile", 0); s.line_levels = kw.pop("line_levels", 99); s.njac = kw.pop("njac", 3)
+        s.tile = kw.pop("tile", 0); s.line_levels = kw.pop("line_levels", 99); s.njac = kw.pop("njac", 3); s.om = kw.pop("om", 0.9)
         super().__init__(A, H, W, **kw); s.sm = smoother; s.fac = {}
 
     def smooth(s, l, x, b, pre):
         A, Dinv, P, H, W = s.lv[l]
-        if s.sm == "jac" or ((s.sm.startswith("line") or s.sm.startswith("jl")) and l >= s.line_levels):
+        if s.sm == "jac" or ((s.sm.startswith("line") or s.sm.startswith("jl")) and l >= s.line_levels) or (s.sm.startswith("adi") and l > 0):
             if l not in s.fac:                                      # the product's safe diagonal: dt = max(d, (|d| + sum |w|) / 2)
                 d = A.diagonal(); off = np.asarray(abs(A).sum(1)).ravel() - abs(d)
                 s.fac[l] = 1.0 / np.maximum(d, (abs(d) + off) / 2)
@@ -43,6 +43,24 @@ class VMGx(M.VMG):
             x = x + spl.spsolve_triangular(L, b - A @ x, lower=True)
             x = x + spl.spsolve_triangular(U, b - A @ x, lower=False)
             return x
+        if s.sm.startswith("adi") and l == 0:                          # tile-local ADI block step FIRST in the pre-smoother (from zero: no residual needed, no halo), LAST in the post-smoother (mirrored)
+            if "adi" not in s.fac:
+                d = A.diagonal(); off = np.asarray(abs(A).sum(1)).ravel() - abs(d)
+                coo = A.tocoo(); tx, ty = s.tile
+                r0, c0, r1, c1 = coo.row // W, coo.row % W, coo.col // W, coo.col % W
+                same_tile = (r0 // ty == r1 // ty) & (c0 // tx == c1 // tx)
+                mk = lambda m: sp.csr_matrix((coo.data[m], (coo.row[m], coo.col[m])), shape=A.shape)
+                s.fac["adi"] = (1.0 / np.maximum(d, (abs(d) + off) / 2), spl.splu(mk(same_tile & (r0 == r1)).tocsc()), spl.splu(mk(same_tile & (c0 == c1)).tocsc()), mk(same_tile))
+            Di, Lx, Ly, Att = s.fac["adi"]; om = s.om
+            def block(r, first, second):
+                e1 = first.solve(r); e2 = second.solve(r - Att @ e1); return om * (e1 + e2)
+            ws = list(s.ws[:s.njac])
+            if pre:
+                x = block(b, Lx, Ly)
+                for w in ws: x = x + w * Di * (b - A @ x)
+                return x
+            for w in ws: x = x + w * Di * (b - A @ x)
+            return x + block(b - A @ x, Ly, Lx)
         if s.sm.startswith("jl") and l < s.line_levels:                # Jacobi sweeps + one tile-cut x/y line pair (symmetric: lines last before the coarse grid, first after)
             key = ("jl", l)
             if key not in s.fac:
@@ -102,7 +120,7 @@ for lam_f in (253.0, 4.0):
         rng = np.random.default_rng(5); x0 = rng.random(S * S); b = r.ravel() * x0
         res = []
         W2 = (0.5808, 2.6437)
-        for sm, kw in (("jac", {}), ("line L0 t32", dict(line_levels=1, tile=32)), ("jl3 L0 t32", dict(line_levels=1, tile=32)), ("jl2 L0 t32", dict(line_levels=1, tile=32, njac=2)), ("jl1 L0 t32", dict(line_levels=1, tile=32, njac=1)), ("jl3 L0 t16", dict(line_levels=1, tile=16))):
+        for sm, kw in (("jac", {}), ("jl3 L0 t32", dict(line_levels=1, tile=32)), ("adi3 32x16 .9", dict(tile=(32, 16))), ("adi3 32x16 1.", dict(tile=(32, 16), om=1.0)), ("adi3 32x14", dict(tile=(32, 14))), ("adi2 32x16", dict(tile=(32, 16), njac=2)), ("adi3 32x32", dict(tile=(32, 32)))):
             t = time.time(); mg = VMGx(A, S, S, sm, mode="opdep", ws=W3, **kw)
             _, it = M.pcg(A, b, x0, lambda v: mg.vcycle(0, v)); res.append("%s %d (%.0fs)" % (sm, it, time.time() - t))
         print("lambda x%-5.0f %-10s | " % (lam_f, name) + " | ".join(res), flush=True)
