@@ -73,7 +73,8 @@ struct Lvl { int H, W, n, nine;                                  // nine: 9-poin
              vf *fd, *fdinv, *fE, *fS, *fSE, *fSW;               // fp32 copies; fdinv = (float)(omega_0 / dt), dt = the safe smoother diagonal (k_mg_finish)
              vf *fpst, *fpw;                                     // transfer to the next coarser level: fpst[I][9] = column I of P as a 3x3 block (restriction reads it),
                                                                  // fpw[4][n] = the same numbers per FINE point, one plane per parent NW, NE, SW, SE / W, E / N, S (prolongation)
-             vf *b, *x, *x2; };                                  // V-cycle vectors, planar [6][n]
+             vf *b, *x, *x2;                                     // V-cycle vectors, planar [6][n]
+             vf *lxm, *lxp, *lym, *lyp; };                       // finest level, block step only (NCT_S2_LINES): Thomas factors of the x / y lines cut at the blocks (k_mg_lines_setup)
 // pa / pb (fp64, construction only) of a fine point on a coarse grid line = its weights from the W / E (even y, odd x) or N / S (odd y, even x) coarse point;
 // of a cell centre (odd, odd): pa = 1 / d (the centre is eliminated exactly). k_mg_pstencil turns them into the columns of P.
 
@@ -427,14 +428,17 @@ __device__ __forceinline__ int mg_tile_of_block(int bid, int ntiles) {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
-constexpr int mg_threads(int TX, int TY) { return ((TX + 2 * MG_NS + 1) * (TY + 2 * MG_NS + 1) + 63) / 64 * 64; }
+constexpr int mg_threads(int TX, int TY, bool X0 = false) { return ((TX + 2 * MG_NS + 1 + (X0 ? 2 : 0)) * (TY + 2 * MG_NS + 1 + (X0 ? 2 : 0)) + 63) / 64 * 64; }
 // TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below.
 // Sweep k produces its iterate on ring(k) = the thread grid shrunk by k from every side; the residual lives on ring(MG_NS) = the tile + one pixel to the left / top.
 // Restriction R = P^T (oracle: mg_restrict): the thread of a coarse point sums fpst[I][k] * res over the 3x3 block around it, row-major.
-template <int NQ, int TX, int TY, typename TB, bool NINE>
-__global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc) {
+// X0 (block step, NCT_S2_LINES): the leg starts from the iterate x1 instead of zero, so sweep 0 is a regular sweep too and every ring moves in by one: one more halo pixel per side.
+template <int NQ, int TX, int TY, typename TB, bool NINE, bool X0 = false>
+__global__ __launch_bounds__(mg_threads(TX, TY, X0)) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc, const vf* __restrict__ x1 = nullptr) {
     if (st->nactive == 0) return;
-    constexpr int HA = MG_NS + 1, HB = MG_NS, LW = TX + HA + HB, LH = TY + HA + HB, LN = LW * LH;
+    constexpr int S0 = X0 ? 1 : 0;
+    constexpr int HA = MG_NS + 1 + S0, HB = MG_NS + S0, LW = TX + HA + HB, LH = TY + HA + HB, LN = LW * LH;
+    static_assert(LN <= mg_threads(TX, TY, X0) && mg_threads(TX, TY, X0) <= 1024, "one thread per pixel of the tile and its halo");
     __shared__ vf s_a[NQ * LN], s_b[NQ * LN];
     const int tiles_x = (F.W + TX - 1) / TX, tile = mg_tile_of_block(blockIdx.x, gridDim.x);
     const int x0 = (tile % tiles_x) * TX, y0 = (tile / tiles_x) * TY;
@@ -455,25 +459,25 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_down(const PState* __
             for (int k = 0; k < 9; ++k) ps[k] = pp[k];
         }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * F.n + i]; xk[q] = bq[q] * c.dinv; s_a[q * LN + p] = xk[q]; }     // sweep 0 (from zero)
+        for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * F.n + i]; xk[q] = X0 ? x1[(size_t)q * F.n + i] : bq[q] * c.dinv; s_a[q * LN + p] = xk[q]; }     // sweep 0 (from zero) / the given iterate
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 1; k < MG_NS; ++k) {
-        vf* src = (k & 1) ? s_a : s_b; vf* dst = (k & 1) ? s_b : s_a;
-        if (ring(k)) {
+    for (int k = 1 - S0; k < MG_NS; ++k) {
+        vf* src = ((k + S0) & 1) ? s_a : s_b; vf* dst = ((k + S0) & 1) ? s_b : s_a;
+        if (ring(k + S0)) {
             vf y[NQ]; lds_op<NQ, LW, LN, NINE>(c, src, p, xk, y);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                xk[q] = xk[q] + (bq[q] - y[q]) * (c.dinv * mg_rk(k));
+                xk[q] = xk[q] + (bq[q] - y[q]) * (k == 0 ? c.dinv : c.dinv * mg_rk(k));
                 dst[q * LN + p] = xk[q];
                 if (k == MG_NS - 1 && interior) x[(size_t)q * F.n + i] = xk[q];
             }
         }
         __syncthreads();
     }
-    vf* xs = (MG_NS & 1) ? s_a : s_b; vf* rs = (MG_NS & 1) ? s_b : s_a;       // the smoothed iterate, and where the residual goes
-    if (ring(MG_NS)) {
+    vf* xs = ((MG_NS + S0) & 1) ? s_a : s_b; vf* rs = ((MG_NS + S0) & 1) ? s_b : s_a;       // the smoothed iterate, and where the residual goes
+    if (ring(MG_NS + S0)) {
         vf yv[NQ]; lds_op<NQ, LW, LN, NINE>(c, xs, p, xk, yv);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) rs[q * LN + p] = bq[q] - yv[q];
@@ -563,6 +567,138 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
         if (k < MG_NS - 1) __syncthreads();
     }
 }
+// ---- EXPERIMENTAL, off by default (NCT_S2_LINES=1; oracle: orc_set_mg_lines, mg_block_step): a BLOCK STEP on the finest level — first thing of the pre-smoother (from zero: the residual
+// is the right-hand side, no halo at all), last thing of the post-smoother. The grid is cut into fixed LBX x LBY blocks (aligned at 0, independent of the legs' tiles); inside a block
+//     pre:  e1 = Lx^-1 r, e2 = Ly^-1 (Sy e1), x += OM (e1 + e2)          post (the adjoint):  e1 = Ly^-1 r, e2 = Lx^-1 (Sx e1), x += OM (e1 + e2)
+// with Lx / Ly the tridiagonal matrices of the diagonal and the x / y couplings inside the block, Sy / Sx the y / x couplings inside the block: an alternating-direction solve of the
+// block's own system. Point Jacobi cannot smooth along the runs of exactly flat neighbour pairs a photograph has next to its edges (couplings 10^4 apart); the line solves can
+// (PCG iterations 19 -> 13 on the synthetic pair, 35 -> 19 / 44 -> 23 on photographs). Thomas factors: fp64 at set-up, rounded once (k_mg_lines_setup); the
+// solves are fp32 in the oracle's order:  y(0) = r(0), y(i) = r(i) + lm(i) y(i-1);  e(last) = y(last) lp(last), e(i) = (y(i) + w(i, i+1) e(i+1)) lp(i).
+constexpr int LBX = 32, LBY = 16, LBP = LBX + 1, LBN = LBY * LBP + 1;      // block, padded row pitch and plane size in LDS
+constexpr float LINE_OM = 0.9f;
+// lm(i) = w(i-1, i) / p(i-1) (0 at the start of a line), lp(i) = 1 / p(i), p(i) = d(i) - w(i-1, i) lm(i): one thread per line piece
+__global__ void k_mg_lines_setup(Lvl L) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = L.W, H = L.H, nbx = (W + LBX - 1) / LBX, nby = (H + LBY - 1) / LBY;
+    if (t < H * nbx) {
+        const int r = t / nbx, c0 = (t - r * nbx) * LBX;
+        double p = 0.0;
+        for (int c = c0; c < W && c < c0 + LBX; ++c) {
+            const int i = r * W + c;
+            if (c == c0) { p = L.d[i]; L.lxm[i] = 0.0f; }
+            else { const double w = L.wE[i - 1], m = w / p; p = L.d[i] - w * m; L.lxm[i] = (vf)m; }
+            L.lxp[i] = (vf)(1.0 / p);
+        }
+    } else if (t < H * nbx + W * nby) {
+        const int u = t - H * nbx, c = u / nby, r0 = (u - c * nby) * LBY;
+        double p = 0.0;
+        for (int r = r0; r < H && r < r0 + LBY; ++r) {
+            const int i = r * W + c;
+            if (r == r0) { p = L.d[i]; L.lym[i] = 0.0f; }
+            else { const double w = L.wS[i - W], m = w / p; p = L.d[i] - w * m; L.lym[i] = (vf)m; }
+            L.lyp[i] = (vf)(1.0 / p);
+        }
+    }
+}
+// one line of at most LEN points at LDS stride STR: right-hand side in s_r, result to s_e (may be the same array); factors / forward couplings in s_m, s_p, s_w at the same positions
+template <int LEN, int STR>
+__device__ __forceinline__ void line_solve(const vf* __restrict__ s_r, vf* __restrict__ s_e, const vf* __restrict__ s_m, const vf* __restrict__ s_p, const vf* __restrict__ s_w, int len) {
+    vf y[LEN];
+#pragma unroll
+    for (int k = 0; k < LEN; ++k) if (k < len) y[k] = s_r[k * STR];
+    vf t = y[0];
+#pragma unroll
+    for (int k = 1; k < LEN; ++k) if (k < len) { t = y[k] + s_m[k * STR] * t; y[k] = t; }
+#pragma unroll
+    for (int k = LEN - 1; k >= 0; --k)
+        if (k < len) {
+            if (k == len - 1) t = y[k] * s_p[k * STR];
+            else t = (y[k] + s_w[k * STR] * t) * s_p[k * STR];
+            s_e[k * STR] = t;
+        }
+}
+template <int NQ, bool POST>
+__global__ __launch_bounds__(LBX * LBY) void k_mg_block(const PState* __restrict__ st, Lvl L, const double* __restrict__ b, const vf* __restrict__ xin, vf* __restrict__ xout) {
+    if (st->nactive == 0) return;
+    __shared__ vf s_r[NQ * LBN], s_e1[NQ * LBN];
+    __shared__ vf s_xm[LBN], s_xp[LBN], s_xw[LBN], s_ym[LBN], s_yp[LBN], s_yw[LBN];
+    constexpr int XW = LBX + 2, XN = XW * (LBY + 2);
+    __shared__ vf s_x[POST ? NQ * XN : 1];
+    const int W = L.W, H = L.H, nbx = (W + LBX - 1) / LBX;
+    const int blk = mg_tile_of_block(blockIdx.x, gridDim.x);
+    const int x0 = (blk % nbx) * LBX, y0 = (blk / nbx) * LBY;
+    const int bw = x0 + LBX <= W ? LBX : W - x0, bh = y0 + LBY <= H ? LBY : H - y0;
+    const int p = threadIdx.x, ly = p / LBX, lx = p - ly * LBX, gy = y0 + ly, gx = x0 + lx;
+    const bool valid = ly < bh && lx < bw;
+    const int i = gy * W + gx, lp = ly * LBP + lx;
+    vf own[NQ], bq[NQ];
+    if (POST) {                                                                  // the iterate with one ring of halo (whatever block owns it)
+        for (int h = p; h < XN; h += LBX * LBY) {
+            const int hy = h / XW, hx = h - hy * XW, yy = y0 + hy - 1, xx = x0 + hx - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) s_x[q * XN + h] = xin[(size_t)q * L.n + yy * W + xx];
+            }
+        }
+    }
+    vf fE_own = 0.f, fS_own = 0.f;
+    if (valid) {
+        s_xm[lp] = L.lxm[i]; s_xp[lp] = L.lxp[i]; s_ym[lp] = L.lym[i]; s_yp[lp] = L.lyp[i];
+        fE_own = L.fE[i]; fS_own = L.fS[i]; s_xw[lp] = fE_own; s_yw[lp] = fS_own;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) bq[q] = (vf)b[(size_t)q * L.n + i];
+    }
+    if (POST) __syncthreads();
+    if (valid) {
+        if (POST) {                                                              // residual, the stencil in lds_op's order E, W, S, N (level 0 is 5-point)
+            const vf d = L.fd[i];
+            const bool xr = gx + 1 < W, xl = gx > 0, yd = gy + 1 < H, yu = gy > 0;
+            const vf wW = xl ? L.fE[i - 1] : 0.f, wN = yu ? L.fS[i - W] : 0.f;
+            const int hp = (ly + 1) * XW + lx + 1;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                own[q] = s_x[q * XN + hp];
+                vf y = d * own[q];
+                if (xr) y -= fE_own * s_x[q * XN + hp + 1];
+                if (xl) y -= wW * s_x[q * XN + hp - 1];
+                if (yd) y -= fS_own * s_x[q * XN + hp + XW];
+                if (yu) y -= wN * s_x[q * XN + hp - XW];
+                s_r[q * LBN + lp] = bq[q] - y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) s_r[q * LBN + lp] = bq[q];
+        }
+    }
+    __syncthreads();
+    // stage 0: x lines (pre) / y lines (post)
+    if (!POST) { if (p < LBY * NQ) { const int row = p % LBY, q = p / LBY; if (row < bh) { const int o = row * LBP; line_solve<LBX, 1>(s_r + q * LBN + o, s_e1 + q * LBN + o, s_xm + o, s_xp + o, s_xw + o, bw); } } }
+    else       { if (p < LBX * NQ) { const int col = p % LBX, q = p / LBX; if (col < bw) line_solve<LBY, LBP>(s_r + q * LBN + col, s_e1 + q * LBN + col, s_ym + col, s_yp + col, s_yw + col, bh); } }
+    __syncthreads();
+    // what the first stage's lines left out, inside the block: forward neighbour, then backward
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            vf acc = 0.0f;
+            if (!POST) { if (ly + 1 < bh) acc += fS_own * s_e1[q * LBN + lp + LBP]; if (ly > 0) acc += s_yw[lp - LBP] * s_e1[q * LBN + lp - LBP]; }
+            else       { if (lx + 1 < bw) acc += fE_own * s_e1[q * LBN + lp + 1];   if (lx > 0) acc += s_xw[lp - 1] * s_e1[q * LBN + lp - 1]; }
+            s_r[q * LBN + lp] = acc;
+        }
+    }
+    __syncthreads();
+    // stage 1, in place in s_r
+    if (!POST) { if (p < LBX * NQ) { const int col = p % LBX, q = p / LBX; if (col < bw) line_solve<LBY, LBP>(s_r + q * LBN + col, s_r + q * LBN + col, s_ym + col, s_yp + col, s_yw + col, bh); } }
+    else       { if (p < LBY * NQ) { const int row = p % LBY, q = p / LBY; if (row < bh) { const int o = row * LBP; line_solve<LBX, 1>(s_r + q * LBN + o, s_r + q * LBN + o, s_xm + o, s_xp + o, s_xw + o, bw); } } }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const vf u = (s_e1[q * LBN + lp] + s_r[q * LBN + lp]) * LINE_OM;
+            xout[(size_t)q * L.n + i] = POST ? own[q] + u : u;
+        }
+    }
+}
+
 // Middle + tail of the V-cycle in ONE launch, one 1024-thread workgroup PER RIGHT-HAND SIDE: the first fused level has <= 4096 pixels
 // (44x44 at 700x700, 63x63 at 1000x1000), the deeper ones <= 1024 (22x22, 11x11, 6x6). The six systems share the operator but not a single
 // value, so no workgroup ever waits for another and the whole sub-cycle needs only __syncthreads(). Everything a level needs for the way
@@ -919,6 +1055,7 @@ struct PartBufs {
     int maxit, graph;
     bool trace;
     bool forecast;                                                  // size the batches by the convergence forecast (pcg_part)
+    bool lines;                                                     // block step on the finest level (NCT_S2_LINES, experimental)
     int iters[NQMAX];
 };
 template <int NQ>
@@ -944,7 +1081,14 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     constexpr int TXB = NCT_MG_TXB, TYB = NCT_MG_TYB;
     auto down = [&](int l) {
         const dim3 gb(cdiv(lv[l].W, TXB) * cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16) * cdiv(lv[l].H, 8));      // 1-D: mg_tile_of_block maps block -> tile
-        if (l == 0) {
+        if (l == 0 && B.lines) {
+            // block step from zero into x2 (free until the up leg), then the leg from that iterate: one more halo pixel per side, so 32 x 14 tiles (41 x 23 = 943 threads)
+            constexpr int TYL = TYB - 2;
+            const dim3 gl(cdiv(lv[0].W, LBX) * cdiv(lv[0].H, LBY)), gbl(cdiv(lv[0].W, TXB) * cdiv(lv[0].H, TYL));
+            hipLaunchKernelGGL((k_mg_block<NQ, false>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const double*)r, (const vf*)nullptr, lv[0].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYL, double, false, true>), gbl, dim3(mg_threads(TXB, TYL, true)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b, (const vf*)lv[0].x2);
+            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, double, false, true>), gs, dim3(mg_threads(16, 8, true)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b, (const vf*)lv[0].x2);
+        } else if (l == 0) {
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, double, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
             else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, double, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
         } else {
@@ -958,6 +1102,10 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
         if (l == 0) {
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, double, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
             else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, double, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (B.lines) {                                   // the mirrored block step: x2 -> x (the pre-smoothed iterate there is dead now)
+                const dim3 gl(cdiv(lv[0].W, LBX) * cdiv(lv[0].H, LBY));
+                hipLaunchKernelGGL((k_mg_block<NQ, true>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const double*)r, (const vf*)lv[0].x2, lv[0].x);
+            }
         } else {
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, vf, true>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
             else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, vf, true>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
@@ -997,7 +1145,7 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
         for (int l = tail0 - 1; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
         return 0;
     };
-    const vf* z = lv[0].x2;
+    const vf* z = B.lines ? lv[0].x : lv[0].x2;
     // Convergence is polled without draining the stream: after every batch of `batch` iterations the solver state is copied to
     // page-locked host memory and an event is recorded; the host then enqueues the NEXT batch before it waits for that event, so
     // the GPU always has a batch queued. The batch enqueued past convergence costs only empty launches (nactive == 0).
@@ -1160,6 +1308,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             if (!last) { L.pa = newd(L.n); L.pb = newd(L.n); }
             if (!last) { L.fpst = newf((size_t)((h + 1) / 2) * ((w + 1) / 2) * 9); L.fpw = newf((size_t)L.n * 4); }
             L.b = l == 0 ? nullptr : newf((size_t)L.n * nq0); L.x = newf((size_t)L.n * nq0); L.x2 = newf((size_t)L.n * nq0);
+            if (l == 0 && ctx->wls_lines) { L.lxm = newf(L.n); L.lxp = newf(L.n); L.lym = newf(L.n); L.lyp = newf(L.n); if (!L.lxm || !L.lxp || !L.lym || !L.lyp) return NCT_ERR_HIP; }
             if (!L.d || !L.fd || !L.fdinv || !L.fE || !L.fS || (!last && (!L.pa || !L.pb || !L.fpst || !L.fpw)) || (l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
             lv.push_back(L);
             if (last) break;
@@ -1172,6 +1321,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
         double* pst = newd((size_t)lv[1].n * 9);                  // columns of P as 3x3 blocks, reused level by level
         if (!pst) return NCT_ERR_HIP;
         hipLaunchKernelGGL(k_mg_diag, dim3(cdiv(lv[0].n, 256)), dim3(256), 0, s, lv[0], rough); LCHK();
+        if (ctx->wls_lines) { hipLaunchKernelGGL(k_mg_lines_setup, dim3(cdiv(lv[0].H * cdiv(lv[0].W, LBX) + lv[0].W * cdiv(lv[0].H, LBY), 128)), dim3(128), 0, s, lv[0]); LCHK(); }
         int l_tail = nl;                                        // first level built by k_mg_setup_tail
         for (int l = 1; l < nl; ++l) if (lv[l].n <= MG_TAIL_N) { l_tail = l; break; }
         if (nl > MG_MAXL) l_tail = nl;
@@ -1210,7 +1360,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
             if ((l > 0 && !L.b) || !L.x || !L.x2) return NCT_ERR_HIP;
         }
         B.hst = (PState*)ctx->pinned + 2 * h; B.ev[0] = ctx->ev_poll[2 * h]; B.ev[1] = ctx->ev_poll[2 * h + 1];
-        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph; B.forecast = ctx->wls_forecast != 0; B.trace = getenv("NCT_WLS_TRACE") != nullptr; B.rough = rough; B.kt = (ctx->kt_on && !split && !ctx->wls_graph) ? ctx : nullptr;   /* events recorded inside a stream capture cannot be read back: no kernel clock under NCT_WLS_GRAPH */
+        B.maxit = ctx->wls_maxit; B.graph = ctx->wls_graph; B.forecast = ctx->wls_forecast != 0; B.lines = ctx->wls_lines != 0; B.trace = getenv("NCT_WLS_TRACE") != nullptr; B.rough = rough; B.kt = (ctx->kt_on && !split && !ctx->wls_graph) ? ctx : nullptr;   /* events recorded inside a stream capture cannot be read back: no kernel clock under NCT_WLS_GRAPH */
         memset(B.iters, 0, sizeof B.iters);
     }
     if (!split) {

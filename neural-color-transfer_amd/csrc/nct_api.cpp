@@ -99,6 +99,7 @@ int nct_create(int device, nct_ctx** out) {
         if ((e = hipEventCreateWithFlags(&c->ev_poll[l], hipEventDisableTiming)) != hipSuccess) { g_create_err = std::string("event creation: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     if ((e = hipHostMalloc(&c->pinned, 4096 + 64, hipHostMallocDefault)) != hipSuccess) { g_create_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); delete c; return NCT_ERR_HIP; }
     if (const char* g = getenv("NCT_WLS_GRAPH")) c->wls_graph = atoi(g);
+    if (const char* g = getenv("NCT_S2_LINES")) c->wls_lines = atoi(g) != 0;
     if (const char* f = getenv("NCT_WLS_FORECAST")) { const int v = atoi(f); if (v == 0 || v == 1) c->wls_forecast = v; }
     if (const char* r = getenv("NCT_WLS_RTOL")) { const double v = atof(r); if (v > 0 && v < 1) c->wls_rtol = v; }
     if (const char* f = getenv("NCT_CONV_POOL_FUSE")) { const int v = atoi(f); if (v == 0 || v == 1) c->conv_pool_fuse = v; }
