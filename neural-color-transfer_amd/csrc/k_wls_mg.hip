@@ -604,6 +604,32 @@ __global__ void k_mg_lines_setup(Lvl L) {
 template <int LEN, int STR>
 __device__ __forceinline__ void line_solve(const vf* __restrict__ s_r, vf* __restrict__ s_e, const vf* __restrict__ s_m, const vf* __restrict__ s_p, const vf* __restrict__ s_w, int len) {
     vf y[LEN];
+    if (len == LEN) {                                   // every block but the ones at the right / bottom edge: no predicates, so all LDS reads are issued ahead of the dependent chain
+        constexpr int CH = 8;                             // factors are fetched CH at a time, ahead of the CH dependent steps that use them
+        static_assert(LEN % CH == 0, "line length");
+#pragma unroll
+        for (int k = 0; k < LEN; ++k) y[k] = s_r[k * STR];
+        vf t = 0.0f;
+#pragma unroll
+        for (int k0 = 0; k0 < LEN; k0 += CH) {
+            vf m[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) m[j] = s_m[(k0 + j) * STR];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { const int k = k0 + j; if (k == 0) t = y[0]; else { t = y[k] + m[j] * t; y[k] = t; } }
+        }
+#pragma unroll
+        for (int k0 = LEN - CH; k0 >= 0; k0 -= CH) {
+            vf pp[CH], ww[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { pp[j] = s_p[(k0 + j) * STR]; ww[j] = s_w[(k0 + j) * STR]; }
+#pragma unroll
+            for (int j = CH - 1; j >= 0; --j) { const int k = k0 + j; t = k == LEN - 1 ? y[k] * pp[j] : (y[k] + ww[j] * t) * pp[j]; y[k] = t; }
+        }
+#pragma unroll
+        for (int k = 0; k < LEN; ++k) s_e[k * STR] = y[k];
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < LEN; ++k) if (k < len) y[k] = s_r[k * STR];
     vf t = y[0];
@@ -618,12 +644,13 @@ __device__ __forceinline__ void line_solve(const vf* __restrict__ s_r, vf* __res
         }
 }
 template <int NQ, bool POST>
-__global__ __launch_bounds__(LBX * LBY) void k_mg_block(const PState* __restrict__ st, Lvl L, const double* __restrict__ b, const vf* __restrict__ xin, vf* __restrict__ xout) {
+__global__ __launch_bounds__(LBX * LBY, 8) void k_mg_block(const PState* __restrict__ st, Lvl L, const double* __restrict__ b, const vf* __restrict__ xin, vf* __restrict__ xout) {
     if (st->nactive == 0) return;
-    __shared__ vf s_r[NQ * LBN], s_e1[NQ * LBN];
-    __shared__ vf s_xm[LBN], s_xp[LBN], s_xw[LBN], s_ym[LBN], s_yp[LBN], s_yw[LBN];
     constexpr int XW = LBX + 2, XN = XW * (LBY + 2);
-    __shared__ vf s_x[POST ? NQ * XN : 1];
+    static_assert(NQ * XN <= (NQ + 6) * LBN, "the halo tile of the iterate lives where e1 and the factors go afterwards");
+    __shared__ vf s_all[(2 * NQ + 6) * LBN];
+    vf* const s_r = s_all; vf* const s_e1 = s_all + NQ * LBN; vf* const s_x = s_e1;          // s_x (post only): dead once the residual is in registers
+    vf* const s_xm = s_all + 2 * NQ * LBN; vf* const s_xp = s_xm + LBN; vf* const s_xw = s_xp + LBN; vf* const s_ym = s_xw + LBN; vf* const s_yp = s_ym + LBN; vf* const s_yw = s_yp + LBN;
     const int W = L.W, H = L.H, nbx = (W + LBX - 1) / LBX;
     const int blk = mg_tile_of_block(blockIdx.x, gridDim.x);
     const int x0 = (blk % nbx) * LBX, y0 = (blk / nbx) * LBY;
@@ -641,16 +668,15 @@ __global__ __launch_bounds__(LBX * LBY) void k_mg_block(const PState* __restrict
             }
         }
     }
-    vf fE_own = 0.f, fS_own = 0.f;
+    vf fE_own = 0.f, fS_own = 0.f, c_xm = 0.f, c_xp = 0.f, c_ym = 0.f, c_yp = 0.f;
     if (valid) {
-        s_xm[lp] = L.lxm[i]; s_xp[lp] = L.lxp[i]; s_ym[lp] = L.lym[i]; s_yp[lp] = L.lyp[i];
-        fE_own = L.fE[i]; fS_own = L.fS[i]; s_xw[lp] = fE_own; s_yw[lp] = fS_own;
+        c_xm = L.lxm[i]; c_xp = L.lxp[i]; c_ym = L.lym[i]; c_yp = L.lyp[i]; fE_own = L.fE[i]; fS_own = L.fS[i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) bq[q] = (vf)b[(size_t)q * L.n + i];
     }
-    if (POST) __syncthreads();
-    if (valid) {
-        if (POST) {                                                              // residual, the stencil in lds_op's order E, W, S, N (level 0 is 5-point)
+    if (POST) {
+        __syncthreads();
+        if (valid) {                                                             // residual, the stencil in lds_op's order E, W, S, N (level 0 is 5-point)
             const vf d = L.fd[i];
             const bool xr = gx + 1 < W, xl = gx > 0, yd = gy + 1 < H, yu = gy > 0;
             const vf wW = xl ? L.fE[i - 1] : 0.f, wN = yu ? L.fS[i - W] : 0.f;
@@ -663,12 +689,15 @@ __global__ __launch_bounds__(LBX * LBY) void k_mg_block(const PState* __restrict
                 if (xl) y -= wW * s_x[q * XN + hp - 1];
                 if (yd) y -= fS_own * s_x[q * XN + hp + XW];
                 if (yu) y -= wN * s_x[q * XN + hp - XW];
-                s_r[q * LBN + lp] = bq[q] - y;
+                bq[q] = bq[q] - y;
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) s_r[q * LBN + lp] = bq[q];
         }
+        __syncthreads();
+    }
+    if (valid) {
+        s_xm[lp] = c_xm; s_xp[lp] = c_xp; s_ym[lp] = c_ym; s_yp[lp] = c_yp; s_xw[lp] = fE_own; s_yw[lp] = fS_own;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s_r[q * LBN + lp] = bq[q];
     }
     __syncthreads();
     // stage 0: x lines (pre) / y lines (post)
