@@ -74,7 +74,7 @@ struct Lvl { int H, W, n, nine;                                  // nine: 9-poin
              vf *fpst, *fpw;                                     // transfer to the next coarser level: fpst[I][9] = column I of P as a 3x3 block (restriction reads it),
                                                                  // fpw[4][n] = the same numbers per FINE point, one plane per parent NW, NE, SW, SE / W, E / N, S (prolongation)
              vf *b, *x, *x2;                                     // V-cycle vectors, planar [6][n]
-             vf *lxm, *lxp, *lym, *lyp; };                       // finest level, block step only (NCT_S2_LINES): Thomas factors of the x / y lines cut at the blocks (k_mg_lines_setup)
+             vf *lxm, *lxp, *lym, *lyp; };                       // finest level, block step: Thomas factors of the x / y lines cut at the blocks (k_mg_lines_setup)
 // pa / pb (fp64, construction only) of a fine point on a coarse grid line = its weights from the W / E (even y, odd x) or N / S (odd y, even x) coarse point;
 // of a cell centre (odd, odd): pa = 1 / d (the centre is eliminated exactly). k_mg_pstencil turns them into the columns of P.
 
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
         if (k < MG_NS - 1) __syncthreads();
     }
 }
-// ---- EXPERIMENTAL, off by default (NCT_S2_LINES=1; oracle: orc_set_mg_lines, mg_block_step): a BLOCK STEP on the finest level — first thing of the pre-smoother (from zero: the residual
+// ---- Round 5 (NCT_S2_LINES=0 switches it off; oracle: orc_set_mg_lines, mg_block_step): a BLOCK STEP on the finest level — first thing of the pre-smoother (from zero: the residual
 // is the right-hand side, no halo at all), last thing of the post-smoother. The grid is cut into fixed LBX x LBY blocks (aligned at 0, independent of the legs' tiles); inside a block
 //     pre:  e1 = Lx^-1 r, e2 = Ly^-1 (Sy e1), x += OM (e1 + e2)          post (the adjoint):  e1 = Ly^-1 r, e2 = Lx^-1 (Sx e1), x += OM (e1 + e2)
 // with Lx / Ly the tridiagonal matrices of the diagonal and the x / y couplings inside the block, Sy / Sx the y / x couplings inside the block: an alternating-direction solve of the
@@ -644,7 +644,7 @@ __device__ __forceinline__ void line_solve(const vf* __restrict__ s_r, vf* __res
         }
 }
 template <int NQ, bool POST>
-__global__ __launch_bounds__(LBX * LBY, 8) void k_mg_block(const PState* __restrict__ st, Lvl L, const double* __restrict__ b, const vf* __restrict__ xin, vf* __restrict__ xout) {
+__global__ __launch_bounds__(LBX * LBY, 8) void k_mg_block(const PState* __restrict__ st, Lvl L, const vf* __restrict__ b, const vf* __restrict__ xin, vf* __restrict__ xout) {
     if (st->nactive == 0) return;
     constexpr int XW = LBX + 2, XN = XW * (LBY + 2);
     static_assert(NQ * XN <= (NQ + 6) * LBN, "the halo tile of the iterate lives where e1 and the factors go afterwards");
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(LBX * LBY, 8) void k_mg_block(const PState* __restr
     if (valid) {
         c_xm = L.lxm[i]; c_xp = L.lxp[i]; c_ym = L.lym[i]; c_yp = L.lyp[i]; fE_own = L.fE[i]; fS_own = L.fS[i];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) bq[q] = (vf)b[(size_t)q * L.n + i];
+        for (int q = 0; q < NQ; ++q) bq[q] = b[(size_t)q * L.n + i];
     }
     if (POST) {
         __syncthreads();
@@ -950,7 +950,7 @@ __device__ __forceinline__ void pcg_publish(PState* __restrict__ host_out, const
     __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 template <int NQ>
-__global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restrict__ rough, const double* __restrict__ X /*[2][n][3]*/, double* __restrict__ x6, double* __restrict__ r, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restrict__ rough, const double* __restrict__ X /*[2][n][3]*/, double* __restrict__ x6, double* __restrict__ r, vf* __restrict__ rf, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc[2 * NQ];
 #pragma unroll
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void k_pcg_start(Lvl L, const double* __restri
             const double x0 = xv(i, q);
             const double bq = rg * x0;
             const double rv = bq - y[q];
-            x6[(size_t)q * L.n + i] = x0; r[(size_t)q * L.n + i] = rv;
+            x6[(size_t)q * L.n + i] = x0; r[(size_t)q * L.n + i] = rv; rf[(size_t)q * L.n + i] = (vf)rv;
             acc[q] = rv * rv; acc[NQ + q] = bq * bq;
         }
     }
@@ -1017,7 +1017,7 @@ __global__ void k_cg_fin(const PState* __restrict__ st, const double* __restrict
 template <int NQ>
 __global__ __launch_bounds__(256) void k_cg_update(int n, const PState* __restrict__ sc, PState* __restrict__ sn, const double* __restrict__ sums, double rtol2, int first,
                                                    const vf* __restrict__ z, const double* __restrict__ w, double* __restrict__ p, double* __restrict__ s,
-                                                   double* __restrict__ x, double* __restrict__ r, PState* __restrict__ host_out, int seq) {
+                                                   double* __restrict__ x, double* __restrict__ r, vf* __restrict__ rf, PState* __restrict__ host_out, int seq) {
     if (sc->nactive == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) { *sn = *sc; if (host_out) pcg_publish(host_out, *sc, seq); } return; }
     double al[NQ], be[NQ]; bool act[NQ];
 #pragma unroll
@@ -1050,7 +1050,8 @@ __global__ __launch_bounds__(256) void k_cg_update(int n, const PState* __restri
         const double sv = first ? wv : wv + be[q] * s[j];
         p[j] = pn; s[j] = sv;
         x[j] += al[q] * pn;
-        r[j] -= al[q] * sv;
+        const double rn = r[j] - al[q] * sv;
+        r[j] = rn; rf[j] = (vf)rn;                       // the V-cycle reads the residual rounded to fp32 (four kernels on the finest level): rounded once here, half the bytes there
     }
 }
 template <int NQ>
@@ -1077,6 +1078,7 @@ struct ErrSink {
 static std::atomic<int> g_seq{0};                         // publication numbers of the host-visible solver states: unique per process, so a slot never shows a stale match
 struct PartBufs {
     double *x6, *r, *p, *sv, *w, *partial, *sums; PState* st;      // Krylov vectors [NQ][N], reduction scratch, double-buffered state
+    vf* rf;                                                         // the residual rounded to fp32: what the V-cycle's finest level reads (written next to r by k_pcg_start / k_cg_update)
     std::vector<Lvl> lv;                                            // the shared operator hierarchy with THIS part's V-cycle vectors (b, x, x2)
     PState* hst; hipEvent_t ev[2];                                  // two page-locked read-back slots and their events
     const double* rough;                                            // the data term (right-hand side = rough * x0)
@@ -1084,7 +1086,7 @@ struct PartBufs {
     int maxit, graph;
     bool trace;
     bool forecast;                                                  // size the batches by the convergence forecast (pcg_part)
-    bool lines;                                                     // block step on the finest level (NCT_S2_LINES, experimental)
+    bool lines;                                                     // block step on the finest level (default; NCT_S2_LINES=0: without)
     int iters[NQMAX];
 };
 template <int NQ>
@@ -1094,10 +1096,11 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     const Lvl& F = lv[0];
     const int N = F.n, nb = cdiv(N, 256);
     double *x6 = B.x6, *r = B.r, *p = B.p, *sv = B.sv, *w = B.w, *partial = B.partial, *sums = B.sums;
+    vf* rf = B.rf;
     PState* st = B.st;                                 // st[0] / st[1]; `cur` = the state the iteration being enqueued reads
     const PState* cur = st;
     const double rtol2 = rtol * rtol;
-    hipLaunchKernelGGL(k_pcg_start<NQ>, dim3(nb), dim3(256), 0, s, F, B.rough, (const double*)X, (double*)x6, (double*)r, (double*)partial); LCHK();
+    hipLaunchKernelGGL(k_pcg_start<NQ>, dim3(nb), dim3(256), 0, s, F, B.rough, (const double*)X, (double*)x6, (double*)r, rf, (double*)partial); LCHK();
     const bool zero_copy = !B.graph;                       // the graph hook replays fixed kernel arguments: it keeps the copy + event form
     int seq_of_slot[2] = {0, 0};
     seq_of_slot[0] = ++g_seq;
@@ -1114,12 +1117,12 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
             // block step from zero into x2 (free until the up leg), then the leg from that iterate: one more halo pixel per side, so 32 x 14 tiles (41 x 23 = 943 threads)
             constexpr int TYL = TYB - 2;
             const dim3 gl(cdiv(lv[0].W, LBX) * cdiv(lv[0].H, LBY)), gbl(cdiv(lv[0].W, TXB) * cdiv(lv[0].H, TYL));
-            hipLaunchKernelGGL((k_mg_block<NQ, false>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const double*)r, (const vf*)nullptr, lv[0].x2);
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYL, double, false, true>), gbl, dim3(mg_threads(TXB, TYL, true)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b, (const vf*)lv[0].x2);
-            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, double, false, true>), gs, dim3(mg_threads(16, 8, true)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b, (const vf*)lv[0].x2);
+            hipLaunchKernelGGL((k_mg_block<NQ, false>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const vf*)rf, (const vf*)nullptr, lv[0].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYL, vf, false, true>), gbl, dim3(mg_threads(TXB, TYL, true)), 0, s, cur, lv[l], (const vf*)rf, lv[l].x, lv[l + 1], lv[l + 1].b, (const vf*)lv[0].x2);
+            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, vf, false, true>), gs, dim3(mg_threads(16, 8, true)), 0, s, cur, lv[l], (const vf*)rf, lv[l].x, lv[l + 1], lv[l + 1].b, (const vf*)lv[0].x2);
         } else if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, double, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
-            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, double, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, lv[l].x, lv[l + 1], lv[l + 1].b);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, vf, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)rf, lv[l].x, lv[l + 1], lv[l + 1].b);
+            else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, vf, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)rf, lv[l].x, lv[l + 1], lv[l + 1].b);
         } else {
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYB, vf, true>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
             else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, vf, true>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
@@ -1129,11 +1132,11 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
         const dim3 gb(cdiv(lv[l].W, TXB) * cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16) * cdiv(lv[l].H, 8));
         const int Wc = lv[l + 1].W, nc = lv[l + 1].n;
         if (l == 0) {
-            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, double, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, double, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const double*)r, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, vf, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)rf, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
+            else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, vf, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)rf, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
             if (B.lines) {                                   // the mirrored block step: x2 -> x (the pre-smoothed iterate there is dead now)
                 const dim3 gl(cdiv(lv[0].W, LBX) * cdiv(lv[0].H, LBY));
-                hipLaunchKernelGGL((k_mg_block<NQ, true>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const double*)r, (const vf*)lv[0].x2, lv[0].x);
+                hipLaunchKernelGGL((k_mg_block<NQ, true>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const vf*)rf, (const vf*)lv[0].x2, lv[0].x);
             }
         } else {
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, vf, true>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
@@ -1192,7 +1195,7 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
         hipLaunchKernelGGL(k_cg_fin<NQ>, dim3(3), dim3(256), 0, s, cur, (const double*)partial, nb, (double*)sums); LCHK();
         rc = kt_b(NCT_KT_WLS_UPDATE); if (rc) return rc;
         hipLaunchKernelGGL(k_cg_update<NQ>, dim3(nb), dim3(256), 0, s, N, cur, nxt, (const double*)sums, rtol2, it == 0 ? 1 : 0, z, (const double*)w,
-                           (double*)p, (double*)sv, (double*)x6, (double*)r, pub_to, pub_seq); LCHK();
+                           (double*)p, (double*)sv, (double*)x6, (double*)r, rf, pub_to, pub_seq); LCHK();
         rc = kt_e(); if (rc) return rc;
         cur = nxt;
         return 0;
@@ -1379,6 +1382,7 @@ int nctk_wls_solve_mg(nct_ctx* ctx, hipStream_t s, double* X, const double* roug
     for (int h = 0; h < nparts; ++h) {
         PartBufs& B = part[h];
         const size_t v = (size_t)N * nq0;
+        B.rf = newf(v); if (!B.rf) return NCT_ERR_HIP;
         B.x6 = newd(v); B.r = newd(v); B.p = newd(v); B.sv = newd(v); B.w = newd(v); B.partial = newd((size_t)nb * 3 * nq0); B.sums = newd(3 * nq0);
         B.st = (PState*)ctx->alloc(2 * sizeof(PState)); if (B.st) owned.push_back(B.st);
         if (!B.x6 || !B.r || !B.p || !B.sv || !B.w || !B.partial || !B.sums || !B.st) return NCT_ERR_HIP;

@@ -36,7 +36,7 @@ struct nct_ctx {
     // (no host syncs in between: see nct_pair_timing in nct.h)
     int wls_split = 0;                          // NCT_FLAG_LATENCY of the running pair: a- and b-half of the WLS solve on two streams
     int wls_forecast = 1;                       // size the PCG iteration batches by the host's convergence forecast (k_wls_mg.hip: pcg_part); NCT_WLS_FORECAST=0: fixed batches
-    int wls_lines = 0;                          // EXPERIMENTAL (env NCT_S2_LINES=1; oracle: orc_set_mg_lines): block step of alternating line solves on the finest S2 level (k_wls_mg.hip: k_mg_block) — changes the arithmetic
+    int wls_lines = 1;                          // block step of alternating line solves on the finest S2 level (k_wls_mg.hip: k_mg_block; oracle: mg_block_step). NCT_S2_LINES=0: the cycle without it (other arithmetic; comparison only)
     int wls_graph = 0;                          // experiment hook (env NCT_WLS_GRAPH=1): replay the PCG iteration batch as a HIP graph
     int conv_pool_fuse = -1;                    // VGG: 2x2 max-pool inside the conv epilogue: -1 = where the tile shape fits the map (nctk_conv3x3_pool_fits), 0 never, 1 always (NCT_CONV_POOL_FUSE; tests)
     double wls_rtol = 1e-7;                     // relative residual at which the WLS solve stops. 1e-7: the 8-bit result of every level equals the EXACT solve's on the

@@ -150,8 +150,8 @@ static void mg_prolong(const lvl_t* L, const lvl_t* C, const float* ec, float* e
     }
 }
 
-/* ---- EXPERIMENTAL (orc_set_mg_lines(1); off by default, mirrors the product's NCT_S2_LINES=1): a block step on the FINEST level, first thing of the pre-smoother and last
- * thing of the post-smoother. The grid is cut into fixed blocks of LINE_BX x LINE_BY pixels (aligned at 0); inside a block, for a residual r:
+/* ---- Round 5: a BLOCK STEP on the FINEST level, first thing of the pre-smoother and last thing of the post-smoother (orc_set_mg_lines(0) / the product's NCT_S2_LINES=0
+ * select the cycle without it: rounds 1-5a, kept for comparison). The grid is cut into fixed blocks of LINE_BX x LINE_BY pixels (aligned at 0); inside a block, for a residual r:
  *     pre :  e1 = Lx^-1 r,  e2 = Ly^-1 (Sy e1),   x += LINE_OM (e1 + e2)        post (the adjoint):  e1 = Ly^-1 r,  e2 = Lx^-1 (Sx e1),  x += LINE_OM (e1 + e2)
  * Lx / Ly = the tridiagonal matrices of the level's diagonal and the x / y couplings INSIDE the block, Sy / Sx = the y / x couplings inside the block (Sy e1 = r - A_block e1
  * in exact arithmetic: an alternating-direction block solve). Point Jacobi cannot smooth along the strong couplings of a photograph's flat runs (12-37 % of the neighbour
@@ -161,7 +161,7 @@ static void mg_prolong(const lvl_t* L, const lvl_t* C, const float* ec, float* e
 #define LINE_BX 32
 #define LINE_BY 16
 #define LINE_OM 0.9f
-static int MG_LINES = 0;
+static int MG_LINES = 1;
 void orc_set_mg_lines(int on) { MG_LINES = on ? 1 : 0; }
 int orc_get_mg_lines(void) { return MG_LINES; }
 static void mg_lines_setup(lvl_t* L) {

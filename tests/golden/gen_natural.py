@@ -43,7 +43,14 @@ if __name__ == "__main__":
             rec["level_crc_" + k] = np.array([crc(keep[k][l]) for l in range(5)], np.uint32)
         secs = [t_c]
         if exact_too:
-            t = time.time(); exact, exact_lv = orc.process_pair(src, ref, ws, bs, params=prm, want_levels=True, s2_exact=True); secs.append(time.time() - t)
+            # NCT_GEN_REUSE_EXACT=1 (a change of the canonical S2 order only; the exact-solve run does not depend on it): keep the stored exact run when the new canonical run has its CRCs
+            fo = os.path.join(HERE, "natural", f"pair_{name}.npz")
+            old = np.load(fo) if os.environ.get("NCT_GEN_REUSE_EXACT") == "1" and os.path.exists(fo) else None
+            if old is not None and "crc_exact" in old and int(old["crc_exact"]) == crc(canon) and [int(v) for v in old["level_crc_exact"]] == [crc(canon_lv[l]) for l in range(5)]:
+                exact, exact_lv = canon, canon_lv; secs.append(float(old["seconds"][1]))
+            else:
+                t = time.time(); exact, exact_lv = orc.process_pair(src, ref, ws, bs, params=prm, want_levels=True, s2_exact=True); secs.append(time.time() - t)
+                if old is not None and "crc_exact" in old: assert int(old["crc_exact"]) == crc(exact), "the exact-solve run changed"
             d = exact.astype(np.int16).reshape(-1) - canon.astype(np.int16).reshape(-1)
             idx = np.flatnonzero(d).astype(np.uint32)
             rec.update(idx=idx, delta=d[idx].astype(np.int16), crc_exact=np.uint32(crc(exact)),

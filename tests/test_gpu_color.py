@@ -142,27 +142,31 @@ def test_local_color_transfer_stages(ctx, oracle, case):
 
 
 @pytest.mark.parametrize("case", [(40, 56, 20, 28, (5, 7), 4, 3), (100, 141, 100, 141, (5, 7), 8, 1), (372, 368, 372, 368, (23, 23), 16, 4), (372, 368, 372, 368, (23, 23), 16, 0, "flat")])
-def test_local_color_transfer_block_step(oracle, case, monkeypatch):
-    """EXPERIMENTAL S2 smoother (NCT_S2_LINES=1 / orc_set_mg_lines(1), off by default: DESIGN.md section 8): a block step of alternating line solves on the finest level, first
-    in the pre- and last in the post-smoother (k_mg_block / mg_block_step). Same bar as the default cycle: iteration counts and solution bit-identical to the oracle's mirror —
-    at sizes that leave partial blocks at the right and bottom edges, in the 32 x 14 (>= 100 000 pixels) and 16 x 8 tile forms of the leg that follows the step — and fewer iterations
-    than the point smoother needs (the split 3 + 3 solve: test_gpu_pipeline.py::test_pair_block_step_matches_oracle)."""
+def test_local_color_transfer_block_step(ctx, oracle, case, monkeypatch):
+    """S2's block step (round 5: alternating line solves in 32 x 16 blocks on the finest level, first in the pre- and last in the post-smoother; k_mg_block / mg_block_step):
+    iteration counts and solution bit-identical to the oracle's mirror at sizes that leave partial blocks at the right and bottom edges, in the 32 x 14 (>= 100 000 pixels)
+    and 16 x 8 tile forms of the leg that follows the step — and fewer iterations than the cycle without it, which stays selectable (NCT_S2_LINES=0 / orc_set_mg_lines(0))
+    and bit-identical to ITS mirror (the split 3 + 3 solve: test_gpu_pipeline.py::test_pair_block_step_matches_oracle)."""
     import nct
     H, W, h, w, grid, samples, layer = case[:7]
     err, s_lvl, g_lvl, s_full, ids, ws = _level_case(30 + layer, H, W, h, w, grid, samples, oracle, len(case) > 7)
-    _, base = oracle.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
-    monkeypatch.setenv("NCT_S2_LINES", "1")
-    oracle.l.orc_set_mg_lines(1)
-    try:
-        with nct.Context(0) as c:
-            go, gs = c.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
-        oo, os_ = oracle.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
-    finally:
-        oracle.l.orc_set_mg_lines(0)
+    go, gs = ctx.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
+    oo, os_ = oracle.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
     assert gs["wls_iters"].tolist() == os_["wls_iters"].tolist()
     assert np.array_equal(gs["ab_wls"].view(np.uint64), os_["ab_wls"].view(np.uint64))
     assert np.array_equal(go, oo)
-    assert max(os_["wls_iters"]) < max(base["wls_iters"]), (os_["wls_iters"], base["wls_iters"])
+    monkeypatch.setenv("NCT_S2_LINES", "0")
+    oracle.l.orc_set_mg_lines(0)
+    try:
+        with nct.Context(0) as c:
+            g0, gs0 = c.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
+        o0, os0 = oracle.local_color_transfer(err, s_lvl, g_lvl, s_full, ids, ws, layer, want_stages=True)
+    finally:
+        oracle.l.orc_set_mg_lines(1)
+    assert gs0["wls_iters"].tolist() == os0["wls_iters"].tolist()
+    assert np.array_equal(gs0["ab_wls"].view(np.uint64), os0["ab_wls"].view(np.uint64))
+    assert np.array_equal(g0, o0)
+    assert max(os_["wls_iters"]) < max(os0["wls_iters"]), (os_["wls_iters"], os0["wls_iters"])
 
 
 def test_local_color_transfer_with_nan_matching_error(ctx, oracle):
