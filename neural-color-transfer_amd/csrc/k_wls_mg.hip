@@ -429,7 +429,7 @@ __device__ __forceinline__ int mg_tile_of_block(int bid, int ntiles) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 constexpr int mg_threads(int TX, int TY, bool X0 = false) { return ((TX + 2 * MG_NS + 1 + (X0 ? 2 : 0)) * (TY + 2 * MG_NS + 1 + (X0 ? 2 : 0)) + 63) / 64 * 64; }
-// TB = type of this level's right-hand side in memory: double at level 0 (the PCG residual, rounded on load), vf below.
+// TB = type of this level's right-hand side in memory (vf everywhere since round 5: the finest level reads the fp32 copy of the PCG residual that k_cg_update writes next to the fp64 one).
 // Sweep k produces its iterate on ring(k) = the thread grid shrunk by k from every side; the residual lives on ring(MG_NS) = the tile + one pixel to the left / top.
 // Restriction R = P^T (oracle: mg_restrict): the thread of a coarse point sums fpst[I][k] * res over the 3x3 block around it, row-major.
 // X0 (block step, NCT_S2_LINES): the leg starts from the iterate x1 instead of zero, so sweep 0 is a regular sweep too and every ring moves in by one: one more halo pixel per side.

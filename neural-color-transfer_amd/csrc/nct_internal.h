@@ -39,8 +39,9 @@ struct nct_ctx {
     int wls_lines = 1;                          // block step of alternating line solves on the finest S2 level (k_wls_mg.hip: k_mg_block; oracle: mg_block_step). NCT_S2_LINES=0: the cycle without it (other arithmetic; comparison only)
     int wls_graph = 0;                          // experiment hook (env NCT_WLS_GRAPH=1): replay the PCG iteration batch as a HIP graph
     int conv_pool_fuse = -1;                    // VGG: 2x2 max-pool inside the conv epilogue: -1 = where the tile shape fits the map (nctk_conv3x3_pool_fits), 0 never, 1 always (NCT_CONV_POOL_FUSE; tests)
-    double wls_rtol = 1e-7;                     // relative residual at which the WLS solve stops. 1e-7: the 8-bit result of every level equals the EXACT solve's on the
-                                                // full-size fixtures (1e-6: 55.4 / 50.1 dB; +4.3 ms per 700x700 pair; DESIGN.md §4 rtol sweep). Experiment hook: env NCT_WLS_RTOL
+    double wls_rtol = 3e-8;                     // relative residual at which the WLS solve stops. The loosest tolerance at which the 8-bit result of every level equals the EXACT solve's on the
+                                                // 700x700, mixed and 1000x1000 fixtures: 1e-7 with the point smoother of rounds 3-5a (1e-6: 55.4 / 50.1 dB), 3e-8 with the block step (the same residual norm
+                                                // leaves more low-frequency error: 5e-8 differs in 53 bytes on the mixed pair; profiles/round5_wls_rtol_sweep.json). Experiment hook: env NCT_WLS_RTOL
     int wls_maxit = 5000;                       // iteration budget of the WLS solve (test hook: env NCT_WLS_MAXIT)
     bool tm_on = false;
     std::vector<hipEvent_t> tm_events;          // pool, reused across pairs

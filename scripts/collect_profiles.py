@@ -218,7 +218,7 @@ if nat:
     rt = os.path.join(src, "wls_rtol_natural.txt")
     if os.path.exists(rt):
         T = [f"# {RN} — S2 stopping tolerance on the natural fixtures (`scripts/wls_rtol_natural.py`), build {bench['build_id']}", "",
-             "The GPU result at `NCT_WLS_RTOL` = r against the CPU oracle's EXACT-S2 image (the reference's direct-solve semantics; rebuilt from tests/golden/natural/pair_<case>.npz). At the shipped 1e-7 the GPU",
+             "The GPU result at `NCT_WLS_RTOL` = r against the CPU oracle's EXACT-S2 image (the reference's direct-solve semantics; rebuilt from tests/golden/natural/pair_<case>.npz). At the shipped 3e-8 the GPU",
              "equals the canonical-order oracle byte for byte at every level (the fixtures' CRCs); whether that canonical image also equals the exact solve's is a matter of 8-bit rounding luck at one of the",
              "coarse levels, amplified by the chaotic truncated CG downstream (DESIGN.md 4 items 5, 10).", "", "```"] + [l.rstrip("\n") for l in open(rt)] + ["```"]
         open(os.path.join(dst, f"{R}_wls_rtol_natural.md"), "w").write("\n".join(T) + "\n")

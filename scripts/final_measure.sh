@@ -17,7 +17,7 @@ timeout 300 python bench.py --workload mixed256 --batch 32 --steps 1 --warmup 1 
 timeout 300 python scripts/mixed_batch_cli.py 32 4 > $out/cli_mixed.txt 2>&1; tail -1 $out/cli_mixed.txt
 timeout 600 python scripts/cli_8gpu_shape.py 64 700 > $out/cli_8gpu_shape.txt 2>&1; tail -1 $out/cli_8gpu_shape.txt | cut -c1-300
 timeout 300 python bench.py --gpus 2 --dist-backend gloo --device-override 0 --inflight 2 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc > $out/bench_2rank_gloo.json 2>/dev/null
-SWEEP_RTOLS=1e-7,1e-6,1e-8 timeout 900 python scripts/wls_rtol_sweep.py > $out/wls_rtol_sweep.json 2> $out/wls_rtol_sweep.err
+SWEEP_RTOLS=3e-8,1e-7,5e-8,2e-8,1e-8,1e-10 timeout 900 python scripts/wls_rtol_sweep.py > $out/wls_rtol_sweep.json 2> $out/wls_rtol_sweep.err
 # counters: PatchMatch instantiations of one real pair (SQ / TA / TCP / TCC, fabric bytes), conv MFMA utilisation
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \

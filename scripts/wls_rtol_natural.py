@@ -18,22 +18,22 @@ for name in %(cases)r:
     c.pair_upload(src, ref); c.pair_run(prm); tm = c.pair_run(prm, want_timing=True); got = c.pair_download()
     canon_ok = zlib.crc32(got.tobytes()) == int(g["crc_canonical"])
     exact = None
-    # the exact-S2 image = canonical + delta, and the canonical image is what rtol 1e-7 gives: rebuild it from the fixture's CRC-checked run only when this run IS canonical
+    # the exact-S2 image = canonical + delta, and the canonical image is what the default rtol (3e-8) gives: rebuild it from the fixture's CRC-checked run only when this run IS canonical
     out[name] = {"wls_ms": round(tm["wls_ms"], 2), "iters": list(tm["wls_iters"]), "crc": zlib.crc32(got.tobytes()), "canonical": canon_ok}
-    np.save(os.path.join(%(tmp)r, "%%s_%%s.npy" %% (name, os.environ.get("NCT_WLS_RTOL", "1e-7"))), got)
+    np.save(os.path.join(%(tmp)r, "%%s_%%s.npy" %% (name, os.environ.get("NCT_WLS_RTOL", "3e-8"))), got)
 print(json.dumps(out))
 '''
 cases = sys.argv[1:] or ["in0_tar0_2", "in1_tar1_2", "in4_tar4_2"]
 import tempfile, numpy as np
 tmp = tempfile.mkdtemp()
 res = {}
-for rtol in ("1e-7", "1e-8", "1e-9", "1e-10"):
+for rtol in ("3e-8", "1e-7", "1e-8", "1e-9", "1e-10"):           # 3e-8 = the default (DESIGN.md 4.2)
     r = subprocess.run([sys.executable, "-c", CODE % {"repo": REPO, "cases": cases, "tmp": tmp}], env=dict(os.environ, NCT_WLS_RTOL=rtol), capture_output=True, text=True)
     res[rtol] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 for name in cases:
     g = np.load(os.path.join(REPO, "tests", "golden", "natural", "pair_%s.npz" % name))
-    canon = np.load(os.path.join(tmp, "%s_1e-7.npy" % name))
-    assert res["1e-7"][name]["canonical"], "the default tolerance must reproduce the canonical fixture"
+    canon = np.load(os.path.join(tmp, "%s_3e-8.npy" % name))
+    assert res["3e-8"][name]["canonical"], "the default tolerance must reproduce the canonical fixture"
     exact = canon.astype(np.int16).reshape(-1); exact[g["idx"]] += g["delta"]; exact = exact.astype(np.uint8).reshape(canon.shape)
     print("##", name, "(exact-S2 oracle vs canonical: %d differing bytes)" % g["idx"].size)
     for rtol in res:
