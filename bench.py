@@ -409,8 +409,9 @@ def pmc_traffic(device, live):
 
 
 # the colour-solver kernels of roofline_color in the same counter passes (the pair of scripts/pair_only.py runs them all): name prefix in the trace per roofline_color key
-COLOR_KERNELS = {"s1_apply": "void k_s1_apply<true>", "s1_update": "void k_s1_update<false>", "wls_down": "void (anonymous namespace)::k_mg_down<6, 32, 16, double",
-                 "wls_up": "void (anonymous namespace)::k_mg_up<6, 32, 16, double", "wls_apply": "void (anonymous namespace)::k_cg_apply<6>", "wls_update": "void (anonymous namespace)::k_cg_update<6>"}
+COLOR_KERNELS = {"s1_apply": "void k_s1_apply<true>", "s1_update": "void k_s1_update<false>", "wls_down": "void (anonymous namespace)::k_mg_down<6, 32, 14, float, false, true>",
+                 "wls_up": "void (anonymous namespace)::k_mg_up<6, 32, 16, float, false>", "wls_block_pre": "void (anonymous namespace)::k_mg_block<6, false>",
+                 "wls_block_post": "void (anonymous namespace)::k_mg_block<6, true>", "wls_apply": "void (anonymous namespace)::k_cg_apply<6>", "wls_update": "void (anonymous namespace)::k_cg_update<6>"}
 COLOR_PMC = {}
 
 
@@ -579,10 +580,12 @@ def color_roofline(nct, ctx, prm, sshape):
     model = {
         "s1_apply": (48 + 8 * 48 + 8 * 60 + 72 + 16 + 32 + 64 + 48, "r + 8 out-neighbour records + 8 in-edge (src, w, record) + coefficients + w = Op(r)"),
         "s1_update": (48 * 5 + 48 * 4, "r, w, p, s, x in; p, s, x, r out (fp64 x 6 each: the single-reduction recurrence's one vector pass)"),
-        "wls_down": (48 + 16 + 24 + 6 + 9, "r (fp64 x 6) + fp32 coefficients in; x (fp32 x 6) + coarse rhs + P columns"),
-        "wls_up": (48 + 24 + 16 + 16 + 6 + 24, "r, x, coefficients, P weights, coarse correction in; z out"),
+        "wls_block_pre": (24 + 16 + 8 + 24, "r rounded to fp32 (x 6), Thomas factors of the x / y lines (4 floats), couplings in; the block step's iterate (fp32 x 6) out"),
+        "wls_down": (24 + 24 + 16 + 24 + 6 + 9, "r (fp32 x 6), the block step's iterate + fp32 coefficients in; x (fp32 x 6) + coarse rhs + P columns"),
+        "wls_up": (24 + 24 + 16 + 16 + 6 + 24, "r (fp32), x, coefficients, P weights, coarse correction in; the leg's iterate out"),
+        "wls_block_post": (24 + 24 + 16 + 12 + 24, "r (fp32), the up leg's iterate, Thomas factors, diagonal + couplings in; z out"),
         "wls_apply": (24 + 48 + 24 + 48, "z (fp32 x 6), r, fp64 coefficients in; w out"),
-        "wls_update": (48 * 4 + 24 + 48 + 48 * 4, "p, s, x, r, z, w in; p, s, x, r out"),
+        "wls_update": (48 * 4 + 24 + 48 + 48 * 4 + 24, "p, s, x, r, z, w in; p, s, x, r and the fp32 copy of r out"),
     }
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "pixels": N, "kernels": {},
            "traffic_note": "traffic = fabric-side bytes per full-resolution launch from the live FETCH_SIZE (x2, profiles/round4_fetch_calibration.md) and WRITE_SIZE passes of the roofline object "
@@ -603,12 +606,12 @@ def color_roofline(nct, ctx, prm, sshape):
     if ns.get("wls_coarse"):
         out["kernels"]["wls_coarse"] = {"avg_us": us["wls_coarse"], "samples": ns["wls_coarse"], "what": "everything below the finest level of one V-cycle (latency bound: 7 launches)"}
     it_s1 = sum(us[k] for k in ("s1_apply", "s1_scalars", "s1_update") if ns.get(k))
-    it_wls = sum(us[k] for k in ("wls_down", "wls_up", "wls_apply", "wls_update", "wls_coarse") if ns.get(k))
+    it_wls = sum(us[k] for k in ("wls_block_pre", "wls_down", "wls_up", "wls_block_post", "wls_apply", "wls_update", "wls_coarse") if ns.get(k))
     # WLS per PCG iteration ~ (5 nnz + 6 vectors) x 8 B x n per right-hand side; nonlocal CG per iteration 2 passes over ~25 n rows x (2 idx + 2 val) + 4 vectors of 2 n fp64, per channel
     if it_wls:
         b = (5 + 6) * 8 * N * 6
         out["wls_iteration"] = {"us": it_wls, "survey_8d_bytes": b, "survey_8d_GBs": b / it_wls / 1e3, "survey_8d_frac": b / it_wls / 1e3 / HBM_PEAK_GBS,
-                                "compulsory_bytes": sum(model[k][0] for k in ("wls_down", "wls_up", "wls_apply", "wls_update")) * N}
+                                "compulsory_bytes": sum(model[k][0] for k in ("wls_block_pre", "wls_down", "wls_up", "wls_block_post", "wls_apply", "wls_update")) * N}
     if it_s1:
         b = 3 * (2 * 25 * N * (2 * 4 + 2 * 8) + 4 * 2 * N * 8)
         out["s1_iteration"] = {"us": it_s1, "survey_8d_bytes": b, "survey_8d_GBs": b / it_s1 / 1e3, "survey_8d_frac": b / it_s1 / 1e3 / HBM_PEAK_GBS,

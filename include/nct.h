@@ -213,10 +213,11 @@ typedef struct nct_pair_timing {
     /* NCT_FLAG_TIME_KERNELS only, else 0: average microseconds per launch (HIP events on the pair's stream around kernel_samples[i] single launches) of the
        colour-solver kernels at full resolution — index NCT_KT_*: the operator pass, the one-workgroup scalar step and the vector pass of the finest level's truncated CG (S1), and the WLS
        PCG's finest V-cycle legs, operator + dot products, vector update, and everything below the finest level of one V-cycle */
-    double kernel_us[8];
-    int kernel_samples[8];
+    double kernel_us[10];
+    int kernel_samples[10];
 } nct_pair_timing;
-enum { NCT_KT_S1_APPLY = 0, NCT_KT_S1_SCALARS = 1, NCT_KT_S1_UPDATE = 2, NCT_KT_WLS_DOWN = 3, NCT_KT_WLS_UP = 4, NCT_KT_WLS_APPLY = 5, NCT_KT_WLS_UPDATE = 6, NCT_KT_WLS_COARSE = 7 };
+enum { NCT_KT_S1_APPLY = 0, NCT_KT_S1_SCALARS = 1, NCT_KT_S1_UPDATE = 2, NCT_KT_WLS_DOWN = 3, NCT_KT_WLS_UP = 4, NCT_KT_WLS_APPLY = 5, NCT_KT_WLS_UPDATE = 6, NCT_KT_WLS_COARSE = 7,
+       NCT_KT_WLS_BLOCK_PRE = 8, NCT_KT_WLS_BLOCK_POST = 9 /* the block step of alternating line solves in front of the finest down leg / behind the finest up leg */ };
 /* per-level intermediates for level-wise validation (all pointers nullable; level 0 = coarsest … 4 = finest; arrays have the level's
  * size ah*aw / bh*bw except `result`, the full-resolution intermediate result after that level, H*W*3 like level_out of the oracle) */
 typedef struct nct_pair_levels {

@@ -1114,10 +1114,9 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     auto down = [&](int l) {
         const dim3 gb(cdiv(lv[l].W, TXB) * cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16) * cdiv(lv[l].H, 8));      // 1-D: mg_tile_of_block maps block -> tile
         if (l == 0 && B.lines) {
-            // block step from zero into x2 (free until the up leg), then the leg from that iterate: one more halo pixel per side, so 32 x 14 tiles (41 x 23 = 943 threads)
+            // the leg from the block step's iterate (block_pre: x2, free until the up leg): one more halo pixel per side, so 32 x 14 tiles (41 x 23 = 943 threads)
             constexpr int TYL = TYB - 2;
-            const dim3 gl(cdiv(lv[0].W, LBX) * cdiv(lv[0].H, LBY)), gbl(cdiv(lv[0].W, TXB) * cdiv(lv[0].H, TYL));
-            hipLaunchKernelGGL((k_mg_block<NQ, false>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const vf*)rf, (const vf*)nullptr, lv[0].x2);
+            const dim3 gbl(cdiv(lv[0].W, TXB) * cdiv(lv[0].H, TYL));
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_down<NQ, TXB, TYL, vf, false, true>), gbl, dim3(mg_threads(TXB, TYL, true)), 0, s, cur, lv[l], (const vf*)rf, lv[l].x, lv[l + 1], lv[l + 1].b, (const vf*)lv[0].x2);
             else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, vf, false, true>), gs, dim3(mg_threads(16, 8, true)), 0, s, cur, lv[l], (const vf*)rf, lv[l].x, lv[l + 1], lv[l + 1].b, (const vf*)lv[0].x2);
         } else if (l == 0) {
@@ -1128,16 +1127,19 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
             else                   hipLaunchKernelGGL((k_mg_down<NQ, 16, 8, vf, true>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, lv[l].x, lv[l + 1], lv[l + 1].b);
         }
     };
+    // the block step (finest level): from zero into x2 in front of the down leg; mirrored, x2 -> x (the pre-smoothed iterate there is dead by then), behind the up leg
+    auto block_step = [&](bool post) {
+        if (!B.lines) return;
+        const dim3 gl(cdiv(lv[0].W, LBX) * cdiv(lv[0].H, LBY));
+        if (!post) hipLaunchKernelGGL((k_mg_block<NQ, false>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const vf*)rf, (const vf*)nullptr, lv[0].x2);
+        else       hipLaunchKernelGGL((k_mg_block<NQ, true>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const vf*)rf, (const vf*)lv[0].x2, lv[0].x);
+    };
     auto up = [&](int l, const vf* ec) {
         const dim3 gb(cdiv(lv[l].W, TXB) * cdiv(lv[l].H, TYB)), gs(cdiv(lv[l].W, 16) * cdiv(lv[l].H, 8));
         const int Wc = lv[l + 1].W, nc = lv[l + 1].n;
         if (l == 0) {
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, vf, false>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)rf, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
             else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, vf, false>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)rf, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
-            if (B.lines) {                                   // the mirrored block step: x2 -> x (the pre-smoothed iterate there is dead now)
-                const dim3 gl(cdiv(lv[0].W, LBX) * cdiv(lv[0].H, LBY));
-                hipLaunchKernelGGL((k_mg_block<NQ, true>), gl, dim3(LBX * LBY), 0, s, cur, lv[0], (const vf*)rf, (const vf*)lv[0].x2, lv[0].x);
-            }
         } else {
             if (lv[l].n >= 100000) hipLaunchKernelGGL((k_mg_up<NQ, TXB, TYB, vf, true>), gb, dim3(mg_threads(TXB, TYB)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
             else                   hipLaunchKernelGGL((k_mg_up<NQ, 16, 8, vf, true>), gs, dim3(mg_threads(16, 8)), 0, s, cur, lv[l], (const vf*)lv[l].b, (const vf*)lv[l].x, Wc, nc, ec, lv[l].x2);
@@ -1159,7 +1161,9 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
     auto kt_e = [&]() -> int { if (ktime && B.kt->kt_end(s)) return ctx->fail(NCT_ERR_HIP, "%s", B.kt->err.c_str()); return 0; };
     auto vcycle = [&]() -> int {
         if (ktime) {
-            int rc = kt_b(NCT_KT_WLS_DOWN); if (rc) return rc; down(0); LCHK(); rc = kt_e(); if (rc) return rc;
+            int rc = 0;
+            if (B.lines) { rc = kt_b(NCT_KT_WLS_BLOCK_PRE); if (rc) return rc; block_step(false); LCHK(); rc = kt_e(); if (rc) return rc; }
+            rc = kt_b(NCT_KT_WLS_DOWN); if (rc) return rc; down(0); LCHK(); rc = kt_e(); if (rc) return rc;
             rc = kt_b(NCT_KT_WLS_COARSE); if (rc) return rc;
             for (int l = 1; l < tail0; ++l) { down(l); LCHK(); }
             if (lv[tail0].n <= MID_T) hipLaunchKernelGGL(k_mg_mid<1>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
@@ -1168,13 +1172,16 @@ int pcg_part(ErrSink* ctx, hipStream_t s, double* X /* this part's [N][3] block(
             for (int l = tail0 - 1; l >= 1; --l) { up(l, lv[l + 1].x2); LCHK(); }
             rc = kt_e(); if (rc) return rc;
             rc = kt_b(NCT_KT_WLS_UP); if (rc) return rc; up(0, lv[1].x2); LCHK(); rc = kt_e(); if (rc) return rc;
+            if (B.lines) { rc = kt_b(NCT_KT_WLS_BLOCK_POST); if (rc) return rc; block_step(true); LCHK(); rc = kt_e(); if (rc) return rc; }
             return 0;
         }
+        block_step(false); LCHK();
         for (int l = 0; l < tail0; ++l) { down(l); LCHK(); }
         if (lv[tail0].n <= MID_T) hipLaunchKernelGGL(k_mg_mid<1>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
         else                      hipLaunchKernelGGL(k_mg_mid<2>, dim3(NQ), dim3(MID_T), 0, s, cur, pack, 60);
         LCHK();
         for (int l = tail0 - 1; l >= 0; --l) { up(l, lv[l + 1].x2); LCHK(); }
+        block_step(true); LCHK();
         return 0;
     };
     const vf* z = B.lines ? lv[0].x : lv[0].x2;

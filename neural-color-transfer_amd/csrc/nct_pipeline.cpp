@@ -288,9 +288,9 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
             float ms = 0.f;
             NCT_HIP(hipEventElapsedTime(&ms, ctx->kt_events[2 * i], ctx->kt_events[2 * i + 1]));
             const int id = ctx->kt_ids[i];
-            if (id >= 0 && id < 8) { timing->kernel_us[id] += 1e3 * ms; timing->kernel_samples[id] += 1; }
+            if (id >= 0 && id < 10) { timing->kernel_us[id] += 1e3 * ms; timing->kernel_samples[id] += 1; }
         }
-        for (int id = 0; id < 8; ++id) if (timing->kernel_samples[id]) timing->kernel_us[id] /= timing->kernel_samples[id];
+        for (int id = 0; id < 10; ++id) if (timing->kernel_samples[id]) timing->kernel_us[id] /= timing->kernel_samples[id];
         if (count) {
             unsigned long long h[32];
             NCT_HIP(hipMemcpy(h, ctx->d_counter, sizeof h, hipMemcpyDeviceToHost));

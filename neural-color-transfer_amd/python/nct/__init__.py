@@ -139,7 +139,7 @@ class PairTiming(C.Structure):
                 ("pm_level_ms", C.c_double * 5), ("pm_level_launches", C.c_int * 5),
                 ("vote_level_ms", C.c_double * 5), ("nonlocal_level_ms", C.c_double * 5), ("wls_level_ms", C.c_double * 5),
                 ("pm_level_evals", C.c_ulonglong * 5), ("pm_level_accepted", C.c_ulonglong * 5),
-                ("kernel_us", C.c_double * 8), ("kernel_samples", C.c_int * 8)]
+                ("kernel_us", C.c_double * 10), ("kernel_samples", C.c_int * 10)]
 
     def as_dict(self):
         d = {}
@@ -155,7 +155,7 @@ FLAG_COUNT_EVALS = 2
 FLAG_LATENCY = 4
 FLAG_LAB2BGR_CUBE = 8
 FLAG_TIME_KERNELS = 16
-KT_NAMES = ("s1_apply", "s1_scalars", "s1_update", "wls_down", "wls_up", "wls_apply", "wls_update", "wls_coarse")      # nct.h NCT_KT_*
+KT_NAMES = ("s1_apply", "s1_scalars", "s1_update", "wls_down", "wls_up", "wls_apply", "wls_update", "wls_coarse", "wls_block_pre", "wls_block_post")      # nct.h NCT_KT_*
 LAB2BGR_PIECEWISE, LAB2BGR_CUBE = 0, 1
 
 

@@ -60,7 +60,7 @@ def test_bench_emits_contract_json():
     assert d["build_id_so"] == hashlib.sha256(open(so, "rb").read()).hexdigest()[:16] and len(d["build_id"]) == 16
     rc = d["roofline_color"]                     # colour-solver kernels: event-timed single launches vs their compulsory bytes (the WLS kernels exist at every size)
     assert rc["bound"] == "hbm" and rc["pixels"] == 128 * 128
-    for k in ("wls_down", "wls_up", "wls_apply", "wls_update"):
+    for k in ("wls_block_pre", "wls_down", "wls_up", "wls_block_post", "wls_apply", "wls_update"):
         e = rc["kernels"][k]
         assert e["samples"] == 20 and e["avg_launch_us"] > 0 and abs(e["frac"] - e["achieved"] / rc["peak"]) < 1e-9 and e["bytes_per_launch"] == e["bytes_per_pixel"] * 128 * 128
     assert rc["wls_iteration"]["us"] > 0 and rc["wls_iteration"]["survey_8d_bytes"] == 11 * 8 * 128 * 128 * 6
