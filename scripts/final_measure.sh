@@ -29,7 +29,8 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU S
 done
 for pre in "void k_pm_step<1, 1," "void k_pm_prop<1, 1," "void k_pm_step<2, 1," "void k_pm_prop<2, 1," "void k_pm_step<4, 0," "void k_pm_step<8, 0,"; do echo "== $pre"; python scripts/pmc_summary.py $out/pmc "$pre"; done > $out/pmc_pm_all.txt 2>&1
 # colour-solver kernels out of the same six passes (round 4)
-for pre in "void (anonymous namespace)::k_mg_down<6, 32, 16, double" "void (anonymous namespace)::k_mg_up<6, 32, 16, double" "void (anonymous namespace)::k_mg_down<6, 32, 16, float" "void (anonymous namespace)::k_mg_up<6, 32, 16, float" \
+for pre in "void (anonymous namespace)::k_mg_block<6, false>" "void (anonymous namespace)::k_mg_down<6, 32, 14, float, false, true>" "void (anonymous namespace)::k_mg_up<6, 32, 16, float, false>" "void (anonymous namespace)::k_mg_block<6, true>" \
+           "void (anonymous namespace)::k_mg_down<6, 32, 16, float, true" "void (anonymous namespace)::k_mg_up<6, 32, 16, float, true" \
            "void (anonymous namespace)::k_cg_apply" "void (anonymous namespace)::k_cg_update" "void k_s1_apply<true>" "void k_s1_update<false>" "k_s1_scal(" "k_s1_hub("; do
     echo "== $pre"; python scripts/pmc_summary.py $out/pmc "$pre"
 done > $out/pmc_color_all.txt 2>&1
