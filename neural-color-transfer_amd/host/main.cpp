@@ -20,6 +20,7 @@
 #include <cstring>
 #include <iostream>
 #include <mutex>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,12 +33,35 @@ namespace {
 constexpr int MAX_SIZE = 1000;                 // Config.h:5
 
 struct Param { std::string flag, comment; enum { STR, INT, DBL } kind; void* dst; };
+// Utility::CmdLine (CmdLine.h:58-69,132-147; CmdLine.cpp:21-56,93-109) re-created; pinned against the reference's own parser compiled unmodified
+// (oracle/ref_cmdline.cpp -> tests/golden/cmdline_ref.json -> tests/test_cli.py). The rules, all the reference's:
+//  * a token is an "argument" when it starts with '-' or '/' (Parameter::IsArg) — "-5" and "/x" included; any other token is a positional file (collected, unused);
+//  * "-h" "-?" "-help" (and the '/' forms) print the help and end the run; an argument that names no parameter prints "Unrecognized parameter: …", the help, and ends it;
+//  * the token after a parameter is its value unless it is missing, empty or itself an argument (TParm::Parse) — then the parameter keeps its value and the
+//    token is looked at again; numbers are read with operator>> (so "12abc" is 12, "abc" is 0, "3.7" for -g is 3).
+// Two portable extensions, each a case the reference ends with "Unrecognized parameter" (recorded as such in the fixture): a value of the form -<digit|.>… is taken
+// as a negative number by numeric parameters, and a value that starts with '/' but names no parameter is taken as a unix path by the string parameters (the reference
+// is a Windows tool: "-m /data/models" cannot be passed to it at all). A string value keeps its blanks (operator>> into a std::string stops at the first one).
 struct CmdLine {
     std::vector<Param> params;
+    int files = 0;
     void add(const char* flag, std::string& v, const char* c) { params.push_back({flag, c, Param::STR, &v}); }
     void add(const char* flag, int& v, const char* c) { params.push_back({flag, c, Param::INT, &v}); }
     void add(const char* flag, double& v, const char* c) { params.push_back({flag, c, Param::DBL, &v}); }
-    static bool is_arg(const char* a) { return a && (a[0] == '-' || a[0] == '/') && a[1] != 0 && !(a[1] >= '0' && a[1] <= '9') && a[1] != '.'; }
+    static bool is_arg(const char* a) { return a && (a[0] == '-' || a[0] == '/'); }                       // Parameter::IsArg, CmdLine.h:68-70
+    static bool is_help(const std::string& a) { return a == "h" || a == "?" || a == "help"; }              // CmdLine.cpp:93-100
+    bool names_a_parameter(const char* a) const {
+        const std::string n(a + 1);
+        if (is_help(n)) return true;
+        for (const auto& p : params) if (n == p.flag) return true;
+        return false;
+    }
+    bool is_value(const Param& p, const char* v) const {                                                    // TParm::Parse's test, CmdLine.h:133-136, + the two extensions
+        if (!v || !*v) return false;
+        if (!is_arg(v)) return true;
+        if (p.kind != Param::STR) return v[0] == '-' && ((v[1] >= '0' && v[1] <= '9') || v[1] == '.');
+        return v[0] == '/' && !names_a_parameter(v);
+    }
     void help(const char* prog) const {
         std::cout << "Running: " << prog << std::endl;
         for (const auto& p : params) {                                          // TParm::Print, CmdLine.h:140-142
@@ -48,19 +72,18 @@ struct CmdLine {
             std::cout << ") " << p.comment << std::endl;
         }
     }
-    bool parse(int argc, char** argv) const {
-        int i = 1;
+    bool parse(int argc, char** argv, int first = 1) {
+        int i = first;
         while (i < argc) {
-            if (!is_arg(argv[i])) { ++i; continue; }                       // positional "files" are collected and ignored (CmdLine.cpp:26-29)
+            if (!is_arg(argv[i])) { ++files; ++i; continue; }              // positional "files" are collected and never used (CmdLine.cpp:26-29)
             const std::string a(argv[i] + 1);
-            if (a == "h" || a == "?" || a == "help") { help(argv[0]); return false; }
+            if (is_help(a)) { help(argv[0]); return false; }
             bool done = false;
             for (const auto& p : params)
                 if (a == p.flag) {
-                    if (i + 1 < argc) {
+                    if (i + 1 < argc && is_value(p, argv[i + 1])) {
                         if (p.kind == Param::STR) *(std::string*)p.dst = argv[i + 1];
-                        else if (p.kind == Param::INT) *(int*)p.dst = atoi(argv[i + 1]);
-                        else *(double*)p.dst = atof(argv[i + 1]);
+                        else { std::istringstream is(argv[i + 1]); if (p.kind == Param::INT) is >> *(int*)p.dst; else is >> *(double*)p.dst; }
                         ++i;
                     }
                     ++i; done = true; break;
@@ -432,7 +455,19 @@ int main(int argc, char** argv) {
     cl.add("resume", resume, "[extension] 1 = skip pairs whose output file exists and is a complete PNG; every pair appends a JSON line to <output>/status.jsonl.");
     cl.add("vis", vis, "[extension] 1 = the reference's ENABLE_VIS dumps per level (flow maps, level images, error heat map, coefficient and cluster images) next to the output.");
     cl.add("feat16", feat16, "[extension] 1 = fp16 PatchMatch feature tiles (fp32 accumulate); not bit-identical to the default (about 45 dB against it).");
-    if (!cl.parse(argc, argv)) return -1;
+    // parser self-test hook (no GPU): `--parse-only <args…>` parses the rest like a normal run and prints what main would go on with, in the format of
+    // oracle/ref_cmdline.cpp (the reference's own parser): tests/test_cli.py compares the two on the vectors of tests/golden/cmdline_ref.json
+    const bool parse_only = argc >= 2 && !strcmp(argv[1], "--parse-only");
+    const bool parsed = cl.parse(argc, argv, parse_only ? 2 : 1);
+    if (parse_only) {
+        std::cout << std::flush;
+        printf("@@RESULT rc=%d\n", parsed ? 1 : 0);
+        printf("m=%s\ni=%s\no=%s\ng=%d\n", cfg.model_dir.c_str(), cfg.input_dir.c_str(), cfg.output_dir.c_str(), gpu);
+        printf("bds=%.17g\neps=%.17g\nnl=%.17g\nl=%.17g\nw=%.17g\n", cfg.prm.bds_weight, cfg.prm.eps, cfg.prm.nonlocal_weight, cfg.prm.local_weight, cfg.prm.wls_lambda_init);
+        printf("files=%d\n", cl.files);
+        return 0;
+    }
+    if (!parsed) return -1;
     cfg.prm.seed = (uint32_t)seed;
     cfg.prm.levels = levels < 1 ? 1 : (levels > 5 ? 5 : levels);
     if (feat16) cfg.prm.flags |= NCT_FLAG_FEAT16;

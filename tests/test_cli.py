@@ -541,3 +541,56 @@ def test_contexts_share_one_weight_copy(ctx, tmp_path):
         nct.Model(str(tmp_path / "absent.caffemodel"))
     for o in others:
         o.close()
+
+
+def _parse_only(argv):
+    r = run("--parse-only", *argv)
+    assert r.returncode == 0, r.stdout
+    head, tail = r.stdout.split("@@RESULT ", 1)
+    lines = tail.strip().split("\n")
+    vals = dict(l.split("=", 1) for l in lines[1:])
+    values = {"m": vals["m"], "i": vals["i"], "o": vals["o"], "g": int(vals["g"]), "files": int(vals["files"]),
+              **{k: float(vals[k]) for k in ("bds", "eps", "nl", "l", "w")}}
+    return int(lines[0].split("=")[1]), head.split("\n"), values
+
+
+def test_cli_parser_matches_the_reference_cmdline():
+    """D1 pinned by the reference's own parser: tests/golden/cmdline_ref.json was written by oracle/_ref/ref_cmdline = the reference's CmdLine.cpp + CmdLine.h
+    compiled unmodified with get_input's registrations (main.cu:29-44; generator tests/golden/gen_cmdline_ref.py). For every recorded argument vector the product
+    CLI must return the same verdict (parsed / `return -1`), leave the same values in the nine parameters, count the same positional tokens and print the same
+    text: "Unrecognized parameter: …", and the help lines of the nine reference parameters with the values parsed so far as "(default=…)" — the product's
+    [extension] flags follow them. The two portable extensions (negative numbers, unix paths as values) are the cases the reference cannot take at all; the
+    fixture records its refusal and the product's specified result."""
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cmdline_ref.json")))
+    assert len(fx["cases"]) >= 30
+    n_ext = 0
+    for c in fx["cases"]:
+        rc, printed, values = _parse_only(c["argv"])
+        if "extension" in c:
+            n_ext += 1
+            assert c["rc"] == 0 and rc == c["extension"]["rc"], c["argv"]
+            for k, v in c["extension"].items():
+                if k != "rc":
+                    assert values[k] == v, (c["argv"], k)
+            continue
+        assert rc == c["rc"], c["argv"]
+        assert values == c["values"], (c["argv"], values, c["values"])
+        ref = [l for l in c["printed"] if not l.startswith("Running: ")]
+        got = [l for l in printed if not l.startswith("Running: ") and "[extension]" not in l]
+        assert got == ref, (c["argv"], got, ref)
+        assert sum(l.startswith("Running: ") for l in printed) == sum(l.startswith("Running: ") for l in c["printed"])
+    assert n_ext == 3
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(nct.PKG_ROOT), "oracle", "_ref", "ref_cmdline")), reason="oracle/_ref not built (reference not mounted)")
+def test_cmdline_fixture_is_what_the_reference_parser_prints_now():
+    """Where oracle/_ref exists (the build container), the committed fixture is re-derived live for a few vectors, so it cannot drift from the generator."""
+    import json
+    exe = os.path.join(os.path.dirname(nct.PKG_ROOT), "oracle", "_ref", "ref_cmdline")
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cmdline_ref.json")))
+    for c in fx["cases"][::4]:
+        r = subprocess.run([exe] + c["argv"], capture_output=True, text=True, check=True)
+        head, tail = r.stdout.split("@@RESULT ", 1)
+        assert int(tail.split("\n")[0].split("=")[1]) == c["rc"]
+        assert [l for l in head.split("\n") if not l.startswith("Running: ")] == [l for l in c["printed"] if not l.startswith("Running: ")]
