@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define NCT_VERSION 100
+/* bumped whenever a struct of this header changes layout or an entry point changes meaning (round 6: 110 — nct_model_layer; nct_pair_timing grew in round 5 without a
+ * bump). A caller checks `nct_version() == NCT_VERSION` before it passes any struct: the CLI and the python binding do. */
+#define NCT_VERSION 110
 
 typedef enum {
     NCT_OK = 0,
@@ -98,6 +100,9 @@ int nct_vgg19_load_raw(nct_ctx* ctx, const float* const* weights, const float* c
 typedef struct nct_model nct_model;
 int nct_model_parse_caffemodel(const char* path, nct_model** out);
 void nct_model_free(nct_model* m);
+/* read access to a parsed model (host memory, valid until nct_model_free): layer 0..12 = conv1_1 .. conv5_1 in net order; weights [cout][cin][3][3], bias [cout].
+ * What Net::CopyTrainedLayersFrom leaves in the layer's blobs (net.cpp:776-792) — lets a caller (and the CPU tests) check an ingest without a device. */
+int nct_model_layer(const nct_model* m, int layer, const float** weights, const float** bias, int* cout, int* cin);
 const char* nct_model_last_error(void);
 int nct_vgg19_load_model(nct_ctx* ctx, const nct_model* m);
 int nct_vgg19_share_weights(nct_ctx* ctx, nct_ctx* from);

@@ -94,6 +94,7 @@ static bool parse_blob(PB b, BlobView& out) {
         if (f >= 1 && f <= 4 && wt == 0) { legacy[f - 1] = (int64_t)b.varint(); has_legacy = true; }
         else if (f == 5 && wt == 2) { PB d = b.sub(); size_t n = (size_t)(d.end - d.p) / 4; size_t o = out.data.size(); out.data.resize(o + n); memcpy(out.data.data() + o, d.p, n * 4); }
         else if (f == 5 && wt == 5) { if (b.end - b.p < 4) return false; float v; memcpy(&v, b.p, 4); b.p += 4; out.data.push_back(v); }
+        else if (f == 8 && wt == 1) { if (b.end - b.p < 8) return false; double v; memcpy(&v, b.p, 8); b.p += 8; out.data.push_back((float)v); }      // double_data, not packed
         else if (f == 8 && wt == 2) { PB d = b.sub(); size_t n = (size_t)(d.end - d.p) / 8; for (size_t i = 0; i < n; ++i) { double v; memcpy(&v, d.p + 8 * i, 8); out.data.push_back((float)v); } }
         else if (f == 7 && wt == 2) {   // BlobShape { repeated int64 dim = 1 [packed] }
             PB s = b.sub(); uint32_t f2, w2; out.ndim = 0;
@@ -306,6 +307,14 @@ int nct_model_parse_caffemodel(const char* path, nct_model** out) {
     return NCT_OK;
 }
 void nct_model_free(nct_model* m) { delete m; }
+int nct_model_layer(const nct_model* m, int layer, const float** weights, const float** bias, int* cout, int* cin) {
+    if (!m || layer < 0 || layer >= kNeeded || m->w[layer].empty()) { g_model_err = "nct_model_layer: no such layer in the parsed model"; return NCT_ERR_INVALID; }
+    if (weights) *weights = m->w[layer].data();
+    if (bias) *bias = m->b[layer].data();
+    if (cout) *cout = kCout[layer];
+    if (cin) *cin = kCin[layer];
+    return NCT_OK;
+}
 const char* nct_model_last_error(void) { return g_model_err.c_str(); }
 
 int nct_vgg19_load_model(nct_ctx* ctx, const nct_model* m) {

@@ -431,6 +431,7 @@ int main(int argc, char** argv) {
         printf("ok\n");
         return 0;
     }
+    if (nct_version() != NCT_VERSION) { printf("Error: libnct is version %d, this driver was built against %d.\n", nct_version(), NCT_VERSION); return -1; }
     CmdLine cl;
     Config cfg;
     nct_params_default(&cfg.prm);

@@ -32,9 +32,13 @@ def lib():
             raise NctError(-4, f"{LIB_PATH} not found — run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
+        if _lib.nct_version() != NCT_VERSION:        # the structs below mirror include/nct.h at this version
+            v = _lib.nct_version(); _lib = None
+            raise NctError(-2, f"{LIB_PATH} is nct version {v}, this binding was written against {NCT_VERSION}: rebuild")
     return _lib
 
 
+NCT_VERSION = 110        # include/nct.h
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
@@ -60,6 +64,7 @@ SIGNATURES = {
     "nct_vgg19_load_caffemodel": (C.c_int, [C.c_void_p, C.c_char_p]),
     "nct_model_parse_caffemodel": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "nct_model_free": (None, [C.c_void_p]),
+    "nct_model_layer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nct_model_last_error": (C.c_char_p, []),
     "nct_vgg19_load_model": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nct_vgg19_share_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -169,6 +174,14 @@ class Model:
         if rc != 0:
             raise NctError(rc, (lib().nct_model_last_error() or b"").decode())
         self._m = m
+
+    def layer(self, i):
+        """(weights [cout, cin, 3, 3], bias [cout]) of conv layer i (0 = conv1_1 … 12 = conv5_1) as numpy copies (nct_model_layer)"""
+        w, b, co, ci = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.c_int(), C.c_int()
+        rc = lib().nct_model_layer(self._m, i, C.byref(w), C.byref(b), C.byref(co), C.byref(ci))
+        if rc != 0:
+            raise NctError(rc, (lib().nct_model_last_error() or b"").decode())
+        return (np.ctypeslib.as_array(w, (co.value, ci.value, 3, 3)).copy(), np.ctypeslib.as_array(b, (co.value,)).copy())
 
     def close(self):
         if self._m:

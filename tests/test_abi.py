@@ -32,7 +32,10 @@ def test_binding_covers_every_declared_symbol():
 
 
 def test_version():
-    assert nct.lib().nct_version() == 100
+    import re
+    hdr = open(os.path.join(os.path.dirname(nct.PKG_ROOT), "include", "nct.h")).read()
+    v = int(re.search(r"#define\s+NCT_VERSION\s+(\d+)", hdr).group(1))
+    assert nct.lib().nct_version() == v == nct.NCT_VERSION        # header, library and binding agree (the binding refuses a library of another version)
 
 
 def test_no_cpu_fallback_create_fails_loudly_without_gpu():

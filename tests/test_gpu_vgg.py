@@ -107,6 +107,25 @@ def test_caffemodel_ingest_matches_raw(ctx, oracle, weights, tmp_path, fmt, unpa
         assert np.array_equal(bits(g[t]), bits(o[t]))
 
 
+@pytest.mark.parametrize("fmt,unpacked,as_double", [("v1", False, False), ("v2", True, False), ("v1", False, True)])
+def test_caffemodel_written_by_googles_encoder(ctx, oracle, weights, tmp_path, fmt, unpacked, as_double):
+    """V1 against an independent writer: the file comes from google.protobuf over descriptors checked against the reference's caffe.proto
+    (tests/caffe_pb.py) — V1 layers with legacy dims, V2 layers with unpacked `data`, V1 with `double_data` — with all the clutter of a real file; the features the
+    library computes from it equal the oracle's on the arrays that went in."""
+    pytest.importorskip("google.protobuf")
+    import caffe_pb
+    from caffemodel_io import VGG_NAMES
+    ws, bs = weights
+    path = os.path.join(tmp_path, "google_%s.caffemodel" % fmt)
+    caffe_pb.write_vgg19(path, ws, bs, VGG_NAMES, fmt, unpacked_floats=unpacked, as_double=as_double)
+    ctx.vgg19_load_caffemodel(path)
+    img = synth.image(9, 26, 31)
+    g = ctx.vgg19_features(img, 5)
+    o = oracle.vgg19_features(img, ws, bs, 5)
+    for t in range(5):
+        assert np.array_equal(bits(g[t]), bits(o[t]))
+
+
 def test_caffemodel_errors(ctx, weights, tmp_path):
     import nct
     ws, bs = weights

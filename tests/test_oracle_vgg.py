@@ -1,4 +1,5 @@
 """CPU tests pinning the oracle's VGG19 pieces: Caffe's own known-answer tests restated + torch-CPU cross-checks."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -81,3 +82,57 @@ def test_vgg19_forward_vs_torch(oracle):
     # stopping early gives identical shallow taps (quirk 9: the reference runs to pool5 regardless)
     t2 = oracle.vgg19_features(img, ws, bs, 2)
     assert np.array_equal(t2[0], taps[0]) and np.array_equal(t2[1], taps[1])
+
+
+# ---- V1 (caffemodel ingest) against an INDEPENDENT writer: Google's protobuf encoder over descriptors built from caffe.proto's field numbers (tests/caffe_pb.py).
+# nct_model_parse_caffemodel / nct_model_layer are host-only entry points of the C ABI: no device is needed to check what the reader leaves in the layers.
+def _pb():
+    return pytest.importorskip("google.protobuf") and __import__("caffe_pb")
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/code/src/caffe/proto/caffe.proto"), reason="reference not mounted")
+def test_caffe_pb_descriptors_match_the_reference_proto_text():
+    """every field the test writer uses (name, number, label, type, packed option) compared with the text of the reference's caffe.proto"""
+    assert _pb().check_against_proto_text("/root/reference/code/src/caffe/proto/caffe.proto") >= 40
+
+
+@pytest.mark.parametrize("fmt,unpacked,as_double", [("v1", False, False), ("v2", False, False), ("v1", True, False), ("v2", False, True), ("v1", True, True)])
+def test_caffemodel_reader_against_googles_encoder(tmp_path, fmt, unpacked, as_double):
+    """A VGG19-shaped net serialised by google.protobuf — V1 `layers` with legacy num/channels/height/width (the Oxford file's form) and V2 `layer` with BlobShape;
+    `data` packed, not packed (tag + fixed32 per value), or carried in `double_data`; with everything a real file has beside the conv blobs (net name, input_dim,
+    bottoms / tops, blobs_lr, convolution_param, a 1001-numbered string field, ReLU / pooling / softmax layers, fc6-fc8 WITH blobs) — must come out of
+    nct_model_parse_caffemodel as exactly the arrays that went in."""
+    import nct
+    from caffemodel_io import VGG_NAMES
+    pb = _pb()
+    ws, bs = synthetic_vgg19(23, bias_scale=0.1)
+    path = str(tmp_path / "g.caffemodel")
+    pb.write_vgg19(path, ws, bs, VGG_NAMES, fmt, unpacked_floats=unpacked, as_double=as_double)
+    m = nct.Model(path)
+    for i in range(13):
+        w, b = m.layer(i)
+        assert np.array_equal(w.view(np.uint32), np.ascontiguousarray(ws[i], np.float32).view(np.uint32)), VGG_NAMES[i]
+        assert np.array_equal(b.view(np.uint32), np.ascontiguousarray(bs[i], np.float32).view(np.uint32)), VGG_NAMES[i]
+    with pytest.raises(nct.NctError):
+        m.layer(13)
+    m.close()
+
+
+def test_own_writer_and_googles_encoder_agree(tmp_path):
+    """tests/caffemodel_io.py (this project's writer, used by the GPU ingest tests) parsed BY GOOGLE's decoder gives the arrays back: the two readings of the
+    wire format are the same one."""
+    from caffemodel_io import write_caffemodel, VGG_NAMES
+    pb = _pb()
+    ws, bs = synthetic_vgg19(29, nlayers=4)
+    for fmt in ("v1", "v2"):
+        path = str(tmp_path / (fmt + ".caffemodel"))
+        write_caffemodel(path, ws, bs, names=VGG_NAMES[:4], fmt=fmt)
+        net = pb.messages()["NetParameter"]()
+        net.ParseFromString(open(path, "rb").read())
+        layers = [l for l in (net.layers if fmt == "v1" else net.layer) if l.name.startswith("conv")]
+        assert [l.name for l in layers] == VGG_NAMES[:4]
+        for l, w, b in zip(layers, ws, bs):
+            assert np.array_equal(np.asarray(l.blobs[0].data, np.float32), np.asarray(w, np.float32).reshape(-1))
+            assert np.array_equal(np.asarray(l.blobs[1].data, np.float32), np.asarray(b, np.float32).reshape(-1))
+            dims = list(l.blobs[0].shape.dim) if fmt == "v2" else [l.blobs[0].num, l.blobs[0].channels, l.blobs[0].height, l.blobs[0].width]
+            assert dims == list(w.shape)
