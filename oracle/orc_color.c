@@ -518,6 +518,13 @@ int orc_wls_solve_mg(double* a, double* b, const double* lab, int H, int W, doub
 /* relative residual of the S2 solve (the product's default; orc_set_wls_rtol is the oracle side of the NCT_WLS_RTOL experiment hook) */
 static double g_wls_rtol = 3e-8;   /* round 5 (with the block step of orc_wls_mg.c): the loosest tolerance at which the 700x700, mixed and 1000x1000 fixtures equal the exact solve (5e-8: the mixed pair differs in 53 bytes) */
 void orc_set_wls_rtol(double r) { if (r > 0 && r < 1) g_wls_rtol = r; }
+/* S1 form of the whole-pair run: 0 (default) = the canonical truncated CG the product reproduces bit for bit (orc_color_canon.c: matrix-free operator, fixed summation
+ * trees, single-reduction recurrence); 1 = the LITERAL one — A assembled explicitly, A^T(A p) as two sparse products, the textbook recurrence of
+ * SparseSolver_GPU.cu:132-159 with sequential dot products (orc_nonlocal_solve_explicit above). S1 stops after 50 / 100 iterations far from convergence and is chaotic
+ * in its rounding, so the two forms differ end to end: tests/golden/gen_s1_band.py measures by how much (tests/golden/s1_band.json). */
+static int g_s1_form = 0;
+void orc_set_s1_form(int f) { g_s1_form = f ? 1 : 0; }
+int orc_get_s1_form(void) { return g_s1_form; }
 
 /* Same contract as nct_local_color_transfer (include/nct.h). S1 = canonical-order truncated CG (orc_color_canon.c).
  * s2_exact == 0: S2 by the canonical-order PCG; != 0: S2 by the exact solve (banded Cholesky / converged PCG). */
@@ -535,8 +542,10 @@ int orc_local_color_transfer(const float* err, const uint8_t* s_bgr_level, const
     orc_err_weight(err, n, wgt);
     const double normFactor = (double)(W * H) / (double)(w * h);
     int cg[3];
-    orc_nonlocal_solve(a, b, src, ref, wgt, knn_id, knn_w, k, h, w, layer, (float)prm->local_weight, (float)prm->wls_alpha, (float)normFactor,
-                       prm->nonlocal_weight, prm->k_num, cg, 0);
+    if (g_s1_form) orc_nonlocal_solve_explicit(a, b, src, ref, wgt, knn_id, knn_w, k, h, w, layer, (float)prm->local_weight, (float)prm->wls_alpha, (float)normFactor,
+                                               prm->nonlocal_weight, prm->k_num, cg, 0);
+    else orc_nonlocal_solve(a, b, src, ref, wgt, knn_id, knn_w, k, h, w, layer, (float)prm->local_weight, (float)prm->wls_alpha, (float)normFactor,
+                            prm->nonlocal_weight, prm->k_num, cg, 0);
     if (st && st->cg_iters) memcpy(st->cg_iters, cg, sizeof cg);
     if (st && st->ab_nonlocal) { memcpy(st->ab_nonlocal, a, sizeof(double) * 3 * n); memcpy(st->ab_nonlocal + (size_t)3 * n, b, sizeof(double) * 3 * n); }
     double* A = (double*)malloc(sizeof(double) * 3 * N); double* B = (double*)malloc(sizeof(double) * 3 * N); double* rough = (double*)malloc(sizeof(double) * N);

@@ -306,6 +306,10 @@ class Oracle:
         """which PatchMatch schedule process_pair runs: 0 = the product's (default), 1 / 2 = the reference's in-place schedule"""
         self.l.orc_set_pm_schedule(int(s))
 
+    def set_s1_form(self, f):
+        """which S1 recurrence process_pair runs: 0 = canonical (default, what the GPU reproduces), 1 = the literal textbook CG on the assembled A (SparseSolver_GPU.cu:132-159)"""
+        self.l.orc_set_s1_form(int(f))
+
     def feature_distance(self, a, b):
         a = np.ascontiguousarray(a, np.float32)
         b = np.ascontiguousarray(b, np.float32)
