@@ -4,6 +4,7 @@
 #pragma once
 #include <zlib.h>
 #include <atomic>
+#include <random>
 #include <cerrno>
 #include <fcntl.h>
 #include <unistd.h>
@@ -123,15 +124,16 @@ inline bool write(const std::string& path, const uint8_t* bgr, int h, int w, std
     // which -resume would take for a finished pair
     // The temporary name is unique per writer (pid + a process-wide counter) and created exclusively: two pairs.txt lines that map to the same output name may be
     // encoded concurrently by the I/O pool, and a stale file of a killed run must not be appended to. The last finished writer wins the rename.
-    // A run killed mid-write leaves its temporary behind, and in a container the next run often has the SAME pid (and the counter restarts at 0): a name taken by
-    // such a stale file (EEXIST) is skipped — within this process the counter makes names unique, so an existing file can only be a dead process's.
+    // A run killed mid-write leaves its temporary behind, and in a container the next run often has the SAME pid (and the counter restarts at 0) — while two LIVE
+    // processes in different pid namespaces that share the output directory may have the same pid too: a name that exists (EEXIST) is therefore never deleted, only
+    // skipped, and the name carries a per-process random tag besides pid and counter, so a collision needs the same pid AND the same 32 random bits.
     static std::atomic<unsigned long> seq{0};
+    static const unsigned long tag = [] { std::random_device rd; return (unsigned long)rd(); }();
     std::string tmp; int fd = -1;
     for (int attempt = 0; attempt < 64 && fd < 0; ++attempt) {
-        tmp = path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(seq.fetch_add(1));
+        tmp = path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(tag) + "." + std::to_string(seq.fetch_add(1));
         fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0644);
-        if (fd < 0 && errno == EEXIST) { remove(tmp.c_str()); continue; }     // stale: delete it (nobody alive owns this name) and take the next counter value
-        if (fd < 0) break;
+        if (fd < 0 && errno != EEXIST) break;
     }
     FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
     if (!f) { if (fd >= 0) close(fd); err = "cannot create"; return false; }

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/natural/pair_<case>.npz: the CPU oracle on the REFERENCE'S OWN DEMO INPUTS (demo/example/in/*.png, copied as data into
+"""Generates tests/golden/natural/pair_<case>.npz: the CPU oracle on the REFERENCE'S OWN DEMO INPUTS (demo/example/in/*.png, staged by tests/natural_inputs.py, never committed, into
 tests/golden/natural/ — natural photographs with 10^4-pixel groups of one colour, unlike tests/synth.py's cosines + noise), with the synthetic VGG19 (the
 Oxford weights do not exist here), for the lines of demo/example/pairs.txt:1-9 named in CASES. Same record as gen_pair700_exact.py: the canonical-order oracle
 result (the one the GPU must reproduce byte for byte) as CRC-32 per pyramid level and of the final image, and the run with the EXACT S2 solve (the reference's
 direct-solve semantics, SparseSolver_CPU.cpp:104-286) as a sparse delta on it, plus per-level CRCs of the NNFs / guidance / matching error of the canonical run
 so that a divergence names its stage. Also stores the kNN in-degree statistics of every level (max / p99 / >64 / >512), the quantity the S1 kernels are sized on.
 
-PNG decode = PIL, alpha dropped (cv::imread's default flag does the same: main.cu:483,491). Runs where tests/golden/natural/*.png exist (they are committed);
+PNG decode = PIL, alpha dropped (cv::imread's default flag does the same: main.cu:483,491). Runs where tests/golden/natural/*.png exist (python tests/natural_inputs.py stages them);
 ~10-40 min per case on 8 cores."""
 import os, sys, time, zlib
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -263,11 +263,12 @@ def test_cli_batch_matches_library(tmp_path, ctx):
 @pytest.mark.gpu
 def test_cli_on_the_reference_demo_inputs(tmp_path):
     """The reference's own demo batch through the console driver: `demo/example/pairs.txt`'s layout (an `in/` sub-directory, RGBA and RGB PNGs of unequal sizes, the bds
-    sweep on one pair) with the committed demo inputs (tests/golden/natural/*.png) and the synthetic VGG19; every output PNG must carry the CRC the CPU oracle produced for that
+    sweep on one pair) with the demo inputs (staged into tests/golden/natural/*.png by tests/natural_inputs.py) and the synthetic VGG19; every output PNG must carry the CRC the CPU oracle produced for that
     line (tests/golden/natural/pair_<case>.npz) — i.e. host PNG decode, alpha drop, naming, scheduling over two workers and PNG encode add nothing to the library's result."""
     import zlib, shutil, glob
     from caffemodel_io import synthetic_vgg19, write_caffemodel
-    nat = os.path.join(os.path.dirname(__file__), "golden", "natural")
+    import natural_inputs
+    nat = natural_inputs.require()
     cases = sorted(os.path.basename(f)[5:-4] for f in glob.glob(os.path.join(nat, "pair_*.npz")))
     if not cases:
         pytest.skip("natural fixtures not generated")
