@@ -26,6 +26,9 @@
 #include "nct_internal.h"
 #include "nct_device.h"
 #include <cfloat>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
 #include <climits>
 #include <hip/hip_fp16.h>
 
@@ -319,6 +322,35 @@ __device__ __forceinline__ float pm_dist(const float* __restrict__ A, const floa
     return (n == 0) ? 1.0f : (-sum) / (float)n;
 }
 
+// ---- NNF word / distance accesses. PLAIN (COH = false): ordinary loads and stores — the one-launch-per-step kernels, whose steps are ordered by kernel boundaries.
+// COHERENT (COH = true): system-scope relaxed accesses (global_load / global_store ... sc0 sc1: served by memory, never by a CU's L1 or an XCD's L2) — the persistent
+// level kernel, whose steps are ordered by per-tile flags inside ONE launch, where a neighbour tile's words were written by a workgroup of another XCD microseconds ago
+// (MI355X_MICROARCH.md "inter-workgroup visibility": {sc0 sc1 stores and loads on both sides} is a valid hand-off without any fence). The feature maps are read-only
+// and stay ordinary (cached) loads in both.
+#ifndef NCT_PM_STEP_COH
+#define NCT_PM_STEP_COH false      // experiment hooks: the per-step kernels with coherent accesses / the level kernel with plain ones (wrong results, timing only)
+#endif
+#ifndef NCT_PM_LEVEL_COH
+#define NCT_PM_LEVEL_COH true
+#endif
+#ifndef NCT_PM_COH_SYSTEM
+#define PM_COH_SCOPE __HIP_MEMORY_SCOPE_AGENT        // sc1: loads bypass the L1 and are served by the XCD's L2, stores write through
+#else
+#define PM_COH_SCOPE __HIP_MEMORY_SCOPE_SYSTEM       // sc0 sc1: served by memory (measured: 1.5 - 2.4 x slower levels — every NNF word a fabric request to a handful of channels)
+#endif
+template <bool COH> __device__ __forceinline__ uint32_t pm_ld(const uint32_t* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, PM_COH_SCOPE); else return *p;
+}
+template <bool COH> __device__ __forceinline__ float pm_ld(const float* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, PM_COH_SCOPE); else return *p;
+}
+template <bool COH> __device__ __forceinline__ void pm_st(uint32_t* p, uint32_t v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, PM_COH_SCOPE); else *p = v;
+}
+template <bool COH> __device__ __forceinline__ void pm_st(float* p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, PM_COH_SCOPE); else *p = v;
+}
+
 // mode 0: init (dist of the current NNF, no cutoff); mode 1: propagation step with `jump`; random search if jump==1
 // A launch carries up to two independent jobs (the S->R and the R->S field of one level): workgroups [0, nblk0) belong to
 // job 0, the rest to job 1. Fusing the two directions doubles the number of resident workgroups at the coarse levels
@@ -333,26 +365,16 @@ struct PMJob { const float* A; const float* B; const uint2* Bh; const uint32_t* 
 // The staged region limits C = 512 to two workgroups per CU (2 waves per SIMD): telling the compiler so (second launch-bounds argument) lets its scheduler
 // keep a patch row's loads in flight together instead of serialising them to save registers for an occupancy the LDS rules out.
 // LPQ = 8 (C = 64, 128 with fp32 tiles): 32 queries per pass, an 8x4 sub-tile, two queries per DPP row (see pm_dist).
-template <int NCH, int MODE, int TQX, int TQY, int LPQ>
-__global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
-                                                 int tstep, int strip, unsigned long long* __restrict__ counter) {
+// One tile of one step (the body of k_pm_step and of the persistent k_pm_level): the workgroup serves the 4 TQX x 4 TQY queries of tile (tx, ty) of job J.
+// s_a: the dynamic LDS region for the staged part of A. nevals / naccept: per-thread counters, accumulated.
+template <int NCH, int MODE, int TQX, int TQY, int LPQ, bool COH>
+__device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int mode, int jump, int iter, int tstep, int strip, float4* __restrict__ s_a, unsigned& nevals, unsigned& naccept) {
     constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2;
-    const bool second = (int)blockIdx.x >= nblk0;
-    const PMJob& J = second ? j1 : j0;
     const float* __restrict__ A = J.A; const float* __restrict__ B = J.B; const uint2* __restrict__ Bh = J.Bh;
     constexpr bool EX = MODE == NCT_PM_ROWREJECT;
-    const uint32_t* __restrict__ nnf_in = J.nnf_in; const float* __restrict__ d_in = J.d_in;
-    uint32_t* __restrict__ nnf_out = J.nnf_out; float* __restrict__ d_out = J.d_out;
+    const uint32_t* nnf_in = J.nnf_in; const float* d_in = J.d_in;
+    uint32_t* nnf_out = J.nnf_out; float* d_out = J.d_out;
     const PMGeom g = J.g; const int rs_max = J.rs_max; const uint32_t seed = J.seed;
-    // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs; give each XCD a contiguous
-    // band of tiles so that overlapping candidate tiles of neighbouring queries meet in the same L2.
-    const int ntiles = g.tiles_x * g.tiles_y;
-    int bid = (int)blockIdx.x - (second ? nblk0 : 0);
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int ty = bid / g.tiles_x, tx = bid - ty * g.tiles_x;
     constexpr int QW = LPQ == 16 ? 4 : 8, QH = 256 / LPQ / QW;      // the sub-tile of one pass: QW x QH queries (4x4 or 8x4)
     static_assert((LPQ == 16 || (LPQ == 8 && NCH == 1 && MODE != NCT_PM_FP16)) && (4 * TQX) % QW == 0 && (4 * TQY) % QH == 0, "8 lanes per query: C = 64, fp32 tiles");
     const int grp = threadIdx.x / LPQ, lane = threadIdx.x % LPQ;
@@ -368,13 +390,13 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
         const int qx = ox + sx * QW + (grp % QW), qy = oy + sy * QH + (grp / QW);
         const int ax = qx < g.aw ? qx : g.aw - 1, ay = qy < g.ah ? qy : g.ah - 1;
         const int qi = ay * g.aw + ax;
-        q.vbest = nnf_in[qi];
+        q.vbest = pm_ld<COH>(nnf_in + qi);
         if (mode != 0) {
-            q.d = d_in[qi];
+            q.d = pm_ld<COH>(d_in + qi);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int nx = ax + ((k == 0) ? -jump : (k == 1 ? jump : 0)), ny = ay + ((k == 2) ? -jump : (k == 3 ? jump : 0));
-                q.vnb[k] = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
+                q.vnb[k] = pm_ld<COH>(nnf_in + clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1));
             }
         }
     };
@@ -386,7 +408,6 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
 
     // stage the region of A that the queries of this workgroup read (their 3x3 tiles overlap) into LDS once per launch. Without it every
     // evaluation re-reads its 9*C*4-byte query tile through L1.
-    extern __shared__ float4 s_a[];
     if constexpr (NCH >= 1) {
         const int c4 = g.C >> 2;
         for (int e = threadIdx.x; e < RW * RH * c4; e += 256) {
@@ -400,7 +421,6 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
     { const int mx = g.bw > g.bh ? g.bw : g.bh; if (rs_start > mx) rs_start = mx; }
     int nrand = 0;
     if (jump == 1) for (int mag = rs_start; mag >= 1; mag >>= 1) ++nrand;
-    unsigned nevals = 0, naccept = 0;
 
     QIn qcur;
 #pragma unroll 1
@@ -520,11 +540,20 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
             if (mode != 0) {
                 // top byte: the step this match last changed in (0 = still the initial one); the last step of a run writes the plain (y << 12) | x word
                 const uint32_t stamp = (xbest != x0 || ybest != y0) ? (uint32_t)tstep : (vbest >> 24);
-                nnf_out[qi] = xy_pack(xbest, ybest) | (strip ? 0u : stamp << 24);
+                pm_st<COH>(nnf_out + qi, xy_pack(xbest, ybest) | (strip ? 0u : stamp << 24));
             }
-            d_out[qi] = dbest;
+            pm_st<COH>(d_out + qi, dbest);
         }
     }
+}
+
+// XCD-aware tile order of the one-launch-per-step kernels: consecutive workgroup ids round-robin over the 8 XCDs; give each XCD a contiguous
+// band of tiles so that overlapping candidate tiles of neighbouring queries meet in the same L2.
+__device__ __forceinline__ int pm_xcd_tile(int bid, int ntiles) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+__device__ __forceinline__ void pm_count(unsigned long long* __restrict__ counter, int v, unsigned nevals, unsigned naccept) {
     if (counter) {
         __shared__ unsigned s_cnt[2];
         if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -533,6 +562,19 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
         __syncthreads();
         if (threadIdx.x < 2) atomicAdd(counter + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]);
     }
+}
+
+template <int NCH, int MODE, int TQX, int TQY, int LPQ>
+__global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) void k_pm_step(PMJob j0, PMJob j1, int nblk0, int mode, int jump, int iter,
+                                                 int tstep, int strip, unsigned long long* __restrict__ counter) {
+    const bool second = (int)blockIdx.x >= nblk0;
+    const PMJob& J = second ? j1 : j0;
+    const int bid = pm_xcd_tile((int)blockIdx.x - (second ? nblk0 : 0), J.g.tiles_x * J.g.tiles_y);
+    const int ty = bid / J.g.tiles_x, tx = bid - ty * J.g.tiles_x;
+    extern __shared__ float4 s_a[];
+    unsigned nevals = 0, naccept = 0;
+    pm_step_tile<NCH, MODE, TQX, TQY, LPQ, NCT_PM_STEP_COH>(J, tx, ty, mode, jump, iter, tstep, strip, s_a, nevals, naccept);
+    pm_count(counter, (int)(threadIdx.x % LPQ), nevals, naccept);
 }
 
 // ---- C = 64 / 128, propagation-only steps (jump 8 / 4 / 2: three of the four launches of an iteration) with the candidates of a wave's SIXTEEN (C = 128: eight) queries packed (round 4).
@@ -549,25 +591,16 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
 #define NCT_PM_PROP_OCC NCT_PM_OCC8        // workgroups per CU the packed kernel is compiled for, and how it fetches a candidate's rows (pm_dist8 STAGE): one row at a time
 #define NCT_PM_PROP_STAGE 0                // measured 11.41 ms for the finest level of a 700x700 pair vs 12.17 (first row, then two together) / 12.18 (whole tile); five workgroups per CU 11.53, six 13.5
 #endif
-template <int NCH, int MODE, int TQX, int TQY, int LPQ>
-__global__ __launch_bounds__(256, LPQ == 8 ? NCT_PM_PROP_OCC : (NCH == 8 ? 2 : 1)) void k_pm_prop(PMJob j0, PMJob j1, int nblk0, int jump, int tstep, int strip, unsigned long long* __restrict__ counter) {
+template <int NCH, int MODE, int TQX, int TQY, int LPQ, bool COH>
+__device__ __forceinline__ void pm_prop_tile(const PMJob& J, int tx, int ty, int jump, int tstep, int strip, float4* __restrict__ s_a, unsigned& nevals, unsigned& naccept) {
     constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2, QW = LPQ == 16 ? 4 : 8, QH = 256 / LPQ / QW, NSX = 4 * TQX / QW, NSUB = NSX * (4 * TQY / QH);
     constexpr int GPW = 64 / LPQ;                          // lane groups (= queries per pass) of a wave
     static_assert(NSUB == 1 || NSUB == 2, "one or two passes per workgroup: 16 (C = 64), 8 (C = 128) or 4 (C >= 256) queries per wave");
     constexpr bool EX = MODE == NCT_PM_ROWREJECT;
-    const bool second = (int)blockIdx.x >= nblk0;
-    const PMJob& J = second ? j1 : j0;
     const float* __restrict__ A = J.A; const float* __restrict__ B = J.B; const uint2* __restrict__ Bh = J.Bh;
-    const uint32_t* __restrict__ nnf_in = J.nnf_in; const float* __restrict__ d_in = J.d_in;
-    uint32_t* __restrict__ nnf_out = J.nnf_out; float* __restrict__ d_out = J.d_out;
+    const uint32_t* nnf_in = J.nnf_in; const float* d_in = J.d_in;
+    uint32_t* nnf_out = J.nnf_out; float* d_out = J.d_out;
     const PMGeom g = J.g;
-    const int ntiles = g.tiles_x * g.tiles_y;
-    int bid = (int)blockIdx.x - (second ? nblk0 : 0);
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int ty = bid / g.tiles_x, tx = bid - ty * g.tiles_x;
     const int grp = threadIdx.x / LPQ, v = threadIdx.x % LPQ, wv = threadIdx.x >> 6, gw = grp % GPW;
     const int ox = tx * 4 * TQX, oy = ty * 4 * TQY;
     __shared__ uint32_t s_list[4][4 * NSUB * GPW];     // per wave: live (slot, k, candidate) entries
@@ -582,14 +615,13 @@ __global__ __launch_bounds__(256, LPQ == 8 ? NCT_PM_PROP_OCC : (NCH == 8 ? 2 : 1
         live[sub] = qx < g.aw && qy < g.ah;
         const int ax = live[sub] ? qx : 0, ay = live[sub] ? qy : 0;
         qi[sub] = ay * g.aw + ax;
-        vbest[sub] = nnf_in[qi[sub]]; dq[sub] = d_in[qi[sub]];
+        vbest[sub] = pm_ld<COH>(nnf_in + qi[sub]); dq[sub] = pm_ld<COH>(d_in + qi[sub]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int nx = ax + ((k == 0) ? -jump : (k == 1 ? jump : 0)), ny = ay + ((k == 2) ? -jump : (k == 3 ? jump : 0));
-            vnb[sub][k] = nnf_in[clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1)];
+            vnb[sub][k] = pm_ld<COH>(nnf_in + clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1));
         }
     }
-    extern __shared__ float4 s_a[];
     {
         constexpr int c4 = 16 * NCH;
         for (int e = threadIdx.x; e < RW * RH * c4; e += 256) {
@@ -660,7 +692,6 @@ __global__ __launch_bounds__(256, LPQ == 8 ? NCT_PM_PROP_OCC : (NCH == 8 ? 2 : 1
     }
     __syncthreads();
     // ---- phase C: every query scans its candidates in order (accept d < dbest: the first of equal distances wins, as in the sequential walk)
-    unsigned nevals = 0, naccept = 0;
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         if (!(live[sub] && v == 0)) continue;
@@ -675,17 +706,181 @@ __global__ __launch_bounds__(256, LPQ == 8 ? NCT_PM_PROP_OCC : (NCH == 8 ? 2 : 1
                 ++nevals;
             }
         const uint32_t stamp = best != (vbest[sub] & 0xFFFFFFu) ? (uint32_t)tstep : (vbest[sub] >> 24);
-        nnf_out[qi[sub]] = best | (strip ? 0u : stamp << 24);
-        d_out[qi[sub]] = dbest;
+        pm_st<COH>(nnf_out + qi[sub], best | (strip ? 0u : stamp << 24));
+        pm_st<COH>(d_out + qi[sub], dbest);
     }
-    if (counter) {
-        __shared__ unsigned s_cnt[2];
-        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+}
+
+template <int NCH, int MODE, int TQX, int TQY, int LPQ>
+__global__ __launch_bounds__(256, LPQ == 8 ? NCT_PM_PROP_OCC : (NCH == 8 ? 2 : 1)) void k_pm_prop(PMJob j0, PMJob j1, int nblk0, int jump, int tstep, int strip, unsigned long long* __restrict__ counter) {
+    const bool second = (int)blockIdx.x >= nblk0;
+    const PMJob& J = second ? j1 : j0;
+    const int bid = pm_xcd_tile((int)blockIdx.x - (second ? nblk0 : 0), J.g.tiles_x * J.g.tiles_y);
+    const int ty = bid / J.g.tiles_x, tx = bid - ty * J.g.tiles_x;
+    extern __shared__ float4 s_a[];
+    unsigned nevals = 0, naccept = 0;
+    pm_prop_tile<NCH, MODE, TQX, TQY, LPQ, NCT_PM_STEP_COH>(J, tx, ty, jump, tstep, strip, s_a, nevals, naccept);
+    pm_count(counter, (int)(threadIdx.x % LPQ), nevals, naccept);
+}
+
+// ---- Round 6: one PERSISTENT launch per pyramid level — k_pm_level. The 1 + 4 iters Jacobi steps of a level used to be as many launches (41), each with its own
+// fill and drain of ~15 rounds of resident workgroups (and at the coarse levels — 242 tiles per step for 44x44 queries — hardly anything but launch latency). Here the
+// level's work items (step, tile) are handed out in step-major order by per-(step, XCD) ticket counters to however many workgroups are resident, and what orders two steps
+// is DATA FLOW, not a grid barrier: tile T may run step s once T and the tiles a jump of 8 reaches in its row and its column have published step s - 1 (their words are
+// read by T at step s — and T's own words of two steps ago, which step s overwrites, were read by exactly those tiles at step s - 1: the same set covers the write-after-read
+// hazard of the double buffer). NNF words and distances cross workgroups through system-scope accesses (pm_ld / pm_st<true>), a tile's flag is stored after its words have
+// been acknowledged (s_waitcnt vmcnt(0) + workgroup barrier): no fence anywhere, the feature maps stay L2-resident across steps.
+// Placement independence (MI355X_MICROARCH.md: HIP promises no co-residency, and up to four pairs are in flight on one device): a workgroup draws tickets of step s + 1 only
+// after it has seen all eight queues of step s exhausted, so whoever holds an item of step s + 1 waits only for items that resident workgroups already hold — a single
+// resident workgroup would finish the level alone. The XCC id only picks the queue a workgroup tries first (its XCD's band of tiles, the same bands as the XCD-aware
+// order of the per-step launches), never correctness. Spins are bounded by a wall-clock watchdog: on expiry (or when another workgroup has flagged one) the workgroup
+// sets ctl[0] and leaves; the host reads the word at the end of the pair and fails it.
+// Same arithmetic per (step, tile) as k_pm_step / k_pm_prop (the same device functions): NNFs and distances are the same bits.
+struct PMLevel {
+    PMJob j0, j1;                                       // nnf_in / d_in / nnf_out / d_out are set per step from the buffers below
+    uint32_t* nn0[2]; float* dd0[2]; uint32_t* nn1[2]; float* dd1[2];       // double-buffered NNF words and distances of the two directions
+    int nblk0, nblk1, nsteps, packed;
+    uint32_t* err;                                      // context-lifetime word the host reads (nctk_pm_check): set when the watchdog fires
+    uint32_t* ctl;                                      // [0] watchdog / error word, [16 + 8 s + x] ticket counter of (step s, XCD queue x), [PM_FLAG0 + tile] last step published + 1
+    unsigned long long* counter;
+    long long timeout_ticks;                            // wall_clock64 ticks (100 MHz)
+};
+constexpr int PM_MAX_STEPS = 256, PM_FLAG0 = 16 + 8 * PM_MAX_STEPS;
+__device__ __forceinline__ int pm_band_start(int n, int x) { const int q = n >> 3, r = n & 7; return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q; }
+__device__ __forceinline__ int pm_band_cnt(int n, int x) { return (n >> 3) + (x < (n & 7) ? 1 : 0); }
+
+// uniform 32- / 64-bit values read back from LDS, forced into scalar registers (the tile bodies address the maps from SGPR bases, as in the per-step kernels)
+__device__ __forceinline__ int pm_sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T> __device__ __forceinline__ T* pm_sgpr(T* p) {
+    const unsigned long long u = (unsigned long long)p;
+    // through a GLOBAL-address-space pointer: a pointer that comes out of LDS has lost what the compiler knew about kernel arguments, and every access through it would be a
+    // FLAT instruction (aperture check, counted in lgkmcnt as well as vmcnt: the candidate loads would serialise with the LDS reads)
+    typedef T __attribute__((address_space(1))) GT;
+    return (T*)(GT*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)u));
+}
+// what a tile body is called with: written to LDS by lane 0 of wave 0, read back (into scalar registers) by every wave inside the body's own function
+struct PMCall { PMJob J; int tx, ty, mode, jump, iter, tstep, strip, counting; };
+typedef __attribute__((address_space(3))) float4 pm_lds_f4;
+typedef __attribute__((address_space(3))) const PMCall pm_lds_call;
+typedef __attribute__((address_space(3))) unsigned pm_lds_u32;
+__device__ __forceinline__ PMJob pm_job_sgpr(pm_lds_call* c) {
+    PMJob r;
+    r.A = pm_sgpr(c->J.A); r.B = pm_sgpr(c->J.B); r.Bh = pm_sgpr(c->J.Bh);
+    r.nnf_in = pm_sgpr(c->J.nnf_in); r.d_in = pm_sgpr(c->J.d_in); r.nnf_out = pm_sgpr(c->J.nnf_out); r.d_out = pm_sgpr(c->J.d_out);
+    r.g.C = pm_sgpr(c->J.g.C); r.g.ah = pm_sgpr(c->J.g.ah); r.g.aw = pm_sgpr(c->J.g.aw); r.g.bh = pm_sgpr(c->J.g.bh); r.g.bw = pm_sgpr(c->J.g.bw);
+    r.g.tiles_x = pm_sgpr(c->J.g.tiles_x); r.g.tiles_y = pm_sgpr(c->J.g.tiles_y); r.rs_max = pm_sgpr(c->J.rs_max); r.seed = (uint32_t)pm_sgpr((int)c->J.seed);
+    return r;
+}
+// The two tile bodies as functions of their OWN (noinline): inlined into the persistent kernel next to each other and to the ticket logic, the scheduler gave up on
+// clustering the candidate loads (one s_waitcnt vmcnt(0) behind every load of a patch row where the per-step kernels keep five in flight — the register pressure of the
+// merged regions exceeded its occupancy target and it fell back to source order: levels 1.5 - 2.3 x slower). As functions they are scheduled and allocated like the
+// per-step kernels; their arguments are LDS addresses, everything uniform is read back into scalar registers inside.
+template <int NCH, int MODE, int TQX, int TQY, int LPQ>
+__device__ __attribute__((noinline)) void pm_level_step_fn(pm_lds_f4* s_a, pm_lds_call* c, pm_lds_u32* cnt) {
+    const PMJob J = pm_job_sgpr(c);
+    unsigned nevals = 0, naccept = 0;
+    pm_step_tile<NCH, MODE, TQX, TQY, LPQ, NCT_PM_LEVEL_COH>(J, pm_sgpr(c->tx), pm_sgpr(c->ty), pm_sgpr(c->mode), pm_sgpr(c->jump), pm_sgpr(c->iter), pm_sgpr(c->tstep), pm_sgpr(c->strip),
+                                                             (float4*)s_a, nevals, naccept);
+    if (pm_sgpr(c->counting) && (threadIdx.x % LPQ) == 0 && (nevals | naccept)) { atomicAdd((unsigned*)cnt, nevals); atomicAdd((unsigned*)cnt + 1, naccept); }
+}
+template <int NCH, int MODE, int TQX, int TQY, int LPQ>
+__device__ __attribute__((noinline)) void pm_level_prop_fn(pm_lds_f4* s_a, pm_lds_call* c, pm_lds_u32* cnt) {
+    const PMJob J = pm_job_sgpr(c);
+    unsigned nevals = 0, naccept = 0;
+    pm_prop_tile<NCH, MODE, TQX, TQY, LPQ, NCT_PM_LEVEL_COH>(J, pm_sgpr(c->tx), pm_sgpr(c->ty), pm_sgpr(c->jump), pm_sgpr(c->tstep), pm_sgpr(c->strip), (float4*)s_a, nevals, naccept);
+    if (pm_sgpr(c->counting) && (threadIdx.x % LPQ) == 0 && (nevals | naccept)) { atomicAdd((unsigned*)cnt, nevals); atomicAdd((unsigned*)cnt + 1, naccept); }
+}
+
+template <int NCH, int MODE, int TQX, int TQY, int LPQ>
+__global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) void k_pm_level(PMLevel L) {
+    extern __shared__ float4 s_a[];
+    __shared__ PMCall s_call;
+    __shared__ int s_ok;
+    __shared__ unsigned s_cnt2[2];
+    if (threadIdx.x < 2) s_cnt2[threadIdx.x] = 0;
+    constexpr int TW = 4 * TQX, TH = 4 * TQY, DX = (8 + TW - 1) / TW, DY = (8 + TH - 1) / TH;      // tiles a jump of 8 reaches in x / in y
+    static_assert(2 * DX + 2 * DY + 1 <= 64, "one lane of wave 0 per dependency");
+    const int lane = threadIdx.x & 63;
+    unsigned home;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(home));
+    home &= 7u;
+    const int nt0 = L.nblk0, nt1 = L.nblk1, nsteps = L.nsteps;
+    uint32_t* const ctl = L.ctl;
+    int cur = 0, tryq = (int)home;                      // wave 0: the step this workgroup draws tickets from; the queue that gave it its last ticket (-1: look at all eight)
+    for (;;) {
+        int flag_tile = 0, flag_step = 0;
+        if (threadIdx.x < 64) {                          // ---- wave 0: ticket, dependencies, the call record
+            int step = -1, job = 0, tile = 0, ok = 0;
+            while (cur < nsteps) {
+                int xs = tryq;
+                if (xs < 0) {                            // lanes 0..7 look at the eight counters of the step; the first open queue from home on is tried
+                    const int x = lane & 7;
+                    const uint32_t cv = pm_ld<true>(ctl + 16 + cur * 8 + x);
+                    const unsigned open = (unsigned)__builtin_amdgcn_ballot_w64(lane < 8 && (int)cv < pm_band_cnt(nt0, x) + pm_band_cnt(nt1, x)) & 0xFFu;
+                    if (!open) { ++cur; tryq = (int)home; continue; }        // every item of this step is in some resident workgroup's hands (or done): the next step may be drawn
+                    const unsigned rot = ((open >> home) | (open << (8 - home))) & 0xFFu;
+                    xs = (int)((home + (unsigned)__builtin_ctz(rot)) & 7u);
+                }
+                uint32_t c = 0;
+                if (lane == 0) c = __hip_atomic_fetch_add(ctl + 16 + cur * 8 + xs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                const int c0 = pm_band_cnt(nt0, xs), c1 = pm_band_cnt(nt1, xs);
+                if ((int)c < c0 + c1) {
+                    step = cur; job = (int)c >= c0 ? 1 : 0; tile = job ? pm_band_start(nt1, xs) + ((int)c - c0) : pm_band_start(nt0, xs) + (int)c; ok = 1; tryq = xs;
+                    break;
+                }
+                tryq = -1;                               // that queue is exhausted: look at all of them
+            }
+            const PMGeom& g = job ? L.j1.g : L.j0.g;
+            const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+            if (ok && step > 0) {                        // dependencies: own tile, DX tiles either side in the row, DY either side in the column, all at step - 1
+                int dx = 0, dy = 0; bool has = false;
+                if (lane <= 2 * DX) { dx = lane - DX; has = true; }
+                else if (lane <= 2 * DX + 2 * DY) { const int r = lane - 2 * DX - 1; dy = r < DY ? r - DY : r - DY + 1; has = true; }
+                const int nx = tx + dx, ny = ty + dy;
+                has = has && nx >= 0 && nx < g.tiles_x && ny >= 0 && ny < g.tiles_y;
+                const uint32_t* f = ctl + PM_FLAG0 + (job ? nt0 : 0) + (has ? ny * g.tiles_x + nx : 0);
+                const long long t0 = wall_clock64();
+                for (;;) {
+                    const uint32_t v = has ? pm_ld<true>(f) : (uint32_t)step;
+                    if (__builtin_amdgcn_ballot_w64(v >= (uint32_t)step) == ~0ull) break;
+                    if (pm_ld<true>(ctl) != 0u || wall_clock64() - t0 > L.timeout_ticks) { if (lane == 0) { pm_st<true>(ctl, 1u); pm_st<true>(L.err, 1u); } ok = -1; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (lane == 0) {
+                s_ok = ok;
+                if (ok > 0) {
+                    PMCall c;
+                    c.J = job ? L.j1 : L.j0;
+                    uint32_t* const* nn = job ? L.nn1 : L.nn0; float* const* dd = job ? L.dd1 : L.dd0;
+                    c.tx = tx; c.ty = ty; c.counting = L.counter != nullptr; c.tstep = step;
+                    if (step == 0) {                     // init: distances of the level's start field
+                        c.J.nnf_in = nn[0]; c.J.d_in = dd[0]; c.J.nnf_out = nullptr; c.J.d_out = dd[0];
+                        c.mode = 0; c.jump = 0; c.iter = 0; c.strip = 0;
+                    } else {
+                        const int in = (step - 1) & 1, out = step & 1;
+                        c.J.nnf_in = nn[in]; c.J.d_in = dd[in]; c.J.nnf_out = nn[out]; c.J.d_out = dd[out];
+                        c.iter = (step - 1) >> 2; c.jump = 8 >> ((step - 1) & 3); c.strip = step == nsteps - 1 ? 1 : 0;
+                        c.mode = (c.jump != 1 && L.packed && MODE != NCT_PM_FP16) ? 2 : 1;
+                    }
+                    s_call = c;
+                }
+            }
+            flag_tile = (job ? nt0 : 0) + tile; flag_step = step;
+        }
         __syncthreads();
-        if (v == 0) { atomicAdd(&s_cnt[0], nevals); atomicAdd(&s_cnt[1], naccept); }
-        __syncthreads();
-        if (threadIdx.x < 2) atomicAdd(counter + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]);
+        if (s_ok <= 0) break;                            // no items left (0) or the watchdog fired (-1)
+        if constexpr (MODE != NCT_PM_FP16) {
+            if (s_call.mode == 2) pm_level_prop_fn<NCH, MODE, TQX, TQY, LPQ>((pm_lds_f4*)s_a, (pm_lds_call*)&s_call, (pm_lds_u32*)s_cnt2);
+            else pm_level_step_fn<NCH, MODE, TQX, TQY, LPQ>((pm_lds_f4*)s_a, (pm_lds_call*)&s_call, (pm_lds_u32*)s_cnt2);
+        } else pm_level_step_fn<NCH, MODE, TQX, TQY, LPQ>((pm_lds_f4*)s_a, (pm_lds_call*)&s_call, (pm_lds_u32*)s_cnt2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's words have been acknowledged by memory …
+        __syncthreads();                                       // … and so have everybody's: the tile's step may be published (also: s_a and s_call are free again)
+        if (threadIdx.x == 0) pm_st<true>(ctl + PM_FLAG0 + flag_tile, (uint32_t)(flag_step + 1));
     }
+    __syncthreads();
+    if (L.counter && threadIdx.x < 2) atomicAdd(L.counter + threadIdx.x, (unsigned long long)s_cnt2[threadIdx.x]);
 }
 
 // query tile of a workgroup per channel count: 8x8 at C = 64 (25 KB of LDS), 8x4 at C = 128 (31 KB), 4x4 above (37 / 74 KB)
@@ -741,6 +936,46 @@ static int launch_step(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob
     return launch_mode<NCH, NCT_PM_PLAIN>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, counter);
 }
 
+// one persistent launch for the whole level (k_pm_level); false = this channel count / mode has no persistent form
+template <int NCH, int MODE>
+static int launch_level_mode(nct_ctx* ctx, hipStream_t s, PMLevel& L) {
+    constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY, LPQ = PMLanes<NCH>::LPQ;
+    const size_t lds = (size_t)(4 * TQX + 2) * (4 * TQY + 2) * NCH * 16 * sizeof(float4);
+    const void* fn = reinterpret_cast<const void*>(&k_pm_level<NCH, MODE, TQX, TQY, LPQ>);
+    if (lds > 32768) NCT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      // > 32 KB of dynamic LDS: per-device opt-in (a host-side call, five per pair)
+    static int occ = 0;                                  // per instantiation; every device of this process is the same part
+    if (!occ) { int o = 0; NCT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, 256, lds)); occ = o > 0 ? o : 1; }
+#if defined(NCT_PM_EVAL_STALE) || defined(NCT_PM_EVAL_SAME)
+    L.packed = 0;
+#else
+    L.packed = ((NCH == 1 || (NCH == 2 && NCT_PM_PACK >= 2) || (NCH >= 4 && NCT_PM_PACK >= 3)) && MODE != NCT_PM_FP16 && NCT_PM_PACK != 0) ? 1 : 0;
+#endif
+    int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int wgs = ctx->pm_persist_wgs > 0 ? ctx->pm_persist_wgs : cus * occ;
+    if (wgs > L.nblk0 + L.nblk1) wgs = L.nblk0 + L.nblk1;
+    hipLaunchKernelGGL((k_pm_level<NCH, MODE, TQX, TQY, LPQ>), dim3(wgs), dim3(256), lds, s, L);
+    NCT_LAUNCH_CHECK();
+    return 0;
+}
+template <int NCH>
+static int launch_level(nct_ctx* ctx, hipStream_t s, PMLevel& L, int pm_mode) {
+    if constexpr (NCH >= 2) { if (pm_mode == NCT_PM_FP16) return launch_level_mode<NCH, NCT_PM_FP16>(ctx, s, L); }
+    if (NCH == 1 && pm_mode == NCT_PM_FP16) pm_mode = NCT_PM_PLAIN;
+    if (NCH <= NCT_PM_FAST_MAX && pm_mode == NCT_PM_ROWREJECT) return launch_level_mode<NCH, NCT_PM_ROWREJECT>(ctx, s, L);
+    return launch_level_mode<NCH, NCT_PM_PLAIN>(ctx, s, L);
+}
+int nctk_pm_check(nct_ctx* ctx) {
+    if (!ctx->d_pm_err) return 0;
+    uint32_t e = 0;
+    NCT_HIP(hipMemcpyAsync(&e, ctx->d_pm_err, sizeof e, hipMemcpyDeviceToHost, ctx->stream));
+    NCT_HIP(hipStreamSynchronize(ctx->stream));
+    if (e) {
+        (void)hipMemsetAsync(ctx->d_pm_err, 0, sizeof e, ctx->stream);
+        return ctx->fail(NCT_ERR_HIP, "patchmatch: the persistent level kernel's watchdog fired (a tile waited > 0.25 s for a neighbour's step); results are invalid");
+    }
+    return 0;
+}
+
 // Runs one PatchMatch (bnn == nullptr) or both directions of a level fused in the same launches (A->B in ann, B->A in bnn).
 static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, const void* a_h16, const void* b_h16, int C, int ah, int aw, int bh, int bw, int iters, int rs_max,
                   uint32_t seed_ab, uint32_t seed_ba, uint32_t* ann, float* annd, uint32_t* bnn, float* bnnd, unsigned long long* eval_counter, int pm_mode) {
@@ -786,6 +1021,26 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
             default:  return launch_step<0>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, eval_counter, pm_mode == NCT_PM_FP16 ? NCT_PM_PLAIN : pm_mode);
         }
     };
+    // ---- one persistent launch for the level (NCT_PM_PERSIST=1): the same steps, handed out as (step, tile) items inside k_pm_level
+    if (ctx->pm_persist && stamps && 1 + 4 * iters <= PM_MAX_STEPS && (C == 64 || C == 128 || C == 256 || C == 512)) {
+        if (!ctx->d_pm_err) { NCT_HIP(hipMalloc(&ctx->d_pm_err, sizeof(uint32_t))); NCT_HIP(hipMemsetAsync(ctx->d_pm_err, 0, sizeof(uint32_t), s)); }
+        const size_t nctl = (size_t)PM_FLAG0 + nblk0 + nblk1;
+        DevBuf<uint32_t> ctl(ctx, nctl);
+        if (!ctl.ok()) return NCT_ERR_HIP;
+        NCT_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(uint32_t), s));
+        PMLevel L;
+        L.j0 = PMJob{a_hwc, b_hwc, (const uint2*)b_h16, nullptr, nullptr, nullptr, nullptr, ga, rs_max, seed_ab};
+        L.j1 = PMJob{b_hwc, a_hwc, (const uint2*)a_h16, nullptr, nullptr, nullptr, nullptr, gb, rs_max, seed_ba};
+        for (int i = 0; i < 2; ++i) { L.nn0[i] = na_buf[i]; L.dd0[i] = da_buf[i]; L.nn1[i] = nb_buf[i]; L.dd1[i] = db_buf[i]; }
+        L.nblk0 = nblk0; L.nblk1 = nblk1; L.nsteps = 1 + 4 * iters; L.packed = 0; L.ctl = ctl; L.err = ctx->d_pm_err; L.counter = eval_counter;
+        L.timeout_ticks = 25000000;                    // 0.25 s of the 100 MHz wall clock
+        switch (C) {
+            case 64:  return launch_level<1>(ctx, s, L, pm_mode);
+            case 128: return launch_level<2>(ctx, s, L, pm_mode);
+            case 256: return launch_level<4>(ctx, s, L, pm_mode);
+            default:  return launch_level<8>(ctx, s, L, pm_mode);
+        }
+    }
     // the total number of Jacobi steps is even (iters*4), so ping-ponging (nnf,dist) <-> (tmp) ends in (nnf,dist)
     int rc = step(0, 0, 0, 0, 0, 0, 0);            // init: dist(current NNF), NNF untouched
     if (rc) return rc;

@@ -105,6 +105,8 @@ int nct_create(int device, nct_ctx** out) {
     if (const char* f = getenv("NCT_CONV_POOL_FUSE")) { const int v = atoi(f); if (v == 0 || v == 1) c->conv_pool_fuse = v; }
     if (const char* q = getenv("NCT_CONV_PAIR")) { const int v = atoi(q); if (v == 0 || v == 1) c->conv_pair = v; }
     if (const char* q = getenv("NCT_KNN_RUNS")) { const int v = atoi(q); if (v == 0 || v == 1) c->knn_runs = v; }
+    if (const char* q = getenv("NCT_PM_PERSIST")) { const int v = atoi(q); if (v == 0 || v == 1) c->pm_persist = v; }
+    if (const char* q = getenv("NCT_PM_PERSIST_WGS")) { const int v = atoi(q); if (v > 0) c->pm_persist_wgs = v; }
     if (const char* q = getenv("NCT_S1_HUB_HINT")) { const int v = atoi(q); if (v == 0 || v == 1) c->s1_hub_hint = v; }
     if (const char* m = getenv("NCT_WLS_MAXIT")) { const int v = atoi(m); if (v > 0) c->wls_maxit = v; }
     *out = c;
@@ -151,6 +153,7 @@ void nct_destroy(nct_ctx* ctx) {
     for (hipEvent_t e : ctx->tm_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->kt_events) (void)hipEventDestroy(e);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+    if (ctx->d_pm_err) (void)hipFree(ctx->d_pm_err);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -180,7 +183,7 @@ int nct_synchronize(nct_ctx* ctx) {
     if (!ctx) return NCT_ERR_INVALID;
     NCT_HIP(hipSetDevice(ctx->device));
     NCT_HIP(hipDeviceSynchronize());
-    return NCT_OK;
+    return nctk_pm_check(ctx);
 }
 
 #define CTX_ENTER() do { if (!ctx) return NCT_ERR_INVALID; NCT_HIP(hipSetDevice(ctx->device)); } while (0)
@@ -251,6 +254,7 @@ int nct_patchmatch(nct_ctx* ctx, const float* a_chw, const float* b_chw, int C, 
     RC(nctk_patchmatch(ctx, ctx->stream, A, B, C, ah, aw, bh, bw, iters, rs_max, seed, n, d, nullptr));
     D2H(nnf, n, sizeof(uint32_t) * na);
     D2H(dist, d, sizeof(float) * na);
+    RC(nctk_pm_check(ctx));
     SYNC();
     return NCT_OK;
 }
@@ -352,6 +356,7 @@ int nct_pm_bench_run(nct_ctx* ctx, int iters, int rs_max, uint32_t seed, float* 
     RC(nctk_patchmatch(ctx, ctx->stream, ctx->bench_a, ctx->bench_b, C, ah, aw, bh, bw, iters, rs_max, seed, n, d, counter));
     NCT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     NCT_HIP(hipEventSynchronize(ctx->ev1));
+    RC(nctk_pm_check(ctx));
     float ms = 0.f;
     NCT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (kernel_ms) *kernel_ms = ms;
@@ -380,6 +385,7 @@ int nct_pm_bench_run_bidir(nct_ctx* ctx, int iters, int rs_max, uint32_t seed, i
                              an, ad, bn, bd, pm_mode, counter));
     NCT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     NCT_HIP(hipEventSynchronize(ctx->ev1));
+    RC(nctk_pm_check(ctx));
     float ms = 0.f;
     NCT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (kernel_ms) *kernel_ms = ms;

@@ -31,6 +31,9 @@ struct nct_ctx {
     void* pair = nullptr;             // struct pair_state* (nct_pipeline.cpp): device-resident source/reference/result images
     unsigned long long* d_counter = nullptr;   // device counters of the pm kernels (NCT_FLAG_COUNT_EVALS): [0] distance evaluations performed, [1] accepted candidates;
                                                 // 4 slots per pyramid level in pair runs (nct_pipeline.cpp reads [4 l] and [4 l + 1])
+    int pm_persist = 0;                         // PatchMatch: one persistent launch per pyramid level (k_pm_level) instead of 1 + 4 iters launches (env NCT_PM_PERSIST)
+    int pm_persist_wgs = 0;                     // workgroups of that launch (0: CUs x occupancy; env NCT_PM_PERSIST_WGS, experiments)
+    uint32_t* d_pm_err = nullptr;               // device word the persistent kernel's watchdog sets; read by nctk_pm_check at the synchronisation points
     unsigned pm_attr_mask = 0;                 // k_pm_step instantiations whose dynamic-LDS opt-in has been set on this context's device
     // stage clock: events recorded on the main stream at stage boundaries, read once after the pair's final synchronise
     // (no host syncs in between: see nct_pair_timing in nct.h)
@@ -97,6 +100,8 @@ int nctk_hwc_to_chw(nct_ctx* ctx, hipStream_t s, const float* src, float* dst, i
 int nctk_normalize(nct_ctx* ctx, hipStream_t s, const float* src_hwc, float* dst_hwc, float* resp /*nullable*/, int C, int HW,
                    void* dst_h16 = nullptr /* nullable: fp16 (round-to-nearest) shadow copy of dst, same HWC layout */);
 int nctk_feature_distance(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, float* err, int C, int HW);
+// k_patchmatch.hip: after a stream synchronise — has a persistent PatchMatch level's watchdog fired since the last check? (NCT_ERR_HIP then; no-op without pm_persist)
+int nctk_pm_check(nct_ctx* ctx);
 // k_nnf.hip
 int nctk_nnf_init(nct_ctx* ctx, hipStream_t s, uint32_t* nnf, int ah, int aw, int bh, int bw);
 int nctk_nnf_upsample(nct_ctx* ctx, hipStream_t s, const uint32_t* nnf_half, uint32_t* nnf, int ah, int aw, int bh, int bw, int ah_half, int aw_half);

@@ -224,7 +224,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         rc = nctk_patchmatch_bidir(ctx, s, na, nb, (const uint16_t*)na_h, (const uint16_t*)nb_h, C, ah[l], aw[l], bh[l], bw[l], prm->pm_iters, rs_range[l], seed_ab, seed_ba,
                                    ann, annd, bnn, bnnd, pm_mode, count ? ctx->d_counter + 4 * l : nullptr); if (rc) return rc;
         MARK(ST_PM, l);
-        if (timing) timing->pm_level_launches[l] = 1 + 4 * prm->pm_iters;
+        if (timing) timing->pm_level_launches[l] = (ctx->pm_persist && 4 * prm->pm_iters <= 250) ? 1 : 1 + 4 * prm->pm_iters;
         if (lv) {
             rc = d2h(lv->ann[l], ann, sizeof(uint32_t) * na_px); if (rc) return rc;
             rc = d2h(lv->bnn[l], bnn, sizeof(uint32_t) * nb_px); if (rc) return rc;
@@ -281,6 +281,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
     }
     // the side stream's kNN graphs (one per level that ran) finish before their buffers go back (Cleanup3 synchronises stream2)
     NCT_HIP(hipStreamSynchronize(s));
+    rc = nctk_pm_check(ctx); if (rc) return rc;
     if (timing) {
         timing->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         rc = read_marks(ctx, timing); if (rc) return rc;

@@ -8,6 +8,9 @@
 // config 1: "L=5 only" = -levels 1), `-resume 1` (skip pairs whose output exists; <out>/status.jsonl gets one JSON line per pair)
 // and `-feat16 1` (reduced-precision PatchMatch features; not bit-identical).
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -103,7 +106,7 @@ std::string stem(const std::string& path) {          // main.cu:524-531 (find_la
 struct Pair { std::string cnt, stl; float bds; };
 std::mutex g_print;
 
-struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; bool resume = false, vis = false; };
+struct Config { std::string input_dir, output_dir, model_dir; nct_params prm; bool resume = false, vis = false; int rank = 0, world = 1; };
 
 // ---- ENABLE_VIS debug outputs (Config.h:8) behind the runtime flag -vis 1: per pyramid level the flow maps of both NNFs (reconstruct_flow,
 // GeneralizedPatchMatch.cu:337-353), the level images tCnt / tStl (main.cu:343-347), the matching-error heat map (getHeat,
@@ -252,7 +255,8 @@ std::string json_escape(const std::string& s) {
 void write_status(const Config& cfg, size_t index, const char* status, const std::string& cnt, const std::string& stl, double bds, const std::string& out, double sec,
                   const std::string& msg) {
     std::lock_guard<std::mutex> g(g_status);
-    FILE* f = fopen((cfg.output_dir + "/status.jsonl").c_str(), "a");
+    // one process per GPU (-world N): every rank appends to its own file, status.<rank>.jsonl — appends of different processes to one file could interleave
+    FILE* f = fopen((cfg.output_dir + (cfg.world > 1 ? "/status." + std::to_string(cfg.rank) + ".jsonl" : std::string("/status.jsonl"))).c_str(), "a");
     if (!f) return;
     fprintf(f, "{\"pair\": %zu, \"content\": \"%s\", \"style\": \"%s\", \"bds\": %.6g, \"status\": \"%s\", \"output\": \"%s\", \"seconds\": %.4f, \"message\": \"%s\"}\n",
             index, json_escape(cnt).c_str(), json_escape(stl).c_str(), bds, status, json_escape(out).c_str(), sec, json_escape(msg).c_str());
@@ -344,17 +348,44 @@ void store_pair(Job& j) {
 
 // Bounded hand-over between the I/O pool and the GPU workers. `ready` holds decoded pairs (at most `cap`: the decoders stay a little ahead of the GPUs, not a
 // whole batch), `results` finished ones waiting for the PNG encoder (the same bound: a worker blocks rather than pile up results if zlib falls behind).
+// Which pairs.txt lines this process runs. One process (-world 1): all of them, in order. One process per GPU (-world N -rank r; what `-procs N` forks): line i belongs to
+// rank i mod N — or, with -steal 1, to whichever rank draws it: a counter in <output>/.tickets, advanced under an fcntl lock, hands the lines out in order to whoever is
+// free (BASELINE config 5, mixed sizes; north_star's "work-stealing" — a file lock rather than RCCL: the ranks exchange one integer per pair, and a lock file also works
+// between ranks that were started by hand on different devices, with no rendezvous). Which rank runs a pair has no influence on its result.
+struct Tickets {
+    size_t total = 0, next = 0; int rank = 0, world = 1, fd = -1;
+    long draw() {                                                // next global line index, -1 when there is none left for this process
+        if (fd >= 0) {
+            struct flock lk; memset(&lk, 0, sizeof lk); lk.l_type = F_WRLCK; lk.l_whence = SEEK_SET;
+            if (fcntl(fd, F_SETLKW, &lk) != 0) return -1;
+            unsigned long long v = 0;
+            if (pread(fd, &v, sizeof v, 0) != (ssize_t)sizeof v) v = 0;
+            const long got = v < total ? (long)v : -1;
+            if (got >= 0) { ++v; if (pwrite(fd, &v, sizeof v, 0) != (ssize_t)sizeof v) { /* the lock is released below; the next reader sees the old value and redoes the line: harmless */ } }
+            lk.l_type = F_UNLCK; (void)fcntl(fd, F_SETLK, &lk);
+            return got;
+        }
+        while (next < total && (int)(next % (size_t)world) != rank) ++next;
+        return next < total ? (long)next++ : -1;
+    }
+};
+
+// Bounded hand-over between the I/O pool and the GPU workers. `ready` holds decoded pairs (at most `cap`: the decoders stay a little ahead of the GPUs, not a
+// whole batch), `results` finished ones waiting for the PNG encoder (the same bound: a worker blocks rather than pile up results if zlib falls behind).
 struct Pipeline {
     std::mutex m; std::condition_variable cv;
     std::deque<std::unique_ptr<Job>> ready, results;
-    size_t cap = 4, total = 0, next_load = 0, loading = 0, finished = 0;
+    Tickets tickets;
+    size_t cap = 4, taken = 0, loading = 0, finished = 0;
+    bool exhausted = false;                                      // the ticket source has nothing left for this process
     // decoded pixels waiting for a GPU worker: images are queued BEFORE the GPU-side shrink to MAX_SIZE and a decoder accepts up to 64 MP (192 MB), so the queue is
     // bounded by bytes as well as by count — a new load starts only while the decoded backlog is below byte_cap (or nothing at all is queued or loading)
     // Loads in flight are charged too: a load reserves `load_estimate` bytes when it starts — the largest decoded pair seen so far, at least two 1000 x 1000
     // images — and is corrected to its real size when it lands in `ready`, so several I/O threads cannot all pass the test while the backlog is still being decoded.
     size_t ready_bytes = 0, byte_cap = (size_t)1 << 30, loading_bytes = 0, load_estimate = (size_t)6 << 20;
-    bool may_load() const { return next_load < total && ready.size() + loading < cap && (ready_bytes + loading_bytes < byte_cap || ready.size() + loading == 0); }
-    bool loads_done() const { return next_load >= total && loading == 0; }
+    bool may_load() const { return !exhausted && ready.size() + loading < cap && (ready_bytes + loading_bytes < byte_cap || ready.size() + loading == 0); }
+    bool loads_done() const { return exhausted && loading == 0; }
+    bool all_done() const { return exhausted && finished == taken; }
 };
 
 void io_thread(Pipeline& P, const Config& cfg, const std::vector<Pair>& pairs) {
@@ -362,10 +393,14 @@ void io_thread(Pipeline& P, const Config& cfg, const std::vector<Pair>& pairs) {
         std::unique_ptr<Job> j; bool store = false; size_t idx = 0, reserved = 0;
         {
             std::unique_lock<std::mutex> lk(P.m);
-            P.cv.wait(lk, [&] { return !P.results.empty() || P.may_load() || P.finished == P.total; });
+            P.cv.wait(lk, [&] { return !P.results.empty() || P.may_load() || P.all_done(); });
             if (!P.results.empty()) { j = std::move(P.results.front()); P.results.pop_front(); store = true; }       // encoding first: it frees memory and unblocks workers
-            else if (P.may_load()) { idx = P.next_load++; ++P.loading; reserved = P.load_estimate; P.loading_bytes += reserved; }
-            else return;                                                                                                 // finished == total
+            else if (P.may_load()) {
+                const long t = P.tickets.draw();
+                if (t < 0) { P.exhausted = true; lk.unlock(); P.cv.notify_all(); continue; }
+                idx = (size_t)t; ++P.taken; ++P.loading; reserved = P.load_estimate; P.loading_bytes += reserved;
+            }
+            else return;                                                                                                 // every ticket of this process is finished
         }
         P.cv.notify_all();
         if (store) {
@@ -435,7 +470,7 @@ int main(int argc, char** argv) {
     CmdLine cl;
     Config cfg;
     nct_params_default(&cfg.prm);
-    int gpu = 0, ngpus = 1, seed = 1, inflight = 1, levels = 5, resume = 0, feat16 = 0, vis = 0, io = -1, pin = 1;
+    int gpu = 0, ngpus = 1, seed = 1, inflight = 1, levels = 5, resume = 0, feat16 = 0, vis = 0, io = -1, pin = 1, world = 1, rank = 0, steal = 0, procs = 0;
     cl.add("m", cfg.model_dir, "Directory of network models.");
     cl.add("i", cfg.input_dir, "Input directory of content and style images and pairs.txt.");
     cl.add("o", cfg.output_dir, "Output directory of result images.");
@@ -455,6 +490,10 @@ int main(int argc, char** argv) {
     cl.add("levels", levels, "[extension] pyramid levels to run, coarse to fine: 5 = the full L=5..1 loop, 1 = L=5 only.");
     cl.add("resume", resume, "[extension] 1 = skip pairs whose output file exists and is a complete PNG; every pair appends a JSON line to <output>/status.jsonl.");
     cl.add("vis", vis, "[extension] 1 = the reference's ENABLE_VIS dumps per level (flow maps, level images, error heat map, coefficient and cluster images) next to the output.");
+    cl.add("procs", procs, "[extension] N > 0: fork N processes, one per GPU (-g, -g + 1, ...): process r runs with -rank r -world N on its own device, HIP runtime and status.<r>.jsonl (the process-per-GPU shape; -gpus N keeps all GPUs in one process).");
+    cl.add("world", world, "[extension] number of cooperating processes that share this pairs.txt and output directory (default 1); set by -procs, or by hand with -rank.");
+    cl.add("rank", rank, "[extension] this process's rank in [0, world): it runs the pairs.txt lines i with i mod world = rank (or the ones it draws, -steal 1).");
+    cl.add("steal", steal, "[extension] 1 = with -world > 1, lines are drawn from a shared counter (<output>/.tickets under a file lock) by whichever rank is free, instead of i mod world: mixed-size batches.");
     cl.add("feat16", feat16, "[extension] 1 = fp16 PatchMatch feature tiles (fp32 accumulate); not bit-identical to the default (about 45 dB against it).");
     // parser self-test hook (no GPU): `--parse-only <args…>` parses the rest like a normal run and prints what main would go on with, in the format of
     // oracle/ref_cmdline.cpp (the reference's own parser): tests/test_cli.py compares the two on the vectors of tests/golden/cmdline_ref.json
@@ -469,6 +508,32 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (!parsed) return -1;
+    if (world < 1 || rank < 0 || rank >= world) { printf("Error: -rank %d is not in [0, -world %d).\n", rank, world); return -1; }
+    mkdir(cfg.output_dir.c_str(), 0777);                                    // main.cu:458
+    const std::string tickets_path = cfg.output_dir + "/.tickets";
+    if (procs > 0) {
+        // one process per GPU: fork BEFORE anything touches the HIP runtime (a forked HIP context is unusable), every child goes on as rank r of `procs` on device -g + r
+        if (world != 1) { printf("Error: -procs and -world are exclusive (-procs sets -world for its children).\n"); return -1; }
+        if (steal) { unlink(tickets_path.c_str()); }                         // a fresh counter for this run
+        fflush(stdout);
+        std::vector<pid_t> kids;
+        int my = -1;
+        for (int r = 0; r < procs; ++r) {
+            const pid_t k = fork();
+            if (k < 0) { printf("Error: fork failed.\n"); return -1; }
+            if (k == 0) { my = r; break; }
+            kids.push_back(k);
+        }
+        if (my < 0) {                                                       // the parent only waits: exit status = the worst child's
+            const auto t0 = std::chrono::steady_clock::now();
+            int worst = 0;
+            for (pid_t k : kids) { int st = 0; if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = -1; }
+            printf("All %d process(es) finished in %.3f sec%s.\n", procs, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), worst ? " (at least one failed)" : "");
+            return worst;
+        }
+        world = procs; rank = my; gpu += my; ngpus = 1;
+    }
+    cfg.rank = rank; cfg.world = world;
     cfg.prm.seed = (uint32_t)seed;
     cfg.prm.levels = levels < 1 ? 1 : (levels > 5 ? 5 : levels);
     if (feat16) cfg.prm.flags |= NCT_FLAG_FEAT16;
@@ -483,7 +548,6 @@ int main(int argc, char** argv) {
     if (io < 0) io = std::min(2 * ngpus, hw > 0 ? hw : 2 * ngpus);
     if (io > 64) io = 64;
 
-    mkdir(cfg.output_dir.c_str(), 0777);                                    // main.cu:458
     const std::string pairsFile = cfg.input_dir + "/pairs.txt";
     FILE* fp = fopen(pairsFile.c_str(), "r");
     if (!fp) { printf("Error: File %s does not exist in the input directory.\n", pairsFile.c_str()); return -1; }
@@ -538,9 +602,15 @@ int main(int argc, char** argv) {
     // pairs are independent and of mixed sizes: every worker takes the next decoded pair (work stealing inside the node, BASELINE config 5);
     // which worker runs a pair has no influence on its result
     std::vector<std::thread> threads;
-    Pipeline P; P.total = pairs.size(); P.cap = (size_t)std::max(2, 2 * nworkers);
+    Pipeline P; P.cap = (size_t)std::max(2, 2 * nworkers);
+    P.tickets.total = pairs.size(); P.tickets.rank = rank; P.tickets.world = world;
+    if (world > 1 && steal) {
+        P.tickets.fd = open(tickets_path.c_str(), O_RDWR | O_CREAT, 0644);     // 8 bytes: the next line to hand out (absent or short = 0). A hand-started set of ranks removes it between runs.
+        if (P.tickets.fd < 0) { printf("Error: cannot open %s for -steal.\n", tickets_path.c_str()); return -1; }
+    }
     if (const char* e = getenv("NCT_IO_READY_MB")) P.byte_cap = (size_t)std::max(0L, atol(e)) << 20;      // test hook: decoded backlog allowed in front of the GPU workers (default 1 GiB)
-    std::atomic<size_t> next{0};
+    std::mutex next_m;
+    size_t mine = 0;
     if (io > 0) {
         for (int t = 0; t < io; ++t) threads.emplace_back([&, t] { if (pin) affinity::pin_current_thread(loc[t % ngpus].cpus); io_thread(P, cfg, pairs); });
         for (int j = 0; j < nworkers; ++j) threads.emplace_back([&, j] { if (pin) affinity::pin_current_thread(loc[j % ngpus].cpus); gpu_worker(P, ctxs[j], cfg); });
@@ -548,7 +618,10 @@ int main(int argc, char** argv) {
         for (int j = 0; j < nworkers; ++j)
             threads.emplace_back([&, j] {
                 if (pin) affinity::pin_current_thread(loc[j % ngpus].cpus);
-                for (size_t i; (i = next.fetch_add(1)) < pairs.size();) {
+                for (;;) {
+                    long t; { std::lock_guard<std::mutex> lk(next_m); t = P.tickets.draw(); if (t >= 0) ++mine; }
+                    if (t < 0) break;
+                    const size_t i = (size_t)t;
                     Job job; job.index = i; job.p = pairs[i];
                     load_pair(cfg, job);
                     if (job.state == Job::LOADED) run_pair(ctxs[j], cfg, job);
@@ -559,7 +632,10 @@ int main(int argc, char** argv) {
     }
     for (auto& t : threads) t.join();
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("Processed %zu pair(s) on %d GPU(s), %d in flight each, %d I/O thread(s), in %.3f sec (%.3f pairs/sec).\n", pairs.size(), ngpus, inflight, io, sec, pairs.empty() ? 0.0 : pairs.size() / sec);
+    const size_t done = io > 0 ? P.taken : mine;
+    if (P.tickets.fd >= 0) close(P.tickets.fd);
+    if (world > 1) printf("Rank %d of %d: ", rank, world);
+    printf("Processed %zu pair(s) on %d GPU(s), %d in flight each, %d I/O thread(s), in %.3f sec (%.3f pairs/sec).\n", done, ngpus, inflight, io, sec, done == 0 ? 0.0 : done / sec);
     for (auto* c : ctxs) nct_destroy(c);
     return 0;
 }

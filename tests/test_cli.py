@@ -320,6 +320,68 @@ def test_cli_inflight_workers_give_identical_files(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_process_per_gpu_shapes_give_identical_files(tmp_path):
+    """the process-per-GPU shape of the driver. `-procs 2` forks two processes (rank r of 2, device -g + r — both mapped to device 0 here through
+    NCT_DEVICE_OVERRIDE) that share pairs.txt by i mod 2 and write status.<r>.jsonl; `-world 2 -rank r -steal 1` started by hand draws lines from <out>/.tickets under a
+    file lock. Every shape must leave the files of the one-process run, each pair exactly once."""
+    import json
+    from caffemodel_io import synthetic_vgg19, write_caffemodel
+    ws, bs = synthetic_vgg19(19)
+    (tmp_path / "model" / "vgg19").mkdir(parents=True)
+    write_caffemodel(str(tmp_path / "model" / "vgg19" / "VGG_ILSVRC_19_layers.caffemodel"), ws, bs)
+    inp = tmp_path / "in"; inp.mkdir()
+    lines = []
+    for i, (h, w) in enumerate([(64, 64), (72, 56), (48, 80), (96, 64), (64, 96)]):
+        Image.fromarray(synth.image(30 + i, h, w)[..., ::-1].copy()).save(inp / f"s{i}.png")
+        Image.fromarray(synth.image(40 + i, w, h)[..., ::-1].copy()).save(inp / f"r{i}.png")
+        lines.append(f"s{i}.png r{i}.png 2.0\n")
+    (inp / "pairs.txt").write_text("".join(lines))
+    common = ["-m", str(tmp_path / "model"), "-i", str(inp)]
+    env = dict(os.environ, NCT_DEVICE_OVERRIDE="0")
+
+    def pngs(d):
+        return {n: np.asarray(Image.open(d / n)) for n in sorted(os.listdir(d)) if n.endswith(".png")}
+
+    def status(d, files):
+        recs = []
+        for f in files:
+            if os.path.exists(d / f):            # a rank that drew no line (-steal: the other one was faster) writes no file
+                recs += [json.loads(l) for l in open(d / f)]
+        return recs
+    r = run(*common, "-o", str(tmp_path / "one"), "-g", "0")
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = pngs(tmp_path / "one")
+    assert len(ref) == 5
+    # -procs 2: static split
+    r = subprocess.run([BIN, *common, "-o", str(tmp_path / "procs"), "-g", "0", "-procs", "2"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "Rank 0 of 2: Processed 3 pair(s)" in r.stdout and "Rank 1 of 2: Processed 2 pair(s)" in r.stdout and "All 2 process(es) finished" in r.stdout
+    got = pngs(tmp_path / "procs")
+    assert list(got) == list(ref) and all(np.array_equal(got[n], ref[n]) for n in ref)
+    recs = status(tmp_path / "procs", ["status.0.jsonl", "status.1.jsonl"])
+    assert sorted(x["pair"] for x in recs) == [0, 1, 2, 3, 4] and all(x["status"] == "done" for x in recs)
+    assert not os.path.exists(tmp_path / "procs" / "status.jsonl")
+    # -procs 2 -steal 1: the shared counter
+    r = subprocess.run([BIN, *common, "-o", str(tmp_path / "steal"), "-g", "0", "-procs", "2", "-steal", "1", "-inflight", "2"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    got = pngs(tmp_path / "steal")
+    assert list(got) == list(ref) and all(np.array_equal(got[n], ref[n]) for n in ref)
+    recs = status(tmp_path / "steal", ["status.0.jsonl", "status.1.jsonl"])
+    assert sorted(x["pair"] for x in recs) == [0, 1, 2, 3, 4]
+    # two ranks started by hand, one after the other: the second finds the counter where the first left it (nothing left) — each pair still exactly once
+    out = tmp_path / "hand"
+    r0 = subprocess.run([BIN, *common, "-o", str(out), "-g", "0", "-world", "2", "-rank", "0", "-steal", "1"], capture_output=True, text=True, env=env)
+    r1 = subprocess.run([BIN, *common, "-o", str(out), "-g", "0", "-world", "2", "-rank", "1", "-steal", "1"], capture_output=True, text=True, env=env)
+    assert r0.returncode == 0 and r1.returncode == 0, r0.stdout[-2000:] + r1.stdout[-2000:]
+    assert "Rank 0 of 2: Processed 5 pair(s)" in r0.stdout and "Rank 1 of 2: Processed 0 pair(s)" in r1.stdout
+    got = pngs(out)
+    assert list(got) == list(ref) and all(np.array_equal(got[n], ref[n]) for n in ref)
+    # a rank outside the world is refused
+    r = run(*common, "-o", str(tmp_path / "bad"), "-world", "2", "-rank", "2")
+    assert r.returncode == 255 and "is not in [0, -world 2)" in r.stdout
+
+
+@pytest.mark.gpu
 def test_cli_shrink_jpeg_resume_levels(tmp_path, ctx):
     """transfer_single's shrink-to-1000 path (main.cu:500-522: int truncation of the shorter side) on a JPEG input, `-levels 1`
     (BASELINE config 1), and `-resume 1` (existing outputs are skipped; status.jsonl gets a line per pair)."""

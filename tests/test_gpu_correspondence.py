@@ -164,6 +164,30 @@ def test_patchmatch_bidir_bit_exact(ctx, oracle, C, ah, aw, bh, bw, rs):
     assert counts[0] == counts[1] and counts[0][0] > 0 and counts[0][1] > 0           # same candidates, same acceptances
 
 
+@pytest.mark.parametrize("C,ah,aw,bh,bw,rs", [(64, 37, 41, 33, 45, 8), (128, 30, 26, 28, 31, 16), (256, 21, 24, 23, 20, 8), (512, 14, 13, 12, 15, 4), (64, 120, 90, 100, 110, 32)])
+def test_patchmatch_persistent_level_kernel_bit_exact(oracle, monkeypatch, C, ah, aw, bh, bw, rs):
+    """Round 6: NCT_PM_PERSIST=1 runs a pyramid level as ONE persistent launch — k_pm_level: (step, tile) items from per-(step, XCD) ticket counters,
+    steps ordered by per-tile flags instead of kernel boundaries, NNF words exchanged through agent-scope accesses. Opt-in (measured slower than the per-step launches on
+    MI355X: DESIGN §9), but it must compute the same field: both directions, both evaluation modes, same evaluation counts as the oracle's schedule."""
+    import nct
+    monkeypatch.setenv("NCT_PM_PERSIST", "1")
+    fa, fb = synth.features(21, C, ah, aw), synth.features(22, C, bh, bw)
+    a, b = oracle.feat_normalize(fa), oracle.feat_normalize(fb)
+    seed = 77
+    o_ann, o_annd = oracle.patchmatch(a, b, oracle.nnf_init(ah, aw, bh, bw), iters=5, rs_max=rs, seed=seed)
+    o_bnn, o_bnnd = oracle.patchmatch(b, a, oracle.nnf_init(bh, bw, ah, aw), iters=5, rs_max=rs, seed=seed ^ 0x5bd1e995)
+    with nct.Context(0) as c:                              # the flag is read when a context is created
+        c.pm_bench_setup(fa, fb)
+        counts = []
+        for mode in (0, 1):
+            for rep in range(2):                           # twice: the control block (tickets, flags) is rebuilt per level, nothing may leak from the first run
+                ms, cnt, ann, annd, bnn, bnnd = c.pm_bench_run_bidir(iters=5, rs_max=rs, seed=seed, pm_mode=mode, count=True, fetch=True, both=True)
+                assert np.array_equal(ann, o_ann) and np.array_equal(bnn, o_bnn), f"mode {mode}: NNF differs from the oracle"
+                assert np.array_equal(annd.view(np.uint32), o_annd.view(np.uint32)) and np.array_equal(bnnd.view(np.uint32), o_bnnd.view(np.uint32)), f"mode {mode}: distances differ"
+            counts.append(cnt)
+        assert counts[0] == counts[1] and counts[0][0] > 0
+
+
 def _same_or_both_nan(a, b):
     """bit-identical where finite; NaN where the other is NaN (x86 and gfx950 produce different NaN payloads for 0/0: 0xFFC00000 vs 0x7FC00000)"""
     na, nb = np.isnan(a), np.isnan(b)
