@@ -30,6 +30,9 @@ Extra objects:
                  fabric-side bytes are HBM bytes), from two live counter passes.
   cpu_baseline — the CPU oracle ("port") end-to-end on a bounded sample of the same workload, on this box's host cores.
   stages_ms    — per-stage device time of one extra pair (events on the stream; not part of the timed region).
+  natural      — the reference's own demo photographs (in0/tar0, in1/tar1, in4/tar4 of demo/example/pairs.txt, sizes as shipped, synthetic weights), one pair in flight, next to
+                 synthetic pairs of the same sizes: ms per pair, pairs/s, the natural/synthetic ratio, WLS iterations (outside the timed region; `available: false` where the
+                 photographs are not staged — they are never committed). `--workload natural` makes them the timed workload.
 """
 import argparse
 import hashlib
@@ -52,7 +55,50 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 MALL_BYTES = 256.0 * 1024 * 1024     # Infinity Cache
-WORKLOADS = ("pair700", "pair1000", "pair256l5", "batch64", "mixed256")
+WORKLOADS = ("pair700", "pair1000", "pair256l5", "batch64", "mixed256", "natural")
+NATURAL = (("in0", "tar0"), ("in1", "tar1"), ("in4", "tar4"))      # demo/example/pairs.txt:1-3 (bds 2.0): the photographs tests/natural_inputs.py stages
+
+
+def load_natural():
+    """the three demo pairs as BGR arrays, or None where the photographs are not staged (they are never committed: tests/natural_inputs.py)"""
+    try:
+        import natural_inputs
+        from PIL import Image
+        if not natural_inputs.stage():
+            return None
+        ld = lambda n: np.ascontiguousarray(np.asarray(Image.open(os.path.join(natural_inputs.DIR, n + ".png")).convert("RGB"))[..., ::-1])
+        return [(ld(a), ld(b)) for a, b in NATURAL]
+    except Exception:       # noqa: BLE001
+        return None
+
+
+def natural_extra(ctx, prm, synth):
+    """One pair in flight, outside the timed region: the reference's own demo photographs (synthetic weights) next to tests/synth.py pairs of the SAME sizes — the
+    driver-visible natural/synthetic ratio. median of 3 runs each."""
+    imgs = load_natural()
+    if imgs is None:
+        return {"available": False, "why": "demo photographs not staged on this box (tests/natural_inputs.py; never committed)"}
+
+    def med(src, ref):
+        ctx.pair_upload(src, ref)
+        ctx.pair_run(prm)
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter(); ctx.pair_run(prm); ts.append(time.perf_counter() - t)
+        tm = ctx.pair_run(prm, want_timing=True)
+        return 1e3 * sorted(ts)[1], tm
+    out = {"available": True, "pairs": {}, "basis": "one pair in flight, inputs resident, median of 3; synthetic = tests/synth.py images of the same sizes"}
+    nat, syn = [], []
+    for (a, b), (src, ref) in zip(NATURAL, imgs):
+        n_ms, n_tm = med(src, ref)
+        s_ms, s_tm = med(synth.image(1000, *src.shape[:2]), synth.image(1001, *ref.shape[:2]))
+        out["pairs"][f"{a}_{b}"] = {"size": list(src.shape[:2]) + list(ref.shape[:2]), "ms": round(n_ms, 2), "synthetic_ms": round(s_ms, 2),
+                                    "wls_iters": n_tm["wls_iters"], "synthetic_wls_iters": s_tm["wls_iters"],
+                                    "stages_ms": {k: round(n_tm[k], 2) for k in ("vgg_ms", "patchmatch_ms", "vote_ms", "knn_ms", "nonlocal_ms", "wls_ms")}}
+        nat.append(n_ms); syn.append(s_ms)
+    out["mean_ms"] = round(sum(nat) / len(nat), 2); out["synthetic_mean_ms"] = round(sum(syn) / len(syn), 2)
+    out["pairs_per_s"] = round(1e3 / out["mean_ms"], 3); out["natural_over_synthetic"] = round(out["mean_ms"] / out["synthetic_mean_ms"], 3)
+    return out
 
 
 def pm_bytes(evals, n_queries, n_launches, C):
@@ -101,6 +147,7 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the oracle on the full SxS pair even on a small host (the default from 32 host threads on: ~2 min)")
     ap.add_argument("--cpu-baseline-sample", action="store_true", help="time the oracle on the bounded 350x350 sample only (seconds) and scale by pixel count")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-natural", action="store_true", help="skip the extra single-pair runs on the reference's demo photographs (key `natural`)")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 PMC passes (traffic falls back to profiles/)")
     ap.add_argument("--no-pmc-1000", action="store_true", help="skip the two counter passes on the 1000x1000 pair (roofline_1000)")
     ap.add_argument("--no-vary", action="store_true", help="every step re-runs the same resident pairs (rounds 1-3); default: two resident sets of pairs per GPU, alternating step by step")
@@ -185,7 +232,7 @@ def main():
 
     prm = nct.Params.default()
     wl = args.workload
-    S = args.size or {"pair700": 700, "pair1000": 1000, "pair256l5": 256, "batch64": 700, "mixed256": 0}[wl]
+    S = args.size or {"pair700": 700, "pair1000": 1000, "pair256l5": 256, "batch64": 700, "mixed256": 0, "natural": 0}[wl]
     if wl == "pair256l5":
         prm.levels = 1
 
@@ -234,8 +281,16 @@ def main():
                 + {"pair700": " (BASELINE config 2)", "pair1000": " (BASELINE config 4)"}.get(wl, ""))
     else:
         # a step = one whole batch through nct_process_pair (host in -> host out), K workers per GPU
-        nb = args.batch or (64 if wl == "batch64" else 256)
-        if wl == "batch64":
+        nb = args.batch or {"batch64": 64, "natural": 12}.get(wl, 256)
+        nat_imgs = None
+        if wl == "natural":
+            # the reference's own demo photographs (sizes as shipped, synthetic weights): each of the three pairs nb / 3 times per step, static i mod N
+            nat_imgs = load_natural()
+            if nat_imgs is None:
+                raise SystemExit("bench.py --workload natural: the demo photographs are not staged (python tests/natural_inputs.py where the reference is mounted, or NCT_DEMO_DIR)")
+            sizes = [nat_imgs[i % len(NATURAL)][0].shape[:2] + nat_imgs[i % len(NATURAL)][1].shape[:2] for i in range(nb)]
+            mine = shard_pairs(nb, rank, world)
+        elif wl == "batch64":
             sizes = [(S, S, S, S)] * nb
             mine = shard_pairs(nb, rank, world)                     # static i mod N (config 3)
         else:
@@ -247,6 +302,8 @@ def main():
         cache = {}
 
         def images(i):
+            if nat_imgs is not None:
+                return nat_imgs[i % len(NATURAL)]
             if i not in cache:
                 sh, sw, rh, rw = sizes[i]
                 cache[i] = (synth.image(1000 + 2 * i, sh, sw), synth.image(1001 + 2 * i, rh, rw))
@@ -297,7 +354,7 @@ def main():
         src, ref = images(mine[0] if mine else 0)
         ctx.pair_upload(src, ref)
         desc = (f"{nb} pairs per step through nct_process_pair (host in -> host out), {K} workers per GPU; " +
-                ("700x700, static i mod N (BASELINE config 3)" if wl == "batch64" else "sides 256..1000, dynamic tickets (BASELINE config 5)"))
+                {"batch64": "700x700, static i mod N (BASELINE config 3)", "natural": "the reference's demo photographs in0/tar0, in1/tar1, in4/tar4 (700x466 .. 700x525), static i mod N"}.get(wl, "sides 256..1000, dynamic tickets (BASELINE config 5)"))
 
     # single-pair latency (nothing else on the GPU) and per-stage device times of one more pair
     ctx.pair_run(prm)
@@ -362,6 +419,8 @@ def main():
         res["roofline_color"] = color_roofline(nct, ctx, prm, src.shape)
     if rank == 0 and not args.no_roofline and not args.no_pmc and not args.no_pmc_1000 and world == 1 and wl == "pair700" and S == 700:
         res["roofline_1000"] = patchmatch_roofline_1000(local_rank)
+    if rank == 0 and world == 1 and wl == "pair700" and not args.no_natural:
+        res["natural"] = natural_extra(ctx, prm, synth)
     if rank == 0 and not args.no_cpu_baseline and world == 1:               # the CPU port is timed on rank 0 of the 1-GPU run only
         res["cpu_baseline"] = cpu_baseline(synth, ws, bs, src.shape[0], full=(args.cpu_baseline_full or (os.cpu_count() or 1) >= 32) and not args.cpu_baseline_sample)
     if dist is not None:
