@@ -476,9 +476,11 @@ int nctk_s1_solve(nct_ctx* ctx, hipStream_t s, const nct_s1_graph& g, const int*
     const bool coop = n >= 100000;                                  // shared in-edge gathers pay off on the bandwidth-bound levels only
     const bool fused = nbl <= S1_FUSE_NB;
     // hub pass: only where the host knows (or cannot exclude) that the level has in-edge lists longer than one block
-    const int hub_grid = g.nseg_hint == 0 ? 0 : (g.nseg_hint > 0 ? (cdiv(g.nseg_hint, 4) < 4096 ? cdiv(g.nseg_hint, 4) : 4096) : 256);
+    // (unknown — the host has not seen the count yet: a grid that covers the most blocks the level can have, (8 n - 1) / 64, four per workgroup, at most 256 workgroups)
+    const int hub_blind = cdiv(cdiv(8 * n, S1_SEG), 4) < 256 ? cdiv(cdiv(8 * n, S1_SEG), 4) : 256;
+    const int hub_grid = g.nseg_hint == 0 ? 0 : (g.nseg_hint > 0 ? (cdiv(g.nseg_hint, 4) < 4096 ? cdiv(g.nseg_hint, 4) : 4096) : hub_blind);
     // the second level only where some pixel has more than 64 hub blocks (in-degree above 4160), by the same rule
-    const int hub2_grid = (g.nseg_hint == 0 || g.nsup_hint == 0) ? 0 : (g.nsup_hint > 0 ? (cdiv(g.nsup_hint, 4) < 1024 ? cdiv(g.nsup_hint, 4) : 1024) : 64);
+    const int hub2_grid = (g.nseg_hint == 0 || g.nsup_hint == 0) ? 0 : (g.nsup_hint > 0 ? (cdiv(g.nsup_hint, 4) < 1024 ? cdiv(g.nsup_hint, 4) : 1024) : (cdiv(hub_blind, S1_SEG) < 64 ? cdiv(hub_blind, S1_SEG) : 64));
     auto hub = [&](const double* v) -> int {
         if (hub_grid) { hipLaunchKernelGGL(k_s1_hub, dim3(hub_grid), dim3(256), 0, s, g, v); LCHK(); }
         if (hub2_grid) { hipLaunchKernelGGL(k_s1_hub2, dim3(hub2_grid), dim3(256), 0, s, g); LCHK(); }

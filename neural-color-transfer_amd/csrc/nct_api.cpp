@@ -108,6 +108,7 @@ int nct_create(int device, nct_ctx** out) {
     if (const char* q = getenv("NCT_PM_PERSIST")) { const int v = atoi(q); if (v == 0 || v == 1) c->pm_persist = v; }
     if (const char* q = getenv("NCT_PM_PERSIST_WGS")) { const int v = atoi(q); if (v > 0) c->pm_persist_wgs = v; }
     if (const char* q = getenv("NCT_S1_HUB_HINT")) { const int v = atoi(q); if (v == 0 || v == 1) c->s1_hub_hint = v; }
+    if (const char* q = getenv("NCT_S1_HUB_WAIT")) { const int v = atoi(q); if (v == 0 || v == 1) c->s1_hub_wait = v; }
     if (const char* m = getenv("NCT_WLS_MAXIT")) { const int v = atoi(m); if (v > 0) c->wls_maxit = v; }
     *out = c;
     return NCT_OK;

@@ -57,6 +57,8 @@ struct nct_ctx {
     long long s1_hub_blocks_last[5] = {0, 0, 0, 0, 0};            // the counts the last pair's solves were launched with (-1: not known when the solve was enqueued); nct_ctx_counter
     int knn_runs = -1;                          // kNN search form: -1 = one search per (cluster, colour) run where runs average > 2.5 entries, decided on the device; 0 / 1 = NCT_KNN_RUNS (tests)
     int s1_hub_hint = 1;                        // use the host-side hub block counts (NCT_S1_HUB_HINT=0: always launch the hub pass — the conservative path, for tests)
+    int s1_hub_wait = 1;                        // level 0 only: the host waits for the coarsest graph's event instead of launching 101 + 101 hub passes blind (NCT_S1_HUB_WAIT=0: no host wait inside a pair;
+                                                // measured in round 6, profiles/round6_ab.md: waiting is 0.8 ms faster per single pair and +0.5-1 % with four in flight)
     bool kt_on = false;
     std::vector<hipEvent_t> kt_events; std::vector<int> kt_ids;
     int kt_begin(hipStream_t s, int id);        // nct_api.cpp; no-ops unless kt_on

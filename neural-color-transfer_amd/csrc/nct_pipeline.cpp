@@ -257,9 +257,11 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         // what the host knows about level l's hub blocks right now: the count, if the side stream has passed ev_level[l] (always, from the second level on: the host
         // has just waited for the previous level's WLS solve); else -1 and the hub pass is launched on the device-side count. The result does not depend on it.
         int hub_hint = -1, sup_hint = -1;
-        // the coarsest level's graph is built while the host is still far ahead of the GPU (the VGG forwards are running): it waits for that one event — the GPU has
-        // the level's correspondence work queued meanwhile, and the solve's 200 launches are enqueued faster than they execute — rather than launch 101 hub passes blind
-        if (ctx->s1_hub_hint && l == 0) (void)hipEventSynchronize(ctx->ev_level[0]);
+        // the coarsest level's graph is built while the host is still far ahead of the GPU (the VGG forwards are running), so its count has not arrived when the host gets
+        // here. Default: wait for that one event — the GPU has the level's correspondence work queued meanwhile and the solve's 200 launches are enqueued faster than they
+        // execute. NCT_S1_HUB_WAIT=0 (no host wait inside a pair): the level's 101 hub passes (+ 101 second-level passes) are launched blind on grids sized by
+        // the level and exit on the device-side count. Measured (profiles/round6_ab.md): 77.9 vs 78.7 ms per single pair, 15.44-15.49 vs 15.31-15.38 pairs/s with four in flight.
+        if (ctx->s1_hub_hint && ctx->s1_hub_wait && l == 0) (void)hipEventSynchronize(ctx->ev_level[0]);
         if (ctx->s1_hub_hint && hipEventQuery(ctx->ev_level[l]) == hipSuccess) { hub_hint = *(volatile int*)(ctx->s1_hub_blocks() + 2 * l); sup_hint = *(volatile int*)(ctx->s1_hub_blocks() + 2 * l + 1); }
         (void)hipGetLastError();                                     // hipEventQuery's hipErrorNotReady is not an error
         ctx->s1_hub_blocks_last[l] = hub_hint;

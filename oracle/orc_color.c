@@ -10,7 +10,7 @@
  *   S2  solve_WLS_roughness_cpu + solve_direct_cpu (PARDISO)      ColorTransfer.cpp:951-1125, SparseSolver_CPU.cpp:104-286
  *   A1  apply + Lab->BGR                                          ColorTransfer.cpp:1436-1469
  *
- * Documented divergences:
+ * Documented divergences (SPEC.md):
  *  - k-means initial centres / kNN tie order: std::rand + std::random_shuffle are implementation defined (MSVC vs
  *    libstdc++); here: SplitMix64 Fisher-Yates for the centres, and "k smallest by (dist, id)" per cluster for kNN
  *    (consistent with the final cmpDist ordering, ColorTransfer.cpp:44,87). kNN is pinned against the reference's own

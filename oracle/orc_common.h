@@ -21,7 +21,7 @@ static inline int orc_int_to_y(uint32_t v) { return (int)((v >> 12) & 0xFFFu); }
 static inline int orc_clamp(int x, int x_max, int x_min) { return x > x_max ? x_max : (x < x_min ? x_min : x); }
 
 /* Counter-based RNG replacing cuRAND XORWOW (GeneralizedPatchMatch.cu:54-66; curand_init(seed = global x index)
- * is not reproducible here and the reference schedule is racy — documented divergence).
+ * is not reproducible here and the reference schedule is racy — documented divergence, DESIGN.md §4.4, SPEC.md).
  * Returns u in (0,1] like curand_uniform. */
 static inline uint32_t orc_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;

@@ -11,7 +11,7 @@
  *
  * Feature tensors at this boundary are CHW fp32 exactly like the reference kernels' a1/b1 arguments.
  *
- * Two documented divergences from the reference:
+ * Two documented divergences from the reference (SPEC.md):
  *  (1) schedule: the reference kernel is one racy launch (both __syncthreads commented out, :801,:827).
  *      Here every (iteration, jump) step is a Jacobi step on a double-buffered NNF: all queries read the
  *      previous step's NNF/dist, write the next one. Random search is fused into the jump==1 step.

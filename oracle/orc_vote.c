@@ -6,7 +6,7 @@
  *       avg_vote_bds_b    GeneralizedPatchMatch.cu:1128-1178 (completeness, float atomicAdd scatter)
  *       avg_vote_bds      GeneralizedPatchMatch.cu:1180-1202 (divide by weight)
  *
- * Divergences:
+ * Divergences (SPEC.md):
  *  - vote_weight is zeroed first (the reference does `pw[aid] += wa` on an uninitialised cudaMalloc, main.cu:299).
  *  - the completeness scatter's atomic order is nondeterministic in the reference; any fixed order is one of its legal realisations. Canonical order v2 (round 5; rounds
  *    1-4 added in ascending source pixel across all taps): AFTER all coherence contributions (kernel a completes before kernel b starts), TAP-MAJOR: for the nine
