@@ -9,7 +9,9 @@ import numpy as np, nct, synth
 from PIL import Image
 from caffemodel_io import synthetic_vgg19
 CASES = {"in1_tar1_2": ("in1", "tar1", 2.0), "in4_tar4_2": ("in4", "tar4", 2.0), "in4_tar4_0": ("in4", "tar4", 0.0), "in4_tar4_8": ("in4", "tar4", 8.0),
-         "in0_tar0_2": ("in0", "tar0", 2.0)}
+         "in0_tar0_2": ("in0", "tar0", 2.0),
+         # round 6: the remaining lines of demo/example/pairs.txt (3, 4, 6, 8) — all nine demo pairs are fixtures now
+         "in2_tar2_2": ("in2", "tar2", 2.0), "in3_tar3_2": ("in3", "tar3", 2.0), "in4_tar4_1": ("in4", "tar4", 1.0), "in4_tar4_4": ("in4", "tar4", 4.0)}
 
 
 def load_bgr(name):

@@ -1,4 +1,4 @@
-"""The reference's demo photographs (demo/example/in/{in0,in1,in4,tar0,tar1,tar4}.png) as test INPUTS — not committed (third-party images of unknown licence).
+"""The reference's demo photographs (demo/example/in/{in,tar}{0,1,2,3,4}.png: all ten images of demo/example/pairs.txt) as test INPUTS — not committed (third-party images of unknown licence).
 
 They are staged, byte for byte, into tests/golden/natural/ (git-ignored, but not gpurun-ignored: like oracle/_ref they travel to the GPU box with the snapshot) by
 `python tests/natural_inputs.py`, which __graft_entry__.build() runs wherever a source directory exists: $NCT_DEMO_DIR, else /root/reference/demo/example/in.
@@ -7,7 +7,7 @@ that is not the generator's is noticed). Tests call require() and are skipped wh
 import os
 import shutil
 
-NAMES = ("in0", "in1", "in4", "tar0", "tar1", "tar4")
+NAMES = ("in0", "in1", "in2", "in3", "in4", "tar0", "tar1", "tar2", "tar3", "tar4")
 DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "natural")
 
 
@@ -23,7 +23,7 @@ def present():
 
 
 def stage():
-    """copies the six photographs from the source directory if they are not there yet; returns True when they are present afterwards"""
+    """copies the ten photographs from the source directory if they are not there yet; returns True when they are present afterwards"""
     src = source_dir()
     if src and not present():
         os.makedirs(DIR, exist_ok=True)
