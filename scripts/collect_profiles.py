@@ -9,7 +9,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(REPO, "gpurun_out", tag)
 dst = os.path.join(REPO, "profiles")
-R = sys.argv[2] if len(sys.argv) > 2 else "round5"
+R = sys.argv[2] if len(sys.argv) > 2 else "round6"
 RN = R.replace("round", "round ")
 
 
@@ -191,13 +191,11 @@ if os.path.exists(vg):
 # ---- round 5: the reference's demo inputs (natural photographs)
 nat = [f for f in sorted(os.listdir(src)) if f.startswith("natural_") and f.endswith(".md")]
 if nat:
-    N = [f"# {RN} — the reference's own demo inputs (`demo/example/in/*.png`, committed as data under tests/golden/natural/) through the stage clock, build {bench['build_id']}", "",
+    N = [f"# {RN} — the reference's own demo inputs (`demo/example/in/*.png`, staged into tests/golden/natural/ by tests/natural_inputs.py, never committed; all nine lines of demo/example/pairs.txt) through the stage clock, build {bench['build_id']}", "",
          "`scripts/natural_report.py 5 <case>`: the natural pair next to a `tests/synth.py` pair of the SAME sizes (median of 5 runs, one pair in flight; stream events), then per pyramid level the",
          "kNN in-degree distribution (what S1's in-edge blocks are sized on: `deg_gt64` pixels have blocks beyond their first 64 in-edges -> k_s1_hub) and the completeness sources per vote target",
-         "(`vote_gt72` targets have lists with blocks beyond the first 64 -> k_vote_hub). The same pairs on the round-4 kernels: profiles/round5_natural_before.md (nonlocal 1 235 / 406 / 45 ms,",
-         "votes 11.5 / 36.6 / 11.6 ms, 45 ms for one kNN graph). What is left above 1.3x is the WLS solve: its PCG needs 2-3x the iterations on these images (`wls_iters`; scripts/wls_natural_probe.py:",
-         "no low-roughness regions — the edge-aware weights of photographs, with 12-37 % exactly flat neighbour pairs beside strong edges, are a harder operator for the point-Jacobi V-cycle), and",
-         "S1's operator passes where most pixels' first in-edge block is full (64 dependent gathers per thread instead of ~8).", ""]
+         "(`vote_gt72` targets have lists with blocks beyond the first 64 -> k_vote_hub). The same pairs on the round-4 kernels: profiles/round5_natural_before.md (0.5-1.3 s per pair). What is left above",
+         "the synthetic pairs (1.15-1.3x) is the WLS solve — its PCG needs ~1.7x the iterations on photographs (`wls_iters`; DESIGN.md 8 item 3) — and S1's operator passes where most pixels' first in-edge block is full.", ""]
     for f in nat:
         N += open(os.path.join(src, f)).read().splitlines()[2:] + [""]
     ks = os.path.join(src, "nat_prof", "n_kernel_stats.csv")
