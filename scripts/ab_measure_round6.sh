@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, second pass: (a) level-0 hub pass blind vs host wait, (b) PatchMatch one persistent launch per level vs one per step (times + kernel trace + fabric counters),
 # (c) fabric counters of the finest PatchMatch level on a demo photograph
-tag=r6b
+tag=${1:-r6b}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
