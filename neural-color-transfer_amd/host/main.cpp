@@ -31,6 +31,7 @@
 #include "png_io.h"
 #include "jpeg_io.h"
 #include "affinity.h"
+#include "rccl_sync.h"
 
 namespace {
 constexpr int MAX_SIZE = 1000;                 // Config.h:5
@@ -470,7 +471,7 @@ int main(int argc, char** argv) {
     CmdLine cl;
     Config cfg;
     nct_params_default(&cfg.prm);
-    int gpu = 0, ngpus = 1, seed = 1, inflight = 1, levels = 5, resume = 0, feat16 = 0, vis = 0, io = -1, pin = 1, world = 1, rank = 0, steal = 0, procs = 0;
+    int gpu = 0, ngpus = 1, seed = 1, inflight = 1, levels = 5, resume = 0, feat16 = 0, vis = 0, io = -1, pin = 1, world = 1, rank = 0, steal = 0, procs = 0, rccl = 0;
     cl.add("m", cfg.model_dir, "Directory of network models.");
     cl.add("i", cfg.input_dir, "Input directory of content and style images and pairs.txt.");
     cl.add("o", cfg.output_dir, "Output directory of result images.");
@@ -493,6 +494,7 @@ int main(int argc, char** argv) {
     cl.add("procs", procs, "[extension] N > 0: fork N processes, one per GPU (-g, -g + 1, ...): process r runs with -rank r -world N on its own device, HIP runtime and status.<r>.jsonl (the process-per-GPU shape; -gpus N keeps all GPUs in one process).");
     cl.add("world", world, "[extension] number of cooperating processes that share this pairs.txt and output directory (default 1); set by -procs, or by hand with -rank.");
     cl.add("rank", rank, "[extension] this process's rank in [0, world): it runs the pairs.txt lines i with i mod world = rank (or the ones it draws, -steal 1).");
+    cl.add("rccl", rccl, "[extension] 1 = the ranks of -procs / -world form an RCCL communicator (one rank per GPU, over xGMI on a node): a start barrier, and the job's time = MAX over ranks and its pair count = SUM over ranks by all-reduce, printed by rank 0. Nothing of a pair's data crosses GPUs; without RCCL (or with 0, the default) the ranks simply run.");
     cl.add("steal", steal, "[extension] 1 = with -world > 1, lines are drawn from a shared counter (<output>/.tickets under a file lock) by whichever rank is free, instead of i mod world: mixed-size batches.");
     cl.add("feat16", feat16, "[extension] 1 = fp16 PatchMatch feature tiles (fp32 accumulate); not bit-identical to the default (about 45 dB against it).");
     // parser self-test hook (no GPU): `--parse-only <args…>` parses the rest like a normal run and prints what main would go on with, in the format of
@@ -510,11 +512,13 @@ int main(int argc, char** argv) {
     if (!parsed) return -1;
     if (world < 1 || rank < 0 || rank >= world) { printf("Error: -rank %d is not in [0, -world %d).\n", rank, world); return -1; }
     mkdir(cfg.output_dir.c_str(), 0777);                                    // main.cu:458
+    uint64_t run_token = getenv("NCT_RUN_TOKEN") ? strtoull(getenv("NCT_RUN_TOKEN"), nullptr, 0) : 0;      // hand-started ranks of one run share it (and remove <output>/.rccl_id between runs)
     const std::string tickets_path = cfg.output_dir + "/.tickets";
     if (procs > 0) {
         // one process per GPU: fork BEFORE anything touches the HIP runtime (a forked HIP context is unusable), every child goes on as rank r of `procs` on device -g + r
         if (world != 1) { printf("Error: -procs and -world are exclusive (-procs sets -world for its children).\n"); return -1; }
         if (steal) { unlink(tickets_path.c_str()); }                         // a fresh counter for this run
+        run_token = ((uint64_t)getpid() << 32) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();      // children are forks: they inherit it; an id file of another run carries another token
         fflush(stdout);
         std::vector<pid_t> kids;
         int my = -1;
@@ -598,6 +602,15 @@ int main(int argc, char** argv) {
             if (!loc[g].cpus.empty()) printf("GPU %d (%s): NUMA node %d, host threads pinned to CPUs %s.\n", device_of(g), addr, loc[g].numa_node, affinity::cpus_to_string(loc[g].cpus).c_str());
         }
 
+    // -rccl 1: one communicator over the ranks of this run (one process per GPU), used for the start barrier and for the two reductions at the end — never on a pair's data path
+    rccl_sync::Group rg;
+    const std::string rccl_id_path = cfg.output_dir + "/.rccl_id";
+    if (rccl) {
+        if (ngpus != 1) printf("Note: -rccl 1 is for one process per GPU (-procs / -world); this process drives %d GPUs and joins with its first.\n", ngpus);
+        if (!rg.init(world, rank, device_of(0), rccl_id_path, run_token) || !rg.barrier())
+            printf("Note: -rccl 1: no RCCL group (%s); rank %d goes on without the barrier.\n", rg.why().c_str(), rank);
+        else printf("RCCL: rank %d of %d joined, start barrier passed.\n", rank, world);
+    }
     const auto t0 = std::chrono::steady_clock::now();
     // pairs are independent and of mixed sizes: every worker takes the next decoded pair (work stealing inside the node, BASELINE config 5);
     // which worker runs a pair has no influence on its result
@@ -636,6 +649,13 @@ int main(int argc, char** argv) {
     if (P.tickets.fd >= 0) close(P.tickets.fd);
     if (world > 1) printf("Rank %d of %d: ", rank, world);
     printf("Processed %zu pair(s) on %d GPU(s), %d in flight each, %d I/O thread(s), in %.3f sec (%.3f pairs/sec).\n", done, ngpus, inflight, io, sec, done == 0 ? 0.0 : done / sec);
+    if (rg.ok()) {
+        double sec_max = sec, total = (double)done;
+        const bool r1 = rg.reduce(sec, rccl_sync::kMax, &sec_max), r2 = rg.reduce((double)done, rccl_sync::kSum, &total);
+        if (r1 && r2) { if (rank == 0) printf("All %d rank(s) over RCCL: %.0f pair(s) in %.3f sec = MAX over ranks (%.3f pairs/sec).\n", world, total, sec_max, sec_max > 0 ? total / sec_max : 0.0); }
+        else printf("Note: RCCL reduction failed (%s).\n", rg.why().c_str());
+        rg.finish(rccl_id_path);
+    }
     for (auto* c : ctxs) nct_destroy(c);
     return 0;
 }

@@ -379,6 +379,20 @@ def test_cli_process_per_gpu_shapes_give_identical_files(tmp_path):
     # a rank outside the world is refused
     r = run(*common, "-o", str(tmp_path / "bad"), "-world", "2", "-rank", "2")
     assert r.returncode == 255 and "is not in [0, -world 2)" in r.stdout
+    # -rccl 1 (round 6): the ranks form an RCCL communicator for the start barrier and the MAX / SUM reductions of the job's time and pair count. One rank on this 1-GPU box
+    # executes the whole code path (id file, ncclCommInitRank, three all-reduces, destroy); the files do not depend on it
+    r = subprocess.run([BIN, *common, "-o", str(tmp_path / "rccl1"), "-g", "0", "-world", "1", "-rccl", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "RCCL: rank 0 of 1 joined, start barrier passed." in r.stdout and "All 1 rank(s) over RCCL: 5 pair(s) in " in r.stdout, r.stdout[-2000:]
+    got = pngs(tmp_path / "rccl1")
+    assert list(got) == list(ref) and all(np.array_equal(got[n], ref[n]) for n in ref)
+    assert not os.path.exists(tmp_path / "rccl1" / ".rccl_id")
+    # two ranks on ONE device: RCCL refuses a communicator with a duplicate GPU — every rank says so and goes on without the barrier; same files, each pair once
+    r = subprocess.run([BIN, *common, "-o", str(tmp_path / "rccl2"), "-g", "0", "-procs", "2", "-rccl", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("goes on without the barrier") == 2 or r.stdout.count("start barrier passed") == 2, r.stdout[-3000:]
+    got = pngs(tmp_path / "rccl2")
+    assert list(got) == list(ref) and all(np.array_equal(got[n], ref[n]) for n in ref)
 
 
 @pytest.mark.gpu
