@@ -30,7 +30,7 @@ Extra objects:
                  fabric-side bytes are HBM bytes), from two live counter passes.
   cpu_baseline — the CPU oracle ("port") end-to-end on a bounded sample of the same workload, on this box's host cores.
   stages_ms    — per-stage device time of one extra pair (events on the stream; not part of the timed region).
-  natural      — the reference's own demo photographs (in0/tar0, in1/tar1, in4/tar4 of demo/example/pairs.txt, sizes as shipped, synthetic weights), one pair in flight, next to
+  natural      — the reference's own demo photographs (the five image pairs of demo/example/pairs.txt, sizes as shipped, synthetic weights), one pair in flight, next to
                  synthetic pairs of the same sizes: ms per pair, pairs/s, the natural/synthetic ratio, WLS iterations (outside the timed region; `available: false` where the
                  photographs are not staged — they are never committed). `--workload natural` makes them the timed workload.
 """
@@ -56,11 +56,11 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 MALL_BYTES = 256.0 * 1024 * 1024     # Infinity Cache
 WORKLOADS = ("pair700", "pair1000", "pair256l5", "batch64", "mixed256", "natural")
-NATURAL = (("in0", "tar0"), ("in1", "tar1"), ("in4", "tar4"))      # demo/example/pairs.txt:1-3 (bds 2.0): the photographs tests/natural_inputs.py stages
+NATURAL = (("in0", "tar0"), ("in1", "tar1"), ("in2", "tar2"), ("in3", "tar3"), ("in4", "tar4"))      # demo/example/pairs.txt lines 1-4 and 7: the five image pairs of the demo at bds 2.0 (tests/natural_inputs.py stages the photographs)
 
 
 def load_natural():
-    """the three demo pairs as BGR arrays, or None where the photographs are not staged (they are never committed: tests/natural_inputs.py)"""
+    """the five demo pairs as BGR arrays, or None where the photographs are not staged (they are never committed: tests/natural_inputs.py)"""
     try:
         import natural_inputs
         from PIL import Image
@@ -281,10 +281,10 @@ def main():
                 + {"pair700": " (BASELINE config 2)", "pair1000": " (BASELINE config 4)"}.get(wl, ""))
     else:
         # a step = one whole batch through nct_process_pair (host in -> host out), K workers per GPU
-        nb = args.batch or {"batch64": 64, "natural": 12}.get(wl, 256)
+        nb = args.batch or {"batch64": 64, "natural": 15}.get(wl, 256)
         nat_imgs = None
         if wl == "natural":
-            # the reference's own demo photographs (sizes as shipped, synthetic weights): each of the three pairs nb / 3 times per step, static i mod N
+            # the reference's own demo photographs (sizes as shipped, synthetic weights): each of the five pairs nb / 5 times per step, static i mod N
             nat_imgs = load_natural()
             if nat_imgs is None:
                 raise SystemExit("bench.py --workload natural: the demo photographs are not staged (python tests/natural_inputs.py where the reference is mounted, or NCT_DEMO_DIR)")
@@ -354,7 +354,7 @@ def main():
         src, ref = images(mine[0] if mine else 0)
         ctx.pair_upload(src, ref)
         desc = (f"{nb} pairs per step through nct_process_pair (host in -> host out), {K} workers per GPU; " +
-                {"batch64": "700x700, static i mod N (BASELINE config 3)", "natural": "the reference's demo photographs in0/tar0, in1/tar1, in4/tar4 (700x466 .. 700x525), static i mod N"}.get(wl, "sides 256..1000, dynamic tickets (BASELINE config 5)"))
+                {"batch64": "700x700, static i mod N (BASELINE config 3)", "natural": "the reference's demo photographs in0/tar0 ... in4/tar4 (520x600 .. 700x528 sources), static i mod N"}.get(wl, "sides 256..1000, dynamic tickets (BASELINE config 5)"))
 
     # single-pair latency (nothing else on the GPU) and per-stage device times of one more pair
     ctx.pair_run(prm)
