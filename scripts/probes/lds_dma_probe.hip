@@ -1,7 +1,7 @@
 // Compile-only probe (round 6): does hipcc keep an LDS-direct prefetch (global_load_lds_dwordx4 into a second static __shared__ array) in flight across LDS reads of the first array
 // and across a workgroup barrier?  hipcc --offload-arch=gfx950 -O3 -c lds_dma_probe.hip -save-temps; grep "global_load_lds\|s_waitcnt\|s_barrier" *.s
 // Findings: reads of the other array carry no vmcnt wait (alias-aware LDS-DMA tracking); __syncthreads() and __builtin_amdgcn_fence(.., "workgroup", "local") both wait vmcnt(0);
-// an asm barrier "s_waitcnt lgkmcnt(0); s_barrier" with a memory clobber does not. DESIGN.md 8 item 7.
+// an asm barrier "s_waitcnt lgkmcnt(0); s_barrier" with a memory clobber does not. DESIGN.md 9.
 #include <hip/hip_runtime.h>
 __shared__ float4 buf0[1600];
 __shared__ float4 buf1[1600];
