@@ -41,7 +41,16 @@ struct S1Sys {
     const int* knn_id;                      // [n][8]
     nct_s1_graph g;                         // iw2, compact in-edge arrays, hub block table
     int xcd;                                // workgroups of one XCD take a contiguous range of pixel blocks (the shared-gather levels; NCT_S1_XCD=0: plain order)
+    int one_xcd;                            // small levels: 1 + h = the launch is 8 x the grid and only the workgroups that land on XCD h work (s1_one_xcd below); 0: off
 };
+// Small levels (<= 32 workgroups: 44 x 44 and 88 x 88 of a 700 x 700 pair) are pure latency chains — own record -> neighbour ids -> gathers -> in-edge ids -> gathers —
+// and what the chain fetches was written by the PREVIOUS launch (the vector pass writes r, the operator pass w). Workgroup b runs on XCD b % 8 and the eight L2s are not
+// coherent with each other: a line written on another XCD comes from memory (Infinity Cache), a line written on the same XCD from its L2 (MI355X_MICROARCH.md: same-XCD
+// hand-offs 1.7 x faster). So both passes are launched with 8 x the workgroups, those with b % 8 != 0 exit at once, and the solve's vectors (1.9 MB at 88 x 88) live in
+// ONE L2 for the whole solve (the context's home XCD: contexts of a process take different ones, so four pairs in flight do not queue on the same 32 CUs). Placement is an
+// observed property, not a promise: it changes the time, never the result. Measured (700 x 700 pair, one in flight): 3.17 -> 2.03 ms at 44 x 44, 2.04 -> 1.74 at 88 x 88;
+// 175 x 175 (120 workgroups, 7 MB of vectors) does not fit one XCD: 2.2 -> 5.2 ms. sel = 1 + home XCD. -1: not a working workgroup.
+__device__ __forceinline__ int s1_one_xcd(int bid, int sel) { return (bid & 7) == sel - 1 ? (bid >> 3) : -1; }
 // workgroup ids go round-robin over the 8 XCDs: XCD x takes the x-th eighth of the logical blocks
 __device__ __forceinline__ int s1_block_of(int bid, int nblocks, int xcd) {
     if (!xcd) return bid;
@@ -346,7 +355,8 @@ __global__ __launch_bounds__(256) void k_s1_residual(S1Sys S, const double* __re
 // w = Op(r); block partials of gamma = r.r (slots 0..2) and delta = r.w (slots 3..5), per Lab channel over both parts
 template <bool COOP>
 __global__ __launch_bounds__(256) void k_s1_apply(S1Sys S, const double* __restrict__ r6, double* __restrict__ w6, double* __restrict__ partial /*[nb][6]*/) {
-    const int lb = s1_block_of(blockIdx.x, gridDim.x, S.xcd);
+    const int lb = S.one_xcd ? s1_one_xcd(blockIdx.x, S.one_xcd) : s1_block_of(blockIdx.x, gridDim.x, S.xcd);
+    if (lb < 0) return;
     const int i = lb * 256 + threadIdx.x;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     double a[3], b[3], ya[3], yb[3];
@@ -397,9 +407,11 @@ constexpr int S1_FUSE_NB = 512;
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_s1_update(int n, int nb, const double* __restrict__ partial, const S1State* __restrict__ sin, S1State* __restrict__ sout,
                                                    int first_scal, double tol2, int first_vec, double* __restrict__ r6, const double* __restrict__ w6,
-                                                   double* __restrict__ p6, double* __restrict__ s6, double* __restrict__ x6) {
+                                                   double* __restrict__ p6, double* __restrict__ s6, double* __restrict__ x6, int one_xcd) {
+    const int bid = one_xcd ? s1_one_xcd(blockIdx.x, one_xcd) : (int)blockIdx.x;
+    if (bid < 0) return;
     const size_t total = (size_t)3 * n;                       // double2 elements per vector
-    const size_t base = (size_t)blockIdx.x * 768 + threadIdx.x;
+    const size_t base = (size_t)bid * 768 + threadIdx.x;
     double2 rv[3], wv[3], pv[3], sv[3], xv[3];
     const double2* r2 = reinterpret_cast<const double2*>(r6); const double2* w2 = reinterpret_cast<const double2*>(w6);
     const double2* x2 = reinterpret_cast<const double2*>(x6); const double2* p2 = reinterpret_cast<const double2*>(p6); const double2* s2 = reinterpret_cast<const double2*>(s6);
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(256) void k_s1_update(int n, int nb, const double* 
     if constexpr (FUSED) {
         double sm[6]; final_reduce<6>(partial, nb, sm);
         S1State o; s1_scalars(first_scal != 0, sm, sin, tol2, o);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = o;
+        if (bid == 0 && threadIdx.x == 0) *sout = o;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { al[c] = o.al[c]; be[c] = o.be[c]; act[c] = o.active[c] != 0; }
     } else {
@@ -470,7 +482,10 @@ int nctk_s1_solve(nct_ctx* ctx, hipStream_t s, const nct_s1_graph& g, const int*
     // finest level of the bench pair, same bits — the partial sums keep their logical block slot). A cluster-major pixel order on top of it (scripts/s1_cluster_probe.py)
     // LOSES: only 41 % of the bench pair's kNN edges stay inside the pixel's own k-means cluster.
     static const int s1_xcd = [] { const char* e = getenv("NCT_S1_XCD"); return e ? atoi(e) : 1; }();
-    S1Sys S{n, h, w, daa, dab, dbb, gx, gy, knn_id, g, (s1_xcd && n >= 100000) ? 1 : 0};
+    static const int s1_one_max = [] { const char* e = getenv("NCT_S1_ONE_XCD_MAX"); return e ? atoi(e) : 32; }();    // largest grid (workgroups) that runs on one XCD; 0: off
+    const int one_xcd = (nbl <= s1_one_max && nbl <= S1_FUSE_NB) ? 1 + (ctx->home_xcd & 7) : 0;
+    const int ogrid = one_xcd ? nbl * 8 : nbl;
+    S1Sys S{n, h, w, daa, dab, dbb, gx, gy, knn_id, g, (s1_xcd && n >= 100000) ? 1 : 0, one_xcd};
     const double tol2 = 1e-6 * 1e-6;
     const int maxit = layer == 4 ? 50 : 100;                       // ColorTransfer.cpp:916-921
     const bool coop = n >= 100000;                                  // shared in-edge gathers pay off on the bandwidth-bound levels only
@@ -489,7 +504,7 @@ int nctk_s1_solve(nct_ctx* ctx, hipStream_t s, const nct_s1_graph& g, const int*
     auto apply = [&](bool kt) -> int {
         if (kt) { int rk = ctx->kt_begin(s, NCT_KT_S1_APPLY); if (rk) return rk; }
         if (coop) hipLaunchKernelGGL(k_s1_apply<true>, dim3(nbl), dim3(256), 0, s, S, (const double*)r6, (double*)w6, (double*)partial);
-        else      hipLaunchKernelGGL(k_s1_apply<false>, dim3(nbl), dim3(256), 0, s, S, (const double*)r6, (double*)w6, (double*)partial);
+        else      hipLaunchKernelGGL(k_s1_apply<false>, dim3(ogrid), dim3(256), 0, s, S, (const double*)r6, (double*)w6, (double*)partial);
         LCHK();
         if (kt) { int rk = ctx->kt_end(s); if (rk) return rk; }
         return 0;
@@ -505,14 +520,14 @@ int nctk_s1_solve(nct_ctx* ctx, hipStream_t s, const nct_s1_graph& g, const int*
     for (int k = 1; k <= maxit; ++k) {
         const bool kt = ctx->kt_on && layer == 4 && k >= 3 && k < 11;          // NCT_FLAG_TIME_KERNELS: eight iterations of the finest level, one event pair per launch
         if (fused) {
-            hipLaunchKernelGGL(k_s1_update<true>, dim3(nbl), dim3(256), 0, s, n, nbl, (const double*)partial, (const S1State*)slot[k & 1], slot[(k - 1) & 1], k == 1 ? 1 : 0, tol2,
-                               k == 1 ? 1 : 0, (double*)r6, (const double*)w6, (double*)p6, (double*)s6, (double*)x6); LCHK();
+            hipLaunchKernelGGL(k_s1_update<true>, dim3(ogrid), dim3(256), 0, s, n, nbl, (const double*)partial, (const S1State*)slot[k & 1], slot[(k - 1) & 1], k == 1 ? 1 : 0, tol2,
+                               k == 1 ? 1 : 0, (double*)r6, (const double*)w6, (double*)p6, (double*)s6, (double*)x6, one_xcd); LCHK();
         } else {
             if (kt) { int rk = ctx->kt_begin(s, NCT_KT_S1_SCALARS); if (rk) return rk; }
             hipLaunchKernelGGL(k_s1_scal, dim3(1), dim3(256), 0, s, (const double*)partial, nbl, (const S1State*)slot[k & 1], slot[(k - 1) & 1], k == 1 ? 1 : 0, tol2); LCHK();
             if (kt) { int rk = ctx->kt_end(s); if (rk) return rk; rk = ctx->kt_begin(s, NCT_KT_S1_UPDATE); if (rk) return rk; }
             hipLaunchKernelGGL(k_s1_update<false>, dim3(nbl), dim3(256), 0, s, n, nbl, (const double*)partial, (const S1State*)slot[(k - 1) & 1], slot[(k - 1) & 1], 0, tol2,
-                               k == 1 ? 1 : 0, (double*)r6, (const double*)w6, (double*)p6, (double*)s6, (double*)x6); LCHK();
+                               k == 1 ? 1 : 0, (double*)r6, (const double*)w6, (double*)p6, (double*)s6, (double*)x6, 0); LCHK();
             if (kt) { int rk = ctx->kt_end(s); if (rk) return rk; }
         }
         if (k < maxit) { int rc = hub(r6); if (rc) return rc; rc = apply(kt); if (rc) return rc; }

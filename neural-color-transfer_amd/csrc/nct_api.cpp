@@ -1,5 +1,6 @@
 // nct_api.cpp — C-ABI entry points (host-pointer variants) + context / arena management.
 // Every function here is a thin marshalling layer: upload, call the device launcher (nctk_*), download.
+#include <atomic>
 #include "nct_internal.h"
 #include <chrono>
 #include <cstring>
@@ -103,6 +104,7 @@ int nct_create(int device, nct_ctx** out) {
     if (const char* f = getenv("NCT_WLS_FORECAST")) { const int v = atoi(f); if (v == 0 || v == 1) c->wls_forecast = v; }
     if (const char* r = getenv("NCT_WLS_RTOL")) { const double v = atof(r); if (v > 0 && v < 1) c->wls_rtol = v; }
     if (const char* f = getenv("NCT_CONV_POOL_FUSE")) { const int v = atoi(f); if (v == 0 || v == 1) c->conv_pool_fuse = v; }
+    { static std::atomic<int> next_home{0}; c->home_xcd = next_home.fetch_add(1) & 7; }
     if (const char* q = getenv("NCT_CONV_PAIR")) { const int v = atoi(q); if (v == 0 || v == 1) c->conv_pair = v; }
     if (const char* q = getenv("NCT_KNN_RUNS")) { const int v = atoi(q); if (v == 0 || v == 1) c->knn_runs = v; }
     if (const char* q = getenv("NCT_PM_PERSIST")) { const int v = atoi(q); if (v == 0 || v == 1) c->pm_persist = v; }

@@ -31,6 +31,7 @@ struct nct_ctx {
     void* pair = nullptr;             // struct pair_state* (nct_pipeline.cpp): device-resident source/reference/result images
     unsigned long long* d_counter = nullptr;   // device counters of the pm kernels (NCT_FLAG_COUNT_EVALS): [0] distance evaluations performed, [1] accepted candidates;
                                                 // 4 slots per pyramid level in pair runs (nct_pipeline.cpp reads [4 l] and [4 l + 1])
+    int home_xcd = 0;                           // the XCD this context's single-XCD launches aim at (k_s1.hip: small S1 levels); contexts of a process count round-robin (nct_create)
     int pm_persist = 0;                         // PatchMatch: one persistent launch per pyramid level (k_pm_level) instead of 1 + 4 iters launches (env NCT_PM_PERSIST)
     int pm_persist_wgs = 0;                     // workgroups of that launch (0: CUs x occupancy; env NCT_PM_PERSIST_WGS, experiments)
     uint32_t* d_pm_err = nullptr;               // device word the persistent kernel's watchdog sets; read by nctk_pm_check at the synchronisation points
