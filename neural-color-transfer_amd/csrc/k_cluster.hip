@@ -26,6 +26,23 @@
 __device__ float l2_fd(const float* __restrict__ a, const double* __restrict__ b, int n) {
     float result = 0.f;
     int i = 0;
+    // sixteen elements per trip, their loads issued together (the loop below, one group of four at a time, ran one L1 round trip per group: 37 us for the 19 360 (pixel,
+    // centre) pairs of a 700 x 700 pair's conv5_1 map). Same operations in the same order: the groups of four are summed and added exactly as below.
+    if ((((size_t)a | (size_t)b) & 15) == 0) {
+        for (; i + 15 < n; i += 16) {
+            float4 av[4]; double2 bv[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] = reinterpret_cast<const float4*>(a + i)[u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = reinterpret_cast<const double2*>(b + i)[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d0 = (float)((double)av[u].x - bv[2 * u].x), d1 = (float)((double)av[u].y - bv[2 * u].y);
+                const float d2 = (float)((double)av[u].z - bv[2 * u + 1].x), d3 = (float)((double)av[u].w - bv[2 * u + 1].y);
+                result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+        }
+    }
     for (; i + 3 < n; i += 4) {
         const float d0 = (float)((double)a[i] - b[i]), d1 = (float)((double)a[i + 1] - b[i + 1]);
         const float d2 = (float)((double)a[i + 2] - b[i + 2]), d3 = (float)((double)a[i + 3] - b[i + 3]);
@@ -37,6 +54,18 @@ __device__ float l2_fd(const float* __restrict__ a, const double* __restrict__ b
 __device__ float l2_ff(const float* __restrict__ a, const float* __restrict__ b, int n) {
     float result = 0.f;
     int i = 0;
+    if ((((size_t)a | (size_t)b) & 15) == 0) {                   // sixteen elements per trip as in l2_fd: the same groups of four in the same order
+        for (; i + 15 < n; i += 16) {
+            float4 av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = reinterpret_cast<const float4*>(a + i)[u]; bv[u] = reinterpret_cast<const float4*>(b + i)[u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d0 = av[u].x - bv[u].x, d1 = av[u].y - bv[u].y, d2 = av[u].z - bv[u].z, d3 = av[u].w - bv[u].w;
+                result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+        }
+    }
     for (; i + 3 < n; i += 4) {
         const float d0 = a[i] - b[i], d1 = a[i + 1] - b[i + 1], d2 = a[i + 2] - b[i + 2], d3 = a[i + 3] - b[i + 3];
         result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
@@ -61,7 +90,7 @@ __device__ __forceinline__ uint64_t sm64_at(uint64_t seed, uint64_t draw /*0-bas
 }
 __global__ __launch_bounds__(256) void k_km_init(const float* __restrict__ feat, int n, int C, int K, uint64_t seed, int* __restrict__ perm, KMState* __restrict__ st,
                                                  int* __restrict__ labels) {
-    __shared__ int s_perm[KM_LDS_PERM], s_j[KM_LDS_PERM];
+    __shared__ int s_perm[KM_LDS_PERM]; __shared__ __attribute__((aligned(16))) int s_j[KM_LDS_PERM];
     __shared__ int s_cand, s_dup, s_stop;
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += 256) labels[i] = 0;
@@ -85,31 +114,66 @@ __global__ __launch_bounds__(256) void k_km_init(const float* __restrict__ feat,
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        if (lds) {
-            for (int i = n - 1; i > 0; --i) { const int j = s_j[i]; const int t = pm[i]; pm[i] = pm[j]; pm[j] = t; }
-        } else {
-            for (int i = n - 1; i > 0; --i) { const int j = (int)(sm64_at(seed, (uint64_t)(n - 1 - i)) % (uint64_t)(i + 1)); const int t = pm[i]; pm[i] = pm[j]; pm[j] = t; }
+    // Only the HEAD of the permutation is ever read (K candidates + one per duplicate). The n dependent swaps in one thread cost 210 us at n = 1 936; the value that ends
+    // up at position l is found without performing them: walk the swaps backwards in time (i = 1 ... n - 1: the last one executed first) and follow where the element at l
+    // came from — lane l of wave 0 for positions 0 ... 63, every step one uniform LDS read and two compares. Same permutation, entry for entry. The full shuffle runs
+    // only if more than 64 positions are consumed (more than 64 - K duplicates: a flat image), or for maps beyond the LDS list (n > 4096).
+    __shared__ int s_head[64];
+    constexpr int HEAD = 64;
+    if (lds) {
+        if (tid < HEAD) {
+            int pos = tid;
+            auto back = [&](int i, int j) { pos = pos == i ? j : (pos == j ? i : pos); };
+            int i = 1;
+            for (; i < n && (i & 15); ++i) back(i, s_j[i]);
+            for (; i + 16 <= n; i += 16) {                       // sixteen swap partners per LDS trip (one read per step left the loop at LDS latency: 120 us)
+                int4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = reinterpret_cast<const int4*>(s_j + i)[u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { back(i + 4 * u, q[u].x); back(i + 4 * u + 1, q[u].y); back(i + 4 * u + 2, q[u].z); back(i + 4 * u + 3, q[u].w); }
+            }
+            for (; i < n; ++i) back(i, s_j[i]);
+            s_head[tid] = pos;                                   // pm[x] = x before the first swap
         }
+    } else if (tid == 0) {
+        for (int i = n - 1; i > 0; --i) { const int j = (int)(sm64_at(seed, (uint64_t)(n - 1 - i)) % (uint64_t)(i + 1)); const int t = pm[i]; pm[i] = pm[j]; pm[j] = t; }
     }
     __syncthreads();
-    if (lds) for (int i = tid; i < n; i += 256) perm[i] = pm[i];
+    bool shuffled = !lds;                                        // thread 0 only: pm holds the complete permutation
+    // The duplicate test compares the candidate's vector with every centre chosen so far (l2_ff: a serial chain per pair). From global memory that chain ran one round trip
+    // per group of four (~20 us per candidate, 190 of the kernel's 195 us at C = 512): the candidate's row and the chosen centres' rows are staged in LDS instead (C <= 512,
+    // K <= 10; rows padded by four floats), the chains read LDS. Same operations in the same order.
+    constexpr int CMAX = 512, KLDS = 10, CST = CMAX + 4;
+    __shared__ __attribute__((aligned(16))) float s_cent[KLDS * CST]; __shared__ __attribute__((aligned(16))) float s_row[CST];
+    const bool rows_lds = C <= CMAX && K <= KLDS && (C & 3) == 0;
     // first K candidates of the permutation that are not duplicates (squared distance < 1e-16) of an earlier centre
     int pos = 0, nc = 0;
     for (int index = 0; index < K; ++index) {
         bool out = false;
         while (true) {
-            if (tid == 0) { s_stop = pos >= n ? 1 : 0; s_dup = 0; if (pos < n) { s_cand = pm[pos]; st->cidx[index] = s_cand; } }
+            if (tid == 0) {
+                s_stop = pos >= n ? 1 : 0; s_dup = 0;
+                if (pos < n) {
+                    if (!shuffled && pos >= HEAD) { for (int i = n - 1; i > 0; --i) { const int j = s_j[i]; const int t = pm[i]; pm[i] = pm[j]; pm[j] = t; } shuffled = true; }
+                    s_cand = shuffled ? pm[pos] : s_head[pos]; st->cidx[index] = s_cand;
+                }
+            }
             __syncthreads();
             if (s_stop) { out = true; break; }
             ++pos;
-            if (tid < index && l2_ff(feat + (size_t)s_cand * C, feat + (size_t)st->cidx[tid] * C, C) < 1e-16) s_dup = 1;
+            if (rows_lds) {
+                for (int e = tid; e < (C >> 2); e += 256) reinterpret_cast<float4*>(s_row)[e] = reinterpret_cast<const float4*>(feat + (size_t)s_cand * C)[e];
+                __syncthreads();
+                if (tid < index && l2_ff(s_row, s_cent + tid * CST, C) < 1e-16) s_dup = 1;
+            } else if (tid < index && l2_ff(feat + (size_t)s_cand * C, feat + (size_t)st->cidx[tid] * C, C) < 1e-16) s_dup = 1;
             __syncthreads();
             const bool dup = s_dup != 0;
             __syncthreads();
             if (!dup) break;
         }
         if (out) break;
+        if (rows_lds) { for (int e = tid; e < (C >> 2); e += 256) reinterpret_cast<float4*>(s_cent + index * CST)[e] = reinterpret_cast<const float4*>(s_row)[e]; __syncthreads(); }
         nc = index + 1;
     }
     if (tid == 0) { st->nc = nc; if (nc < K) st->done = 1; }           // root cannot be split: one label
@@ -145,12 +209,17 @@ __global__ __launch_bounds__(256) void k_km_centres_list(const float* __restrict
     const int c = (blockIdx.x * 256) / C, k = i - c * C;
     if (threadIdx.x < 64) {
         int base = 0;
-        for (int p0 = 0; p0 < n; p0 += 64) {
-            const int p = p0 + threadIdx.x;
-            const bool in = p < n && labels[p] == c;
-            const unsigned long long bal = __ballot(in);
-            if (in) s_list[base + __popcll(bal & ((1ull << threadIdx.x) - 1ull))] = p;
-            base += __popcll(bal);
+        for (int p0 = 0; p0 < n; p0 += 512) {                 // eight chunks of 64 labels per trip (the loads together), compacted chunk by chunk: the list stays ascending
+            int lb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int p = p0 + 64 * u + threadIdx.x; lb[u] = p < n ? labels[p] : -1; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = lb[u] == c;
+                const unsigned long long bal = __ballot(in);
+                if (in) s_list[base + __popcll(bal & ((1ull << threadIdx.x) - 1ull))] = p0 + 64 * u + threadIdx.x;
+                base += __popcll(bal);
+            }
         }
         if (threadIdx.x == 0) s_cnt = base;
     }
@@ -158,6 +227,13 @@ __global__ __launch_bounds__(256) void k_km_centres_list(const float* __restrict
     const int m = s_cnt;
     double s = 0.0;
     int t = 0;
+    for (; t + 32 <= m; t += 32) {                     // the loads of 32 members in flight together; added in list order
+        float f[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) f[u] = feat[(size_t)s_list[t + u] * C + k];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s += (double)f[u];
+    }
     for (; t + 8 <= m; t += 8) {
         float f[8];
 #pragma unroll
@@ -175,17 +251,65 @@ __global__ void k_km_dist(const float* __restrict__ feat, int n, int C, int K, c
     const int p = i / K, c = i - p * K;
     dist[i] = l2_fd(feat + (size_t)p * C, dc + (size_t)c * C, C);
 }
-// first-minimum assignment (`if (sq_dist > new_sq_dist)`), radius = max, counts, change flag
-__global__ void k_km_relabel(int n, int K, const float* __restrict__ dist, int* __restrict__ labels, KMState* __restrict__ st, int first) {
+// The same distances for C = 512 (the pipeline's conv5_1 map) from LDS: a workgroup stages the K centres (fp64) and the rows of KM_DP pixels once — the general kernel
+// re-reads a 2 KB row per thread through an L1 that 26 rows + 40 KB of centres do not fit (34 us for 1 936 pixels) — then thread (pixel, centre) runs the same chain
+// (l2_fd: groups of four, in order). Rows are padded against bank conflicts (threads of one pixel read the same feature address: a broadcast; their centres differ).
+constexpr int KM_DP = 24, KM_DC = 512, KM_FPAD = 4, KM_CPAD = 2;
+__global__ __launch_bounds__(256) void k_km_dist512(const float* __restrict__ feat, int n, int K, const double* __restrict__ dc, const KMState* __restrict__ st, float* __restrict__ dist) {
     if (st->done) return;
+    extern __shared__ double s_km[];
+    double* s_c = s_km;                                                   // [K][KM_DC + KM_CPAD]
+    float* s_f = reinterpret_cast<float*>(s_c + (size_t)K * (KM_DC + KM_CPAD));      // [KM_DP][KM_DC + KM_FPAD]
+    const int p0 = blockIdx.x * KM_DP, np = min(KM_DP, n - p0);
+    for (int e = threadIdx.x; e < K * (KM_DC / 2); e += 256) {
+        const int c = e / (KM_DC / 2), j = e - c * (KM_DC / 2);
+        reinterpret_cast<double2*>(s_c + (size_t)c * (KM_DC + KM_CPAD))[j] = reinterpret_cast<const double2*>(dc + (size_t)c * KM_DC)[j];
+    }
+    for (int e = threadIdx.x; e < np * (KM_DC / 4); e += 256) {
+        const int r = e / (KM_DC / 4), j = e - r * (KM_DC / 4);
+        reinterpret_cast<float4*>(s_f + (size_t)r * (KM_DC + KM_FPAD))[j] = reinterpret_cast<const float4*>(feat + (size_t)(p0 + r) * KM_DC)[j];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= np * K) return;
+    const int r = t / K, c = t - r * K;
+    const float* a = s_f + (size_t)r * (KM_DC + KM_FPAD);
+    const double* b = s_c + (size_t)c * (KM_DC + KM_CPAD);
+    float result = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < KM_DC; i += 4) {
+        const float4 av = *reinterpret_cast<const float4*>(a + i);
+        const double2 b0 = *reinterpret_cast<const double2*>(b + i), b1 = *reinterpret_cast<const double2*>(b + i + 2);
+        const float d0 = (float)((double)av.x - b0.x), d1 = (float)((double)av.y - b0.y), d2 = (float)((double)av.z - b1.x), d3 = (float)((double)av.w - b1.y);
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    dist[(size_t)(p0 + r) * K + c] = result;
+}
+// first-minimum assignment (`if (sq_dist > new_sq_dist)`), radius = max, counts, change flag. The cluster statistics are order-free (integer sums, a max of non-negative
+// floats as unsigned): a workgroup folds them in LDS and issues one global atomic per touched cluster instead of three per pixel (1 936 pixels hammered ten addresses: 16 us)
+__global__ __launch_bounds__(256) void k_km_relabel(int n, int K, const float* __restrict__ dist, int* __restrict__ labels, KMState* __restrict__ st, int first) {
+    if (st->done) return;
+    __shared__ int s_dcount[KM_MAXK]; __shared__ unsigned s_rad[KM_MAXK]; __shared__ int s_changed;
+    if (threadIdx.x < KM_MAXK) { s_dcount[threadIdx.x] = 0; s_rad[threadIdx.x] = 0u; }
+    if (threadIdx.x == 0) s_changed = 0;
+    __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    float sq = dist[(size_t)p * K]; int b = 0;
-    for (int j = 1; j < K; ++j) { const float nsq = dist[(size_t)p * K + j]; if (sq > nsq) { b = j; sq = nsq; } }
-    atomicMax(&st->radius[b], __float_as_uint(sq));
-    if (first) { labels[p] = b; atomicAdd(&st->count[b], 1); return; }
-    const int old = labels[p];
-    if (b != old) { atomicSub(&st->count[old], 1); atomicAdd(&st->count[b], 1); labels[p] = b; st->changed = 1; }
+    if (p < n) {
+        float sq = dist[(size_t)p * K]; int b = 0;
+        for (int j = 1; j < K; ++j) { const float nsq = dist[(size_t)p * K + j]; if (sq > nsq) { b = j; sq = nsq; } }
+        atomicMax(&s_rad[b], __float_as_uint(sq));
+        if (first) { labels[p] = b; atomicAdd(&s_dcount[b], 1); }
+        else {
+            const int old = labels[p];
+            if (b != old) { atomicSub(&s_dcount[old], 1); atomicAdd(&s_dcount[b], 1); labels[p] = b; s_changed = 1; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        if (s_rad[threadIdx.x]) atomicMax(&st->radius[threadIdx.x], s_rad[threadIdx.x]);
+        if (s_dcount[threadIdx.x]) atomicAdd(&st->count[threadIdx.x], s_dcount[threadIdx.x]);
+    }
+    if (threadIdx.x == 0 && s_changed) st->changed = 1;
 }
 // end of a Lloyd step: empty-cluster repair (kmeans_index.h:808-829), convergence, reset for the next step
 __global__ void k_km_step_end(const float* __restrict__ feat, int n, int C, int K, const double* __restrict__ dc, int* __restrict__ labels, KMState* __restrict__ st, int first, int last) {
@@ -223,7 +347,13 @@ int nctk_kmeans_labels(nct_ctx* ctx, hipStream_t s, const float* feat, int n, in
         else
             hipLaunchKernelGGL(k_km_centres, dim3(cdiv(K * C, 256)), dim3(256), 0, s, feat, n, C, K, (const int*)labels, (KMState*)st, (double*)dc, first);
         NCT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_km_dist, dim3(cdiv(n * K, 256)), dim3(256), 0, s, feat, n, C, K, (const double*)dc, (const KMState*)st, (float*)dist); NCT_LAUNCH_CHECK();
+        if (C == KM_DC && KM_DP * K <= 256) {
+            const size_t lds = (size_t)K * (KM_DC + KM_CPAD) * sizeof(double) + (size_t)KM_DP * (KM_DC + KM_FPAD) * sizeof(float);      // 41 KB + 50 KB at K = 10
+            if (lds > 65536) NCT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km_dist512), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     // per device; a host-side call
+            hipLaunchKernelGGL(k_km_dist512, dim3(cdiv(n, KM_DP)), dim3(256), lds, s, feat, n, K, (const double*)dc, (const KMState*)st, (float*)dist);
+        } else
+        hipLaunchKernelGGL(k_km_dist, dim3(cdiv(n * K, 256)), dim3(256), 0, s, feat, n, C, K, (const double*)dc, (const KMState*)st, (float*)dist);
+        NCT_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_km_relabel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, K, (const float*)dist, labels, (KMState*)st, first); NCT_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_km_step_end, dim3(1), dim3(1), 0, s, feat, n, C, K, (const double*)dc, labels, (KMState*)st, first, last); NCT_LAUNCH_CHECK();
     }

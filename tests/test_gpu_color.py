@@ -51,6 +51,23 @@ def test_kmeans_labels_exact(ctx, oracle, shape):
         assert gn == on and np.array_equal(gl, ol)
 
 
+@pytest.mark.parametrize("shape,distinct", [((512, 44, 44), 4), ((512, 30, 30), 1), ((64, 20, 20), 12), ((512, 70, 70), 7)])
+def test_kmeans_few_distinct_vectors(ctx, oracle, shape, distinct):
+    """Centre selection walks the seeded permutation and skips candidates that duplicate an earlier centre (squared distance < 1e-16). Round 6: k_km_init no longer performs
+    the n dependent swaps of the shuffle — it derives the first 64 entries of the SAME permutation by walking the swaps backwards — and falls back to the full shuffle only
+    when more than 64 positions are consumed. Maps with a handful of distinct vectors (a flat photograph) consume hundreds: both paths, the one-label exit (fewer distinct
+    vectors than K) and a map beyond the LDS list (70 x 70 > 4096 pixels) must give the oracle's labels."""
+    C, h, w = shape
+    rng = np.random.default_rng(17)
+    protos = (rng.random((distinct, C), dtype=np.float32) + np.float32(0.05)) * np.float32(3.0)
+    which = rng.integers(0, distinct, size=h * w)
+    f = np.ascontiguousarray(protos[which].T.reshape(C, h, w))
+    for seed in (1, 7):
+        gl, gn = ctx.cluster_features(f, 10, 11, seed)
+        ol, on = oracle.cluster_features(f, 10, 11, seed)
+        assert gn == on and np.array_equal(gl, ol)
+
+
 def test_kmeans_blobs(ctx, oracle):
     rng = np.random.default_rng(5)
     blobs = rng.standard_normal((7, 64)).astype(np.float32) * 3
