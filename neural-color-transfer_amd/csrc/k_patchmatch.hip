@@ -386,6 +386,35 @@ __device__ __forceinline__ float pm_sketch_bound(const float* __restrict__ skc, 
     }
     return LPQ == 8 ? half8_sum(part, 0.f) : row16_sum(part);
 }
+// the bounds of up to NF samples of one query from ONE batch of loads (all requests first, then the products)
+template <int LPQ, int RW, int NF>
+__device__ __forceinline__ void pm_sketch_bounds(const float* __restrict__ skc, const float4* __restrict__ s_sk, int bw, const uint32_t (&pos)[NF], const bool (&in)[NF], int nf,
+                                                 int lx, int ly, int v, float (&bound)[NF]) {
+    constexpr int NJ = (18 + LPQ - 1) / LPQ;
+    asm volatile("" : "+v"(v));
+    float4 b4[NF][NJ];
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = v + LPQ * jj, row = j / 6, i = j - 6 * row;
+            b4[q][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < nf && in[q] && j < 18) b4[q][jj] = reinterpret_cast<const float4*>(skc)[(size_t)(unsigned)((nnf_y(pos[q]) + row - 1) * bw + nnf_x(pos[q]) - 1) * PM_SKF4 + i];
+        }
+    float4 a4[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int j = v + LPQ * jj, row = j / 6, i = j - 6 * row;
+        a4[jj] = j < 18 ? s_sk[((ly + row) * RW + lx) * PM_SKF4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+        float part = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) part = dot4_acc(a4[jj], b4[q][jj], part);
+        bound[q] = LPQ == 8 ? half8_sum(part, 0.f) : row16_sum(part);
+    }
+}
 
 // TQX x TQY = 4x4 query sub-tiles per workgroup: the workgroup stages the (4 TQX + 2) x (4 TQY + 2) x C region of A once and then walks its
 // sub-tiles one after the other (16 queries at a time, one 16-lane row per query as before). A launch of the round-1 kernel (one sub-tile per
@@ -476,11 +505,11 @@ __device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int
         const bool live = qx < g.aw && qy < g.ah;
         // a dead query (beyond the image in a partially filled tile) is clamped PER AXIS, so it stays inside its tile's staged region and has the tap mask of
         // a live border query
-        const int ax = qx < g.aw ? qx : g.aw - 1, ay = qy < g.ah ? qy : g.ah - 1;
+        int ax = qx < g.aw ? qx : g.aw - 1, ay = qy < g.ah ? qy : g.ah - 1;       // (mutable: the far rounds of the random search borrow another query's record)
         // (it walks the candidates of that border query and writes nothing; masking dead queries out of every evaluation instead measured slower: the random
         // search's validity became a per-lane value)
         const int qi = ay * g.aw + ax;
-        const int lx = ax - ox, ly = ay - oy;
+        int lx = ax - ox, ly = ay - oy;
 
         // validity of the query's own taps
         unsigned amask = 0;
@@ -537,55 +566,165 @@ __device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int
             for (int i = 1; i <= 4; ++i) nprop += __builtin_amdgcn_ballot_w64(ncl >= i) != 0 ? 1 : 0;
             int mag = rs_start;
             const int ncand = nprop + nrand;
-            for (int k = 0; k < ncand; ++k) {
-                int xp, yp; bool valid; float rr; bool far = false;
-                if (k < nprop) {
-                    const uint32_t c = k == 0 ? cl0 : (k == 1 ? cl1 : (k == 2 ? cl2 : cl3));
-                    xp = nnf_x(c); yp = nnf_y(c);
-                    valid = k < ncl;
-#ifndef NCT_PM_EVAL_SAME
-                    // a neighbour that proposes the current match cannot improve it (d == dbest is not < dbest): its lanes sit the evaluation out
-                    // (with the wave near the L1 bandwidth limit the unissued tile requests are what is saved, not instructions)
-                    valid = valid && !(xp == xbest && yp == ybest);
-#endif
-                    rr = 0.f;
+            // ---- speculative far block (round 6; SKC instantiations with sketch records). The far samples of a pass (radius >= sk_mag: the first nf <= 3 of the six) are
+            // drawn TOGETHER around the best the propagation left — exactly where the sequential walk draws them unless one of them is accepted (0.1-0.5 % of the far samples)
+            // —, their sketch bounds come from ONE batch of loads, and what survives is packed across the wave's lane groups like k_pm_prop's candidates: any group evaluates
+            // any (query, sample) entry in the SAME evaluation site as its own candidates (it borrows the entry's query record from LDS and restores its own afterwards),
+            // rounds = ceil(survivors / groups) instead of one or two dependent round trips per sample for every query. Then every query consumes ITS results in sample
+            // order with the reference's accept rule; the first accepted one ends the speculation for that query — its later samples are drawn around the new best by the
+            // sequential walk. A sample evaluated against the threshold of the speculation time sees a WEAKER cut-off than the sequential one: same decisions, same bits.
+            constexpr int NFMAX = 3, GPWF = 64 / LPQ;
+            __shared__ uint4 s_fq[4][GPWF]; __shared__ uint32_t s_fl[4][NFMAX * GPWF]; __shared__ float s_fr[4][NFMAX * GPWF];
+            const int wvf = threadIdx.x >> 6, gwf = (threadIdx.x & 63) / LPQ;
+            int fround = -1, nlist = 0, nf = 0;                // far rounds: -1 = not inside; wave-uniform
+            bool fardone = !(SKC && sk_on && nrand > 0 && rs_start >= J.sk_mag);
+            unsigned fst = 0u;                                  // bits 0-2: far sample q survived its sketch test (evaluated in a far round); bits 4-5: random samples of this query the far block has dealt with
+            int k = 0;
+            while (true) {
+                int xp = 0, yp = 0; bool valid = false; float rr = 0.f; bool far = false; float need = -FLT_MAX; int fslot = 0;
+                if (fround >= 0) {
+                    const int e = fround * GPWF + gwf;
+                    valid = e < nlist;
+                    if (valid) {
+                        const uint32_t ent = s_fl[wvf][e];
+                        const uint4 qq = s_fq[wvf][ent >> 28];
+                        ax = qq.x & 0xFFFF; ay = qq.x >> 16; lx = qq.y & 0xFF; ly = (qq.y >> 8) & 0xFF; amask = qq.y >> 16;      // borrowed until the last far round
+                        xp = nnf_x(ent & 0xFFFFFFu); yp = nnf_y(ent & 0xFFFFFFu); need = -9.0f * __uint_as_float(qq.z);
+                        fslot = (int)(ent >> 28) * NFMAX + (int)((ent >> 24) & 15u);
+                    }
+                    far = true;
                 } else {
-                    const int step = k - nprop;
-                    const int xmin = max(xbest - mag, 0), xmax = min(xbest + mag + 1, g.bw);
-                    const int ymin = max(ybest - mag, 0), ymax = min(ybest + mag + 1, g.bh);
-                    // (int)(u * w) % w with u in (0, 1]: the product never exceeds w, so the modulo only folds the value w back to 0 — a
-                    // select instead of two integer divisions
-                    const int wx = xmax - xmin, wy = ymax - ymin;
-                    const int rx = (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)wy);
-                    xp = xmin + (rx == wx ? 0 : rx);
-                    yp = ymin + (ry == wy ? 0 : ry);
-                    far = mag >= NCT_PM_FAR_MAG;
-                    valid = true; rr = FLT_MIN;
+                    if (k >= ncand) break;
                     if constexpr (SKC) {
-                        if (sk_on && mag >= J.sk_mag) {               // wave-uniform
-                            const bool in = amask == 0x1FFu && xp >= 1 && xp < g.bw - 1 && yp >= 1 && yp < g.bh - 1;
-                            const float bound = pm_sketch_bound<LPQ, RW>(skc, s_sk, g.bw, xp, yp, lx, ly, v, in);
-                            // a rejected sample counts as an evaluation (the counters mean "candidates considered", as for a row-rejected one)
-                            const bool rej = in && bound + NCT_PM_SKETCH_MARGIN < -9.0f * dbest;
-                            if (live && v == 0) nsk += 1u + (rej ? 0x10000u : 0u);
-                            if (rej) { valid = false; if (live && v == 0) ++nevals; }
+                        if (!fardone && k == nprop) {
+                            fardone = true;
+                            for (int m = rs_start; m >= J.sk_mag && nf < NFMAX && nf < nrand; m >>= 1) ++nf;
+                            uint32_t fpos[NFMAX]; bool fin[NFMAX];
+                            {
+                                int m = rs_start;
+#pragma unroll
+                                for (int q = 0; q < NFMAX; ++q) {
+                                    fpos[q] = 0u; fin[q] = false;
+                                    if (q < nf) {
+                                        const int xmin = max(xbest - m, 0), xmax = min(xbest + m + 1, g.bw), ymin = max(ybest - m, 0), ymax = min(ybest + m + 1, g.bh);
+                                        const int wx = xmax - xmin, wy = ymax - ymin;
+                                        const int rx = (int)(rand_u01(seed, ax, ay, iter, q, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, q, 1) * (float)wy);
+                                        const int xq = xmin + (rx == wx ? 0 : rx), yq = ymin + (ry == wy ? 0 : ry);
+                                        fpos[q] = xy_pack(xq, yq);
+                                        fin[q] = amask == 0x1FFu && xq >= 1 && xq < g.bw - 1 && yq >= 1 && yq < g.bh - 1;
+                                        m >>= 1;
+                                    }
+                                }
+                            }
+                            {
+                                float bound[NFMAX];
+                                pm_sketch_bounds<LPQ, RW, NFMAX>(skc, s_sk, g.bw, fpos, fin, nf, lx, ly, v, bound);
+                                const float need0 = -9.0f * dbest;
+#pragma unroll
+                                for (int q = 0; q < NFMAX; ++q) {
+                                    const bool rej = q < nf && fin[q] && bound[q] + NCT_PM_SKETCH_MARGIN < need0;
+                                    if (q < nf && !rej) fst |= 1u << q;
+                                    if (live && v == 0 && q < nf && fin[q]) nsk += 1u + (rej ? 0x10000u : 0u);
+                                }
+                            }
+                            // pack the survivors of the wave's queries (sample-major)
+                            if (v == 0) s_fq[wvf][gwf] = make_uint4((unsigned)ax | ((unsigned)ay << 16), (unsigned)lx | ((unsigned)ly << 8) | (amask << 16), __float_as_uint(dbest), 0u);
+                            nlist = 0;
+                            {
+                                const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+#pragma unroll
+                                for (int q = 0; q < NFMAX; ++q) {
+                                    const bool put = v == 0 && ((fst >> q) & 1u);
+                                    const unsigned long long mm = __builtin_amdgcn_ballot_w64(put);
+                                    if (put) s_fl[wvf][nlist + __builtin_popcountll(mm & below)] = ((unsigned)gwf << 28) | ((unsigned)q << 24) | fpos[q];
+                                    nlist += __builtin_popcountll(mm);
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            fround = 0;
+                            continue;                                   // (nlist == 0: the first far round is empty and goes straight to the consumption below)
                         }
                     }
-                    mag >>= 1;
+                    if (k < nprop) {
+                        const uint32_t c = k == 0 ? cl0 : (k == 1 ? cl1 : (k == 2 ? cl2 : cl3));
+                        xp = nnf_x(c); yp = nnf_y(c);
+                        valid = k < ncl;
+#ifndef NCT_PM_EVAL_SAME
+                        // a neighbour that proposes the current match cannot improve it (d == dbest is not < dbest): its lanes sit the evaluation out
+                        // (with the wave near the L1 bandwidth limit the unissued tile requests are what is saved, not instructions)
+                        valid = valid && !(xp == xbest && yp == ybest);
+#endif
+                        rr = 0.f;
+                    } else {
+                        const int step = k - nprop;
+                        const int xmin = max(xbest - mag, 0), xmax = min(xbest + mag + 1, g.bw);
+                        const int ymin = max(ybest - mag, 0), ymax = min(ybest + mag + 1, g.bh);
+                        // (int)(u * w) % w with u in (0, 1]: the product never exceeds w, so the modulo only folds the value w back to 0 — a
+                        // select instead of two integer divisions
+                        const int wx = xmax - xmin, wy = ymax - ymin;
+                        const int rx = (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)wy);
+                        xp = xmin + (rx == wx ? 0 : rx);
+                        yp = ymin + (ry == wy ? 0 : ry);
+                        far = mag >= NCT_PM_FAR_MAG;
+                        valid = step >= (int)(fst >> 4); rr = FLT_MIN;         // samples the speculative far block has dealt with are done
+                        mag >>= 1;
+                    }
+                    need = EX ? -9.0f * dbest : -FLT_MAX;
                 }
+                float d = FLT_MAX;
                 if (valid) {
                     // to win, -sum/9 (+rr) < dbest, i.e. sum > -9 dbest: unreachable sums are cut off (unit-norm features only)
-                    float d;
                     if constexpr (LPQ == 8) {
                         // (wave-uniform branch: the search radius is the same for every query of a step)
-                        if (far) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
-                        else d = pm_dist8<MODE, RW, NCT_PM_NEAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                        if constexpr (NCT_PM_FAR_STAGE == NCT_PM_NEAR_STAGE) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, need);
+                        else if (far) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, need);
+                        else d = pm_dist8<MODE, RW, NCT_PM_NEAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, need);
                     }
-                    else d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                    else d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, need);
+                }
+                if (fround >= 0) {
+                    if (valid && v == 0) s_fr[wvf][fslot] = d;
+                    ++fround;
+                    if (fround * GPWF >= nlist) {
+                        // the last far round: every query consumes its samples in order until one is accepted
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        { const uint4 own = s_fq[wvf][gwf]; ax = own.x & 0xFFFF; ay = own.x >> 16; lx = own.y & 0xFF; ly = (own.y >> 8) & 0xFF; amask = own.y >> 16; }
+                        bool moved = false;
+                        int mq = rs_start;
+#pragma unroll
+                        for (int q = 0; q < NFMAX; ++q) {
+                            if (q < nf && !moved) {
+                                if ((fst >> q) & 1u) {
+                                    float dq = s_fr[wvf][gwf * NFMAX + q];
+                                    if (dq >= dbest) dq = dbest;
+                                    if (dq + FLT_MIN < dbest) {
+                                        // the sample's position once more (the best has not moved since the speculation: the same draw)
+                                        const int xmin = max(xbest - mq, 0), xmax = min(xbest + mq + 1, g.bw), ymin = max(ybest - mq, 0), ymax = min(ybest + mq + 1, g.bh);
+                                        const int wx = xmax - xmin, wy = ymax - ymin;
+                                        const int rx = (int)(rand_u01(seed, ax, ay, iter, q, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, q, 1) * (float)wy);
+                                        xbest = xmin + (rx == wx ? 0 : rx); ybest = ymin + (ry == wy ? 0 : ry); dbest = dq; moved = true; if (live && v == 0) ++naccept;
+                                    }
+                                }
+                                if (live && v == 0) ++nevals;
+                                fst += 16u;
+                            }
+                            mq >>= 1;
+                        }
+                        // the walk goes on with the first sample some query of the wave has not consumed
+                        int cmin = nf;
+#pragma unroll
+                        for (int c = NFMAX - 1; c >= 0; --c) if (c < nf && __builtin_amdgcn_ballot_w64((int)(fst >> 4) == c) != 0) cmin = c;
+                        k = nprop + cmin; mag = rs_start >> cmin;
+                        fround = -1;
+                    }
+                    continue;
+                }
+                if (valid) {
                     if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
                     if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; if (live && v == 0) ++naccept; }
                     if (live && v == 0) ++nevals;
                 }
+                ++k;
             }
         }
         if (live && v == 0) {
