@@ -53,10 +53,8 @@ int nct_device_pci_bus_id(int device, char* buf, int buflen);
 int nct_synchronize(nct_ctx* ctx);
 /* counters of a context (what library code must not print): NCT_CTR_ARENA_BYTES = device memory held by the context's arena; NCT_CTR_S1_HUB_BLOCKS_L0 + l (l = 0 coarsest … 4) =
  * the number of in-edge blocks beyond a pixel's first 64 in level l's kNN graph of the LAST pair, as the host knew it when it enqueued that level's nonlocal solve
- * (0 on the synthetic pairs; thousands on natural photographs, where groups of one colour make kNN hubs — k_s1.hip; -1: not known in time, the hub pass was launched anyway).
- * NCT_CTR_PM_SKETCH_TESTED / _REJECTED: random-search samples of the last COUNTED PatchMatch run (nct_pm_bench_run_bidir with counters, or a pair run with
- * NCT_FLAG_COUNT_EVALS: all levels) that went through the exact sketch pre-rejection (k_pm_sketch.hip), and how many of them it rejected without fetching their tiles. */
-enum { NCT_CTR_ARENA_BYTES = 0, NCT_CTR_S1_HUB_BLOCKS_L0 = 1, NCT_CTR_PM_SKETCH_TESTED = 6, NCT_CTR_PM_SKETCH_REJECTED = 7 };
+ * (0 on the synthetic pairs; thousands on natural photographs, where groups of one colour make kNN hubs — k_s1.hip; -1: not known in time, the hub pass was launched anyway). */
+enum { NCT_CTR_ARENA_BYTES = 0, NCT_CTR_S1_HUB_BLOCKS_L0 = 1 };
 int nct_ctx_counter(nct_ctx* ctx, int which, int64_t* out);
 
 /* ---- N1: feature L2 normalisation — `norm` (GeneralizedPatchMatch.cu:237-283), called main.cu:265,274,313.

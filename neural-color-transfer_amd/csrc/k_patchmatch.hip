@@ -355,66 +355,7 @@ template <bool COH> __device__ __forceinline__ void pm_st(float* p, float v) {
 // A launch carries up to two independent jobs (the S->R and the R->S field of one level): workgroups [0, nblk0) belong to
 // job 0, the rest to job 1. Fusing the two directions doubles the number of resident workgroups at the coarse levels
 // (44x44 queries are only 121 workgroups for 256 CUs) and halves the launch count; each job's result is unaffected.
-struct PMJob { const float* A; const float* B; const uint2* Bh; const uint32_t* nnf_in; const float* d_in; uint32_t* nnf_out; float* d_out; PMGeom g; int rs_max; uint32_t seed;
-               const float* skq; const float* skc; int sk_mag; };   // sketch records of the query map / the candidate map (k_pm_sketch.hip; null: no sketch test), smallest search radius that is tested
-
-// ---- the sketch test of a random sample (round 6; k_pm_sketch.hip has the derivation and the margins). Records are [y0 .. y6, rho] per pixel: the dot product of the query's
-// and the candidate's 3 x 3 x 8 floats is an upper bound of the 9-tap similarity sum; a sample whose bound cannot reach `need` = -9 dbest loses whatever its tile holds
-// and is not fetched. Interior queries and candidates only (all nine taps count); 18 float4 per side spread over the query's 8 / 16 lanes. The A side is staged in LDS
-// behind the query region (s_sk: [RH][RW][2] float4).
-#ifndef NCT_PM_SKETCH_MARGIN
-#define NCT_PM_SKETCH_MARGIN 2e-3f
-#endif
-constexpr int PM_SKF4 = 2;                                   // float4 per sketch record
-template <int LPQ, int RW>
-__device__ __forceinline__ float pm_sketch_bound(const float* __restrict__ skc, const float4* __restrict__ s_sk, int bw, int xp, int yp, int lx, int ly, int v, bool in) {
-    float part = 0.f;
-    // (the lane's record slots depend on v alone; computed per sample on purpose — hoisted out of the candidate loop they stay live across pm_dist8 and cost the kernel its
-    //  fourth wave per SIMD: 128 + 7 spilled / 129 registers against 125 / 121 without the test)
-    asm volatile("" : "+v"(v));
-    if (in) {
-#pragma unroll
-        for (int jj = 0; jj < (18 + LPQ - 1) / LPQ; ++jj) {
-            const int j = v + LPQ * jj;
-            if (j < 18) {
-                const int row = j / 6, i = j - 6 * row;
-                const float4 b4 = reinterpret_cast<const float4*>(skc)[(size_t)(unsigned)((yp + row - 1) * bw + xp - 1) * PM_SKF4 + i];
-                const float4 a4 = s_sk[((ly + row) * RW + lx) * PM_SKF4 + i];
-                part = dot4_acc(a4, b4, part);
-            }
-        }
-    }
-    return LPQ == 8 ? half8_sum(part, 0.f) : row16_sum(part);
-}
-// the bounds of up to NF samples of one query from ONE batch of loads (all requests first, then the products)
-template <int LPQ, int RW, int NF>
-__device__ __forceinline__ void pm_sketch_bounds(const float* __restrict__ skc, const float4* __restrict__ s_sk, int bw, const uint32_t (&pos)[NF], const bool (&in)[NF], int nf,
-                                                 int lx, int ly, int v, float (&bound)[NF]) {
-    constexpr int NJ = (18 + LPQ - 1) / LPQ;
-    asm volatile("" : "+v"(v));
-    float4 b4[NF][NJ];
-#pragma unroll
-    for (int q = 0; q < NF; ++q)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            const int j = v + LPQ * jj, row = j / 6, i = j - 6 * row;
-            b4[q][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < nf && in[q] && j < 18) b4[q][jj] = reinterpret_cast<const float4*>(skc)[(size_t)(unsigned)((nnf_y(pos[q]) + row - 1) * bw + nnf_x(pos[q]) - 1) * PM_SKF4 + i];
-        }
-    float4 a4[NJ];
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        const int j = v + LPQ * jj, row = j / 6, i = j - 6 * row;
-        a4[jj] = j < 18 ? s_sk[((ly + row) * RW + lx) * PM_SKF4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int q = 0; q < NF; ++q) {
-        float part = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) part = dot4_acc(a4[jj], b4[q][jj], part);
-        bound[q] = LPQ == 8 ? half8_sum(part, 0.f) : row16_sum(part);
-    }
-}
+struct PMJob { const float* A; const float* B; const uint2* Bh; const uint32_t* nnf_in; const float* d_in; uint32_t* nnf_out; float* d_out; PMGeom g; int rs_max; uint32_t seed; };
 
 // TQX x TQY = 4x4 query sub-tiles per workgroup: the workgroup stages the (4 TQX + 2) x (4 TQY + 2) x C region of A once and then walks its
 // sub-tiles one after the other (16 queries at a time, one 16-lane row per query as before). A launch of the round-1 kernel (one sub-tile per
@@ -427,7 +368,7 @@ __device__ __forceinline__ void pm_sketch_bounds(const float* __restrict__ skc, 
 // One tile of one step (the body of k_pm_step and of the persistent k_pm_level): the workgroup serves the 4 TQX x 4 TQY queries of tile (tx, ty) of job J.
 // s_a: the dynamic LDS region for the staged part of A. nevals / naccept: per-thread counters, accumulated.
 template <int NCH, int MODE, int TQX, int TQY, int LPQ, bool COH>
-__device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int mode, int jump, int iter, int tstep, int strip, float4* __restrict__ s_a, unsigned& nevals, unsigned& naccept, unsigned& nsk /* sketch tests (low half) and rejections (high half) of this thread's queries */) {
+__device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int mode, int jump, int iter, int tstep, int strip, float4* __restrict__ s_a, unsigned& nevals, unsigned& naccept) {
     constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2;
     const float* __restrict__ A = J.A; const float* __restrict__ B = J.B; const uint2* __restrict__ Bh = J.Bh;
     constexpr bool EX = MODE == NCT_PM_ROWREJECT;
@@ -467,24 +408,12 @@ __device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int
 
     // stage the region of A that the queries of this workgroup read (their 3x3 tiles overlap) into LDS once per launch. Without it every
     // evaluation re-reads its 9*C*4-byte query tile through L1.
-    constexpr bool SKC = EX && NCH >= 1 && NCH <= 2;            // the instantiations with a sketch test (unit-norm levels whose random search is byte bound)
-    const float* __restrict__ skc = J.skc;
-    float4* __restrict__ s_sk = s_a + RW * RH * 16 * (NCH > 0 ? NCH : 1);
-    const bool sk_on = SKC && skc != nullptr && J.skq != nullptr && jump == 1 && mode == 1;
     if constexpr (NCH >= 1) {
         const int c4 = g.C >> 2;
         for (int e = threadIdx.x; e < RW * RH * c4; e += 256) {
             const int r = e / c4, j = e - r * c4;
             const int ry = clampi(oy - 1 + r / RW, 0, g.ah - 1), rx = clampi(ox - 1 + r % RW, 0, g.aw - 1);
             s_a[e] = reinterpret_cast<const float4*>(A + ((size_t)ry * g.aw + rx) * g.C)[j];
-        }
-        if constexpr (SKC) {
-            if (sk_on)
-                for (int e = threadIdx.x; e < RW * RH * PM_SKF4; e += 256) {
-                    const int r = e / PM_SKF4, j = e - r * PM_SKF4;
-                    const int ry = clampi(oy - 1 + r / RW, 0, g.ah - 1), rx = clampi(ox - 1 + r % RW, 0, g.aw - 1);
-                    s_sk[e] = reinterpret_cast<const float4*>(J.skq)[((size_t)ry * g.aw + rx) * PM_SKF4 + j];
-                }
         }
         __syncthreads();
     }
@@ -505,11 +434,11 @@ __device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int
         const bool live = qx < g.aw && qy < g.ah;
         // a dead query (beyond the image in a partially filled tile) is clamped PER AXIS, so it stays inside its tile's staged region and has the tap mask of
         // a live border query
-        int ax = qx < g.aw ? qx : g.aw - 1, ay = qy < g.ah ? qy : g.ah - 1;       // (mutable: the far rounds of the random search borrow another query's record)
+        const int ax = qx < g.aw ? qx : g.aw - 1, ay = qy < g.ah ? qy : g.ah - 1;
         // (it walks the candidates of that border query and writes nothing; masking dead queries out of every evaluation instead measured slower: the random
         // search's validity became a per-lane value)
         const int qi = ay * g.aw + ax;
-        int lx = ax - ox, ly = ay - oy;
+        const int lx = ax - ox, ly = ay - oy;
 
         // validity of the query's own taps
         unsigned amask = 0;
@@ -566,165 +495,45 @@ __device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int
             for (int i = 1; i <= 4; ++i) nprop += __builtin_amdgcn_ballot_w64(ncl >= i) != 0 ? 1 : 0;
             int mag = rs_start;
             const int ncand = nprop + nrand;
-            // ---- speculative far block (round 6; SKC instantiations with sketch records). The far samples of a pass (radius >= sk_mag: the first nf <= 3 of the six) are
-            // drawn TOGETHER around the best the propagation left — exactly where the sequential walk draws them unless one of them is accepted (0.1-0.5 % of the far samples)
-            // —, their sketch bounds come from ONE batch of loads, and what survives is packed across the wave's lane groups like k_pm_prop's candidates: any group evaluates
-            // any (query, sample) entry in the SAME evaluation site as its own candidates (it borrows the entry's query record from LDS and restores its own afterwards),
-            // rounds = ceil(survivors / groups) instead of one or two dependent round trips per sample for every query. Then every query consumes ITS results in sample
-            // order with the reference's accept rule; the first accepted one ends the speculation for that query — its later samples are drawn around the new best by the
-            // sequential walk. A sample evaluated against the threshold of the speculation time sees a WEAKER cut-off than the sequential one: same decisions, same bits.
-            constexpr int NFMAX = 3, GPWF = 64 / LPQ;
-            __shared__ uint4 s_fq[4][GPWF]; __shared__ uint32_t s_fl[4][NFMAX * GPWF]; __shared__ float s_fr[4][NFMAX * GPWF];
-            const int wvf = threadIdx.x >> 6, gwf = (threadIdx.x & 63) / LPQ;
-            int fround = -1, nlist = 0, nf = 0;                // far rounds: -1 = not inside; wave-uniform
-            bool fardone = !(SKC && sk_on && nrand > 0 && rs_start >= J.sk_mag);
-            unsigned fst = 0u;                                  // bits 0-2: far sample q survived its sketch test (evaluated in a far round); bits 4-5: random samples of this query the far block has dealt with
-            int k = 0;
-            while (true) {
-                int xp = 0, yp = 0; bool valid = false; float rr = 0.f; bool far = false; float need = -FLT_MAX; int fslot = 0;
-                if (fround >= 0) {
-                    const int e = fround * GPWF + gwf;
-                    valid = e < nlist;
-                    if (valid) {
-                        const uint32_t ent = s_fl[wvf][e];
-                        const uint4 qq = s_fq[wvf][ent >> 28];
-                        ax = qq.x & 0xFFFF; ay = qq.x >> 16; lx = qq.y & 0xFF; ly = (qq.y >> 8) & 0xFF; amask = qq.y >> 16;      // borrowed until the last far round
-                        xp = nnf_x(ent & 0xFFFFFFu); yp = nnf_y(ent & 0xFFFFFFu); need = -9.0f * __uint_as_float(qq.z);
-                        fslot = (int)(ent >> 28) * NFMAX + (int)((ent >> 24) & 15u);
-                    }
-                    far = true;
-                } else {
-                    if (k >= ncand) break;
-                    if constexpr (SKC) {
-                        if (!fardone && k == nprop) {
-                            fardone = true;
-                            for (int m = rs_start; m >= J.sk_mag && nf < NFMAX && nf < nrand; m >>= 1) ++nf;
-                            uint32_t fpos[NFMAX]; bool fin[NFMAX];
-                            {
-                                int m = rs_start;
-#pragma unroll
-                                for (int q = 0; q < NFMAX; ++q) {
-                                    fpos[q] = 0u; fin[q] = false;
-                                    if (q < nf) {
-                                        const int xmin = max(xbest - m, 0), xmax = min(xbest + m + 1, g.bw), ymin = max(ybest - m, 0), ymax = min(ybest + m + 1, g.bh);
-                                        const int wx = xmax - xmin, wy = ymax - ymin;
-                                        const int rx = (int)(rand_u01(seed, ax, ay, iter, q, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, q, 1) * (float)wy);
-                                        const int xq = xmin + (rx == wx ? 0 : rx), yq = ymin + (ry == wy ? 0 : ry);
-                                        fpos[q] = xy_pack(xq, yq);
-                                        fin[q] = amask == 0x1FFu && xq >= 1 && xq < g.bw - 1 && yq >= 1 && yq < g.bh - 1;
-                                        m >>= 1;
-                                    }
-                                }
-                            }
-                            {
-                                float bound[NFMAX];
-                                pm_sketch_bounds<LPQ, RW, NFMAX>(skc, s_sk, g.bw, fpos, fin, nf, lx, ly, v, bound);
-                                const float need0 = -9.0f * dbest;
-#pragma unroll
-                                for (int q = 0; q < NFMAX; ++q) {
-                                    const bool rej = q < nf && fin[q] && bound[q] + NCT_PM_SKETCH_MARGIN < need0;
-                                    if (q < nf && !rej) fst |= 1u << q;
-                                    if (live && v == 0 && q < nf && fin[q]) nsk += 1u + (rej ? 0x10000u : 0u);
-                                }
-                            }
-                            // pack the survivors of the wave's queries (sample-major)
-                            if (v == 0) s_fq[wvf][gwf] = make_uint4((unsigned)ax | ((unsigned)ay << 16), (unsigned)lx | ((unsigned)ly << 8) | (amask << 16), __float_as_uint(dbest), 0u);
-                            nlist = 0;
-                            {
-                                const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
-#pragma unroll
-                                for (int q = 0; q < NFMAX; ++q) {
-                                    const bool put = v == 0 && ((fst >> q) & 1u);
-                                    const unsigned long long mm = __builtin_amdgcn_ballot_w64(put);
-                                    if (put) s_fl[wvf][nlist + __builtin_popcountll(mm & below)] = ((unsigned)gwf << 28) | ((unsigned)q << 24) | fpos[q];
-                                    nlist += __builtin_popcountll(mm);
-                                }
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            fround = 0;
-                            continue;                                   // (nlist == 0: the first far round is empty and goes straight to the consumption below)
-                        }
-                    }
-                    if (k < nprop) {
-                        const uint32_t c = k == 0 ? cl0 : (k == 1 ? cl1 : (k == 2 ? cl2 : cl3));
-                        xp = nnf_x(c); yp = nnf_y(c);
-                        valid = k < ncl;
+            for (int k = 0; k < ncand; ++k) {
+                int xp, yp; bool valid; float rr; bool far = false;
+                if (k < nprop) {
+                    const uint32_t c = k == 0 ? cl0 : (k == 1 ? cl1 : (k == 2 ? cl2 : cl3));
+                    xp = nnf_x(c); yp = nnf_y(c);
+                    valid = k < ncl;
 #ifndef NCT_PM_EVAL_SAME
-                        // a neighbour that proposes the current match cannot improve it (d == dbest is not < dbest): its lanes sit the evaluation out
-                        // (with the wave near the L1 bandwidth limit the unissued tile requests are what is saved, not instructions)
-                        valid = valid && !(xp == xbest && yp == ybest);
+                    // a neighbour that proposes the current match cannot improve it (d == dbest is not < dbest): its lanes sit the evaluation out
+                    // (with the wave near the L1 bandwidth limit the unissued tile requests are what is saved, not instructions)
+                    valid = valid && !(xp == xbest && yp == ybest);
 #endif
-                        rr = 0.f;
-                    } else {
-                        const int step = k - nprop;
-                        const int xmin = max(xbest - mag, 0), xmax = min(xbest + mag + 1, g.bw);
-                        const int ymin = max(ybest - mag, 0), ymax = min(ybest + mag + 1, g.bh);
-                        // (int)(u * w) % w with u in (0, 1]: the product never exceeds w, so the modulo only folds the value w back to 0 — a
-                        // select instead of two integer divisions
-                        const int wx = xmax - xmin, wy = ymax - ymin;
-                        const int rx = (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)wy);
-                        xp = xmin + (rx == wx ? 0 : rx);
-                        yp = ymin + (ry == wy ? 0 : ry);
-                        far = mag >= NCT_PM_FAR_MAG;
-                        valid = step >= (int)(fst >> 4); rr = FLT_MIN;         // samples the speculative far block has dealt with are done
-                        mag >>= 1;
-                    }
-                    need = EX ? -9.0f * dbest : -FLT_MAX;
+                    rr = 0.f;
+                } else {
+                    const int step = k - nprop;
+                    const int xmin = max(xbest - mag, 0), xmax = min(xbest + mag + 1, g.bw);
+                    const int ymin = max(ybest - mag, 0), ymax = min(ybest + mag + 1, g.bh);
+                    // (int)(u * w) % w with u in (0, 1]: the product never exceeds w, so the modulo only folds the value w back to 0 — a
+                    // select instead of two integer divisions
+                    const int wx = xmax - xmin, wy = ymax - ymin;
+                    const int rx = (int)(rand_u01(seed, ax, ay, iter, step, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, step, 1) * (float)wy);
+                    xp = xmin + (rx == wx ? 0 : rx);
+                    yp = ymin + (ry == wy ? 0 : ry);
+                    far = mag >= NCT_PM_FAR_MAG;
+                    mag >>= 1;
+                    valid = true; rr = FLT_MIN;
                 }
-                float d = FLT_MAX;
                 if (valid) {
                     // to win, -sum/9 (+rr) < dbest, i.e. sum > -9 dbest: unreachable sums are cut off (unit-norm features only)
+                    float d;
                     if constexpr (LPQ == 8) {
                         // (wave-uniform branch: the search radius is the same for every query of a step)
-                        if constexpr (NCT_PM_FAR_STAGE == NCT_PM_NEAR_STAGE) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, need);
-                        else if (far) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, need);
-                        else d = pm_dist8<MODE, RW, NCT_PM_NEAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, need);
+                        if (far) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                        else d = pm_dist8<MODE, RW, NCT_PM_NEAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
                     }
-                    else d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, need);
-                }
-                if (fround >= 0) {
-                    if (valid && v == 0) s_fr[wvf][fslot] = d;
-                    ++fround;
-                    if (fround * GPWF >= nlist) {
-                        // the last far round: every query consumes its samples in order until one is accepted
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        { const uint4 own = s_fq[wvf][gwf]; ax = own.x & 0xFFFF; ay = own.x >> 16; lx = own.y & 0xFF; ly = (own.y >> 8) & 0xFF; amask = own.y >> 16; }
-                        bool moved = false;
-                        int mq = rs_start;
-#pragma unroll
-                        for (int q = 0; q < NFMAX; ++q) {
-                            if (q < nf && !moved) {
-                                if ((fst >> q) & 1u) {
-                                    float dq = s_fr[wvf][gwf * NFMAX + q];
-                                    if (dq >= dbest) dq = dbest;
-                                    if (dq + FLT_MIN < dbest) {
-                                        // the sample's position once more (the best has not moved since the speculation: the same draw)
-                                        const int xmin = max(xbest - mq, 0), xmax = min(xbest + mq + 1, g.bw), ymin = max(ybest - mq, 0), ymax = min(ybest + mq + 1, g.bh);
-                                        const int wx = xmax - xmin, wy = ymax - ymin;
-                                        const int rx = (int)(rand_u01(seed, ax, ay, iter, q, 0) * (float)wx), ry = (int)(rand_u01(seed, ax, ay, iter, q, 1) * (float)wy);
-                                        xbest = xmin + (rx == wx ? 0 : rx); ybest = ymin + (ry == wy ? 0 : ry); dbest = dq; moved = true; if (live && v == 0) ++naccept;
-                                    }
-                                }
-                                if (live && v == 0) ++nevals;
-                                fst += 16u;
-                            }
-                            mq >>= 1;
-                        }
-                        // the walk goes on with the first sample some query of the wave has not consumed
-                        int cmin = nf;
-#pragma unroll
-                        for (int c = NFMAX - 1; c >= 0; --c) if (c < nf && __builtin_amdgcn_ballot_w64((int)(fst >> 4) == c) != 0) cmin = c;
-                        k = nprop + cmin; mag = rs_start >> cmin;
-                        fround = -1;
-                    }
-                    continue;
-                }
-                if (valid) {
+                    else d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
                     if (d >= dbest) d = dbest;                       // cutoff clamp of dist_compute_single
                     if (d + rr < dbest) { xbest = xp; ybest = yp; dbest = d; if (live && v == 0) ++naccept; }
                     if (live && v == 0) ++nevals;
                 }
-                ++k;
             }
         }
         if (live && v == 0) {
@@ -744,14 +553,14 @@ __device__ __forceinline__ int pm_xcd_tile(int bid, int ntiles) {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
-__device__ __forceinline__ void pm_count(unsigned long long* __restrict__ counter, int v, unsigned nevals, unsigned naccept, unsigned nsk = 0) {
-    if (counter) {                 // [0] evaluations, [1] accepted candidates, [2] sketch-tested random samples, [3] of them rejected by the sketch
-        __shared__ unsigned s_cnt[4];
-        if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+__device__ __forceinline__ void pm_count(unsigned long long* __restrict__ counter, int v, unsigned nevals, unsigned naccept) {
+    if (counter) {
+        __shared__ unsigned s_cnt[2];
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        if (v == 0) { atomicAdd(&s_cnt[0], nevals); atomicAdd(&s_cnt[1], naccept); if (nsk) { atomicAdd(&s_cnt[2], nsk & 0xFFFFu); atomicAdd(&s_cnt[3], nsk >> 16); } }
+        if (v == 0) { atomicAdd(&s_cnt[0], nevals); atomicAdd(&s_cnt[1], naccept); }
         __syncthreads();
-        if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(counter + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]);
+        if (threadIdx.x < 2) atomicAdd(counter + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]);
     }
 }
 
@@ -763,9 +572,9 @@ __global__ __launch_bounds__(256, NCH == 8 ? 2 : (LPQ == 8 ? NCT_PM_OCC8 : 1)) v
     const int bid = pm_xcd_tile((int)blockIdx.x - (second ? nblk0 : 0), J.g.tiles_x * J.g.tiles_y);
     const int ty = bid / J.g.tiles_x, tx = bid - ty * J.g.tiles_x;
     extern __shared__ float4 s_a[];
-    unsigned nevals = 0, naccept = 0, nsk = 0;
-    pm_step_tile<NCH, MODE, TQX, TQY, LPQ, NCT_PM_STEP_COH>(J, tx, ty, mode, jump, iter, tstep, strip, s_a, nevals, naccept, nsk);
-    pm_count(counter, (int)(threadIdx.x % LPQ), nevals, naccept, nsk);
+    unsigned nevals = 0, naccept = 0;
+    pm_step_tile<NCH, MODE, TQX, TQY, LPQ, NCT_PM_STEP_COH>(J, tx, ty, mode, jump, iter, tstep, strip, s_a, nevals, naccept);
+    pm_count(counter, (int)(threadIdx.x % LPQ), nevals, naccept);
 }
 
 // ---- C = 64 / 128, propagation-only steps (jump 8 / 4 / 2: three of the four launches of an iteration) with the candidates of a wave's SIXTEEN (C = 128: eight) queries packed (round 4).
@@ -969,9 +778,9 @@ __device__ __forceinline__ PMJob pm_job_sgpr(pm_lds_call* c) {
 template <int NCH, int MODE, int TQX, int TQY, int LPQ>
 __device__ __attribute__((noinline)) void pm_level_step_fn(pm_lds_f4* s_a, pm_lds_call* c, pm_lds_u32* cnt) {
     const PMJob J = pm_job_sgpr(c);
-    unsigned nevals = 0, naccept = 0, nsk = 0;
+    unsigned nevals = 0, naccept = 0;
     pm_step_tile<NCH, MODE, TQX, TQY, LPQ, NCT_PM_LEVEL_COH>(J, pm_sgpr(c->tx), pm_sgpr(c->ty), pm_sgpr(c->mode), pm_sgpr(c->jump), pm_sgpr(c->iter), pm_sgpr(c->tstep), pm_sgpr(c->strip),
-                                                             (float4*)s_a, nevals, naccept, nsk);
+                                                             (float4*)s_a, nevals, naccept);
     if (pm_sgpr(c->counting) && (threadIdx.x % LPQ) == 0 && (nevals | naccept)) { atomicAdd((unsigned*)cnt, nevals); atomicAdd((unsigned*)cnt + 1, naccept); }
 }
 template <int NCH, int MODE, int TQX, int TQY, int LPQ>
@@ -1082,8 +891,7 @@ template <int NCH> struct PMLanes { static constexpr int LPQ = NCH == 1 ? 8 : 16
 template <int NCH, int MODE>
 static int launch_mode(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob& j1, int nblk0, int nblk1, int mode, int jump, int iter, int tstep, int strip, unsigned long long* counter) {
     constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY, LPQ = PMLanes<NCH>::LPQ;
-    // region pixels x C/4 float4 (+ two float4 of sketch record per region pixel where the instantiation has the sketch test)
-    const size_t lds = NCH >= 1 ? (size_t)(4 * TQX + 2) * (4 * TQY + 2) * (NCH * 16 + ((MODE == NCT_PM_ROWREJECT && NCH <= 2) ? PM_SKF4 : 0)) * sizeof(float4) : 0;
+    const size_t lds = NCH >= 1 ? (size_t)(4 * TQX + 2) * (4 * TQY + 2) * NCH * 16 * sizeof(float4) : 0;      // region pixels x C/4 float4
     // > 64 KB of dynamic LDS (C=512: 72 KB for the staged query region) needs the opt-in attribute on this device: set once per context (= per device) and instantiation
     constexpr unsigned abit = 1u << ((NCH > 8 ? 9 : NCH) * 3 + MODE);
     if (lds > 32768 && !(ctx->pm_attr_mask & abit)) {
@@ -1132,7 +940,7 @@ static int launch_step(nct_ctx* ctx, hipStream_t s, const PMJob& j0, const PMJob
 template <int NCH, int MODE>
 static int launch_level_mode(nct_ctx* ctx, hipStream_t s, PMLevel& L) {
     constexpr int TQX = PMTile<NCH>::TQX, TQY = PMTile<NCH>::TQY, LPQ = PMLanes<NCH>::LPQ;
-    const size_t lds = (size_t)(4 * TQX + 2) * (4 * TQY + 2) * (NCH * 16 + ((MODE == NCT_PM_ROWREJECT && NCH <= 2) ? PM_SKF4 : 0)) * sizeof(float4);
+    const size_t lds = (size_t)(4 * TQX + 2) * (4 * TQY + 2) * NCH * 16 * sizeof(float4);
     const void* fn = reinterpret_cast<const void*>(&k_pm_level<NCH, MODE, TQX, TQY, LPQ>);
     if (lds > 32768) NCT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      // > 32 KB of dynamic LDS: per-device opt-in (a host-side call, five per pair)
     static int occ = 0;                                  // per instantiation; every device of this process is the same part
@@ -1186,13 +994,6 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
     const bool lanes8 = C == 64;
     DevBuf<float> a_il(ctx, lanes8 ? (size_t)na * 64 : 1), b_il(ctx, lanes8 ? (size_t)nb * 64 : 1);
     if (!a_il.ok() || !b_il.ok()) return NCT_ERR_HIP;
-    // sketch records of both maps for the random search's exact pre-rejection (k_pm_sketch.hip): the levels with the row-rejection instantiations, from the natural maps
-    const bool sketch = ctx->pm_sketch && pm_mode == NCT_PM_ROWREJECT && (C == 64 || C == 128) && iters > 0 && rs_max >= ctx->pm_sketch_mag && !ctx->pm_persist;
-    DevBuf<float> a_sk(ctx, sketch ? (size_t)na * 8 : 1), b_sk(ctx, sketch ? (size_t)nb * 8 : 1);
-    if (!a_sk.ok() || !b_sk.ok()) return NCT_ERR_HIP;
-    if (sketch) { const int rc = nctk_pm_sketch(ctx, s, a_hwc, na, b_hwc, nb, C, a_sk, b_sk); if (rc) return rc; }
-    const float* skA = sketch ? (const float*)a_sk : nullptr; const float* skB = sketch ? (const float*)b_sk : nullptr;
-    const int sk_mag = ctx->pm_sketch_mag;
     if (lanes8) {
         hipLaunchKernelGGL(k_pm_interleave64, dim3(cdiv(na * 8, 256)), dim3(256), 0, s, (const float4*)a_hwc, (float4*)(float*)a_il, na); NCT_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pm_interleave64, dim3(cdiv(nb * 8, 256)), dim3(256), 0, s, (const float4*)b_hwc, (float4*)(float*)b_il, nb); NCT_LAUNCH_CHECK();
@@ -1210,8 +1011,8 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
     // test then); strip: the run's last step writes NNF words without the step stamp
     const bool stamps = 4 * iters <= 250;
     auto step = [&](int in, int out, int mode, int jump, int iter, int tstep, int strip) -> int {
-        PMJob j0{a_hwc, b_hwc, (const uint2*)b_h16, na_buf[in], da_buf[in], mode ? na_buf[out] : nullptr, da_buf[out], ga, rs_max, seed_ab, skA, skB, sk_mag};
-        PMJob j1{b_hwc, a_hwc, (const uint2*)a_h16, nb_buf[in], db_buf[in], mode ? nb_buf[out] : nullptr, db_buf[out], gb, rs_max, seed_ba, skB, skA, sk_mag};
+        PMJob j0{a_hwc, b_hwc, (const uint2*)b_h16, na_buf[in], da_buf[in], mode ? na_buf[out] : nullptr, da_buf[out], ga, rs_max, seed_ab};
+        PMJob j1{b_hwc, a_hwc, (const uint2*)a_h16, nb_buf[in], db_buf[in], mode ? nb_buf[out] : nullptr, db_buf[out], gb, rs_max, seed_ba};
         switch (C) {
             case 64:  return launch_step<1>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, eval_counter, pm_mode);
             case 128: return launch_step<2>(ctx, s, j0, j1, nblk0, nblk1, mode, jump, iter, tstep, strip, eval_counter, pm_mode);
@@ -1228,8 +1029,8 @@ static int pm_run(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* 
         if (!ctl.ok()) return NCT_ERR_HIP;
         NCT_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(uint32_t), s));
         PMLevel L;
-        L.j0 = PMJob{a_hwc, b_hwc, (const uint2*)b_h16, nullptr, nullptr, nullptr, nullptr, ga, rs_max, seed_ab, nullptr, nullptr, 0};
-        L.j1 = PMJob{b_hwc, a_hwc, (const uint2*)a_h16, nullptr, nullptr, nullptr, nullptr, gb, rs_max, seed_ba, nullptr, nullptr, 0};
+        L.j0 = PMJob{a_hwc, b_hwc, (const uint2*)b_h16, nullptr, nullptr, nullptr, nullptr, ga, rs_max, seed_ab};
+        L.j1 = PMJob{b_hwc, a_hwc, (const uint2*)a_h16, nullptr, nullptr, nullptr, nullptr, gb, rs_max, seed_ba};
         for (int i = 0; i < 2; ++i) { L.nn0[i] = na_buf[i]; L.dd0[i] = da_buf[i]; L.nn1[i] = nb_buf[i]; L.dd1[i] = db_buf[i]; }
         L.nblk0 = nblk0; L.nblk1 = nblk1; L.nsteps = 1 + 4 * iters; L.packed = 0; L.ctl = ctl; L.err = ctx->d_pm_err; L.counter = eval_counter;
         L.timeout_ticks = 25000000;                    // 0.25 s of the 100 MHz wall clock

@@ -108,8 +108,6 @@ int nct_create(int device, nct_ctx** out) {
     if (const char* q = getenv("NCT_CONV_PAIR")) { const int v = atoi(q); if (v == 0 || v == 1) c->conv_pair = v; }
     if (const char* q = getenv("NCT_KNN_RUNS")) { const int v = atoi(q); if (v == 0 || v == 1) c->knn_runs = v; }
     if (const char* q = getenv("NCT_PM_PERSIST")) { const int v = atoi(q); if (v == 0 || v == 1) c->pm_persist = v; }
-    if (const char* q = getenv("NCT_PM_SKETCH")) { const int v = atoi(q); if (v == 0 || v == 1) c->pm_sketch = v; }
-    if (const char* q = getenv("NCT_PM_SKETCH_MAG")) { const int v = atoi(q); if (v >= 1) c->pm_sketch_mag = v; }
     if (const char* q = getenv("NCT_PM_PERSIST_WGS")) { const int v = atoi(q); if (v > 0) c->pm_persist_wgs = v; }
     if (const char* q = getenv("NCT_S1_HUB_HINT")) { const int v = atoi(q); if (v == 0 || v == 1) c->s1_hub_hint = v; }
     if (const char* q = getenv("NCT_S1_HUB_WAIT")) { const int v = atoi(q); if (v == 0 || v == 1) c->s1_hub_wait = v; }
@@ -124,8 +122,6 @@ int nct_ctx_counter(nct_ctx* ctx, int which, int64_t* out) {
         case NCT_CTR_ARENA_BYTES: *out = (int64_t)ctx->bytes_allocated; return NCT_OK;
         case NCT_CTR_S1_HUB_BLOCKS_L0: case NCT_CTR_S1_HUB_BLOCKS_L0 + 1: case NCT_CTR_S1_HUB_BLOCKS_L0 + 2: case NCT_CTR_S1_HUB_BLOCKS_L0 + 3: case NCT_CTR_S1_HUB_BLOCKS_L0 + 4:
             *out = ctx->s1_hub_blocks_last[which - NCT_CTR_S1_HUB_BLOCKS_L0]; return NCT_OK;
-        case NCT_CTR_PM_SKETCH_TESTED: *out = ctx->pm_sketch_last[0]; return NCT_OK;
-        case NCT_CTR_PM_SKETCH_REJECTED: *out = ctx->pm_sketch_last[1]; return NCT_OK;
     }
     return ctx->fail(NCT_ERR_INVALID, "nct_ctx_counter: unknown counter %d", which);
 }
@@ -396,8 +392,7 @@ int nct_pm_bench_run_bidir(nct_ctx* ctx, int iters, int rs_max, uint32_t seed, i
     float ms = 0.f;
     NCT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (kernel_ms) *kernel_ms = ms;
-    if (counters) { unsigned long long h[4] = {0, 0, 0, 0}; NCT_HIP(hipMemcpy(h, counter, sizeof h, hipMemcpyDeviceToHost)); for (int i = 0; i < 2; ++i) counters[i] = (uint64_t)h[i];
-                    ctx->pm_sketch_last[0] = (long long)h[2]; ctx->pm_sketch_last[1] = (long long)h[3]; }
+    if (counters) { unsigned long long h[2] = {0, 0}; NCT_HIP(hipMemcpy(h, counter, sizeof h, hipMemcpyDeviceToHost)); for (int i = 0; i < 2; ++i) counters[i] = (uint64_t)h[i]; }
     if (ann_out) NCT_HIP(hipMemcpy(ann_out, an, sizeof(uint32_t) * na, hipMemcpyDeviceToHost));
     if (annd_out) NCT_HIP(hipMemcpy(annd_out, ad, sizeof(float) * na, hipMemcpyDeviceToHost));
     if (bnn_out) NCT_HIP(hipMemcpy(bnn_out, bn, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost));

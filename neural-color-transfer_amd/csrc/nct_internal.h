@@ -34,9 +34,6 @@ struct nct_ctx {
     int home_xcd = 0;                           // the XCD this context's single-XCD launches aim at (k_s1.hip: small S1 levels); contexts of a process count round-robin (nct_create)
     int pm_persist = 0;                         // PatchMatch: one persistent launch per pyramid level (k_pm_level) instead of 1 + 4 iters launches (env NCT_PM_PERSIST)
     int pm_persist_wgs = 0;                     // workgroups of that launch (0: CUs x occupancy; env NCT_PM_PERSIST_WGS, experiments)
-    int pm_sketch = 1;                          // PatchMatch: exact pre-rejection of far random samples from 8-float PCA sketch records (k_pm_sketch.hip) at C = 64 / 128; NCT_PM_SKETCH=0: off (same results)
-    int pm_sketch_mag = 8;                      // smallest search radius whose samples are sketch-tested (NCT_PM_SKETCH_MAG)
-    long long pm_sketch_last[2] = {0, 0};       // random samples sketch-tested / rejected in the last COUNTED PatchMatch run (nct_pm_bench_run_bidir with counters; a pair with NCT_FLAG_COUNT_EVALS): nct_ctx_counter
     uint32_t* d_pm_err = nullptr;               // device word the persistent kernel's watchdog sets; read by nctk_pm_check at the synchronisation points
     unsigned pm_attr_mask = 0;                 // k_pm_step instantiations whose dynamic-LDS opt-in has been set on this context's device
     // stage clock: events recorded on the main stream at stage boundaries, read once after the pair's final synchronise
@@ -108,8 +105,6 @@ int nctk_normalize(nct_ctx* ctx, hipStream_t s, const float* src_hwc, float* dst
 int nctk_feature_distance(nct_ctx* ctx, hipStream_t s, const float* a_hwc, const float* b_hwc, float* err, int C, int HW);
 // k_patchmatch.hip: after a stream synchronise — has a persistent PatchMatch level's watchdog fired since the last check? (NCT_ERR_HIP then; no-op without pm_persist)
 int nctk_pm_check(nct_ctx* ctx);
-// k_pm_sketch.hip: [n][8] sketch records (7 principal coordinates + residual norm) of two channel-last maps under their pooled principal directions; C = 64 or 128
-int nctk_pm_sketch(nct_ctx* ctx, hipStream_t s, const float* a_hwc, int na, const float* b_hwc, int nb, int C, float* skA, float* skB);
 // k_nnf.hip
 int nctk_nnf_init(nct_ctx* ctx, hipStream_t s, uint32_t* nnf, int ah, int aw, int bh, int bw);
 int nctk_nnf_upsample(nct_ctx* ctx, hipStream_t s, const uint32_t* nnf_half, uint32_t* nnf, int ah, int aw, int bh, int bw, int ah_half, int aw_half);

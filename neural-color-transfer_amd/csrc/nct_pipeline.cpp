@@ -297,9 +297,7 @@ static int process_resident(nct_ctx* ctx, const nct_params* prm, nct_pair_timing
         if (count) {
             unsigned long long h[32];
             NCT_HIP(hipMemcpy(h, ctx->d_counter, sizeof h, hipMemcpyDeviceToHost));
-            ctx->pm_sketch_last[0] = ctx->pm_sketch_last[1] = 0;
-            for (int l = 0; l < 5; ++l) { timing->pm_level_evals[l] = h[4 * l]; timing->pm_level_accepted[l] = h[4 * l + 1];
-                                          ctx->pm_sketch_last[0] += (long long)h[4 * l + 2]; ctx->pm_sketch_last[1] += (long long)h[4 * l + 3]; }
+            for (int l = 0; l < 5; ++l) { timing->pm_level_evals[l] = h[4 * l]; timing->pm_level_accepted[l] = h[4 * l + 1]; }
         }
     }
     return NCT_OK;

@@ -154,7 +154,7 @@ class PairTiming(C.Structure):
         return d
 
 
-CTR_ARENA_BYTES, CTR_S1_HUB_BLOCKS_L0, CTR_PM_SKETCH_TESTED, CTR_PM_SKETCH_REJECTED = 0, 1, 6, 7
+CTR_ARENA_BYTES, CTR_S1_HUB_BLOCKS_L0 = 0, 1
 FLAG_FEAT16 = 1
 FLAG_COUNT_EVALS = 2
 FLAG_LATENCY = 4

@@ -164,51 +164,6 @@ def test_patchmatch_bidir_bit_exact(ctx, oracle, C, ah, aw, bh, bw, rs):
     assert counts[0] == counts[1] and counts[0][0] > 0 and counts[0][1] > 0           # same candidates, same acceptances
 
 
-def _vgg_tap_features(oracle, tap, n, kind):
-    """raw (un-normalised) CHW taps of two images through the oracle's VGG19 with the synthetic weights: what the pipeline's PatchMatch levels see"""
-    from caffemodel_io import synthetic_vgg19
-    ws, bs = synthetic_vgg19(19)
-    mk = synth.image if kind == "cosines" else synth.image_flat
-    S, R = mk(1000, n, n), mk(1001, n + 8, n - 8)
-    return oracle.vgg19_features(S, ws, bs, deepest_tap=tap)[tap - 1], oracle.vgg19_features(R, ws, bs, deepest_tap=tap)[tap - 1]
-
-
-@pytest.mark.parametrize("tap,n,kind,dead", [(1, 96, "cosines", False), (1, 96, "flat", False), (2, 144, "cosines", False), (2, 144, "flat", True), (1, 80, "cosines", True)])
-@pytest.mark.parametrize("mag", [1, 8])
-def test_patchmatch_sketch_prerejection_bit_exact(oracle, monkeypatch, tap, n, kind, dead, mag):
-    """Round 6: far random samples are pre-rejected from 8-float PCA sketch records (k_pm_sketch.hip: y_a.y_b + rho_a rho_b >= a.b for orthonormal principal
-    directions) before their feature tiles are fetched. EXACT by construction — a sample is dropped only when its bound cannot reach the current best — so the field must
-    stay the oracle's (which evaluates every sample in full) bit for bit, in both directions, on real VGG taps (conv1_1: C = 64, conv2_1: C = 128; cosine images and images
-    with flat regions, where the first-row test rejects nothing), with dead (NaN) feature pixels, with every radius tested (NCT_PM_SKETCH_MAG=1: the tightest margins)
-    and with the default (8). The counters show the path is live: the test rejects a large share of what it sees; NCT_PM_SKETCH=0 tests nothing and gives the same field."""
-    import nct
-    fa, fb = _vgg_tap_features(oracle, tap, n, kind)
-    if dead:
-        fa[:, 5:9, 7:12] = 0; fb[:, 3:8, 2:6] = 0; fb[:, 0, 0] = 0
-    a, b = oracle.feat_normalize(fa), oracle.feat_normalize(fb)
-    C, ah, aw = a.shape; _, bh, bw = b.shape
-    seed, rs = 123, 32
-    o_ann, o_annd = oracle.patchmatch(a, b, oracle.nnf_init(ah, aw, bh, bw), iters=5, rs_max=rs, seed=seed)
-    o_bnn, o_bnnd = oracle.patchmatch(b, a, oracle.nnf_init(bh, bw, ah, aw), iters=5, rs_max=rs, seed=seed ^ 0x5bd1e995)
-    results = {}
-    for sk in ("1", "0"):
-        monkeypatch.setenv("NCT_PM_SKETCH", sk); monkeypatch.setenv("NCT_PM_SKETCH_MAG", str(mag))
-        with nct.Context(0) as c:                              # the switches are read when a context is created
-            c.pm_bench_setup(fa, fb)
-            ms, cnt, ann, annd, bnn, bnnd = c.pm_bench_run_bidir(iters=5, rs_max=rs, seed=seed, pm_mode=1, count=True, fetch=True, both=True)
-            tested, rejected = c.counter(nct.CTR_PM_SKETCH_TESTED), c.counter(nct.CTR_PM_SKETCH_REJECTED)
-        assert np.array_equal(ann, o_ann) and np.array_equal(bnn, o_bnn), f"sketch {sk}, radius >= {mag}: NNF differs from the oracle"
-        assert _same_or_both_nan(annd, o_annd) and _same_or_both_nan(bnnd, o_bnnd), f"sketch {sk}: distances differ"
-        results[sk] = (cnt, tested, rejected)
-    assert results["1"][0] == results["0"][0]                    # same candidates considered, same acceptances
-    assert results["0"][1] == 0 and results["0"][2] == 0
-    cnt, tested, rejected = results["1"]
-    nsamp = sum(1 for r in (32, 16, 8, 4, 2, 1) if r >= mag)
-    assert 0 < tested <= 5 * nsamp * (ah * aw + bh * bw) and 0 < rejected <= tested
-    if mag == 8 and not dead:
-        assert rejected > 0.5 * tested, f"the sketch rejected only {rejected} of {tested} far samples on VGG taps"
-
-
 @pytest.mark.parametrize("C,ah,aw,bh,bw,rs", [(64, 37, 41, 33, 45, 8), (128, 30, 26, 28, 31, 16), (256, 21, 24, 23, 20, 8), (512, 14, 13, 12, 15, 4), (64, 120, 90, 100, 110, 32)])
 def test_patchmatch_persistent_level_kernel_bit_exact(oracle, monkeypatch, C, ah, aw, bh, bw, rs):
     """Round 6: NCT_PM_PERSIST=1 runs a pyramid level as ONE persistent launch — k_pm_level: (step, tile) items from per-(step, XCD) ticket counters,
