@@ -526,7 +526,8 @@ __device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int
                     float d;
                     if constexpr (LPQ == 8) {
                         // (wave-uniform branch: the search radius is the same for every query of a step)
-                        if (far) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
+                        if constexpr (NCT_PM_FAR_STAGE == NCT_PM_NEAR_STAGE) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);   // one inlined copy, not two
+                        else if (far) d = pm_dist8<MODE, RW, NCT_PM_FAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
                         else d = pm_dist8<MODE, RW, NCT_PM_NEAR_STAGE>(B, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
                     }
                     else d = pm_dist<NCH, MODE, RW>(A, B, Bh, g, ax, ay, amask, xp, yp, v, s_a, lx, ly, EX ? -9.0f * dbest : -FLT_MAX);
