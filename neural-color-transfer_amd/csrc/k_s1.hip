@@ -270,10 +270,24 @@ __device__ __forceinline__ void s1_op(const S1Sys& S, const double* __restrict__
 #pragma unroll
             for (int c = 0; c < 3; ++c) { ya[c] += wt * (a[c] - q[c]); yb[c] += wt * (b[c] - q[3 + c]); }
         };
-        if (x + 1 < w) { const double g = S.gx[i]; edge(i + 1, 2.0 * (g * g)); }
-        if (x > 0) { const double g = S.gx[i - 1]; edge(i - 1, 2.0 * (g * g)); }
-        if (y + 1 < h) { const double g = S.gy[i]; edge(i + w, 2.0 * (g * g)); }
-        if (y > 0) { const double g = S.gy[i - w]; edge(i - w, 2.0 * (g * g)); }
+        // raster neighbours: the four gradient weights and the four records are requested TOGETHER (an absent neighbour reads the pixel itself and is not added) — written as
+        // `if (exists) { g = gx[..]; edge(..) }` each term was a branch of its own with two dependent round trips inside: eight serial trips before the first kNN gather
+        // (round 6, from the ISA; 0.85 of the 3.15 ms of the 44 x 44 level). Added in the same order (+x, -x, +y, -y): same bits.
+        {
+            const bool ex[4] = {x + 1 < w, x > 0, y + 1 < h, y > 0};
+            const int nj[4] = {ex[0] ? i + 1 : i, ex[1] ? i - 1 : i, ex[2] ? i + w : i, ex[3] ? i - w : i};
+            const double g4[4] = {S.gx[i], S.gx[ex[1] ? i - 1 : i], S.gy[i], S.gy[ex[3] ? i - w : i]};
+            double q4[4][6];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ld6(p, (size_t)nj[u], q4[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ex[u]) {
+                    const double wt = 2.0 * (g4[u] * g4[u]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { ya[c] += wt * (a[c] - q4[u][c]); yb[c] += wt * (b[c] - q4[u][3 + c]); }
+                }
+        }
         // nonlocal: out-edges (8 independent gathers per thread), then in-edges
 #pragma unroll
         for (int k = 0; k < 8; ++k) edge(S.knn_id[(size_t)i * 8 + k], S.g.iw2[(size_t)i * 8 + k]);

@@ -170,20 +170,24 @@ __device__ __forceinline__ void lvl_op(const Lvl& L, int i, F&& val /* val(j, q)
     const int W = L.W, H = L.H;
     const int r = i / W, c = i - r * W;
     const double d = L.d[i];
+    // The four couplings and the four neighbour values of every right-hand side are requested TOGETHER (an absent neighbour reads the pixel itself and is not subtracted):
+    // written as `if (exists) { w = wE[..]; y -= w * val(..) }` each direction was a branch of its own with two dependent global round trips inside (round 6, from the ISA).
+    // Subtracted in the same order (+x, -x, +y, -y): same bits.
+    const bool e0 = c + 1 < W, e1 = c > 0, e2 = r + 1 < H, e3 = r > 0;
+    const int j0 = e0 ? i + 1 : i, j1 = e1 ? i - 1 : i, j2 = e2 ? i + W : i, j3 = e3 ? i - W : i;
+    const double w0 = L.wE[i], w1 = L.wE[j1], w2 = L.wS[i], w3 = L.wS[j3];
+    double v0[NQ], v1[NQ], v2[NQ], v3[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) y[q] = d * val(i, q);
-    if (c + 1 < W) { const double w = L.wE[i];
+    for (int q = 0; q < NQ; ++q) { y[q] = val(i, q); v0[q] = val(j0, q); v1[q] = val(j1, q); v2[q] = val(j2, q); v3[q] = val(j3, q); }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= w * val(i + 1, q); }
-    if (c > 0) { const double w = L.wE[i - 1];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= w * val(i - 1, q); }
-    if (r + 1 < H) { const double w = L.wS[i];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= w * val(i + W, q); }
-    if (r > 0) { const double w = L.wS[i - W];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q] -= w * val(i - W, q); }
+    for (int q = 0; q < NQ; ++q) {
+        double t = d * y[q];
+        t = e0 ? t - w0 * v0[q] : t;
+        t = e1 ? t - w1 * v1[q] : t;
+        t = e2 ? t - w2 * v2[q] : t;
+        t = e3 ? t - w3 * v3[q] : t;
+        y[q] = t;
+    }
 }
 
 // ---- hierarchy construction (fp64; the oracle mirrors every expression: oracle/orc_wls_mg.c mg_weights / mg_pstencil / mg_galerkin / mg_finish)
@@ -420,6 +424,8 @@ __device__ __forceinline__ void lds_op(const PxCoef& c, const vf* __restrict__ s
 #pragma unroll
             for (int q = 0; q < NQ; ++q) y[q] -= c.w[k] * s_v[q * LN + p + lds_off<LW>(k)];
         }
+    // (round 6: every coupling is a branch of its own with its LDS round trip inside — 58-105 exec-mask branches per leg in the ISA. Reading the neighbours unconditionally
+    //  and adding w * (exists ? v : 0), as mid_op below does, halves the branches but costs the 9-point legs 90 instead of 52 registers: 9.2 / 9.8 against 9.1 / 9.5 us; not kept here)
 }
 // XCD-aware tile order (round 4): consecutive workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2. A 2-D grid puts neighbouring tiles on different
 // XCDs, so every halo pixel was fetched from the fabric again (k_mg_up: 131 MB per launch for 66 MB of compulsory bytes, 84 % L2 misses). The legs run on a 1-D grid and
@@ -539,16 +545,20 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
         const int o1 = (oy && ox) ? -LW + 1 : (ox ? 1 : LW);
         const bool e1 = (oy && ox) ? xr : (ox ? xr : yd);
         const bool e2 = oy && ox && yd, e3 = oy && ox && yd && xr;
+        // (the four parent values of every right-hand side in ONE LDS round trip — an absent parent reads the first one's position and is not added; the conditional
+        //  reads were up to three more dependent round trips per right-hand side)
+        const bool copy = !oy && !ox;
+        const int a1 = e1 ? o1 : o0, a2 = e2 ? LW - 1 : o0, a3 = e3 ? LW + 1 : o0;
+        vf v0[NQ], v1[NQ], v2[NQ], v3[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { v0[q] = s_a[q * LN + p + (copy ? 0 : o0)]; v1[q] = s_a[q * LN + p + (copy ? 0 : a1)]; v2[q] = s_a[q * LN + p + (copy ? 0 : a2)]; v3[q] = s_a[q * LN + p + (copy ? 0 : a3)]; }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            vf e;
-            if (!oy && !ox) e = s_a[q * LN + p];
-            else {
-                e = pw[0] * s_a[q * LN + p + o0];
-                if (e1) e += pw[1] * s_a[q * LN + p + o1];
-                if (e2) e += pw[2] * s_a[q * LN + p + LW - 1];
-                if (e3) e += pw[3] * s_a[q * LN + p + LW + 1];
-            }
+            vf e = pw[0] * v0[q];
+            e = e1 ? e + pw[1] * v1[q] : e;
+            e = e2 ? e + pw[2] * v2[q] : e;
+            e = e3 ? e + pw[3] * v3[q] : e;
+            e = copy ? v0[q] : e;
             xk[q] = xk[q] + e; s_b[q * LN + p] = xk[q];
         }
     }
@@ -757,35 +767,47 @@ __device__ __forceinline__ vf mid_op(const PxCoef& c, const vf* __restrict__ s_v
     const vf v0 = s_v[i];
     if (centre) *centre = v0;
     vf y = c.d * v0;
+    // All eight neighbours in ONE LDS round trip: an absent one (image border) reads the pixel itself and contributes w * 0 with w = +0 (px_coef): y - (+0) = y for every y, -0
+    // included — the bits of the skipped term. Written as `if (exists) y -= w * s_v[..]` every coupling was a branch of its own with its own LDS round trip: eight serialised
+    // round trips per application, ~24 applications per call (round 6, from the ISA: k_mg_mid 36.5 -> 31.3 us).
+    vf t[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (c.ex & (1u << k)) y -= c.w[k] * s_v[i + nb_dy(k) * W + nb_dx(k)];
+    for (int k = 0; k < 8; ++k) t[k] = s_v[(c.ex & (1u << k)) ? i + nb_dy(k) * W + nb_dx(k) : i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y -= c.w[k] * ((c.ex & (1u << k)) ? t[k] : 0.0f);
     return y;
 }
 // restricted residual of coarse pixel I of the grid (Wc wide) below the fine grid (Wf x Hf): sum over the 3x3 block around fine point (2Y, 2X), row-major
 __device__ __forceinline__ vf mid_restrict(const vf* __restrict__ s_res, const vf (&ps)[9], int I, int Wc, int Wf, int Hf) {
     const int Y = I / Wc, X = I - Y * Wc, r = 2 * Y, c = 2 * X;
-    vf acc = 0.0f;
+    vf acc = 0.0f, t[9]; bool in[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < 9; ++k) {                            // nine reads in one LDS round trip (an absent fine point reads the centre and is not added)
         const int yy = r + k / 3 - 1, xx = c + k % 3 - 1;
-        if (yy >= 0 && yy < Hf && xx >= 0 && xx < Wf) acc += ps[k] * s_res[yy * Wf + xx];
+        in[k] = yy >= 0 && yy < Hf && xx >= 0 && xx < Wf;
+        t[k] = s_res[in[k] ? yy * Wf + xx : r * Wf + c];
     }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc = in[k] ? acc + ps[k] * t[k] : acc;
     return acc;
 }
 // P e at fine pixel (gy, gx) from the child's correction s_c (Wc x Hc): the existing parents in the order NW, NE, SW, SE (W, E / N, S on a line)
 __device__ __forceinline__ vf mid_prolong(const vf* __restrict__ s_c, const vf (&pw)[4], int gy, int gx, int Wc, int Hc) {
     const int Y0 = gy >> 1, X0 = gx >> 1;
     const bool oy = (gy & 1) != 0, ox = (gx & 1) != 0;
-    if (!oy && !ox) return s_c[Y0 * Wc + X0];
     const bool xr = X0 + 1 < Wc, yd = Y0 + 1 < Hc;
-    vf e = pw[0] * s_c[Y0 * Wc + X0];
+    // the (up to) four parents in ONE LDS round trip; an absent one reads the first parent and is not added. Terms and order as before:
+    // centre: NW + NE + SW + SE; row line point (ox only): W + E; column line point (oy only): N + S
+    const int i00 = Y0 * Wc + X0, i01 = xr ? i00 + 1 : i00, i10 = yd ? i00 + Wc : i00, i11 = (yd && xr) ? i00 + Wc + 1 : i00;
+    const vf c00 = s_c[i00], c01 = s_c[i01], c10 = s_c[i10], c11 = s_c[i11];
+    if (!oy && !ox) return c00;
+    vf e = pw[0] * c00;
     if (oy && ox) {
-        if (xr) e += pw[1] * s_c[Y0 * Wc + X0 + 1];
-        if (yd) e += pw[2] * s_c[(Y0 + 1) * Wc + X0];
-        if (yd && xr) e += pw[3] * s_c[(Y0 + 1) * Wc + X0 + 1];
-    } else if (ox) { if (xr) e += pw[1] * s_c[Y0 * Wc + X0 + 1]; }
-    else { if (yd) e += pw[1] * s_c[(Y0 + 1) * Wc + X0]; }
+        e = xr ? e + pw[1] * c01 : e;
+        e = yd ? e + pw[2] * c10 : e;
+        e = (yd && xr) ? e + pw[3] * c11 : e;
+    } else if (ox) { e = xr ? e + pw[1] * c01 : e; }
+    else { e = yd ? e + pw[1] * c10 : e; }
     return e;
 }
 // Level D of the fused sub-cycle. In: this level's right-hand side b[] in registers (pixel i = t + k * MID_T). Out: this level's correction
