@@ -429,13 +429,14 @@ __global__ __launch_bounds__(256) void k_s1_update(int n, int nb, const double* 
     double2 rv[3], wv[3], pv[3], sv[3], xv[3];
     const double2* r2 = reinterpret_cast<const double2*>(r6); const double2* w2 = reinterpret_cast<const double2*>(w6);
     const double2* x2 = reinterpret_cast<const double2*>(x6); const double2* p2 = reinterpret_cast<const double2*>(p6); const double2* s2 = reinterpret_cast<const double2*>(s6);
+    // (all fifteen loads in one round trip: elements beyond the end — the last workgroup only — read the vector's last element and are not written. As `if (g < total) { loads }`
+    //  per k the three groups were three dependent round trips: round 6, from the ISA)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const size_t g = base + (size_t)k * 256;
-        if (g < total) {
-            rv[k] = r2[g]; wv[k] = w2[g]; xv[k] = x2[g];
-            if (!first_vec) { pv[k] = p2[g]; sv[k] = s2[g]; } else { pv[k] = make_double2(0.0, 0.0); sv[k] = make_double2(0.0, 0.0); }
-        }
+        const size_t g0 = base + (size_t)k * 256, g = g0 < total ? g0 : total - 1;
+        rv[k] = r2[g]; wv[k] = w2[g]; xv[k] = x2[g];
+        pv[k] = p2[g]; sv[k] = s2[g];
+        if (first_vec) { pv[k] = make_double2(0.0, 0.0); sv[k] = make_double2(0.0, 0.0); }
     }
     double al[3], be[3]; bool act[3];
     if constexpr (FUSED) {

@@ -212,31 +212,55 @@ __global__ __launch_bounds__(256) void k_vote_features(const uint32_t* __restric
     float pw = 0.f;
     const bool img = b_img != nullptr && v < 3;
     int ia = 0, ib = 0, acnt = 0, bcnt = 0;
-    // coherence (avg_vote_bds_a): float += double  ==> evaluate in double, round to float each time
-    if (live)
-    for (int dx = -1; dx <= 1; ++dx)
-        for (int dy = -1; dy <= 1; ++dy) {
+    // coherence (avg_vote_bds_a): float += double  ==> evaluate in double, round to float each time.
+    // The nine NNF words are requested together, then the feature rows of up to G taps together (an absent tap reads row 0 and is not added): as a dx / dy loop with the
+    // loads inside its two conditions, every tap was two dependent round trips — eighteen before the completeness part started (round 6, from the ISA). Same order of
+    // additions (dx outer, dy inner): same bits.
+    if (live) {
+        uint32_t vps[9]; bool ok[9]; int src_px[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dx = t / 3 - 1, dy = t % 3 - 1;
             const int nx = ax + dx, ny = ay + dy;
-            if (nx < aw && nx >= 0 && ny < ah && ny >= 0) {
-                const uint32_t vp = ann[ny * aw + nx];
-                const int xp = nnf_x(vp) - dx, yp = nnf_y(vp) - dy;
-                if (xp < bw && xp >= 0 && yp < bh && yp >= 0) {
+            ok[t] = nx < aw && nx >= 0 && ny < ah && ny >= 0;
+            vps[t] = ann[ok[t] ? ny * aw + nx : ay * aw + ax];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dx = t / 3 - 1, dy = t % 3 - 1;
+            const int xp = nnf_x(vps[t]) - dx, yp = nnf_y(vps[t]) - dy;
+            ok[t] = ok[t] && xp < bw && xp >= 0 && yp < bh && yp >= 0;
+            src_px[t] = ok[t] ? yp * bw + xp : 0;
+        }
+        constexpr int G = NR == 1 ? 9 : (NR == 2 ? 3 : 1);
+#pragma unroll
+        for (int t0 = 0; t0 < 9; t0 += G) {
+            float4 xs[G][NR]; int ib3[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const float4* src = reinterpret_cast<const float4*>(pin + (size_t)src_px[t0 + u] * C);
+#pragma unroll
+                for (int k = 0; k < NR; ++k) xs[u][k] = k < nch ? src[v + 16 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                ib3[u] = img ? (int)b_img[(size_t)src_px[t0 + u] * 3 + v] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+                if (ok[t0 + u]) {
                     pw = (float)((double)pw + wa);
-                    if (img) ia += b_img[((size_t)yp * bw + xp) * 3 + v];
+                    if (img) ia += ib3[u];
                     ++acnt;
-                    const float4* src = reinterpret_cast<const float4*>(pin + ((size_t)yp * bw + xp) * C);
 #pragma unroll
                     for (int k = 0; k < NR; ++k)
                         if (k < nch) {
-                            const float4 x = src[v + 16 * k];
+                            const float4 x = xs[u][k];
                             acc[k].x = (float)((double)acc[k].x + (double)x.x * wa);
                             acc[k].y = (float)((double)acc[k].y + (double)x.y * wa);
                             acc[k].z = (float)((double)acc[k].z + (double)x.z * wa);
                             acc[k].w = (float)((double)acc[k].w + (double)x.w * wa);
                         }
                 }
-            }
         }
+    }
     // completeness (avg_vote_bds_b): atomicAdd(float*, (float)(wb*pin)) in the canonical order of the header comment. The nine lists' first blocks and the block sums
     // of their further blocks form ONE sequence per target (list 0's sources, list 0's block sums, list 1's sources, …); lane u of the row decodes entry j0 + u of it —
     // sixteen inverse-map words requested at once — and the row then consumes the sixteen entries in order, four feature rows in flight.
