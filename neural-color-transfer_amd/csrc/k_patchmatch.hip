@@ -367,6 +367,30 @@ struct PMJob { const float* A; const float* B; const uint2* Bh; const uint32_t* 
 // LPQ = 8 (C = 64, 128 with fp32 tiles): 32 queries per pass, an 8x4 sub-tile, two queries per DPP row (see pm_dist).
 // One tile of one step (the body of k_pm_step and of the persistent k_pm_level): the workgroup serves the 4 TQX x 4 TQY queries of tile (tx, ty) of job J.
 // s_a: the dynamic LDS region for the staged part of A. nevals / naccept: per-thread counters, accumulated.
+// The staged region of A: RW x RH pixels x C floats, 256 threads. All of a thread's 16-byte loads are issued before the first LDS store (batches of at most nine): written as
+// "for (e = tid; e < N; e += 256) s_a[e] = A[..]" hipcc emitted load -> s_waitcnt vmcnt(0) -> ds_write per trip — six to eighteen DEPENDENT global round trips at the head
+// of every workgroup, the larger part of the per-launch floor of the propagation steps (round 6, from the ISA).
+template <int NCH, int RW, int RH>
+__device__ __forceinline__ void pm_stage_region(const float* __restrict__ A, const PMGeom& g, int ox, int oy, float4* __restrict__ s_a) {
+    constexpr int c4 = 16 * NCH, N = RW * RH * c4, NIT = (N + 255) / 256, BATCH = NIT <= 9 ? NIT : 9;
+#pragma unroll
+    for (int it0 = 0; it0 < NIT; it0 += BATCH) {
+        float4 tmp[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e0 = (int)threadIdx.x + 256 * (it0 + u), e = e0 < N ? e0 : N - 1;
+            const int r = e / c4, j = e - r * c4;
+            const int ry = clampi(oy - 1 + r / RW, 0, g.ah - 1), rx = clampi(ox - 1 + r % RW, 0, g.aw - 1);
+            tmp[u] = reinterpret_cast<const float4*>(A + ((size_t)ry * g.aw + rx) * (64 * NCH))[j];
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e0 = (int)threadIdx.x + 256 * (it0 + u);
+            if (it0 + u < NIT && e0 < N) s_a[e0] = tmp[u];
+        }
+    }
+}
+
 template <int NCH, int MODE, int TQX, int TQY, int LPQ, bool COH>
 __device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int mode, int jump, int iter, int tstep, int strip, float4* __restrict__ s_a, unsigned& nevals, unsigned& naccept) {
     constexpr int RW = 4 * TQX + 2, RH = 4 * TQY + 2;
@@ -409,12 +433,7 @@ __device__ __forceinline__ void pm_step_tile(const PMJob& J, int tx, int ty, int
     // stage the region of A that the queries of this workgroup read (their 3x3 tiles overlap) into LDS once per launch. Without it every
     // evaluation re-reads its 9*C*4-byte query tile through L1.
     if constexpr (NCH >= 1) {
-        const int c4 = g.C >> 2;
-        for (int e = threadIdx.x; e < RW * RH * c4; e += 256) {
-            const int r = e / c4, j = e - r * c4;
-            const int ry = clampi(oy - 1 + r / RW, 0, g.ah - 1), rx = clampi(ox - 1 + r % RW, 0, g.aw - 1);
-            s_a[e] = reinterpret_cast<const float4*>(A + ((size_t)ry * g.aw + rx) * g.C)[j];
-        }
+        pm_stage_region<NCH, RW, RH>(A, g, ox, oy, s_a);
         __syncthreads();
     }
     int rs_start = rs_max;
@@ -623,14 +642,7 @@ __device__ __forceinline__ void pm_prop_tile(const PMJob& J, int tx, int ty, int
             vnb[sub][k] = pm_ld<COH>(nnf_in + clampi(ny, 0, g.ah - 1) * g.aw + clampi(nx, 0, g.aw - 1));
         }
     }
-    {
-        constexpr int c4 = 16 * NCH;
-        for (int e = threadIdx.x; e < RW * RH * c4; e += 256) {
-            const int r = e / c4, j = e - r * c4;
-            const int ry = clampi(oy - 1 + r / RW, 0, g.ah - 1), rx = clampi(ox - 1 + r % RW, 0, g.aw - 1);
-            s_a[e] = reinterpret_cast<const float4*>(A + ((size_t)ry * g.aw + rx) * (64 * NCH))[j];
-        }
-    }
+    pm_stage_region<NCH, RW, RH>(A, g, ox, oy, s_a);
     // ---- phase A: every query lists its live candidates (the rules of k_pm_step: inside both images, not stale, not the current match)
     uint32_t cl[NSUB][4]; int ncl[NSUB];
     int base = 0;
