@@ -441,7 +441,7 @@ constexpr int mg_threads(int TX, int TY, bool X0 = false) { return ((TX + 2 * MG
 // X0 (block step, NCT_S2_LINES): the leg starts from the iterate x1 instead of zero, so sweep 0 is a regular sweep too and every ring moves in by one: one more halo pixel per side.
 template <int NQ, int TX, int TY, typename TB, bool NINE, bool X0 = false>
 __global__ __launch_bounds__(mg_threads(TX, TY, X0)) void k_mg_down(const PState* __restrict__ st, Lvl F, const TB* __restrict__ b, vf* __restrict__ x, Lvl C, vf* __restrict__ bc, const vf* __restrict__ x1 = nullptr) {
-    if (st->nactive == 0) return;
+    const int nact = st->nactive;   // checked below, behind the kernel's first loads: as the first statement it was a dependent scalar round trip in front of everything (round 6)
     constexpr int S0 = X0 ? 1 : 0;
     constexpr int HA = MG_NS + 1 + S0, HB = MG_NS + S0, LW = TX + HA + HB, LH = TY + HA + HB, LN = LW * LH;
     static_assert(LN <= mg_threads(TX, TY, X0) && mg_threads(TX, TY, X0) <= 1024, "one thread per pixel of the tile and its halo");
@@ -467,6 +467,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY, X0)) void k_mg_down(const PState
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { bq[q] = (vf)b[(size_t)q * F.n + i]; xk[q] = X0 ? x1[(size_t)q * F.n + i] : bq[q] * c.dinv; s_a[q * LN + p] = xk[q]; }     // sweep 0 (from zero) / the given iterate
     }
+    if (nact == 0) return;                                   // a launch enqueued past convergence: nothing has been stored to global memory yet
     __syncthreads();
 #pragma unroll
     for (int k = 1 - S0; k < MG_NS; ++k) {
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY, X0)) void k_mg_down(const PState
 template <int NQ, int TX, int TY, typename TB, bool NINE>
 __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __restrict__ st, Lvl L, const TB* __restrict__ b, const vf* __restrict__ x, int Wc, int nc,
                                                               const vf* __restrict__ ec, vf* __restrict__ xo) {
-    if (st->nactive == 0) return;
+    const int nact = st->nactive;   // checked below, behind the kernel's first loads: as the first statement it was a dependent scalar round trip in front of everything (round 6)
     constexpr bool ODD = (MG_NS & 1) != 0;
     constexpr int HA = ODD ? MG_NS + 1 : MG_NS, HB = ODD ? MG_NS : MG_NS + 1, LW = TX + HA + HB, LH = TY + HA + HB, LN = LW * LH;
     constexpr int OL = ODD ? 1 : 0, OR = ODD ? 0 : 1;                          // xe lives on the grid minus its first (odd sweep count) / last (even) row and column
@@ -537,6 +538,7 @@ __global__ __launch_bounds__(mg_threads(TX, TY)) void k_mg_up(const PState* __re
             for (int q = 0; q < NQ; ++q) s_a[q * LN + p] = ec[(size_t)q * nc + ip];
         }
     }
+    if (nact == 0) return;
     __syncthreads();
     if (ring(0)) {                                                             // xe = x + P e_coarse -> s_b (s_a keeps the coarse values the neighbours still read)
         const bool xr = (c.ex & 1u) != 0, yd = (c.ex & 4u) != 0;
@@ -655,7 +657,7 @@ __device__ __forceinline__ void line_solve(const vf* __restrict__ s_r, vf* __res
 }
 template <int NQ, bool POST>
 __global__ __launch_bounds__(LBX * LBY, 8) void k_mg_block(const PState* __restrict__ st, Lvl L, const vf* __restrict__ b, const vf* __restrict__ xin, vf* __restrict__ xout) {
-    if (st->nactive == 0) return;
+    const int nact = st->nactive;   // checked below, behind the kernel's first loads: as the first statement it was a dependent scalar round trip in front of everything (round 6)
     constexpr int XW = LBX + 2, XN = XW * (LBY + 2);
     static_assert(NQ * XN <= (NQ + 6) * LBN, "the halo tile of the iterate lives where e1 and the factors go afterwards");
     __shared__ vf s_all[(2 * NQ + 6) * LBN];
@@ -684,6 +686,7 @@ __global__ __launch_bounds__(LBX * LBY, 8) void k_mg_block(const PState* __restr
 #pragma unroll
         for (int q = 0; q < NQ; ++q) bq[q] = b[(size_t)q * L.n + i];
     }
+    if (nact == 0) return;
     if (POST) {
         __syncthreads();
         if (valid) {                                                             // residual, the stencil in lds_op's order E, W, S, N (level 0 is 5-point)
@@ -694,11 +697,12 @@ __global__ __launch_bounds__(LBX * LBY, 8) void k_mg_block(const PState* __restr
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 own[q] = s_x[q * XN + hp];
+                const vf vE = s_x[q * XN + hp + 1], vW = s_x[q * XN + hp - 1], vS = s_x[q * XN + hp + XW], vN = s_x[q * XN + hp - XW];   // all inside the halo tile; read together (lesson (x))
                 vf y = d * own[q];
-                if (xr) y -= fE_own * s_x[q * XN + hp + 1];
-                if (xl) y -= wW * s_x[q * XN + hp - 1];
-                if (yd) y -= fS_own * s_x[q * XN + hp + XW];
-                if (yu) y -= wN * s_x[q * XN + hp - XW];
+                y = xr ? y - fE_own * vE : y;
+                y = xl ? y - wW * vW : y;
+                y = yd ? y - fS_own * vS : y;
+                y = yu ? y - wN * vN : y;
                 bq[q] = bq[q] - y;
             }
         }
@@ -949,13 +953,14 @@ __device__ __forceinline__ void mid_level(const MidPack& P, int q, int t, vf* __
 }
 template <int P0>
 __global__ __launch_bounds__(MID_T) void k_mg_mid(const PState* __restrict__ st, MidPack P, int sweeps) {
-    if (st->nactive == 0) return;
+    const int nact = st->nactive;   // checked below, behind the kernel's first loads: as the first statement it was a dependent scalar round trip in front of everything (round 6)
     __shared__ vf sA[MID_T * P0], sB[MID_T * P0], sC[MID_N1], sS[MID_STASH];
     const int q = blockIdx.x, t = threadIdx.x;
     const Lvl& L0 = P.lv[0];
     vf b[P0];
 #pragma unroll
     for (int k = 0; k < P0; ++k) { const int i = t + k * MID_T; b[k] = i < L0.n ? L0.b[(size_t)q * L0.n + i] : 0.f; }
+    if (nact == 0) return;
     mid_level<P0, 0>(P, q, t, sA, sB, sC, sS, b, sweeps);
 }
 
@@ -1008,7 +1013,7 @@ __global__ void k_pcg_start_fin(const double* __restrict__ partial, int nb, PSta
 template <int NQ>
 __global__ __launch_bounds__(256) void k_cg_apply(const PState* __restrict__ st, Lvl L, const vf* __restrict__ z, const double* __restrict__ r,
                                                   double* __restrict__ w, double* __restrict__ partial) {
-    if (st->nactive == 0) return;
+    const int nact = st->nactive;   // checked below, behind the kernel's first loads: as the first statement it was a dependent scalar round trip in front of everything (round 6)
     // XCD-aware block order (as the V-cycle legs): each XCD takes a contiguous eighth of the image, so the rows above and below a block's pixels are in its own L2
     // (109 MB of fabric traffic per launch for 70 MB of compulsory bytes before). The partial sums keep their LOGICAL block slot: the reduction order is unchanged.
     const int lb = mg_tile_of_block(blockIdx.x, gridDim.x);
@@ -1016,12 +1021,20 @@ __global__ __launch_bounds__(256) void k_cg_apply(const PState* __restrict__ st,
     double acc[3 * NQ];
 #pragma unroll
     for (int q = 0; q < 3 * NQ; ++q) acc[q] = 0.0;
+    auto uv = [&](int j, int q) { return (double)z[(size_t)q * L.n + j]; };
+    double y[NQ], rq[NQ], uq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { y[q] = 0.0; rq[q] = 0.0; uq[q] = 0.0; }
     if (i < L.n) {
-        auto uv = [&](int j, int q) { return (double)z[(size_t)q * L.n + j]; };
-        double y[NQ]; lvl_op<NQ>(L, i, uv, y);
+        lvl_op<NQ>(L, i, uv, y);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { rq[q] = r[(size_t)q * L.n + i]; uq[q] = uv(i, q); }
+    }
+    if (nact == 0) return;                                   // (every thread; before the first store)
+    if (i < L.n) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const double u = uv(i, q), rv = r[(size_t)q * L.n + i];
+            const double u = uq[q], rv = rq[q];
             w[(size_t)q * L.n + i] = y[q];
             acc[q] = rv * u; acc[NQ + q] = y[q] * u; acc[2 * NQ + q] = rv * rv;
         }
